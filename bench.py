@@ -1,0 +1,310 @@
+#!/usr/bin/env python3
+"""bench.py -- Mrays/s of the ray-casting hot path on N MI355X GPUs of one node.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+
+One "step" renders one full frame of the workload: every rank casts the primary
+and ambient-occlusion rays of its image bands (HIP kernel), box-filters them to
+8-bit on the device, and -- for N > 1 -- the bands are gathered to rank 0 over
+RCCL and assembled into the final image.  Scene and image buffers are resident
+in HBM before the timed region starts.  Rays are counted as the reference would
+cast them: one primary ray per sub-pixel plus, with AO on, 28 (default ring
+set) any-hit rays per hit sub-pixel.
+
+Rank 0 prints ONE JSON line (contract in the task description) carrying
+`roofline` (dominant kernel, algorithmic bytes of the REFERENCE traversal over
+the HIP-event kernel time, against the 8 TB/s HBM peak) and, at N = 1,
+`cpu_baseline` (the reference's own kernel compiled for x86-64 when
+oracle/_ref/ holds it, else this repo's C restatement, on the host cores).
+"""
+from __future__ import annotations
+
+import argparse
+import hashlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+# Workloads = the configs of BASELINE.json that fit one GPU; `golden` names the
+# tests/golden/golden.json entry that pins the output and supplies the
+# reference-traversal counters for the algorithmic byte count.
+WORKLOADS = {
+    "bunny_1080p_ao": dict(
+        mesh="bunny", bvh="longest", width=1920, height=1080, ss=1, ao=3, golden="bunny_1080p_s1_a3",
+        label="bunny.off 1920x1080 -s 1 -a 3 (primary + 28 AO rays per hit sub-pixel), longest-axis BVH"),
+    "bunny_1080p_primary": dict(
+        mesh="bunny", bvh="longest", width=1920, height=1080, ss=1, ao=0, golden="bunny_1080p_s1_a0",
+        label="bunny.off 1920x1080 -s 1 -a 0 (primary rays only), longest-axis BVH"),
+    "bunny_600_defaults": dict(
+        mesh="bunny", bvh="longest", width=600, height=600, ss=4, ao=3, golden="bunny_600_defaults",
+        label="bunny.off 600x600 CLI defaults (-s 4 -a 3)"),
+    "bunny_1080p_s64": dict(
+        mesh="bunny", bvh="longest", width=1920, height=1080, ss=64, ao=3, golden=None,
+        label="bunny.off 1920x1080 -s 64 -a 3 (regular 8x8 supersample grid: 15360x8640 sub-pixels)"),
+    "interior_1080p_ao": dict(
+        mesh="interior", bvh="longest", width=1920, height=1080, ss=1, ao=3, golden=None,
+        label="interior stand-in for the missing sibenik.off, 1920x1080 -s 1 -a 3"),
+}
+DEFAULT_WORKLOAD = "bunny_1080p_ao"
+
+
+def workload_options(rt, w):
+    return rt.Options.defaults(width=w["width"], height=w["height"], n_super_samples=w["ss"], ao_num_samples=w["ao"],
+                               enable_ao=int(w["ao"] != 0), bvh_method=0 if w["bvh"] == "longest" else 1)
+
+
+def mesh_path(name: str) -> str:
+    from tools.meshes import bunny_path, interior_path
+
+    return bunny_path() if name == "bunny" else interior_path()
+
+
+def baseline_kernel_params():
+    """(orc params, supersamples) of the default workload: lets build() prebuild
+    the matching reference-kernel object for the cpu_baseline leg."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+
+    class O:  # rt_options look-alike, so this works before the product is built
+        pass
+
+    w = WORKLOADS[DEFAULT_WORKLOAD]
+    o = O()
+    o.width, o.height, o.focal_length, o.n_super_samples = w["width"], w["height"], 1.0, w["ss"]
+    o.enable_shading, o.enable_ao, o.ao_max_distance, o.ao_num_samples = 1, int(w["ao"] != 0), 0.2, w["ao"]
+    o.ao_method, o.ao_alpha_min, o.ao_alpha_max = 0, 4, 90
+    return orc.params_from_options(o), w["ss"]
+
+
+def algorithmic_bytes(counters: dict, subpixels: int) -> int:
+    """B = 36 per node visit (4 B count + 32 B box) + 60 per
+    triangle test (12 B indices + 48 B vertices) + 48 per hit primary (normals)
+    + 4 per sub-pixel written, with the visit/test counts of the REFERENCE
+    traversal on the same tree."""
+    visits = counters["primary_node_visits"] + counters["ao_node_visits"]
+    tests = counters["primary_tri_tests"] + counters["ao_tri_tests"]
+    return 36 * visits + 60 * tests + 48 * counters["primary_hits"] + 4 * subpixels
+
+
+def cpu_baseline(opt, scene, gpu_u8, w):
+    """Times the CPU checker on the same frame (rank 0, N = 1 only) and checks
+    the GPU image against it.  The oracle is used here as the thing to compare
+    with and to time beside -- never as part of the measured GPU path."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+
+    import orc
+
+    p = orc.params_from_options(opt)
+    arrays = orc.SceneArrays.from_scene(scene)
+    cores = len(os.sched_getaffinity(0))
+    full_rays = None
+    # Bound the sample to roughly 10-30 core-seconds: a band of rows in the
+    # middle of the image (where the model is) for the heavy workloads.
+    rows = (0, p.height)
+    est_subpixels = p.width * p.height * (29 if opt.enable_ao else 1)
+    if est_subpixels > 80e6:
+        keep = max(8, int(p.height * 80e6 / est_subpixels) // 8 * 8)
+        y0 = (p.height - keep) // 2 // 8 * 8
+        rows = (y0, y0 + keep)
+    lib = orc.ref_kernel(p, opt.n_super_samples, build=False)
+    oracle = orc.Oracle()
+    # ray count of the sample from the oracle's counters (cheap relative to AO)
+    t0 = time.perf_counter()
+    orc_img, counters, used = oracle.render(p, arrays, rows=rows, nthreads=cores)
+    t_port = time.perf_counter() - t0
+    rays = counters["primary_rays"] + counters["ao_rays"]
+    kind, seconds, img = "port", t_port, orc_img
+    if lib is not None:
+        t0 = time.perf_counter()
+        ref_img, used = orc.ref_render(lib, p, arrays, rows=rows, nthreads=cores)
+        seconds = time.perf_counter() - t0
+        kind, img = "reference", ref_img
+        if not np.array_equal(ref_img.view(np.uint32), orc_img.view(np.uint32)):
+            raise AssertionError("reference kernel and oracle disagree on the baseline sample")
+    identical = None
+    if rows == (0, p.height):
+        cpu_u8 = oracle.resize(img, opt.width, opt.height, opt.n_super_samples)
+        identical = bool(np.array_equal(cpu_u8, gpu_u8))
+        if not identical:
+            raise AssertionError("GPU PGM differs from the CPU baseline image")
+        full_rays = rays
+    return {
+        "value": round(rays / seconds / 1e6, 3), "unit": "Mrays/s", "cores": int(used), "kind": kind,
+        "sample": f"rows {rows[0]}..{rows[1]} of {p.height} ({rays} rays, {seconds:.2f} s wall)"
+                  + ("; PGM byte-identical to the GPU frame" if identical else ""),
+        "port_value": round(rays / t_port / 1e6, 3),
+    }, full_rays
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import opencl_raytracer_amd as rt
+
+    rt.load_library()  # raises if the HIP library is missing: no fallback
+    if not torch.cuda.is_available() or rt.device_count() < 1:
+        sys.exit("bench.py needs a visible MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    w = WORKLOADS[args.workload]
+    opt = workload_options(rt, w)
+    t0 = time.perf_counter()
+    scene = rt.Scene.load_off(mesh_path(w["mesh"])).build_bvh(opt.bvh_method)
+    t_scene = time.perf_counter() - t0
+
+    host = rt.Host(opt, local_rank, rank, world)
+    host.upload_scene(scene)
+    # One explicit torch stream carries the kernels, the resize and (through
+    # torch.distributed's stream sync) the gather, so they are ordered.
+    stream = torch.cuda.Stream(device)
+    torch.cuda.set_stream(stream)
+    host.set_stream(stream.cuda_stream)
+
+    # band buffers: equal-sized on every rank so the gather is one collective
+    local_rows = host.local_rows
+    max_rows = max(int(rt.partition_rows(opt, r, world).size) for r in range(world))
+    band = torch.zeros((max_rows, opt.width), dtype=torch.uint8, device=device)
+    final = torch.zeros((opt.height, opt.width), dtype=torch.uint8, device=device)
+    gather_list, src_index, dst_index = None, None, None
+    if rank == 0 and world > 1:
+        gather_list = [torch.zeros_like(band) for _ in range(world)]
+        src, dst = [], []
+        for r in range(world):
+            rows = rt.partition_rows(opt, r, world)
+            for j, g in enumerate(rows):
+                if g < opt.height:
+                    src.append(r * max_rows + j)
+                    dst.append(int(g))
+        src_index = torch.tensor(src, dtype=torch.long, device=device)
+        dst_index = torch.tensor(dst, dtype=torch.long, device=device)
+
+    def step():
+        host.render_async()
+        host.resize_into_device(band.data_ptr())
+        if world > 1:
+            dist.gather(band, gather_list, dst=0)
+            if rank == 0:
+                stacked = torch.cat(gather_list, dim=0)
+                final.index_copy_(0, dst_index, stacked.index_select(0, src_index))
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    host.sync()
+    host.reset_timers()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    host.sync()  # folds the HIP event pairs into the kernel-time statistics
+
+    # whole-job numbers: max time over ranks, sum of rays over ranks
+    st = host.stats()
+    my_rays = st["primary_rays"] + st["ao_rays"]
+    kernel_ms = host.total_kernel_ms / max(1, host.kernel_launches)
+    if world > 1:
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms_max = float(t[0]), float(t[1])
+        r = torch.tensor([my_rays, st["primary_hits"], st["ao_occluded"]], dtype=torch.int64, device=device)
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        total_rays, total_hits, total_occluded = (int(x) for x in r)
+    else:
+        kernel_ms_max = kernel_ms
+        total_rays, total_hits, total_occluded = my_rays, st["primary_hits"], st["ao_occluded"]
+
+    if rank == 0:
+        if world == 1:
+            final_u8 = band[:opt.height].cpu().numpy()
+        else:
+            final_u8 = final.cpu().numpy()
+        pgm_md5 = hashlib.md5(rt.pgm_bytes(final_u8)).hexdigest()
+        golden_md5, counters = None, None
+        if w["golden"]:
+            with open(os.path.join(ROOT, "tests", "golden", "golden.json")) as f:
+                g = json.load(f)["renders"][w["golden"]]
+            golden_md5, counters = g["pgm_md5"], g["counters"]
+            if pgm_md5 != golden_md5:
+                sys.exit(f"bench.py: PGM md5 {pgm_md5} != golden {golden_md5} -- refusing to report a number")
+            if total_hits != counters["primary_hits"] or total_occluded != counters["ao_occluded"]:
+                sys.exit("bench.py: ray statistics differ from the reference traversal")
+
+        ms_per_step = elapsed / args.steps * 1e3
+        value = total_rays / (elapsed / args.steps) / 1e6
+        out = {
+            "metric": "Mrays/s at 1920x1080 (bunny.off); PGM bit-exact vs CPU" if "1080p" in args.workload
+                      else "Mrays/s; PGM bit-exact vs CPU",
+            "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": f"{w['mesh']}.off mesh asset, fixed camera (no randomness in this path)",
+            "config": {"workload": w["label"], "rays_per_frame": total_rays, "primary_hits": total_hits,
+                       "parallelism": f"image bands x{world}" + (", RCCL gather to rank 0" if world > 1 else ""),
+                       "pgm_md5": pgm_md5, "pgm_matches_golden": golden_md5 is not None,
+                       "scene_build_s": round(t_scene, 3), "device": torch.cuda.get_device_name(device)},
+        }
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu, _ = cpu_baseline(opt, scene, final_u8, w)
+            if counters is None and cpu is not None:
+                pass
+        if counters is not None:
+            sub = opt.total_width * opt.total_height
+            bytes_per_launch = algorithmic_bytes(counters, sub) / world  # per rank, bands are interleaved
+            achieved = bytes_per_launch / (kernel_ms_max * 1e-3) / 1e9
+            out["roofline"] = {
+                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "trace_tiles_kernel",
+                "kernel_ms": round(kernel_ms_max, 4), "algorithmic_bytes_per_launch": int(bytes_per_launch),
+                "note": "algorithmic bytes = reference traversal (36 B/node visit + 60 B/triangle test + 48 B/hit "
+                        "+ 4 B/sub-pixel); the 12 MB scene is L2/Infinity-Cache resident, so this is not an HBM-bound "
+                        "kernel (see DESIGN.md)",
+            }
+        else:
+            out["roofline"] = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                               "traffic": None, "kernel": "trace_tiles_kernel", "kernel_ms": round(kernel_ms_max, 4)}
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        print(json.dumps(out), flush=True)
+
+    host.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

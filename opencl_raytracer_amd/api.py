@@ -1,0 +1,378 @@
+"""ctypes binding of include/rt_hip.h (see that header for the contract)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def lib_path() -> str:
+    return os.path.join(_HERE, "lib", "libocrt_hip.so")
+
+
+class RtError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"[rt {code}] {message}")
+        self.code = code
+        self.message = message
+
+
+RT_E_INVALID, RT_E_NO_DEVICE, RT_E_DEVICE, RT_E_STATE, RT_E_IO = -1, -2, -3, -4, -5
+
+
+class Options(C.Structure):
+    """rt_options == RayTracer::Options (reference include/ray_tracer.h:17-30)."""
+
+    _fields_ = [
+        ("width", C.c_uint32),
+        ("height", C.c_uint32),
+        ("focal_length", C.c_float),
+        ("n_super_samples", C.c_uint32),
+        ("enable_shading", C.c_int32),
+        ("enable_ao", C.c_int32),
+        ("ao_max_distance", C.c_float),
+        ("ao_num_samples", C.c_uint32),
+        ("ao_method", C.c_int32),
+        ("ao_alpha_min", C.c_int32),
+        ("ao_alpha_max", C.c_int32),
+        ("bvh_method", C.c_int32),
+    ]
+
+    @classmethod
+    def defaults(cls, **overrides) -> "Options":
+        o = cls()
+        load_library().rt_options_default(C.byref(o))
+        for k, v in overrides.items():
+            if not hasattr(o, k):
+                raise AttributeError(k)
+            setattr(o, k, v)
+        # the CLI's rule: AO is on iff the sample count is non-zero (reference src/render.cc:42)
+        if "ao_num_samples" in overrides and "enable_ao" not in overrides:
+            o.enable_ao = int(o.ao_num_samples != 0)
+        return o
+
+    @property
+    def total_width(self) -> int:
+        return load_library().rt_total_width(C.byref(self))
+
+    @property
+    def total_height(self) -> int:
+        return load_library().rt_total_height(C.byref(self))
+
+
+class _Stats(C.Structure):
+    _fields_ = [
+        ("primary_rays", C.c_uint64),
+        ("primary_hits", C.c_uint64),
+        ("ao_rays", C.c_uint64),
+        ("ao_occluded", C.c_uint64),
+    ]
+
+
+_LIB: Optional[C.CDLL] = None
+
+# name -> (restype, argtypes); also the list tests check against the header.
+_SIGNATURES = {
+    "rt_last_error": (C.c_char_p, []),
+    "rt_last_error_code": (C.c_int, []),
+    "rt_options_default": (None, [C.POINTER(Options)]),
+    "rt_total_width": (C.c_uint32, [C.POINTER(Options)]),
+    "rt_total_height": (C.c_uint32, [C.POINTER(Options)]),
+    "rt_resize_cpu": (C.c_int, [C.POINTER(Options), C.c_void_p, C.c_void_p]),
+    "rt_scene_load_off": (C.c_void_p, [C.c_char_p]),
+    "rt_scene_from_arrays": (C.c_void_p, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]),
+    "rt_scene_free": (None, [C.c_void_p]),
+    "rt_scene_num_vertices": (C.c_uint32, [C.c_void_p]),
+    "rt_scene_num_faces": (C.c_uint32, [C.c_void_p]),
+    "rt_scene_build_bvh": (C.c_int, [C.c_void_p, C.c_int]),
+    "rt_scene_num_nodes": (C.c_uint32, [C.c_void_p]),
+    "rt_scene_vertices": (C.c_void_p, [C.c_void_p]),
+    "rt_scene_vnormals": (C.c_void_p, [C.c_void_p]),
+    "rt_scene_faces": (C.c_void_p, [C.c_void_p]),
+    "rt_scene_nodes": (C.c_void_p, [C.c_void_p]),
+    "rt_scene_aabbs": (C.c_void_p, [C.c_void_p]),
+    "rt_scene_triangles": (C.c_void_p, [C.c_void_p]),
+    "rt_scene_sorted_faces": (C.c_void_p, [C.c_void_p]),
+    "rt_create": (C.c_void_p, [C.POINTER(Options)]),
+    "rt_create_on": (C.c_void_p, [C.POINTER(Options), C.c_int, C.c_uint32, C.c_uint32]),
+    "rt_destroy": (None, [C.c_void_p]),
+    "rt_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                            C.c_uint32, C.c_void_p]),
+    "rt_upload_scene": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rt_render": (C.c_int, [C.c_void_p]),
+    "rt_render_async": (C.c_int, [C.c_void_p]),
+    "rt_sync": (C.c_int, [C.c_void_p]),
+    "rt_download": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rt_download_u8": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rt_local_rows": (C.c_uint32, [C.c_void_p]),
+    "rt_download_u8_local": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rt_local_to_global_row": (C.c_uint32, [C.c_void_p, C.c_uint32]),
+    "rt_partition_local_rows": (C.c_uint32, [C.POINTER(Options), C.c_uint32, C.c_uint32]),
+    "rt_partition_global_row": (C.c_uint32, [C.POINTER(Options), C.c_uint32, C.c_uint32, C.c_uint32]),
+    "rt_resize_into_device": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rt_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rt_use_private_stream": (C.c_int, [C.c_void_p]),
+    "rt_get_stats": (C.c_int, [C.c_void_p, C.POINTER(_Stats)]),
+    "rt_last_kernel_ms": (C.c_float, [C.c_void_p]),
+    "rt_total_kernel_ms": (C.c_double, [C.c_void_p]),
+    "rt_kernel_launches": (C.c_uint64, [C.c_void_p]),
+    "rt_reset_timers": (None, [C.c_void_p]),
+    "rt_print_info": (None, []),
+    "rt_device_count": (C.c_int, []),
+}
+
+
+def load_library() -> C.CDLL:
+    """Loads lib/libocrt_hip.so; raises if it has not been built (no fallback)."""
+    global _LIB
+    if _LIB is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise ImportError(
+                f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C opencl_raytracer_amd/csrc`). There is no CPU fallback."
+            )
+        lib = C.CDLL(path)
+        for name, (restype, argtypes) in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _LIB = lib
+    return _LIB
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        lib = load_library()
+        raise RtError(rc, lib.rt_last_error().decode("utf-8", "replace"))
+
+
+def _raise_last() -> None:
+    lib = load_library()
+    raise RtError(lib.rt_last_error_code(), lib.rt_last_error().decode("utf-8", "replace"))
+
+
+def device_count() -> int:
+    return load_library().rt_device_count()
+
+
+def _view(ptr: int, count: int, dtype) -> np.ndarray:
+    if count == 0:
+        return np.zeros(0, dtype=dtype)
+    ctype = {np.uint32: C.c_uint32, np.float32: C.c_float}[dtype]
+    arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(count,))
+    return arr.copy()
+
+
+class Scene:
+    """CPU-side mesh + BVH: load_off_mesh / compute_vertex_normals / BVH::buildBVH."""
+
+    def __init__(self, handle: int):
+        self._h = handle
+
+    @classmethod
+    def load_off(cls, path: str) -> "Scene":
+        h = load_library().rt_scene_load_off(os.fsencode(path))
+        if not h:
+            _raise_last()
+        return cls(h)
+
+    @classmethod
+    def from_arrays(cls, vertices: np.ndarray, faces: np.ndarray) -> "Scene":
+        v = np.ascontiguousarray(vertices, dtype=np.float32)
+        if v.ndim != 2 or v.shape[1] not in (3, 4):
+            raise ValueError("vertices must be (V,3) or (V,4)")
+        if v.shape[1] == 3:
+            v = np.concatenate([v, np.zeros((v.shape[0], 1), np.float32)], axis=1)
+        v = np.ascontiguousarray(v)
+        f = np.ascontiguousarray(faces, dtype=np.uint32).reshape(-1)
+        h = load_library().rt_scene_from_arrays(v.ctypes.data, v.shape[0], f.ctypes.data, f.size // 3)
+        if not h:
+            _raise_last()
+        return cls(h)
+
+    def close(self) -> None:
+        if self._h:
+            load_library().rt_scene_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def build_bvh(self, method: int = 0) -> "Scene":
+        _check(load_library().rt_scene_build_bvh(self._h, int(method)))
+        return self
+
+    @property
+    def num_vertices(self) -> int:
+        return load_library().rt_scene_num_vertices(self._h)
+
+    @property
+    def num_faces(self) -> int:
+        return load_library().rt_scene_num_faces(self._h)
+
+    @property
+    def num_nodes(self) -> int:
+        return load_library().rt_scene_num_nodes(self._h)
+
+    def _arr(self, getter: str, count: int, dtype):
+        return _view(getattr(load_library(), getter)(self._h), count, dtype)
+
+    @property
+    def vertices(self) -> np.ndarray:
+        return self._arr("rt_scene_vertices", 4 * self.num_vertices, np.float32).reshape(-1, 4)
+
+    @property
+    def vnormals(self) -> np.ndarray:
+        return self._arr("rt_scene_vnormals", 4 * self.num_vertices, np.float32).reshape(-1, 4)
+
+    @property
+    def faces(self) -> np.ndarray:
+        return self._arr("rt_scene_faces", 3 * self.num_faces, np.uint32)
+
+    @property
+    def nodes(self) -> np.ndarray:
+        return self._arr("rt_scene_nodes", self.num_nodes, np.uint32)
+
+    @property
+    def aabbs(self) -> np.ndarray:
+        return self._arr("rt_scene_aabbs", 8 * self.num_nodes, np.float32).reshape(-1, 4)
+
+    @property
+    def triangles(self) -> np.ndarray:
+        return self._arr("rt_scene_triangles", self.num_faces if self.num_nodes else 0, np.uint32)
+
+    @property
+    def sorted_faces(self) -> np.ndarray:
+        return self._arr("rt_scene_sorted_faces", 3 * self.num_faces if self.num_nodes else 0, np.uint32)
+
+
+class Host:
+    """One render host == one OpenCLHost of the reference (ctor/upload/()/download)."""
+
+    def __init__(self, options: Options, device: int = -1, rank: int = 0, nranks: int = 1):
+        self.options = options
+        self._h = load_library().rt_create_on(C.byref(options), device, rank, nranks)
+        if not self._h:
+            _raise_last()
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            load_library().rt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, faces, nodes, aabbs, vertices, vnormals) -> None:
+        f = np.ascontiguousarray(faces, dtype=np.uint32).reshape(-1)
+        n = np.ascontiguousarray(nodes, dtype=np.uint32).reshape(-1)
+        a = np.ascontiguousarray(aabbs, dtype=np.float32).reshape(-1, 4)
+        v = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 4)
+        vn = np.ascontiguousarray(vnormals, dtype=np.float32).reshape(-1, 4)
+        if a.shape[0] != 2 * n.size:
+            raise RtError(RT_E_INVALID, "aabbs must hold a (min,max) pair per node")
+        if vn.shape[0] != v.shape[0]:
+            raise RtError(RT_E_INVALID, "one normal per vertex expected")
+        _check(load_library().rt_upload(self._h, f.ctypes.data, f.size // 3, n.ctypes.data, n.size, a.ctypes.data,
+                                        v.ctypes.data, v.shape[0], vn.ctypes.data))
+
+    def upload_scene(self, scene: Scene) -> None:
+        _check(load_library().rt_upload_scene(self._h, scene._h))
+
+    def render(self) -> None:
+        _check(load_library().rt_render(self._h))
+
+    __call__ = render
+
+    def render_async(self) -> None:
+        _check(load_library().rt_render_async(self._h))
+
+    def sync(self) -> None:
+        _check(load_library().rt_sync(self._h))
+
+    def download(self) -> np.ndarray:
+        img = np.empty((self.options.total_height, self.options.total_width), dtype=np.float32)
+        _check(load_library().rt_download(self._h, img.ctypes.data))
+        return img
+
+    def download_u8(self) -> np.ndarray:
+        img = np.empty((self.options.height, self.options.width), dtype=np.uint8)
+        _check(load_library().rt_download_u8(self._h, img.ctypes.data))
+        return img
+
+    @property
+    def local_rows(self) -> int:
+        return load_library().rt_local_rows(self._h)
+
+    def local_to_global_rows(self) -> np.ndarray:
+        lib = load_library()
+        return np.array([lib.rt_local_to_global_row(self._h, j) for j in range(self.local_rows)], dtype=np.int64)
+
+    def download_u8_local(self) -> np.ndarray:
+        rows = np.empty((self.local_rows, self.options.width), dtype=np.uint8)
+        _check(load_library().rt_download_u8_local(self._h, rows.ctypes.data))
+        return rows
+
+    def resize_into_device(self, device_ptr: int) -> None:
+        _check(load_library().rt_resize_into_device(self._h, device_ptr))
+
+    def set_stream(self, hip_stream: int) -> None:
+        _check(load_library().rt_set_stream(self._h, hip_stream))
+
+    def use_private_stream(self) -> None:
+        _check(load_library().rt_use_private_stream(self._h))
+
+    def stats(self) -> dict:
+        s = _Stats()
+        _check(load_library().rt_get_stats(self._h, C.byref(s)))
+        return {k: int(getattr(s, k)) for k, _ in _Stats._fields_}
+
+    @property
+    def last_kernel_ms(self) -> float:
+        return float(load_library().rt_last_kernel_ms(self._h))
+
+    @property
+    def total_kernel_ms(self) -> float:
+        return float(load_library().rt_total_kernel_ms(self._h))
+
+    @property
+    def kernel_launches(self) -> int:
+        return int(load_library().rt_kernel_launches(self._h))
+
+    def reset_timers(self) -> None:
+        load_library().rt_reset_timers(self._h)
+
+
+def resize_cpu(options: Options, tmp: np.ndarray) -> np.ndarray:
+    """RayTracer::resize on the host (reference src/ray_tracer.cc:3-16)."""
+    t = np.ascontiguousarray(tmp, dtype=np.float32)
+    if t.size != options.total_width * options.total_height:
+        raise RtError(RT_E_INVALID, "tmp must hold total_width*total_height floats")
+    out = np.empty((options.height, options.width), dtype=np.uint8)
+    _check(load_library().rt_resize_cpu(C.byref(options), t.ctypes.data, out.ctypes.data))
+    return out
+
+
+def partition_rows(options: Options, rank: int, nranks: int) -> np.ndarray:
+    """Global output row of every local row of `rank` (rows >= height are padding)."""
+    lib = load_library()
+    count = lib.rt_partition_local_rows(C.byref(options), rank, nranks)
+    return np.array([lib.rt_partition_global_row(C.byref(options), rank, nranks, j) for j in range(count)],
+                    dtype=np.int64)
+
+
+def pgm_bytes(image_u8: np.ndarray) -> bytes:
+    """The file `render` writes: 'P5 W H 255\\n' + raw bytes (reference src/render.cc:135-136)."""
+    h, w = image_u8.shape
+    return f"P5 {w} {h} 255\n".encode() + np.ascontiguousarray(image_u8, dtype=np.uint8).tobytes()

@@ -1,0 +1,329 @@
+// c_api.cc -- the extern "C" boundary declared in include/rt_hip.h.
+#include "../../include/rt_hip.h"
+
+#include <cstring>
+#include <memory>
+#include <new>
+#include <string>
+
+#include "bvh.h"
+#include "device_renderer.h"
+#include "hip_host.h"
+#include "mesh.h"
+#include "ray_tracer.h"
+#include "scene_pack.h"
+
+struct rt_scene {
+	Mesh mesh;
+	BVH bvh;
+	std::vector<uint32_t> sorted_faces;
+	bool built = false;
+};
+
+struct rt_host {
+	std::unique_ptr<ocrt::DeviceRenderer> dev;
+};
+
+namespace {
+
+thread_local std::string g_error;
+thread_local int g_error_code = RT_OK;
+
+int fail(int code, const std::string &message) {
+	g_error = message;
+	g_error_code = code;
+	return code;
+}
+
+// Maps the exception in flight to an RT_E_* code.
+int fail_from_exception() {
+	try {
+		throw;
+	} catch (const ocrt::DeviceError &e) {
+		return fail(RT_E_DEVICE, e.what());
+	} catch (const std::invalid_argument &e) {
+		return fail(RT_E_INVALID, e.what());
+	} catch (const std::logic_error &e) {
+		return fail(RT_E_STATE, e.what());
+	} catch (const std::runtime_error &e) {
+		const bool no_device = std::strcmp(e.what(), "No device found") == 0;
+		return fail(no_device ? RT_E_NO_DEVICE : RT_E_IO, e.what());
+	} catch (const std::exception &e) {
+		return fail(RT_E_INVALID, e.what());
+	} catch (...) {
+		return fail(RT_E_INVALID, "unknown error");
+	}
+}
+
+RayTracer::Options to_options(const rt_options &o) {
+	RayTracer::Options r;
+	r.width = o.width;
+	r.height = o.height;
+	r.focalLength = o.focal_length;
+	r.nSuperSamples = o.n_super_samples;
+	r.enableShading = o.enable_shading != 0;
+	r.enableAO = o.enable_ao != 0;
+	r.aoMaxDistance = o.ao_max_distance;
+	r.aoNumSamples = o.ao_num_samples;
+	r.aoMethod = o.ao_method == 0 ? RayTracer::AmbientOcclusionMethod::UNIFORM : RayTracer::AmbientOcclusionMethod::RANDOM;
+	r.aoAlphaMin = o.ao_alpha_min;
+	r.aoAlphaMax = o.ao_alpha_max;
+	r.bvhMethod = o.bvh_method == 0 ? BVH::Method::CUT_LONGEST_AXIS : BVH::Method::SURFACE_AREA_HEURISTIC;
+	return r;
+}
+
+template <class F> int guarded(F &&body) {
+	try {
+		body();
+		return RT_OK;
+	} catch (...) {
+		return fail_from_exception();
+	}
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *rt_last_error(void) { return g_error.c_str(); }
+int rt_last_error_code(void) { return g_error_code; }
+
+void rt_options_default(rt_options *out) {
+	const RayTracer::Options d = RayTracer::defaults();
+	out->width = d.width;
+	out->height = d.height;
+	out->focal_length = d.focalLength;
+	out->n_super_samples = d.nSuperSamples;
+	out->enable_shading = d.enableShading;
+	out->enable_ao = d.enableAO;
+	out->ao_max_distance = d.aoMaxDistance;
+	out->ao_num_samples = d.aoNumSamples;
+	out->ao_method = 0;
+	out->ao_alpha_min = d.aoAlphaMin;
+	out->ao_alpha_max = d.aoAlphaMax;
+	out->bvh_method = 0;
+}
+
+uint32_t rt_total_width(const rt_options *o) { return RayTracer(to_options(*o)).totalWidth; }
+uint32_t rt_total_height(const rt_options *o) { return RayTracer(to_options(*o)).totalHeight; }
+
+int rt_resize_cpu(const rt_options *o, const float *tmp, uint8_t *image) {
+	if (!o || !tmp || !image)
+		return fail(RT_E_INVALID, "null argument");
+	if (RayTracer::gridSize(o->n_super_samples) == 0)
+		return fail(RT_E_INVALID, "supersample count must be positive");
+	RayTracer(to_options(*o)).resize(tmp, image);
+	return RT_OK;
+}
+
+rt_scene *rt_scene_load_off(const char *path) {
+	std::unique_ptr<rt_scene> s(new (std::nothrow) rt_scene);
+	if (!s || !path) {
+		fail(RT_E_INVALID, "null argument");
+		return nullptr;
+	}
+	const int rc = guarded([&] {
+		load_off_mesh(path, &s->mesh);
+		compute_vertex_normals(&s->mesh);
+	});
+	return rc == RT_OK ? s.release() : nullptr;
+}
+
+rt_scene *rt_scene_from_arrays(const float *vertices4, uint32_t num_vertices, const uint32_t *faces, uint32_t num_faces) {
+	if ((!vertices4 && num_vertices) || (!faces && num_faces)) {
+		fail(RT_E_INVALID, "null argument");
+		return nullptr;
+	}
+	std::unique_ptr<rt_scene> s(new (std::nothrow) rt_scene);
+	if (!s)
+		return nullptr;
+	for (uint32_t i = 0; i < 3 * num_faces; ++i)
+		if (faces[i] >= num_vertices) {
+			fail(RT_E_INVALID, "face references a vertex out of range");
+			return nullptr;
+		}
+	s->mesh.vertices.resize(num_vertices);
+	for (uint32_t i = 0; i < num_vertices; ++i)
+		s->mesh.vertices[i] = Vec3f(vertices4[4 * i], vertices4[4 * i + 1], vertices4[4 * i + 2]);
+	s->mesh.faces.assign(faces, faces + 3 * (size_t) num_faces);
+	compute_vertex_normals(&s->mesh);
+	return s.release();
+}
+
+void rt_scene_free(rt_scene *s) { delete s; }
+uint32_t rt_scene_num_vertices(const rt_scene *s) { return (uint32_t) s->mesh.vertices.size(); }
+uint32_t rt_scene_num_faces(const rt_scene *s) { return (uint32_t) (s->mesh.faces.size() / 3); }
+
+int rt_scene_build_bvh(rt_scene *s, int method) {
+	if (!s)
+		return fail(RT_E_INVALID, "null scene");
+	return guarded([&] {
+		s->built = false;
+		s->bvh = BVH(method == 0 ? BVH::Method::CUT_LONGEST_AXIS : BVH::Method::SURFACE_AREA_HEURISTIC);
+		s->bvh.buildBVH(s->mesh);
+		s->sorted_faces = sort_faces_by_leaf_order(s->mesh, s->bvh);
+		s->built = true;
+	});
+}
+
+uint32_t rt_scene_num_nodes(const rt_scene *s) { return s->built ? (uint32_t) s->bvh.nodes.size() : 0; }
+const float *rt_scene_vertices(const rt_scene *s) { return &s->mesh.vertices.data()->x; }
+const float *rt_scene_vnormals(const rt_scene *s) { return &s->mesh.vnormals.data()->x; }
+const uint32_t *rt_scene_faces(const rt_scene *s) { return s->mesh.faces.data(); }
+const uint32_t *rt_scene_nodes(const rt_scene *s) { return s->bvh.nodes.data(); }
+const float *rt_scene_aabbs(const rt_scene *s) { return &s->bvh.aabbs.data()->x; }
+const uint32_t *rt_scene_triangles(const rt_scene *s) { return s->bvh.triangles.data(); }
+const uint32_t *rt_scene_sorted_faces(const rt_scene *s) { return s->sorted_faces.data(); }
+
+rt_host *rt_create_on(const rt_options *o, int device, uint32_t rank, uint32_t nranks) {
+	if (!o) {
+		fail(RT_E_INVALID, "null options");
+		return nullptr;
+	}
+	std::unique_ptr<rt_host> h(new (std::nothrow) rt_host);
+	if (!h)
+		return nullptr;
+	const int rc = guarded([&] { h->dev.reset(new ocrt::DeviceRenderer(to_options(*o), device, rank, nranks)); });
+	return rc == RT_OK ? h.release() : nullptr;
+}
+
+rt_host *rt_create(const rt_options *o) { return rt_create_on(o, -1, 0, 1); }
+
+void rt_destroy(rt_host *h) { delete h; }
+
+int rt_upload(rt_host *h, const uint32_t *faces, uint32_t num_faces, const uint32_t *nodes, uint32_t num_nodes,
+              const float *aabbs, const float *vertices, uint32_t num_vertices, const float *vnormals) {
+	if (!h || !faces || !nodes || !aabbs || !vertices || !vnormals)
+		return fail(RT_E_INVALID, "null argument");
+	return guarded([&] {
+		auto as_vec3 = [](const float *p, size_t n) {
+			std::vector<Vec3f> v(n);
+			for (size_t i = 0; i < n; ++i)
+				v[i] = Vec3f(p[4 * i], p[4 * i + 1], p[4 * i + 2]);
+			return v;
+		};
+		const std::vector<uint32_t> f(faces, faces + 3 * (size_t) num_faces);
+		const std::vector<uint32_t> n(nodes, nodes + num_nodes);
+		h->dev->upload(ocrt::pack_scene(f, n, as_vec3(aabbs, 2 * (size_t) num_nodes), as_vec3(vertices, num_vertices),
+		                                as_vec3(vnormals, num_vertices)));
+	});
+}
+
+int rt_upload_scene(rt_host *h, const rt_scene *s) {
+	if (!h || !s)
+		return fail(RT_E_INVALID, "null argument");
+	if (!s->built)
+		return fail(RT_E_STATE, "scene has no BVH yet (call rt_scene_build_bvh)");
+	return guarded([&] {
+		h->dev->upload(ocrt::pack_scene(s->sorted_faces, s->bvh.nodes, s->bvh.aabbs, s->mesh.vertices, s->mesh.vnormals));
+	});
+}
+
+int rt_render(rt_host *h) {
+	if (!h)
+		return fail(RT_E_INVALID, "null host");
+	return guarded([&] {
+		h->dev->enqueueRender();
+		h->dev->synchronize();
+	});
+}
+
+int rt_render_async(rt_host *h) {
+	if (!h)
+		return fail(RT_E_INVALID, "null host");
+	return guarded([&] { h->dev->enqueueRender(); });
+}
+
+int rt_sync(rt_host *h) {
+	if (!h)
+		return fail(RT_E_INVALID, "null host");
+	return guarded([&] { h->dev->synchronize(); });
+}
+
+int rt_download(rt_host *h, float *image) {
+	if (!h || !image)
+		return fail(RT_E_INVALID, "null argument");
+	return guarded([&] { h->dev->downloadFloat(image); });
+}
+
+int rt_download_u8(rt_host *h, uint8_t *image) {
+	if (!h || !image)
+		return fail(RT_E_INVALID, "null argument");
+	return guarded([&] { h->dev->downloadResizedFull(image); });
+}
+
+uint32_t rt_local_rows(const rt_host *h) { return h ? h->dev->localRows() : 0; }
+
+int rt_download_u8_local(rt_host *h, uint8_t *rows) {
+	if (!h || !rows)
+		return fail(RT_E_INVALID, "null argument");
+	return guarded([&] { h->dev->downloadResizedLocal(rows); });
+}
+
+uint32_t rt_partition_local_rows(const rt_options *o, uint32_t rank, uint32_t nranks) {
+	const uint32_t n = RayTracer::gridSize(o->n_super_samples);
+	if (n == 0 || nranks == 0 || rank >= nranks)
+		return 0;
+	const ocrt::Partition part{ rank, nranks, ocrt::band_tile_rows_for(n) };
+	return ocrt::local_tile_rows_for(o->height * n, part) * ocrt::TILE_H / n;
+}
+
+uint32_t rt_partition_global_row(const rt_options *o, uint32_t rank, uint32_t nranks, uint32_t local_row) {
+	const uint32_t n = RayTracer::gridSize(o->n_super_samples);
+	if (n == 0 || nranks == 0)
+		return 0xFFFFFFFFu;
+	const uint32_t rows_per_band = ocrt::band_tile_rows_for(n) * ocrt::TILE_H / n;
+	const uint32_t band_local = local_row / rows_per_band;
+	return (band_local * nranks + rank) * rows_per_band + local_row % rows_per_band;
+}
+
+uint32_t rt_local_to_global_row(const rt_host *h, uint32_t local_row) {
+	const ocrt::KernelParams &p = h->dev->params();
+	const RayTracer::Options &ro = h->dev->rayTracer().options;
+	rt_options o{};
+	o.n_super_samples = ro.nSuperSamples;
+	return rt_partition_global_row(&o, p.part.rank, p.part.nranks, local_row);
+}
+
+int rt_resize_into_device(rt_host *h, void *device_u8) {
+	if (!h || !device_u8)
+		return fail(RT_E_INVALID, "null argument");
+	return guarded([&] { h->dev->enqueueResizeInto(device_u8); });
+}
+
+int rt_set_stream(rt_host *h, void *hip_stream) {
+	if (!h)
+		return fail(RT_E_INVALID, "null host");
+	return guarded([&] { h->dev->setStream(hip_stream); });
+}
+
+int rt_use_private_stream(rt_host *h) {
+	if (!h)
+		return fail(RT_E_INVALID, "null host");
+	return guarded([&] { h->dev->usePrivateStream(); });
+}
+
+int rt_get_stats(rt_host *h, rt_stats *out) {
+	if (!h || !out)
+		return fail(RT_E_INVALID, "null argument");
+	return guarded([&] {
+		const ocrt::RenderStats s = h->dev->stats();
+		out->primary_rays = s.primary_rays;
+		out->primary_hits = s.primary_hits;
+		out->ao_rays = s.ao_rays;
+		out->ao_occluded = s.ao_occluded;
+	});
+}
+
+float rt_last_kernel_ms(const rt_host *h) { return h ? h->dev->lastKernelMs() : 0.0f; }
+double rt_total_kernel_ms(const rt_host *h) { return h ? h->dev->totalKernelMs() : 0.0; }
+uint64_t rt_kernel_launches(const rt_host *h) { return h ? h->dev->kernelLaunches() : 0; }
+void rt_reset_timers(rt_host *h) {
+	if (h)
+		h->dev->resetTimers();
+}
+
+void rt_print_info(void) { HipHost::printInfo(); }
+int rt_device_count(void) { return ocrt::visible_device_count(); }
+
+}  // extern "C"

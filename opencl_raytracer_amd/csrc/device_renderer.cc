@@ -1,0 +1,272 @@
+#include "device_renderer.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <sstream>
+
+namespace ocrt {
+
+namespace {
+
+void hip_check(hipError_t err, const char *what) {
+	if (err != hipSuccess) {
+		std::ostringstream ss;
+		ss << "HIP error: " << hipGetErrorName(err) << " (" << hipGetErrorString(err) << ") in " << what;
+		throw DeviceError(ss.str());
+	}
+}
+#define OCRT_HIP(call) hip_check((call), #call)
+
+void *device_alloc(size_t bytes) {
+	void *p = nullptr;
+	OCRT_HIP(hipMalloc(&p, bytes ? bytes : 1));
+	return p;
+}
+
+void device_free(void *&p) {
+	if (p)
+		(void) hipFree(p);
+	p = nullptr;
+}
+
+}  // namespace
+
+int visible_device_count() {
+	int count = 0;
+	if (hipGetDeviceCount(&count) != hipSuccess)
+		return 0;
+	return count;
+}
+
+DeviceRenderer::DeviceRenderer(const RayTracer::Options &options, int device_, unsigned int rank, unsigned int nranks)
+	: opts(options)
+	, rt(options)
+	, device(device_)
+	, grid(RayTracer::gridSize(options.nSuperSamples))
+	, local_out_rows(0)
+	, own_stream(nullptr)
+	, stream(nullptr)
+	, d_nodes(nullptr)
+	, d_tris(nullptr)
+	, d_shade(nullptr)
+	, d_ao(nullptr)
+	, d_image(nullptr)
+	, d_u8(nullptr)
+	, d_tile_stats(nullptr)
+	, tile_count(0)
+	, scene_ready(false)
+	, frame_ready(false)
+	, last_ms(0)
+	, total_ms(0)
+	, launches(0) {
+	if (nranks == 0 || rank >= nranks)
+		throw std::invalid_argument("rank must be < nranks");
+	if (opts.width == 0 || opts.height == 0 || grid == 0)
+		throw std::invalid_argument("image width, height and supersample count must be positive");
+	const int count = visible_device_count();
+	if (count <= 0)
+		throw std::runtime_error("No device found");
+	if (device < 0) {
+		const char *env = std::getenv("OCRT_DEVICE");
+		device = env ? std::atoi(env) : 0;
+	}
+	if (device >= count)
+		throw std::invalid_argument("HIP device index out of range");
+	part.rank = rank;
+	part.nranks = nranks;
+	part.band_tile_rows = band_tile_rows_for(grid);
+	kp = make_kernel_params(rt, 0, 0, part);
+	local_out_rows = kp.local_tile_rows * TILE_H / grid;
+	tile_count = (size_t) kp.tiles_x * kp.local_tile_rows;
+
+	useDevice();
+	hipStream_t s;
+	OCRT_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+	own_stream = stream = s;
+	// The float image is allocated at full size on every rank (bands are written
+	// in place, like the reference's single image buffer); the uint8 band buffer
+	// is compact.
+	d_image = device_alloc((size_t) rt.totalWidth * rt.totalHeight * sizeof(float));
+	d_u8 = device_alloc((size_t) local_out_rows * opts.width);
+	d_tile_stats = device_alloc(tile_count * sizeof(uint2));
+	OCRT_HIP(hipMemsetAsync(d_image, 0, (size_t) rt.totalWidth * rt.totalHeight * sizeof(float), (hipStream_t) stream));
+	OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));
+}
+
+DeviceRenderer::~DeviceRenderer() {
+	if (hipSetDevice(device) != hipSuccess)
+		return;
+	if (stream)
+		(void) hipStreamSynchronize((hipStream_t) stream);
+	for (auto &pair : pending_events)
+		free_events.push_back(pair);
+	for (auto &pair : free_events) {
+		(void) hipEventDestroy((hipEvent_t) pair.first);
+		(void) hipEventDestroy((hipEvent_t) pair.second);
+	}
+	freeScene();
+	device_free(d_image);
+	device_free(d_u8);
+	device_free(d_tile_stats);
+	if (own_stream)
+		(void) hipStreamDestroy((hipStream_t) own_stream);
+}
+
+void DeviceRenderer::useDevice() const { OCRT_HIP(hipSetDevice(device)); }
+
+void DeviceRenderer::freeScene() {
+	device_free(d_nodes);
+	device_free(d_tris);
+	device_free(d_shade);
+	device_free(d_ao);
+	scene_ready = false;
+}
+
+std::string DeviceRenderer::deviceName() const {
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device) != hipSuccess)
+		return "unknown";
+	return prop.name;
+}
+
+size_t DeviceRenderer::upload(const PackedScene &scene) {
+	useDevice();
+	synchronize();
+	freeScene();
+	uint32_t ao_dirs = 0;
+	std::vector<float> table;
+	if (opts.enableAO && opts.aoNumSamples > 0) {
+		if (opts.aoMethod == RayTracer::AmbientOcclusionMethod::UNIFORM) {
+			table = uniform_ao_table(opts.aoNumSamples, opts.aoAlphaMin, opts.aoAlphaMax);
+			ao_dirs = (uint32_t) (table.size() / 4);
+		} else {
+			throw std::invalid_argument(
+			    "ambient-occlusion method 'random' is not implemented on the HIP path yet (use 'uniform')");
+		}
+	}
+	kp = make_kernel_params(rt, (uint32_t) scene.nodes.size(), ao_dirs, part);
+	const size_t nodes_bytes = scene.nodes.size() * sizeof(NodeRec);
+	const size_t tris_bytes = scene.tris.size() * sizeof(TriRec);
+	const size_t shade_bytes = scene.shade.size() * sizeof(ShadeRec);
+	const size_t ao_bytes = table.size() * sizeof(float);
+	d_nodes = device_alloc(nodes_bytes);
+	d_tris = device_alloc(tris_bytes);
+	d_shade = device_alloc(shade_bytes);
+	d_ao = device_alloc(ao_bytes);
+	OCRT_HIP(hipMemcpy(d_nodes, scene.nodes.data(), nodes_bytes, hipMemcpyHostToDevice));
+	OCRT_HIP(hipMemcpy(d_tris, scene.tris.data(), tris_bytes, hipMemcpyHostToDevice));
+	OCRT_HIP(hipMemcpy(d_shade, scene.shade.data(), shade_bytes, hipMemcpyHostToDevice));
+	if (ao_bytes)
+		OCRT_HIP(hipMemcpy(d_ao, table.data(), ao_bytes, hipMemcpyHostToDevice));
+	OCRT_HIP(hipDeviceSynchronize());
+	scene_ready = true;
+	return nodes_bytes + tris_bytes + shade_bytes + ao_bytes + (size_t) rt.totalWidth * rt.totalHeight * sizeof(float) +
+	       (size_t) local_out_rows * opts.width + tile_count * sizeof(uint2);
+}
+
+void DeviceRenderer::enqueueRender() {
+	if (!scene_ready)
+		throw std::logic_error("render called before upload");
+	useDevice();
+	std::pair<void *, void *> ev;
+	if (!free_events.empty()) {
+		ev = free_events.back();
+		free_events.pop_back();
+	} else {
+		hipEvent_t a, b;
+		OCRT_HIP(hipEventCreate(&a));
+		OCRT_HIP(hipEventCreate(&b));
+		ev = { a, b };
+	}
+	OCRT_HIP(hipEventRecord((hipEvent_t) ev.first, (hipStream_t) stream));
+	launch_trace_tiles(d_nodes, d_tris, d_shade, d_ao, (float *) d_image, kp, d_tile_stats, stream);
+	OCRT_HIP(hipGetLastError());
+	OCRT_HIP(hipEventRecord((hipEvent_t) ev.second, (hipStream_t) stream));
+	pending_events.push_back(ev);
+	frame_ready = true;
+}
+
+void DeviceRenderer::enqueueResizeInto(void *device_u8) {
+	if (!frame_ready)
+		throw std::logic_error("resize called before render");
+	useDevice();
+	launch_resize((const float *) d_image, (unsigned char *) device_u8, kp, opts.width, grid, local_out_rows, stream);
+	OCRT_HIP(hipGetLastError());
+}
+
+void DeviceRenderer::enqueueResize() { enqueueResizeInto(d_u8); }
+
+void DeviceRenderer::synchronize() {
+	useDevice();
+	OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));
+	for (auto &ev : pending_events) {
+		float ms = 0;
+		OCRT_HIP(hipEventElapsedTime(&ms, (hipEvent_t) ev.first, (hipEvent_t) ev.second));
+		last_ms = ms;
+		total_ms += ms;
+		++launches;
+		free_events.push_back(ev);
+	}
+	pending_events.clear();
+}
+
+void DeviceRenderer::downloadFloat(float *host_image) {
+	synchronize();
+	OCRT_HIP(hipMemcpy(host_image, d_image, (size_t) rt.totalWidth * rt.totalHeight * sizeof(float),
+	                   hipMemcpyDeviceToHost));
+}
+
+void DeviceRenderer::downloadResizedLocal(unsigned char *host) {
+	enqueueResize();
+	synchronize();
+	OCRT_HIP(hipMemcpy(host, d_u8, (size_t) local_out_rows * opts.width, hipMemcpyDeviceToHost));
+}
+
+void DeviceRenderer::downloadResizedFull(unsigned char *host) {
+	if (part.nranks != 1)
+		throw std::logic_error("full-image download needs an unpartitioned host");
+	enqueueResize();
+	synchronize();
+	// local_out_rows may include padding rows below the image; copy only the image.
+	OCRT_HIP(hipMemcpy(host, d_u8, (size_t) opts.height * opts.width, hipMemcpyDeviceToHost));
+}
+
+void DeviceRenderer::setStream(void *hip_stream) {
+	synchronize();
+	stream = hip_stream;
+}
+
+void DeviceRenderer::usePrivateStream() {
+	synchronize();
+	stream = own_stream;
+}
+
+RenderStats DeviceRenderer::stats() {
+	RenderStats out{};
+	if (!frame_ready)
+		return out;
+	synchronize();
+	std::vector<uint2> tiles(tile_count);
+	OCRT_HIP(hipMemcpy(tiles.data(), d_tile_stats, tile_count * sizeof(uint2), hipMemcpyDeviceToHost));
+	for (const uint2 &t : tiles) {
+		out.primary_hits += t.x;
+		out.ao_occluded += t.y;
+	}
+	// Primary rays = sub-pixels of this rank's bands that lie inside the image.
+	const uint32_t tile_rows = (kp.height + TILE_H - 1) / TILE_H;
+	unsigned long long rows = 0;
+	for (uint32_t j = 0; j < kp.local_tile_rows; ++j) {
+		const uint32_t band_local = j / part.band_tile_rows;
+		const uint32_t row = (band_local * part.nranks + part.rank) * part.band_tile_rows + j % part.band_tile_rows;
+		if (row >= tile_rows)
+			continue;
+		const uint32_t y0 = row * TILE_H;
+		rows += (kp.height - y0 < TILE_H) ? kp.height - y0 : TILE_H;
+	}
+	out.primary_rays = rows * kp.width;
+	out.ao_rays = kp.ao_mode == AO_UNIFORM ? out.primary_hits * kp.ao_dirs : 0;
+	return out;
+}
+
+}  // namespace ocrt

@@ -1,0 +1,96 @@
+// device_renderer.h -- owns the HIP device state of one render host: scene
+// buffers, image buffers, stream, timing events.  All failures are reported as
+// exceptions (ocrt::DeviceError / std::invalid_argument); the two front ends
+// (HipHost with the reference's print-and-exit convention, the C ABI with
+// return codes) decide what to do with them.
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "device_types.h"
+#include "ray_tracer.h"
+#include "scene_pack.h"
+
+namespace ocrt {
+
+struct DeviceError : std::runtime_error {
+	using std::runtime_error::runtime_error;
+};
+
+// Number of visible HIP devices (0 when the runtime reports none or fails).
+int visible_device_count();
+
+class DeviceRenderer {
+	public:
+		DeviceRenderer(const RayTracer::Options &options, int device, unsigned int rank, unsigned int nranks);
+		~DeviceRenderer();
+		DeviceRenderer(const DeviceRenderer &) = delete;
+		DeviceRenderer &operator=(const DeviceRenderer &) = delete;
+
+		// Blocking upload of a packed scene; returns the bytes requested on the device.
+		size_t upload(const PackedScene &scene);
+
+		// Enqueues the ray-casting kernel for this rank's bands on the stream.
+		void enqueueRender();
+		// Enqueues the device-side resize of this rank's bands into the compact
+		// uint8 band buffer (localRows() x width bytes).
+		void enqueueResize();
+		// Same, but writes into caller-provided DEVICE memory (e.g. a torch tensor).
+		void enqueueResizeInto(void *device_u8);
+		// Waits for everything enqueued so far and folds pending event pairs into
+		// the kernel-time statistics.
+		void synchronize();
+
+		void downloadFloat(float *host_image);          // full totalWidth x totalHeight
+		void downloadResizedLocal(unsigned char *host); // localRows() x width, compact
+		void downloadResizedFull(unsigned char *host);  // width x height (needs nranks == 1)
+
+		// Run on an externally owned hipStream_t (nullptr = the HIP default stream) /
+		// go back to the private non-blocking stream.
+		void setStream(void *hip_stream);
+		void usePrivateStream();
+
+		RenderStats stats();   // sums the per-tile counters of the last frame
+		float lastKernelMs() const { return last_ms; }
+		double totalKernelMs() const { return total_ms; }
+		uint64_t kernelLaunches() const { return launches; }
+		void resetTimers() { total_ms = 0; launches = 0; last_ms = 0; }
+
+		uint32_t localRows() const { return local_out_rows; }  // output rows this rank owns
+		uint32_t width() const { return opts.width; }
+		uint32_t height() const { return opts.height; }
+		const RayTracer &rayTracer() const { return rt; }
+		const KernelParams &params() const { return kp; }
+		int deviceIndex() const { return device; }
+		std::string deviceName() const;
+
+	private:
+		void freeScene();
+		void useDevice() const;
+
+		RayTracer::Options opts;
+		RayTracer rt;
+		int device;
+		Partition part;
+		KernelParams kp;
+		uint32_t grid;            // supersample grid side
+		uint32_t local_out_rows;
+		void *own_stream, *stream;
+		void *d_nodes, *d_tris, *d_shade, *d_ao, *d_image, *d_u8, *d_tile_stats;
+		size_t tile_count;
+		bool scene_ready, frame_ready;
+		std::vector<std::pair<void *, void *>> pending_events, free_events;
+		float last_ms;
+		double total_ms;
+		uint64_t launches;
+};
+
+// kernels.hip
+void launch_trace_tiles(const void *nodes, const void *tris, const void *shade, const void *ao_table, float *image,
+                        const KernelParams &P, void *tile_stats, void *stream);
+void launch_resize(const float *tmp, unsigned char *out, const KernelParams &P, uint32_t out_width, uint32_t n,
+                   uint32_t local_out_rows, void *stream);
+
+}  // namespace ocrt

@@ -1,0 +1,78 @@
+// device_types.h -- records shared by the host-side scene packer and the HIP
+// kernels.  Plain structs, no HIP headers, so host-only code can include it.
+#pragma once
+#include <cstdint>
+
+namespace ocrt {
+
+// One BVH node, 32 bytes = two float4 loads.  Merges the reference's `nodes`
+// (subtree size) and `aabbs` (min,max) arrays (reference
+// src/intersect_kernel.cl:187-192) and adds the leaf's triangle index, which the
+// reference recovers with a running counter.
+struct NodeRec {
+	float lo[3];
+	uint32_t skip;  // subtree size in nodes; 1 = leaf
+	float hi[3];
+	uint32_t leaf;  // leaf index (= triangle index in leaf order), 0xFFFFFFFF for inner nodes
+};
+static_assert(sizeof(NodeRec) == 32, "NodeRec is two float4");
+
+// Per-triangle invariants of the reference's plane/parametric test (reference
+// src/intersect_kernel.cl:67-90), precomputed on the host with the SAME float
+// operations the kernel would execute, so the bits are identical: 64 bytes.
+struct TriRec {
+	float ta[3];
+	float u[3];   // tb - ta
+	float v[3];   // tc - ta
+	float n[3];   // cross(u, v)
+	float uu, uv, vv, D;  // dot(u,u), dot(u,v), dot(v,v), uv*uv - uu*vv
+};
+static_assert(sizeof(TriRec) == 64, "TriRec is four float4");
+
+// The three vertex normals of a leaf's triangle (replaces the faces[] ->
+// normals[] double indirection of reference src/intersect_kernel.cl:118-127).
+struct ShadeRec {
+	float n0[4], n1[4], n2[4];
+};
+static_assert(sizeof(ShadeRec) == 48, "ShadeRec is three float4");
+
+enum AoMode : int32_t { AO_NONE = 0, AO_UNIFORM = 1, AO_RANDOM = 2 };
+
+// Image-band ownership for multi-GPU runs: the image is cut into bands of
+// `band_tile_rows` tile rows; band b belongs to rank b % nranks.
+struct Partition {
+	uint32_t rank;
+	uint32_t nranks;
+	uint32_t band_tile_rows;
+};
+
+// Launch-constant parameters (the reference bakes these into the kernel as -D
+// macros, reference src/opencl_host.cc:42-53).
+struct KernelParams {
+	uint32_t width;        // supersampled width  (WIDTH)
+	uint32_t height;       // supersampled height (HEIGHT)
+	float a;               // FOCAL_LENGTH * max(WIDTH, HEIGHT)
+	float half_w;          // WIDTH  / (2.0f * a)
+	float half_h;          // HEIGHT / (2.0f * a)
+	uint32_t node_count;   // nodes[0]
+	int32_t shading;       // SHADING_ENABLE
+	int32_t ao_mode;       // AoMode
+	float ao_max_distance; // AO_MAX_DISTANCE
+	uint32_t ao_dirs;      // UNIFORM: rays per hit sub-pixel; RANDOM: AO_NUM_SAMPLES
+	uint32_t tiles_x;      // tiles per image row
+	uint32_t local_tile_rows;  // tile rows this rank owns
+	Partition part;
+};
+
+constexpr uint32_t TILE_W = 8;
+constexpr uint32_t TILE_H = 8;
+
+// Ray statistics of the last frame (summed on the host from per-tile counters).
+struct RenderStats {
+	unsigned long long primary_rays;
+	unsigned long long primary_hits;
+	unsigned long long ao_rays;
+	unsigned long long ao_occluded;
+};
+
+}  // namespace ocrt

@@ -1,0 +1,344 @@
+// kernels.hip -- gfx950 ray-casting kernels (the replacement for reference
+// src/intersect_kernel.cl).
+//
+// Arithmetic contract: IEEE binary32 + - * / sqrt in the
+// reference's operation order, NO fma contraction (this file is compiled with
+// -ffp-contract=off), IEEE maxNum/minNum for max/min, double-literal
+// comparisons folded to their exact float thresholds.  Anything else (data
+// layout, traversal order, where a value is computed) is free and is chosen
+// for the CDNA4 wave64 machine.
+//
+// Work decomposition: one 64-lane wavefront owns one 8x8 tile of sub-pixels.
+//   phase 1  every lane casts its primary ray (closest hit);
+//   phase 2  hit lanes compute normal + head-light term + the AO tangent frame
+//            and are ballot-compacted into an LDS table;
+//   phase 3  the (hit, direction) pairs of the tile are dealt round-robin to
+//            all 64 lanes -- lanes that missed help -- as any-hit rays that
+//            stop at the first accepted triangle; occlusion counts are LDS atomics;
+//   phase 4  hit lanes fold the occlusion fraction in and store the float.
+#include <hip/hip_runtime.h>
+
+#include "device_types.h"
+
+namespace ocrt {
+
+namespace {
+
+struct Ray {
+	float ox, oy, oz;
+	float dx, dy, dz;
+	float ix, iy, iz;  // 1.0f / d, hoisted out of the per-node slab test
+};
+
+struct Hit {
+	float distance;
+	uint32_t leaf;
+	float s, t;
+	float px, py, pz;
+};
+
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
+	return (ax * bx + ay * by) + az * bz;
+}
+
+__device__ __forceinline__ Ray make_ray(float ox, float oy, float oz, float dx, float dy, float dz) {
+	Ray r;
+	r.ox = ox; r.oy = oy; r.oz = oz;
+	r.dx = dx; r.dy = dy; r.dz = dz;
+	r.ix = 1.0f / dx;
+	r.iy = 1.0f / dy;
+	r.iz = 1.0f / dz;
+	return r;
+}
+
+// Slab test, reference src/intersect_kernel.cl:21-61.  The reference's early
+// returns only skip work; evaluating everything and AND-ing the same
+// comparisons (kept in their original `a > b` polarity for NaN) is identical.
+__device__ __forceinline__ bool slab_hit(const float4 lo, const float4 hi, const Ray &r, float max_distance) {
+	const bool px = r.ix >= 0.0f, py = r.iy >= 0.0f, pz = r.iz >= 0.0f;
+	float t_min = ((px ? lo.x : hi.x) - r.ox) * r.ix;
+	float t_max = ((px ? hi.x : lo.x) - r.ox) * r.ix;
+	const float ty_min = ((py ? lo.y : hi.y) - r.oy) * r.iy;
+	const float ty_max = ((py ? hi.y : lo.y) - r.oy) * r.iy;
+	bool miss = (t_min > ty_max) | (ty_min > t_max);
+	t_min = fmaxf(t_min, ty_min);
+	t_max = fminf(t_max, ty_max);
+	const float tz_min = ((pz ? lo.z : hi.z) - r.oz) * r.iz;
+	const float tz_max = ((pz ? hi.z : lo.z) - r.oz) * r.iz;
+	miss |= (t_min > tz_max) | (tz_min > t_max);
+	t_min = fmaxf(t_min, tz_min);
+	t_max = fminf(t_max, tz_max);
+	return !miss & (t_min < max_distance) & (t_max > 0.0f);
+}
+
+// Plane hit + parametric (s,t) test, reference src/intersect_kernel.cl:65-114,
+// on the precomputed TriRec.  `x > 1.00001` (double literal) == `x > 0x3F800053`.
+template <bool CLOSEST>
+__device__ __forceinline__ bool tri_hit(const float4 *__restrict__ tri, uint32_t leaf, const Ray &r, Hit &best) {
+	const float4 q0 = tri[0], q1 = tri[1], q2 = tri[2], q3 = tri[3];
+	const float tax = q0.x, tay = q0.y, taz = q0.z;
+	const float ux = q0.w, uy = q1.x, uz = q1.y;
+	const float vx = q1.z, vy = q1.w, vz = q2.x;
+	const float nx = q2.y, ny = q2.z, nz = q2.w;
+	const float uu = q3.x, uv = q3.y, vv = q3.z, D = q3.w;
+	const float a = -dot3(nx, ny, nz, r.ox - tax, r.oy - tay, r.oz - taz);
+	const float b = dot3(nx, ny, nz, r.dx, r.dy, r.dz);
+	if (fabsf(b) < 0.000001f)
+		return false;
+	const float rr = a / b;
+	if (rr < 0.0f)
+		return false;
+	const float ipx = r.ox + rr * r.dx, ipy = r.oy + rr * r.dy, ipz = r.oz + rr * r.dz;
+	const float wx = ipx - tax, wy = ipy - tay, wz = ipz - taz;
+	const float wu = dot3(ux, uy, uz, wx, wy, wz);
+	const float wv = dot3(wx, wy, wz, vx, vy, vz);
+	const float slack_hi = __uint_as_float(0x3F800053u);
+	const float s = (uv * wv - vv * wu) / D;
+	if (s < -0.00001f || s > slack_hi)
+		return false;
+	const float t = (uv * wu - uu * wv) / D;
+	if (t < -0.00001f || (s + t) > slack_hi)
+		return false;
+	if (CLOSEST) {
+		const float ex = ipx - r.ox, ey = ipy - r.oy, ez = ipz - r.oz;
+		const float distance = sqrtf(dot3(ex, ey, ez, ex, ey, ez));
+		if (best.distance > distance) {
+			best.distance = distance;
+			best.leaf = leaf;
+			best.s = s;
+			best.t = t;
+			best.px = ipx; best.py = ipy; best.pz = ipz;
+		}
+	}
+	return true;
+}
+
+// Stackless pre-order walk with skip counts, reference
+// src/intersect_kernel.cl:184-213.  CLOSEST visits every overlapped leaf in
+// ascending leaf order (so the strict `>` update resolves ties exactly like the
+// reference); any-hit rays return at the first accepted triangle -- the
+// reference walks on but only ever uses the boolean (:251).
+template <bool CLOSEST>
+__device__ __forceinline__ bool traverse(const float4 *__restrict__ nodes, const float4 *__restrict__ tris,
+                                         uint32_t node_count, const Ray &r, float max_distance, Hit &best) {
+	bool found = false;
+	uint32_t i = 0;
+	while (i < node_count) {
+		const float4 lo = nodes[2 * i];
+		const float4 hi = nodes[2 * i + 1];
+		const uint32_t skip = __float_as_uint(lo.w);
+		if (slab_hit(lo, hi, r, max_distance)) {
+			if (skip == 1u) {
+				const uint32_t leaf = __float_as_uint(hi.w);
+				if (tri_hit<CLOSEST>(tris + 4 * (size_t) leaf, leaf, r, best)) {
+					if (!CLOSEST)
+						return true;
+					found = true;
+				}
+			}
+			i += 1;
+		} else {
+			i += skip;
+		}
+	}
+	return found;
+}
+
+__device__ __forceinline__ void normalize3(float &x, float &y, float &z) {
+	const float l = sqrtf(dot3(x, y, z, x, y, z));
+	x = x / l;
+	y = y / l;
+	z = z / l;
+}
+
+// Maps a rank-local tile row to the global tile row under the band partition.
+__device__ __forceinline__ uint32_t global_tile_row(const Partition &p, uint32_t local_row) {
+	const uint32_t band_local = local_row / p.band_tile_rows;
+	const uint32_t within = local_row - band_local * p.band_tile_rows;
+	return (band_local * p.nranks + p.rank) * p.band_tile_rows + within;
+}
+
+}  // namespace
+
+// LDS layout of one tile's hit table (structure of arrays, lane-major so that
+// consecutive hits sit in consecutive banks).
+struct TileShared {
+	float frame[12][64];  // origin xyz, basis_x xyz, basis_y xyz, basis_z xyz
+	unsigned int occluded[64];
+};
+
+__global__ __launch_bounds__(64) void trace_tiles_kernel(const float4 *__restrict__ nodes,
+                                                         const float4 *__restrict__ tris,
+                                                         const float4 *__restrict__ shade,
+                                                         const float4 *__restrict__ ao_table,
+                                                         float *__restrict__ image, KernelParams P,
+                                                         uint2 *__restrict__ tile_stats) {
+	__shared__ TileShared sh;
+	const uint32_t lane = threadIdx.x;
+
+	// XCD-aware tile order: blocks b and b+8 share an XCD (and its L2), so give
+	// each of the 8 groups one contiguous run of tiles -- neighbouring tiles walk
+	// the same part of the BVH.  Bijective for any tile count.
+	const uint32_t total_tiles = P.tiles_x * P.local_tile_rows;
+	const uint32_t group = blockIdx.x & 7u, within_group = blockIdx.x >> 3;
+	const uint32_t q = total_tiles >> 3, rem = total_tiles & 7u;
+	const uint32_t tile = (group < rem ? group * (q + 1) : rem * (q + 1) + (group - rem) * q) + within_group;
+
+	const uint32_t local_row = tile / P.tiles_x;
+	const uint32_t tile_x = tile - local_row * P.tiles_x;
+	const uint32_t tile_y = global_tile_row(P.part, local_row);
+	const uint32_t x = tile_x * TILE_W + (lane & 7u);
+	const uint32_t y = tile_y * TILE_H + (lane >> 3);
+	const bool active = x < P.width && y < P.height;
+
+	// ---- phase 1: primary ray, reference src/intersect_kernel.cl:279-295 ----
+	float dx = ((float) x + 0.5f) / P.a - P.half_w;
+	float dy = -(((float) y + 0.5f) / P.a - P.half_h);
+	float dz = -1.0f;
+	normalize3(dx, dy, dz);
+	const Ray primary = make_ray(0.0f, 0.0f, 2.0f, dx, dy, dz);
+	Hit best;
+	best.distance = __builtin_inff();
+	best.leaf = 0;
+	best.s = best.t = 0.0f;
+	best.px = best.py = best.pz = 0.0f;
+	bool hit = false;
+	if (active)
+		hit = traverse<true>(nodes, tris, P.node_count, primary, 100000.0f, best);
+
+	// ---- phase 2: shading inputs for the hit lanes, :296-304 and :215-236 ----
+	float value = 0.0f;
+	float nx = 0.0f, ny = 0.0f, nz = 0.0f;
+	uint32_t occluded_here = 0;
+	if (hit) {
+		const float4 n0 = shade[3 * (size_t) best.leaf + 0];
+		const float4 n1 = shade[3 * (size_t) best.leaf + 1];
+		const float4 n2 = shade[3 * (size_t) best.leaf + 2];
+		const float b0 = 1.0f - best.s - best.t, b1 = best.s, b2 = best.t;
+		nx = (n0.x * b0 + n1.x * b1) + n2.x * b2;
+		ny = (n0.y * b0 + n1.y * b1) + n2.y * b2;
+		nz = (n0.z * b0 + n1.z * b1) + n2.z * b2;
+		normalize3(nx, ny, nz);
+		value = 1.0f;
+		if (P.shading)
+			value = fminf(fmaxf(-dot3(nx, ny, nz, dx, dy, dz), 0.0f), 1.0f);
+	}
+
+	const unsigned long long hit_mask = __ballot(hit);
+	const uint32_t hit_count = (uint32_t) __popcll(hit_mask);
+	const uint32_t slot = (uint32_t) __popcll(hit_mask & ((1ull << lane) - 1ull));
+
+	if (P.ao_mode == AO_UNIFORM && P.ao_dirs > 0 && hit_count > 0) {
+		if (hit) {
+			// p = point + normal * (1.0f / 100000.0f)
+			const float eps = 1.0f / 100000.0f;
+			sh.frame[0][slot] = best.px + nx * eps;
+			sh.frame[1][slot] = best.py + ny * eps;
+			sh.frame[2][slot] = best.pz + nz * eps;
+			// tangent frame: the smallest |component| of the normal is replaced by 1
+			float hx = nx, hy = ny, hz = nz;
+			const float ax = fabsf(nx), ay = fabsf(ny), az = fabsf(nz);
+			if (ax <= ay && ax <= az)
+				hx = 1.0f;
+			else if (ay <= ax && ay <= az)
+				hy = 1.0f;
+			else if (az <= ax && az <= ay)
+				hz = 1.0f;
+			// basis_x = normalize(cross(h, basis_y)), basis_z = normalize(cross(basis_x, basis_y))
+			float bxx = hy * nz - hz * ny, bxy = hz * nx - hx * nz, bxz = hx * ny - hy * nx;
+			normalize3(bxx, bxy, bxz);
+			float bzx = bxy * nz - bxz * ny, bzy = bxz * nx - bxx * nz, bzz = bxx * ny - bxy * nx;
+			normalize3(bzx, bzy, bzz);
+			sh.frame[3][slot] = bxx; sh.frame[4][slot] = bxy; sh.frame[5][slot] = bxz;
+			sh.frame[6][slot] = nx;  sh.frame[7][slot] = ny;  sh.frame[8][slot] = nz;
+			sh.frame[9][slot] = bzx; sh.frame[10][slot] = bzy; sh.frame[11][slot] = bzz;
+			sh.occluded[slot] = 0u;
+		}
+		__syncthreads();
+
+		// ---- phase 3: any-hit AO rays, :237-255, dealt to all 64 lanes ----
+		const uint32_t total = hit_count * P.ao_dirs;
+		for (uint32_t item = lane; item < total; item += 64u) {
+			const uint32_t k = item / hit_count;
+			const uint32_t h = item - k * hit_count;
+			const float4 dir = ao_table[k];
+			const float rx = (sh.frame[3][h] * dir.x + sh.frame[6][h] * dir.y) + sh.frame[9][h] * dir.z;
+			const float ry = (sh.frame[4][h] * dir.x + sh.frame[7][h] * dir.y) + sh.frame[10][h] * dir.z;
+			const float rz = (sh.frame[5][h] * dir.x + sh.frame[8][h] * dir.y) + sh.frame[11][h] * dir.z;
+			const Ray ao = make_ray(sh.frame[0][h], sh.frame[1][h], sh.frame[2][h], rx, ry, rz);
+			Hit unused;
+			if (traverse<false>(nodes, tris, P.node_count, ao, P.ao_max_distance, unused))
+				atomicAdd(&sh.occluded[h], 1u);
+		}
+		__syncthreads();
+
+		// ---- phase 4: value *= 1 - hits / n, :256 and :305-307 ----
+		if (hit) {
+			const uint32_t occluded = sh.occluded[slot];
+			value *= 1.0f - ((float) occluded / (float) P.ao_dirs);
+			occluded_here = occluded;
+		}
+	}
+
+	if (active)
+		image[(size_t) y * P.width + x] = value;
+
+	// Per-tile counters (plain stores, summed on demand by the host): primary
+	// hits and occluded AO rays of this tile.
+	if (tile_stats) {
+		uint32_t occluded_sum = occluded_here;
+		for (int offset = 32; offset > 0; offset >>= 1)
+			occluded_sum += __shfl_xor(occluded_sum, offset);
+		if (lane == 0)
+			tile_stats[tile] = make_uint2(hit_count, occluded_sum);
+	}
+}
+
+// Supersample box filter + 8-bit quantisation on the device: one thread per
+// output pixel, ssY-major / ssX-minor float summation and truncating store,
+// exactly reference src/ray_tracer.cc:3-16.  Works on this rank's bands only:
+// local output row j of the compact band buffer is global row
+// (band_local * nranks + rank) * rows_per_band + j % rows_per_band.
+__global__ __launch_bounds__(256) void resize_kernel(const float *__restrict__ tmp, unsigned char *__restrict__ out,
+                                                     uint32_t width, uint32_t height, uint32_t total_width, uint32_t n,
+                                                     Partition part, uint32_t rows_per_band) {
+	const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t j = blockIdx.y;
+	const uint32_t band_local = j / rows_per_band;
+	const uint32_t y = (band_local * part.nranks + part.rank) * rows_per_band + (j - band_local * rows_per_band);
+	if (x >= width)
+		return;
+	unsigned char q = 0;
+	if (y < height) {
+		float total = 0.0f;
+		for (uint32_t sy = 0; sy < n; ++sy) {
+			const float *row = tmp + (size_t) (y * n + sy) * total_width + (size_t) x * n;
+			for (uint32_t sx = 0; sx < n; ++sx)
+				total += row[sx];
+		}
+		q = (unsigned char) ((total / (float) (n * n)) * 255.0f);
+	}
+	out[(size_t) j * width + x] = q;
+}
+
+// ---- host-callable launchers (keeps the launch syntax inside this TU) ----
+void launch_trace_tiles(const void *nodes, const void *tris, const void *shade, const void *ao_table, float *image,
+                        const KernelParams &P, void *tile_stats, void *stream) {
+	const uint32_t total_tiles = P.tiles_x * P.local_tile_rows;
+	if (total_tiles == 0)
+		return;
+	hipLaunchKernelGGL(trace_tiles_kernel, dim3(total_tiles), dim3(64), 0, (hipStream_t) stream,
+	                   (const float4 *) nodes, (const float4 *) tris, (const float4 *) shade,
+	                   (const float4 *) ao_table, image, P, (uint2 *) tile_stats);
+}
+
+void launch_resize(const float *tmp, unsigned char *out, const KernelParams &P, uint32_t out_width, uint32_t n,
+                   uint32_t local_out_rows, void *stream) {
+	if (local_out_rows == 0 || out_width == 0 || n == 0)
+		return;
+	const uint32_t rows_per_band = P.part.band_tile_rows * TILE_H / n;
+	hipLaunchKernelGGL(resize_kernel, dim3((out_width + 255) / 256, local_out_rows), dim3(256), 0,
+	                   (hipStream_t) stream, tmp, out, out_width, P.height / n, P.width, n, P.part, rows_per_band);
+}
+
+}  // namespace ocrt

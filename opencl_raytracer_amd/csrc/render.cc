@@ -1,0 +1,217 @@
+// render.cc -- `render [OPTIONS] INPUT_MESH OUTPUT_IMAGE`: the reference's CLI
+// (reference src/render.cc:16-139, flag table :23-30) on the HIP render host.
+// Same flags, defaults, phase lines and PGM format; `-h` is HEIGHT, help is
+// `--help` only.  New: `--device N`, and a Mrays/s summary line.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "bvh.h"
+#include "cli_support.h"
+#include "hip_host.h"
+#include "mesh.h"
+#include "ray_tracer.h"
+
+namespace {
+
+struct OptionSpec {
+	char short_name;
+	const char *long_name;
+	const char *help;
+};
+
+const OptionSpec OPTIONS[] = {
+	{ 0, "help", "Print this dialogue." },
+	{ 'w', "width", "Specifies the width to use for the output image." },
+	{ 'h', "height", "Specifies the height to use for the output image." },
+	{ 'a', "ambient-occlusion-samples",
+	  "Specifies the number of samples used for ambient occlusion. If the value `0` is specified, ambient occlusion "
+	  "will be disabled." },
+	{ 'd', "ambient-occlusion-max-distance",
+	  "Specifies the maximum distance that should be allowed for ambient occlusion rays." },
+	{ 'm', "ambient-occlusion-method", "Specifies the method of ambient occlusion [uniform|random]." },
+	{ 'f', "focal-length", "Specifies the focal length that the camera should use." },
+	{ 's', "supersamples", "Specifies the number of supersamples to use." },
+	{ 'r', "bvh-strategy", "Specifies the strategy of BVH construction (longest|sah)." },
+	{ 0, "device", "Specifies the HIP device index to render on (default: $OCRT_DEVICE or 0)." },
+};
+
+void usage(const char *argv0) {
+	std::cout << "A HIP raytracer that renders triangle meshes in OFF format." << std::endl << std::endl;
+	std::cout << "Usage: " << argv0 << " [OPTIONS] INPUT_MESH OUTPUT_IMAGE" << std::endl;
+	size_t widest = 0;
+	for (const OptionSpec &o : OPTIONS)
+		widest = std::max(widest, std::strlen(o.long_name));
+	for (const OptionSpec &o : OPTIONS) {
+		std::cout << "  ";
+		if (o.short_name)
+			std::cout << '-' << o.short_name << ", ";
+		else
+			std::cout << "    ";
+		std::string name = o.long_name;
+		name.resize(widest + 2, ' ');
+		std::cout << "--" << name << o.help << std::endl;
+	}
+}
+
+[[noreturn]] void usage_error(const char *argv0, const std::string &message) {
+	usage(argv0);
+	std::cout << std::endl;
+	std::cerr << "Error: " << message << std::endl;
+	std::exit(EXIT_FAILURE);
+}
+
+struct CliOptions : RayTracer::Options {
+	std::string in, out;
+	int device = -1;
+
+	CliOptions(int argc, const char **argv) : RayTracer::Options(RayTracer::defaults()) {
+		std::vector<std::string> positional;
+		for (int i = 1; i < argc; ++i) {
+			const char *arg = argv[i];
+			const OptionSpec *spec = nullptr;
+			const char *value = nullptr;
+			if (arg[0] == '-' && arg[1] == '-' && arg[2]) {
+				// --name, --name=value, --name value
+				const char *eq = std::strchr(arg + 2, '=');
+				const std::string name = eq ? std::string(arg + 2, eq) : std::string(arg + 2);
+				for (const OptionSpec &o : OPTIONS)
+					if (name == o.long_name)
+						spec = &o;
+				if (!spec)
+					usage_error(argv[0], std::string("Invalid option ") + (arg + 2));
+				if (eq)
+					value = eq + 1;
+			} else if (arg[0] == '-' && arg[1] && arg[1] != '-') {
+				// -x value, -xvalue
+				for (const OptionSpec &o : OPTIONS)
+					if (o.short_name && o.short_name == arg[1])
+						spec = &o;
+				if (!spec)
+					usage_error(argv[0], std::string("Invalid option ") + arg[1]);
+				if (arg[2])
+					value = arg + 2;
+			} else {
+				positional.push_back(arg);
+				if (positional.size() > 2)
+					usage_error(argv[0], "Too much non-optional arguments");
+				continue;
+			}
+			if (std::strcmp(spec->long_name, "help") == 0) {
+				usage(argv[0]);
+				std::exit(EXIT_SUCCESS);
+			}
+			if (!value) {
+				if (i + 1 >= argc)
+					usage_error(argv[0], "Too few non-optional arguments");
+				value = argv[++i];
+			}
+			apply(argv[0], *spec, value);
+			enableAO = aoNumSamples != 0;
+		}
+		if (positional.size() < 2)
+			usage_error(argv[0], "Too few non-optional arguments");
+		in = positional[0];
+		out = positional[1];
+	}
+
+	private:
+	void apply(const char *argv0, const OptionSpec &spec, const char *value) {
+		const std::string name = spec.long_name;
+		// Integers via atoi, floats via atof, as the reference's parser does
+		// (reference include/args.h:47-54).
+		if (name == "width")
+			width = (unsigned int) std::atoi(value);
+		else if (name == "height")
+			height = (unsigned int) std::atoi(value);
+		else if (name == "ambient-occlusion-samples")
+			aoNumSamples = (unsigned int) std::atoi(value);
+		else if (name == "ambient-occlusion-max-distance")
+			aoMaxDistance = (float) std::atof(value);
+		else if (name == "focal-length")
+			focalLength = (float) std::atof(value);
+		else if (name == "supersamples")
+			nSuperSamples = (unsigned int) std::atoi(value);
+		else if (name == "device")
+			device = std::atoi(value);
+		else if (name == "ambient-occlusion-method") {
+			if (std::strcmp(value, "uniform") == 0)
+				aoMethod = RayTracer::AmbientOcclusionMethod::UNIFORM;
+			else if (std::strcmp(value, "random") == 0)
+				aoMethod = RayTracer::AmbientOcclusionMethod::RANDOM;
+			else
+				usage_error(argv0, "Invalid enum value");
+		} else if (name == "bvh-strategy") {
+			if (std::strcmp(value, "longest") == 0)
+				bvhMethod = BVH::Method::CUT_LONGEST_AXIS;
+			else if (std::strcmp(value, "sah") == 0)
+				bvhMethod = BVH::Method::SURFACE_AREA_HEURISTIC;
+			else
+				usage_error(argv0, "Invalid enum value");
+		}
+	}
+};
+
+}  // namespace
+
+int main(int argc, const char **argv) {
+	CliOptions options(argc, argv);
+	std::cout << Color::BLUE << "<- " << Info::Palette::SECTION << "BVH section" << Color::BLUE << " ->" << std::endl;
+	std::cout << Info::Palette::NORMAL << "Reading input mesh\xE2\x80\xA6" << std::endl;
+	Mesh mesh;
+	load_off_mesh(options.in, &mesh);
+	compute_vertex_normals(&mesh);
+	std::cout << Color::BLUE << "- " << Info::Palette::NORMAL << "Vertices: " << Info::Palette::HIGHLIGHT
+	          << mesh.vertices.size() << std::endl
+	          << Color::BLUE << "- " << Info::Palette::NORMAL << "Triangles: " << Info::Palette::HIGHLIGHT
+	          << (mesh.faces.size() / 3) << Color::RESET << std::endl;
+	RayTracer rt(options);
+	BVH bvh(options.bvhMethod);
+	Info::measure("Building BVH", [&] {
+		bvh.buildBVH(mesh);
+		return true;
+	});
+	std::cout << std::endl
+	          << Color::BLUE << "<- " << Info::Palette::SECTION << "Device section" << Color::BLUE << " ->" << std::endl;
+	HipHost::printInfo();
+	std::size_t total_time = 0;
+	HipHost host(rt, options.device);
+	total_time += Info::measure("Loading HIP scene", [&] {
+		std::vector<uint32_t> sorted_faces = sort_faces_by_leaf_order(mesh, bvh);
+		mesh.faces.clear();
+		bvh.triangles.clear();
+		host.upload(sorted_faces, bvh.nodes, bvh.aabbs, mesh.vertices, mesh.vnormals);
+		return true;
+	}, true);
+	std::cout << std::endl
+	          << Color::BLUE << "<- " << Info::Palette::SECTION << "Rendering section" << Color::BLUE << " ->" << std::endl;
+	total_time += Info::measure("Rendering image", [&] { return host(); });
+	std::vector<unsigned char> image((size_t) options.width * options.height);
+	std::cout << std::endl;
+	total_time += Info::measure("Resizing image on device and loading memory", [&] {
+		host.downloadResized(image.data());
+		return true;
+	});
+	const ocrt::RenderStats stats = host.lastStats();
+	const double rays = (double) stats.primary_rays + (double) stats.ao_rays;
+	std::cout << Info::Palette::NORMAL << "Rays: " << Info::Palette::HIGHLIGHT << stats.primary_rays
+	          << Info::Palette::NORMAL << " primary + " << Info::Palette::HIGHLIGHT << stats.ao_rays
+	          << Info::Palette::NORMAL << " ambient occlusion; kernel " << Info::Palette::HIGHLIGHT
+	          << host.lastKernelMs() << " ms" << Info::Palette::NORMAL << " = " << Info::Palette::HIGHLIGHT
+	          << (host.lastKernelMs() > 0 ? rays / (host.lastKernelMs() * 1e3) : 0.0) << " Mrays/s" << Color::RESET
+	          << std::endl;
+	std::cout << Info::Palette::NORMAL << "Total time (without building the BVH): " << Info::formatTime(total_time)
+	          << std::endl;
+	std::FILE *out = std::fopen(options.out.c_str(), "wb");
+	if (!out) {
+		std::cerr << Info::Palette::WARNING << "Error opening output file!" << Color::RESET << std::endl;
+		std::exit(EXIT_FAILURE);
+	}
+	std::fprintf(out, "P5 %u %u 255\n", options.width, options.height);
+	std::fwrite(image.data(), 1, image.size(), out);
+	std::fclose(out);
+	return 0;
+}

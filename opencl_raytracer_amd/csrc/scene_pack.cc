@@ -1,0 +1,165 @@
+#include "scene_pack.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+
+namespace ocrt {
+
+PackedScene pack_scene(const std::vector<uint32_t> &faces, const std::vector<uint32_t> &nodes,
+                       const std::vector<Vec3f> &aabbs, const std::vector<Vec3f> &vertices,
+                       const std::vector<Vec3f> &vnormals) {
+	if (nodes.empty())
+		throw std::invalid_argument("upload: empty node array");
+	const size_t count = nodes.size();
+	if (nodes[0] != count)
+		throw std::invalid_argument("upload: nodes[0] must equal the node count");
+	if (aabbs.size() != 2 * count)
+		throw std::invalid_argument("upload: aabbs must hold a (min,max) pair per node");
+	if (faces.size() % 3 != 0)
+		throw std::invalid_argument("upload: faces must hold 3 vertex ids per triangle");
+	if (vnormals.size() != vertices.size())
+		throw std::invalid_argument("upload: one normal per vertex expected");
+	const size_t tri_count = faces.size() / 3;
+	for (uint32_t v : faces)
+		if (v >= vertices.size())
+			throw std::invalid_argument("upload: face references a vertex out of range");
+
+	PackedScene out;
+	out.nodes.resize(count);
+	size_t leaf = 0;
+	for (size_t i = 0; i < count; ++i) {
+		const uint32_t skip = nodes[i];
+		if (skip == 0 || i + skip > count)
+			throw std::invalid_argument("upload: subtree size runs past the node array");
+		NodeRec &n = out.nodes[i];
+		for (unsigned k = 0; k < 3; ++k) {
+			n.lo[k] = aabbs[2 * i][k];
+			n.hi[k] = aabbs[2 * i + 1][k];
+		}
+		n.skip = skip;
+		n.leaf = 0xFFFFFFFFu;
+		if (skip == 1) {
+			if (leaf >= tri_count)
+				throw std::invalid_argument("upload: more leaves than triangles");
+			n.leaf = (uint32_t) leaf++;
+		}
+	}
+	if (leaf != tri_count)
+		throw std::invalid_argument("upload: leaf count differs from triangle count");
+
+	out.tris.resize(tri_count);
+	out.shade.resize(tri_count);
+	for (size_t t = 0; t < tri_count; ++t) {
+		const uint32_t i0 = faces[3 * t], i1 = faces[3 * t + 1], i2 = faces[3 * t + 2];
+		const Vec3f ta = vertices[i0];
+		const Vec3f u = vertices[i1] - ta;
+		const Vec3f v = vertices[i2] - ta;
+		const Vec3f n = u.cross(v);
+		TriRec &r = out.tris[t];
+		for (unsigned k = 0; k < 3; ++k) {
+			r.ta[k] = ta[k];
+			r.u[k] = u[k];
+			r.v[k] = v[k];
+			r.n[k] = n[k];
+		}
+		r.uu = u.dot(u);
+		r.uv = u.dot(v);
+		r.vv = v.dot(v);
+		r.D = r.uv * r.uv - r.uu * r.vv;
+		ShadeRec &s = out.shade[t];
+		const Vec3f *src[3] = { &vnormals[i0], &vnormals[i1], &vnormals[i2] };
+		float *dst[3] = { s.n0, s.n1, s.n2 };
+		for (unsigned c = 0; c < 3; ++c) {
+			dst[c][0] = src[c]->x;
+			dst[c][1] = src[c]->y;
+			dst[c][2] = src[c]->z;
+			dst[c][3] = 0.0f;
+		}
+	}
+	return out;
+}
+
+float kernel_float(float v) {
+	if (!std::isfinite(v))
+		return v;
+	std::ostringstream ss;
+	ss << v;
+	return std::strtof(ss.str().c_str(), nullptr);
+}
+
+std::vector<float> uniform_ao_table(unsigned int rings, int alpha_min, int alpha_max) {
+	std::vector<float> table;
+	const float degrees = (float) (M_PI / 180);
+	const float amin = (float) alpha_min * degrees;
+	const float amax = (float) alpha_max * degrees;
+	for (unsigned int ring = 0; ring < rings; ++ring) {
+		const float step = amax / rings;
+		const float elevation = (step * ring) + amin;
+		const unsigned int ray_count = (unsigned int) ((2.0f * M_PI * std::cos(elevation)) / step);
+		const float theta = (float) (M_PI_2 - elevation);
+		for (unsigned int k = 0; k <= ray_count; ++k) {
+			// The reference hands an angle that already contains 2*pi to
+			// cospi/sinpi; cospi(x) is cos(pi * x) evaluated in double.
+			const float phi = (float) ((2.0f * M_PI * k) / ray_count);
+			table.push_back(std::sin(theta) * (float) std::cos(M_PI * (double) phi));
+			table.push_back(std::cos(theta));
+			table.push_back(std::sin(theta) * (float) std::sin(M_PI * (double) phi));
+			table.push_back(0.0f);
+		}
+	}
+	return table;
+}
+
+uint32_t band_tile_rows_for(unsigned int grid) {
+	if (grid == 0)
+		grid = 1;
+	uint32_t a = TILE_H, b = grid;
+	while (b) {
+		const uint32_t t = a % b;
+		a = b;
+		b = t;
+	}
+	return grid / a;  // lcm(TILE_H, grid) / TILE_H
+}
+
+uint32_t local_tile_rows_for(uint32_t total_height, const Partition &part) {
+	const uint32_t tile_rows = (total_height + TILE_H - 1) / TILE_H;
+	const uint32_t bands = (tile_rows + part.band_tile_rows - 1) / part.band_tile_rows;
+	uint32_t mine = 0;
+	for (uint32_t b = part.rank; b < bands; b += part.nranks) {
+		const uint32_t first = b * part.band_tile_rows;
+		const uint32_t last = first + part.band_tile_rows < tile_rows ? first + part.band_tile_rows : tile_rows;
+		// Keep the band's full tile-row count so the kernel's local->global map
+		// stays a closed formula; rows past the image are masked off per lane.
+		(void) last;
+		mine += part.band_tile_rows;
+	}
+	return mine;
+}
+
+KernelParams make_kernel_params(const RayTracer &rt, uint32_t node_count, uint32_t ao_dirs, const Partition &part) {
+	KernelParams p{};
+	p.width = rt.totalWidth;
+	p.height = rt.totalHeight;
+	const float focal = kernel_float(rt.options.focalLength);
+	const int longest = (int) (p.width > p.height ? p.width : p.height);
+	p.a = focal * (float) longest;
+	p.half_w = (float) (int) p.width / (2.0f * p.a);
+	p.half_h = (float) (int) p.height / (2.0f * p.a);
+	p.node_count = node_count;
+	p.shading = rt.options.enableShading ? 1 : 0;
+	p.ao_mode = AO_NONE;
+	if (rt.options.enableAO && rt.options.aoNumSamples > 0)
+		p.ao_mode = rt.options.aoMethod == RayTracer::AmbientOcclusionMethod::UNIFORM ? AO_UNIFORM : AO_RANDOM;
+	p.ao_max_distance = kernel_float(rt.options.aoMaxDistance);
+	p.ao_dirs = ao_dirs;
+	p.tiles_x = (p.width + TILE_W - 1) / TILE_W;
+	p.part = part;
+	p.local_tile_rows = local_tile_rows_for(p.height, part);
+	return p;
+}
+
+}  // namespace ocrt

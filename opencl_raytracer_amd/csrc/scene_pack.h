@@ -1,0 +1,45 @@
+// scene_pack.h -- turns the five reference-format scene arrays into the device
+// records of device_types.h and derives the launch constants.  Host only.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "device_types.h"
+#include "ray_tracer.h"
+#include "vec3.h"
+
+namespace ocrt {
+
+struct PackedScene {
+	std::vector<NodeRec> nodes;
+	std::vector<TriRec> tris;
+	std::vector<ShadeRec> shade;
+};
+
+// Validates the arrays against each other (every index and skip count is
+// range-checked, so the kernels can never read out of bounds) and packs them.
+// Throws std::invalid_argument with a description on malformed input.
+PackedScene pack_scene(const std::vector<uint32_t> &faces, const std::vector<uint32_t> &nodes,
+                       const std::vector<Vec3f> &aabbs, const std::vector<Vec3f> &vertices,
+                       const std::vector<Vec3f> &vnormals);
+
+// The value a float option has once it went through the reference's -D string:
+// printed with 6 significant digits ("-DNAME=0.2f", reference
+// include/compiler_options.h:13-19) and re-parsed as a float literal.
+float kernel_float(float v);
+
+// Direction table of the UNIFORM hemisphere, one (xs, ys, zs, 0) per ray in
+// casting order (reference src/intersect_kernel.cl:219-246, which recomputes
+// these pixel-independent values for every pixel).
+std::vector<float> uniform_ao_table(unsigned int rings, int alpha_min, int alpha_max);
+
+// Largest band height (in tile rows) granularity such that a band holds whole
+// supersample blocks: lcm(TILE_H, n) / TILE_H.
+uint32_t band_tile_rows_for(unsigned int grid);
+
+// Number of tile rows rank `rank` owns for an image of `total_height` rows.
+uint32_t local_tile_rows_for(uint32_t total_height, const Partition &part);
+
+KernelParams make_kernel_params(const RayTracer &rt, uint32_t node_count, uint32_t ao_dirs, const Partition &part);
+
+}  // namespace ocrt

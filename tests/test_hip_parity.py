@@ -1,0 +1,143 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU
+oracle on the same inputs and against the golden vectors generated from the
+reference's own kernel.  Bar: bit-exact floats and bytes (integer PGM)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import bits, options_for
+
+pytestmark = pytest.mark.gpu
+
+# golden cases small enough for the oracle to re-render in the test itself
+ORACLE_CASES = [
+    "bunny_256_s1_a0", "bunny_256_s1_a3", "bunny_64_s1_a3", "bunny_101x77_s9_a2", "bunny_50x40_s5_a1_f15",
+    "bunny_96x54_s1_a4_alpha", "blob_128x96_s4_a3", "blob_128x96_s4_a3_sah", "blob_80_s1_a5_noshade",
+    "blob_33x17_s1_a0", "ties_33_s1_a3", "ties_33_s1_a3_sah", "ties_64_s4_a3", "ties_5x3_s1_a1", "single_32_s1_a3",
+]
+# full-size cases are checked against the committed digests only
+DIGEST_CASES = ["bunny_1080p_s1_a0", "bunny_1080p_s1_a3", "bunny_600_defaults"]
+
+
+def render_hip(rt, scene, opt, rank=0, nranks=1):
+    host = rt.Host(opt, 0, rank, nranks)
+    host.upload_scene(scene)
+    host.render()
+    return host
+
+
+@pytest.mark.parametrize("name", ORACLE_CASES)
+def test_matches_oracle_and_golden(rt, oracle, golden, scene_for, name):
+    import orc
+
+    c = golden["renders"][name]
+    opt = options_for(rt, c)
+    scene, arrays = scene_for(c["mesh"], c["bvh"])
+    host = render_hip(rt, scene, opt)
+    img = host.download()
+    u8 = host.download_u8()
+    ref_img, counters, _ = oracle.render(orc.params_from_options(opt), arrays)
+    mism = np.count_nonzero(bits(img) != bits(ref_img))
+    assert mism == 0, f"{mism} float words differ from the oracle"
+    assert np.array_equal(u8, oracle.resize(ref_img, opt.width, opt.height, opt.n_super_samples))
+    assert hashlib.sha256(img.tobytes()).hexdigest() == c["float_sha256"]
+    assert hashlib.md5(rt.pgm_bytes(u8)).hexdigest() == c["pgm_md5"]
+    st = host.stats()
+    assert st["primary_rays"] == counters["primary_rays"]
+    assert st["primary_hits"] == counters["primary_hits"]
+    assert st["ao_rays"] == counters["ao_rays"]
+    assert st["ao_occluded"] == counters["ao_occluded"]
+    host.close()
+
+
+@pytest.mark.parametrize("name", DIGEST_CASES)
+def test_full_size_golden_digests(rt, golden, scene_for, name):
+    c = golden["renders"][name]
+    opt = options_for(rt, c)
+    scene, _ = scene_for(c["mesh"], c["bvh"])
+    host = render_hip(rt, scene, opt)
+    img = host.download()
+    assert hashlib.sha256(img.tobytes()).hexdigest() == c["float_sha256"]
+    assert hashlib.md5(rt.pgm_bytes(host.download_u8())).hexdigest() == c["pgm_md5"]
+    # device resize == host resize of the downloaded floats
+    assert np.array_equal(host.download_u8(), rt.resize_cpu(opt, img))
+    st = host.stats()
+    assert st["primary_hits"] == c["counters"]["primary_hits"]
+    assert st["ao_occluded"] == c["counters"]["ao_occluded"]
+    host.close()
+
+
+def test_tree_independence_1080p(rt, golden, scene_for):
+    """the PGM does not depend on the BVH strategy (bunny has no
+    equal-distance ties between different leaves at these pixels)."""
+    c = dict(golden["renders"]["bunny_1080p_s1_a3"])
+    opt = options_for(rt, c)
+    scene_sah, _ = scene_for("bunny", "sah")
+    host = render_hip(rt, scene_sah, opt)
+    assert hashlib.md5(rt.pgm_bytes(host.download_u8())).hexdigest() == c["pgm_md5"]
+    host.close()
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 8])
+@pytest.mark.parametrize("name", ["bunny_256_s1_a3", "bunny_101x77_s9_a2", "blob_128x96_s4_a3"])
+def test_band_partition_reassembles(rt, golden, scene_for, name, nranks):
+    """Multi-GPU sharding on one device: every rank's bands, reassembled, equal
+    the unpartitioned frame (floats and bytes)."""
+    c = golden["renders"][name]
+    opt = options_for(rt, c)
+    scene, _ = scene_for(c["mesh"], c["bvh"])
+    full = render_hip(rt, scene, opt)
+    full_u8 = full.download_u8()
+    full.close()
+    out = np.full_like(full_u8, 255)
+    seen = np.zeros(opt.height, dtype=np.int32)
+    for rank in range(nranks):
+        host = render_hip(rt, scene, opt, rank, nranks)
+        rows = host.local_to_global_rows()
+        assert np.array_equal(rows, rt.partition_rows(opt, rank, nranks))
+        local = host.download_u8_local()
+        keep = rows < opt.height
+        out[rows[keep]] = local[keep]
+        seen[rows[keep]] += 1
+        host.close()
+    assert np.all(seen == 1)
+    assert np.array_equal(out, full_u8)
+    assert hashlib.md5(rt.pgm_bytes(out)).hexdigest() == c["pgm_md5"]
+
+
+def test_rerender_is_idempotent_and_timed(rt, golden, scene_for):
+    c = golden["renders"]["bunny_256_s1_a3"]
+    opt = options_for(rt, c)
+    scene, _ = scene_for("bunny", "longest")
+    host = render_hip(rt, scene, opt)
+    first = host.download()
+    host.reset_timers()
+    for _ in range(3):
+        host.render_async()
+    host.sync()
+    assert host.kernel_launches == 3
+    assert host.total_kernel_ms > 0 and host.last_kernel_ms > 0
+    assert np.array_equal(bits(first), bits(host.download()))
+    host.close()
+
+
+def test_error_paths(rt, scene_for):
+    opt = rt.Options.defaults(width=16, height=16, n_super_samples=1)
+    host = rt.Host(opt, 0)
+    with pytest.raises(rt.RtError) as e:
+        host.render()
+    assert e.value.code == -4  # RT_E_STATE: render before upload
+    scene, arrays = scene_for("blob", "longest")
+    bad_nodes = arrays.nodes.copy()
+    bad_nodes[1] = 10_000_000  # subtree runs past the array
+    with pytest.raises(rt.RtError) as e:
+        host.upload(arrays.faces, bad_nodes, arrays.aabbs, arrays.vertices, arrays.normals)
+    assert e.value.code == -1
+    bad_faces = arrays.faces.copy()
+    bad_faces[0] = 10_000_000
+    with pytest.raises(rt.RtError):
+        host.upload(bad_faces, arrays.nodes, arrays.aabbs, arrays.vertices, arrays.normals)
+    host.close()
+    with pytest.raises(rt.RtError):
+        rt.Host(opt, 99)  # device index out of range
