@@ -167,25 +167,52 @@ struct TileShared {
 	unsigned int occluded[64];
 };
 
-__global__ __launch_bounds__(64) void trace_tiles_kernel(const float4 *__restrict__ nodes,
+// Waves per workgroup.  The four waves of a workgroup never talk to each other
+// (each owns a tile and a private LDS slice, synchronised with wave-local
+// fences only); grouping them just lets a CU hold 32 waves -- single-wave
+// workgroups with LDS topped out at 16 per CU on gfx950 (profiles/r01_notes.md).
+constexpr uint32_t WAVES_PER_BLOCK = 4;
+
+// Orders this wave's LDS writes before its later LDS reads.  A wave executes in
+// lockstep and the LDS unit serves one wave's requests in order, so only the
+// compiler must be kept from reordering across this point.
+__device__ __forceinline__ void wave_lds_sync() {
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void trace_tiles_kernel(const float4 *__restrict__ nodes,
                                                          const float4 *__restrict__ tris,
                                                          const float4 *__restrict__ shade,
                                                          const float4 *__restrict__ ao_table,
                                                          float *__restrict__ image, KernelParams P,
                                                          uint2 *__restrict__ tile_stats) {
-	__shared__ TileShared sh;
-	const uint32_t lane = threadIdx.x;
+	__shared__ TileShared shared_tiles[WAVES_PER_BLOCK];
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t wave = threadIdx.x >> 6;
+	TileShared &sh = shared_tiles[wave];
 
-	// XCD-aware tile order: blocks b and b+8 share an XCD (and its L2), so give
-	// each of the 8 groups one contiguous run of tiles -- neighbouring tiles walk
-	// the same part of the BVH.  Bijective for any tile count.
-	const uint32_t total_tiles = P.tiles_x * P.local_tile_rows;
-	const uint32_t group = blockIdx.x & 7u, within_group = blockIdx.x >> 3;
-	const uint32_t q = total_tiles >> 3, rem = total_tiles & 7u;
-	const uint32_t tile = (group < rem ? group * (q + 1) : rem * (q + 1) + (group - rem) * q) + within_group;
-
-	const uint32_t local_row = tile / P.tiles_x;
-	const uint32_t tile_x = tile - local_row * P.tiles_x;
+	// Workgroup = 2x2 tiles (16x16 sub-pixels).  Workgroups b and b+8 share an
+	// XCD and its L2 (MI355X_MICROARCH.md, dispatch is round-robin over XCDs), so
+	// the image is cut into vertical strips two tiles wide, strips are dealt
+	// round-robin to the 8 XCD groups, and each group walks its strips top to
+	// bottom: neighbouring workgroups of a group touch the same BVH region, while
+	// every group still sees the whole image height (cost per tile varies 30x
+	// between background and model, so contiguous image blocks would idle XCDs).
+	const uint32_t group = blockIdx.x & 7u, seq = blockIdx.x >> 3;
+	const uint32_t strips = (P.tiles_x + 1u) >> 1;
+	const uint32_t row_pairs = (P.local_tile_rows + 1u) >> 1;
+	const uint32_t strips_here = (strips + 7u - group) >> 3;
+	if (seq >= strips_here * row_pairs)
+		return;  // whole workgroup leaves; no workgroup-wide barrier is used below
+	const uint32_t strip_index = seq / row_pairs;
+	const uint32_t row_pair = seq - strip_index * row_pairs;
+	const uint32_t tile_x = 2u * (group + 8u * strip_index) + (wave & 1u);
+	const uint32_t local_row = 2u * row_pair + (wave >> 1);
+	if (tile_x >= P.tiles_x || local_row >= P.local_tile_rows)
+		return;
+	const uint32_t tile = local_row * P.tiles_x + tile_x;
 	const uint32_t tile_y = global_tile_row(P.part, local_row);
 	const uint32_t x = tile_x * TILE_W + (lane & 7u);
 	const uint32_t y = tile_y * TILE_H + (lane >> 3);
@@ -254,7 +281,7 @@ __global__ __launch_bounds__(64) void trace_tiles_kernel(const float4 *__restric
 			sh.frame[9][slot] = bzx; sh.frame[10][slot] = bzy; sh.frame[11][slot] = bzz;
 			sh.occluded[slot] = 0u;
 		}
-		__syncthreads();
+		wave_lds_sync();
 
 		// ---- phase 3: any-hit AO rays, :237-255, dealt to all 64 lanes ----
 		const uint32_t total = hit_count * P.ao_dirs;
@@ -270,7 +297,7 @@ __global__ __launch_bounds__(64) void trace_tiles_kernel(const float4 *__restric
 			if (traverse<false>(nodes, tris, P.node_count, ao, P.ao_max_distance, unused))
 				atomicAdd(&sh.occluded[h], 1u);
 		}
-		__syncthreads();
+		wave_lds_sync();
 
 		// ---- phase 4: value *= 1 - hits / n, :256 and :305-307 ----
 		if (hit) {
@@ -327,7 +354,9 @@ void launch_trace_tiles(const void *nodes, const void *tris, const void *shade, 
 	const uint32_t total_tiles = P.tiles_x * P.local_tile_rows;
 	if (total_tiles == 0)
 		return;
-	hipLaunchKernelGGL(trace_tiles_kernel, dim3(total_tiles), dim3(64), 0, (hipStream_t) stream,
+	const uint32_t strips = (P.tiles_x + 1u) >> 1, row_pairs = (P.local_tile_rows + 1u) >> 1;
+	const uint32_t blocks = 8u * ((strips + 7u) >> 3) * row_pairs;
+	hipLaunchKernelGGL(trace_tiles_kernel, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, (hipStream_t) stream,
 	                   (const float4 *) nodes, (const float4 *) tris, (const float4 *) shade,
 	                   (const float4 *) ao_table, image, P, (uint2 *) tile_stats);
 }
