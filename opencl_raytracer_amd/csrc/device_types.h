@@ -55,10 +55,16 @@ struct KernelParams {
 	float half_w;          // WIDTH  / (2.0f * a)
 	float half_h;          // HEIGHT / (2.0f * a)
 	uint32_t node_count;   // nodes[0]
+	uint32_t tri_count;    // triangles = leaves
 	int32_t shading;       // SHADING_ENABLE
 	int32_t ao_mode;       // AoMode
 	float ao_max_distance; // AO_MAX_DISTANCE
 	uint32_t ao_dirs;      // UNIFORM: rays per hit sub-pixel; RANDOM: AO_NUM_SAMPLES
+	int32_t variant;       // 1 = per-lane loops, 2 = wave-scheduled traversal (default)
+	int32_t scene_regular; // every box finite, |coord| <= 1e37 and lo <= hi: min/max slab form allowed
+	int32_t ao_regular;    // AO_MAX_DISTANCE > 0 (needed by the folded form of the slab test)
+	float primary_below;   // largest float below the primary rays' max_distance (100000.0f)
+	float ao_below;        // largest float below AO_MAX_DISTANCE
 	uint32_t tiles_x;      // tiles per image row
 	uint32_t local_tile_rows;  // tile rows this rank owns
 	Partition part;

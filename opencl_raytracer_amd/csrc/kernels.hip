@@ -144,6 +144,77 @@ __device__ __forceinline__ bool traverse(const float4 *__restrict__ nodes, const
 	return found;
 }
 
+// ---------------------------------------------------------------------------
+// Wave-scheduled traversal (kernel variant 2).
+//
+// A lane is in one of three states: T (walking nodes), L (a leaf whose box was
+// hit is pending its triangle test), I (no ray).  Instead of letting every lane
+// run its own nested loops -- where the wave pays for the longest ray and a
+// triangle test runs with a handful of live lanes -- the wave picks, per
+// iteration and with scalar ballots only, the one body worth running:
+// refill idle lanes from the tile's ray queue, run the triangle test for the L
+// lanes, or advance the T lanes by one node.  Each body is straight-line and
+// predicated, so exec-mask bookkeeping stays out of the hot loop.
+// ---------------------------------------------------------------------------
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+constexpr uint32_t REFILL_MIN = 16;  // refill once this many lanes are idle ...
+constexpr uint32_t LEAF_MIN = 16;    // ... run triangle tests once this many leaves are pending
+
+// Largest magnitude for which (b - o) cannot overflow; beyond it, or for a ray
+// with an infinite or NaN reciprocal direction, the exact select-based slab test
+// is used instead of the min/max form.
+constexpr float REGULAR_LIMIT = 1.0e37f;
+
+__device__ __forceinline__ bool ray_is_regular(const Ray &r) {
+	return fabsf(r.ox) <= REGULAR_LIMIT && fabsf(r.oy) <= REGULAR_LIMIT && fabsf(r.oz) <= REGULAR_LIMIT &&
+	       fabsf(r.ix) <= REGULAR_LIMIT && fabsf(r.iy) <= REGULAR_LIMIT && fabsf(r.iz) <= REGULAR_LIMIT;
+}
+
+// min/max form of the slab test.  For a regular ray against a regular box
+// (finite, lo <= hi) no NaN can arise, (lo-o)*inv and (hi-o)*inv are ordered by
+// the sign of inv (IEEE rounding is monotonic), and the reference's chain of
+// early-outs (src/intersect_kernel.cl:21-61) reduces to
+//   max(near) <= min(far)  &&  max(near) < max_distance  &&  min(far) > 0,
+// the same comparisons on the same values.  With below = pred(max_distance) and
+// tiny = the smallest positive float, that is  max(near, tiny) <= min(far, below).
+__device__ __forceinline__ bool slab_hit_regular(const float4 lo, const float4 hi, const Ray &r, float below) {
+	const float x0 = (lo.x - r.ox) * r.ix, x1 = (hi.x - r.ox) * r.ix;
+	const float y0 = (lo.y - r.oy) * r.iy, y1 = (hi.y - r.oy) * r.iy;
+	const float z0 = (lo.z - r.oz) * r.iz, z1 = (hi.z - r.oz) * r.iz;
+	const float tiny = __uint_as_float(1u);
+	const float t_near = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tiny));
+	const float t_far = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), below));
+	return t_near <= t_far;
+}
+
+// One node for a lane in state T: box hit -> next node in pre-order (and the leaf,
+// if it is one, becomes pending); miss -> skip the subtree.  Inner nodes carry
+// leaf == NONE, so no leaf/inner branch is needed.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// 128-bit loads through a buffer descriptor (wave-uniform base + 32-bit per-lane
+// byte offset): one instruction per float4, out-of-range offsets return 0
+// instead of faulting, and -- unlike a plain pointer load -- the compiler cannot
+// split off the .w lane and sink it behind the box test (which it did, adding a
+// second dependent memory round trip per node).
+__device__ __forceinline__ float4 load_f4(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_offset) {
+	const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int) byte_offset, 0, 0);
+	return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+// One node for a lane in state T: box hit -> next node in pre-order (and the leaf,
+// if it is one, becomes pending); miss -> skip the subtree.  Inner nodes carry
+// leaf == NONE, so no leaf/inner branch is needed.
+template <bool REGULAR>
+__device__ __forceinline__ void node_step(__amdgpu_buffer_rsrc_t nodes, const Ray &r, float max_distance,
+                                          float below, uint32_t &i, uint32_t &pending) {
+	const float4 lo = load_f4(nodes, i * 32u);
+	const float4 hi = load_f4(nodes, i * 32u + 16u);
+	const bool hit = REGULAR ? slab_hit_regular(lo, hi, r, below) : slab_hit(lo, hi, r, max_distance);
+	pending = hit ? __float_as_uint(hi.w) : NONE;
+	i += hit ? 1u : __float_as_uint(lo.w);
+}
+
 __device__ __forceinline__ void normalize3(float &x, float &y, float &z) {
 	const float l = sqrtf(dot3(x, y, z, x, y, z));
 	x = x / l;
@@ -321,6 +392,253 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void trace_tiles_kernel(const
 	}
 }
 
+// Triangle test for a pending leaf, straight-line.  Same operations and order
+// as tri_hit above (reference src/intersect_kernel.cl:65-114); the early returns
+// become one accumulated predicate so that all L lanes stay converged.
+struct TriResult {
+	bool accepted;
+	float s, t, distance;
+	float px, py, pz;
+};
+
+template <bool CLOSEST>
+__device__ __forceinline__ TriResult tri_test(__amdgpu_buffer_rsrc_t tris, uint32_t leaf, const Ray &r) {
+	const float4 q0 = load_f4(tris, leaf * 64u), q1 = load_f4(tris, leaf * 64u + 16u);
+	const float4 q2 = load_f4(tris, leaf * 64u + 32u), q3 = load_f4(tris, leaf * 64u + 48u);
+	const float tax = q0.x, tay = q0.y, taz = q0.z;
+	const float ux = q0.w, uy = q1.x, uz = q1.y;
+	const float vx = q1.z, vy = q1.w, vz = q2.x;
+	const float nx = q2.y, ny = q2.z, nz = q2.w;
+	const float uu = q3.x, uv = q3.y, vv = q3.z, D = q3.w;
+	const float a = -dot3(nx, ny, nz, r.ox - tax, r.oy - tay, r.oz - taz);
+	const float b = dot3(nx, ny, nz, r.dx, r.dy, r.dz);
+	const float rr = a / b;
+	const float ipx = r.ox + rr * r.dx, ipy = r.oy + rr * r.dy, ipz = r.oz + rr * r.dz;
+	const float wx = ipx - tax, wy = ipy - tay, wz = ipz - taz;
+	const float wu = dot3(ux, uy, uz, wx, wy, wz);
+	const float wv = dot3(wx, wy, wz, vx, vy, vz);
+	const float slack_hi = __uint_as_float(0x3F800053u);
+	const float s = (uv * wv - vv * wu) / D;
+	const float t = (uv * wu - uu * wv) / D;
+	// reject: |b| < 1e-6, r < 0, s < -1e-5, s > 1.00001, t < -1e-5, s + t > 1.00001
+	const bool reject = (fabsf(b) < 0.000001f) | (rr < 0.0f) | (s < -0.00001f) | (s > slack_hi) | (t < -0.00001f) |
+	                    ((s + t) > slack_hi);
+	TriResult out;
+	out.accepted = !reject;
+	out.s = s;
+	out.t = t;
+	out.px = ipx; out.py = ipy; out.pz = ipz;
+	out.distance = 0.0f;
+	if (CLOSEST) {
+		const float ex = ipx - r.ox, ey = ipy - r.oy, ez = ipz - r.oz;
+		out.distance = sqrtf(dot3(ex, ey, ez, ex, ey, ez));
+	}
+	return out;
+}
+
+// Variant 2 of the tile kernel: same phases as trace_tiles_kernel, rays run by
+// the wave scheduler described above.
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void trace_tiles_sched_kernel(
+    const float4 *__restrict__ nodes_ptr, const float4 *__restrict__ tris_ptr, const float4 *__restrict__ shade,
+    const float4 *__restrict__ ao_table, float *__restrict__ image, KernelParams P, uint2 *__restrict__ tile_stats) {
+	__shared__ TileShared shared_tiles[WAVES_PER_BLOCK];
+	// descriptors are built from kernel arguments only, so they live in SGPRs
+	const __amdgpu_buffer_rsrc_t nodes =
+	    __builtin_amdgcn_make_buffer_rsrc((void *) nodes_ptr, 0, (int) (P.node_count * 32u), 0x00020000);
+	const __amdgpu_buffer_rsrc_t tris =
+	    __builtin_amdgcn_make_buffer_rsrc((void *) tris_ptr, 0, (int) (P.tri_count * 64u), 0x00020000);
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t wave = threadIdx.x >> 6;
+	TileShared &sh = shared_tiles[wave];
+
+	// workgroup -> 2x2 tiles, strips dealt round-robin to the 8 XCD groups (see variant 1)
+	const uint32_t group = blockIdx.x & 7u, seq = blockIdx.x >> 3;
+	const uint32_t strips = (P.tiles_x + 1u) >> 1;
+	const uint32_t row_pairs = (P.local_tile_rows + 1u) >> 1;
+	const uint32_t strips_here = (strips + 7u - group) >> 3;
+	if (seq >= strips_here * row_pairs)
+		return;
+	const uint32_t strip_index = seq / row_pairs;
+	const uint32_t row_pair = seq - strip_index * row_pairs;
+	const uint32_t tile_x = 2u * (group + 8u * strip_index) + (wave & 1u);
+	const uint32_t local_row = 2u * row_pair + (wave >> 1);
+	if (tile_x >= P.tiles_x || local_row >= P.local_tile_rows)
+		return;
+	const uint32_t tile = local_row * P.tiles_x + tile_x;
+	const uint32_t tile_y = global_tile_row(P.part, local_row);
+	const uint32_t x = tile_x * TILE_W + (lane & 7u);
+	const uint32_t y = tile_y * TILE_H + (lane >> 3);
+	const bool active = x < P.width && y < P.height;
+	const uint32_t count = P.node_count;
+	const unsigned long long lanes_below = (1ull << lane) - 1ull;
+
+	// ---- phase 1: primary rays (closest hit), no refill ----
+	float dx = ((float) x + 0.5f) / P.a - P.half_w;
+	float dy = -(((float) y + 0.5f) / P.a - P.half_h);
+	float dz = -1.0f;
+	normalize3(dx, dy, dz);
+	Ray ray = make_ray(0.0f, 0.0f, 2.0f, dx, dy, dz);
+	bool regular = P.scene_regular && ray_is_regular(ray);
+	Hit best;
+	best.distance = __builtin_inff();
+	best.leaf = 0;
+	best.s = best.t = 0.0f;
+	best.px = best.py = best.pz = 0.0f;
+	bool hit = false;
+	{
+		uint32_t i = active ? 0u : count;
+		uint32_t pending = NONE;
+		for (;;) {
+			const unsigned long long walking = __ballot(pending == NONE && i < count);
+			const unsigned long long leaves = __ballot(pending != NONE);
+			if (leaves != 0ull && ((uint32_t) __popcll(leaves) >= LEAF_MIN || walking == 0ull)) {
+				if (pending != NONE) {
+					const TriResult tr = tri_test<true>(tris, pending, ray);
+					if (tr.accepted) {
+						hit = true;
+						if (best.distance > tr.distance) {
+							best.distance = tr.distance;
+							best.leaf = pending;
+							best.s = tr.s;
+							best.t = tr.t;
+							best.px = tr.px; best.py = tr.py; best.pz = tr.pz;
+						}
+					}
+					pending = NONE;
+				}
+				continue;
+			}
+			if (walking == 0ull)
+				break;
+			if (pending == NONE && i < count) {
+				if (__ballot(!regular) == 0ull)
+					node_step<true>(nodes, ray, 100000.0f, P.primary_below, i, pending);
+				else
+					node_step<false>(nodes, ray, 100000.0f, P.primary_below, i, pending);
+			}
+		}
+	}
+
+	// ---- phase 2: shading inputs for the hit lanes ----
+	float value = 0.0f;
+	float nx = 0.0f, ny = 0.0f, nz = 0.0f;
+	uint32_t occluded_here = 0;
+	if (hit) {
+		const float4 n0 = shade[3 * (size_t) best.leaf + 0];
+		const float4 n1 = shade[3 * (size_t) best.leaf + 1];
+		const float4 n2 = shade[3 * (size_t) best.leaf + 2];
+		const float b0 = 1.0f - best.s - best.t, b1 = best.s, b2 = best.t;
+		nx = (n0.x * b0 + n1.x * b1) + n2.x * b2;
+		ny = (n0.y * b0 + n1.y * b1) + n2.y * b2;
+		nz = (n0.z * b0 + n1.z * b1) + n2.z * b2;
+		normalize3(nx, ny, nz);
+		value = 1.0f;
+		if (P.shading)
+			value = fminf(fmaxf(-dot3(nx, ny, nz, dx, dy, dz), 0.0f), 1.0f);
+	}
+	const unsigned long long hit_mask = __ballot(hit);
+	const uint32_t hit_count = (uint32_t) __popcll(hit_mask);
+	const uint32_t slot = (uint32_t) __popcll(hit_mask & lanes_below);
+
+	if (P.ao_mode == AO_UNIFORM && P.ao_dirs > 0 && hit_count > 0) {
+		if (hit) {
+			const float eps = 1.0f / 100000.0f;
+			sh.frame[0][slot] = best.px + nx * eps;
+			sh.frame[1][slot] = best.py + ny * eps;
+			sh.frame[2][slot] = best.pz + nz * eps;
+			float hx = nx, hy = ny, hz = nz;
+			const float ax = fabsf(nx), ay = fabsf(ny), az = fabsf(nz);
+			if (ax <= ay && ax <= az)
+				hx = 1.0f;
+			else if (ay <= ax && ay <= az)
+				hy = 1.0f;
+			else if (az <= ax && az <= ay)
+				hz = 1.0f;
+			float bxx = hy * nz - hz * ny, bxy = hz * nx - hx * nz, bxz = hx * ny - hy * nx;
+			normalize3(bxx, bxy, bxz);
+			float bzx = bxy * nz - bxz * ny, bzy = bxz * nx - bxx * nz, bzz = bxx * ny - bxy * nx;
+			normalize3(bzx, bzy, bzz);
+			sh.frame[3][slot] = bxx; sh.frame[4][slot] = bxy; sh.frame[5][slot] = bxz;
+			sh.frame[6][slot] = nx;  sh.frame[7][slot] = ny;  sh.frame[8][slot] = nz;
+			sh.frame[9][slot] = bzx; sh.frame[10][slot] = bzy; sh.frame[11][slot] = bzz;
+			sh.occluded[slot] = 0u;
+		}
+		wave_lds_sync();
+
+		// ---- phase 3: the tile's hit_count * ao_dirs any-hit rays, queue order is
+		// direction-major so that neighbouring lanes cast the same table direction
+		// from neighbouring pixels ----
+		const uint32_t total = hit_count * P.ao_dirs;
+		uint32_t next = 0;  // wave-uniform queue head
+		uint32_t i = count;
+		uint32_t pending = NONE;
+		uint32_t h = 0;
+		regular = true;
+		for (;;) {
+			const bool walking_lane = pending == NONE && i < count;
+			const unsigned long long walking = __ballot(walking_lane);
+			const unsigned long long leaves = __ballot(pending != NONE);
+			const uint32_t idle = 64u - (uint32_t) __popcll(walking) - (uint32_t) __popcll(leaves);
+			if (next < total && (idle >= REFILL_MIN || (walking | leaves) == 0ull)) {
+				const bool idle_lane = !walking_lane && pending == NONE;
+				const unsigned long long idle_mask = __ballot(idle_lane);
+				const uint32_t item = next + (uint32_t) __popcll(idle_mask & lanes_below);
+				if (idle_lane && item < total) {
+					const uint32_t k = item / hit_count;
+					h = item - k * hit_count;
+					const float4 dir = ao_table[k];
+					const float rx = (sh.frame[3][h] * dir.x + sh.frame[6][h] * dir.y) + sh.frame[9][h] * dir.z;
+					const float ry = (sh.frame[4][h] * dir.x + sh.frame[7][h] * dir.y) + sh.frame[10][h] * dir.z;
+					const float rz = (sh.frame[5][h] * dir.x + sh.frame[8][h] * dir.y) + sh.frame[11][h] * dir.z;
+					ray = make_ray(sh.frame[0][h], sh.frame[1][h], sh.frame[2][h], rx, ry, rz);
+					regular = P.scene_regular && P.ao_regular && ray_is_regular(ray);
+					i = 0u;
+				}
+				next += (uint32_t) __popcll(idle_mask);
+				continue;
+			}
+			if (leaves != 0ull && ((uint32_t) __popcll(leaves) >= LEAF_MIN || walking == 0ull)) {
+				if (pending != NONE) {
+					const TriResult tr = tri_test<false>(tris, pending, ray);
+					if (tr.accepted) {
+						atomicAdd(&sh.occluded[h], 1u);
+						i = count;  // any-hit: this ray is done
+					}
+					pending = NONE;
+				}
+				continue;
+			}
+			if (walking == 0ull)
+				break;
+			if (walking_lane) {
+				if (__ballot(!regular) == 0ull)
+					node_step<true>(nodes, ray, P.ao_max_distance, P.ao_below, i, pending);
+				else
+					node_step<false>(nodes, ray, P.ao_max_distance, P.ao_below, i, pending);
+			}
+		}
+		wave_lds_sync();
+
+		// ---- phase 4 ----
+		if (hit) {
+			const uint32_t occluded = sh.occluded[slot];
+			value *= 1.0f - ((float) occluded / (float) P.ao_dirs);
+			occluded_here = occluded;
+		}
+	}
+
+	if (active)
+		image[(size_t) y * P.width + x] = value;
+
+	if (tile_stats) {
+		uint32_t occluded_sum = occluded_here;
+		for (int offset = 32; offset > 0; offset >>= 1)
+			occluded_sum += __shfl_xor(occluded_sum, offset);
+		if (lane == 0)
+			tile_stats[tile] = make_uint2(hit_count, occluded_sum);
+	}
+}
+
 // Supersample box filter + 8-bit quantisation on the device: one thread per
 // output pixel, ssY-major / ssX-minor float summation and truncating store,
 // exactly reference src/ray_tracer.cc:3-16.  Works on this rank's bands only:
@@ -356,9 +674,14 @@ void launch_trace_tiles(const void *nodes, const void *tris, const void *shade, 
 		return;
 	const uint32_t strips = (P.tiles_x + 1u) >> 1, row_pairs = (P.local_tile_rows + 1u) >> 1;
 	const uint32_t blocks = 8u * ((strips + 7u) >> 3) * row_pairs;
-	hipLaunchKernelGGL(trace_tiles_kernel, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, (hipStream_t) stream,
-	                   (const float4 *) nodes, (const float4 *) tris, (const float4 *) shade,
-	                   (const float4 *) ao_table, image, P, (uint2 *) tile_stats);
+	if (P.variant == 1)
+		hipLaunchKernelGGL(trace_tiles_kernel, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, (hipStream_t) stream,
+		                   (const float4 *) nodes, (const float4 *) tris, (const float4 *) shade,
+		                   (const float4 *) ao_table, image, P, (uint2 *) tile_stats);
+	else
+		hipLaunchKernelGGL(trace_tiles_sched_kernel, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, (hipStream_t) stream,
+		                   (const float4 *) nodes, (const float4 *) tris, (const float4 *) shade,
+		                   (const float4 *) ao_table, image, P, (uint2 *) tile_stats);
 }
 
 void launch_resize(const float *tmp, unsigned char *out, const KernelParams &P, uint32_t out_width, uint32_t n,

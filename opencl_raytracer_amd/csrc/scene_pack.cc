@@ -2,6 +2,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <limits>
 #include <sstream>
 #include <stdexcept>
 #include <string>
@@ -23,12 +24,16 @@ PackedScene pack_scene(const std::vector<uint32_t> &faces, const std::vector<uin
 	if (vnormals.size() != vertices.size())
 		throw std::invalid_argument("upload: one normal per vertex expected");
 	const size_t tri_count = faces.size() / 3;
+	// the kernels address nodes (32 B) and triangles (64 B) with 32-bit byte offsets
+	if (count >= (1u << 27) || tri_count >= (1u << 26))
+		throw std::invalid_argument("upload: scene too large for 32-bit device offsets");
 	for (uint32_t v : faces)
 		if (v >= vertices.size())
 			throw std::invalid_argument("upload: face references a vertex out of range");
 
 	PackedScene out;
 	out.nodes.resize(count);
+	out.regular = true;
 	size_t leaf = 0;
 	for (size_t i = 0; i < count; ++i) {
 		const uint32_t skip = nodes[i];
@@ -38,6 +43,9 @@ PackedScene pack_scene(const std::vector<uint32_t> &faces, const std::vector<uin
 		for (unsigned k = 0; k < 3; ++k) {
 			n.lo[k] = aabbs[2 * i][k];
 			n.hi[k] = aabbs[2 * i + 1][k];
+			// negated comparisons so that NaN counts as irregular
+			if (!(std::fabs(n.lo[k]) <= 1.0e37f) || !(std::fabs(n.hi[k]) <= 1.0e37f) || !(n.lo[k] <= n.hi[k]))
+				out.regular = false;
 		}
 		n.skip = skip;
 		n.leaf = 0xFFFFFFFFu;
@@ -140,7 +148,8 @@ uint32_t local_tile_rows_for(uint32_t total_height, const Partition &part) {
 	return mine;
 }
 
-KernelParams make_kernel_params(const RayTracer &rt, uint32_t node_count, uint32_t ao_dirs, const Partition &part) {
+KernelParams make_kernel_params(const RayTracer &rt, uint32_t node_count, uint32_t tri_count, uint32_t ao_dirs,
+                                const Partition &part, bool scene_regular) {
 	KernelParams p{};
 	p.width = rt.totalWidth;
 	p.height = rt.totalHeight;
@@ -150,12 +159,19 @@ KernelParams make_kernel_params(const RayTracer &rt, uint32_t node_count, uint32
 	p.half_w = (float) (int) p.width / (2.0f * p.a);
 	p.half_h = (float) (int) p.height / (2.0f * p.a);
 	p.node_count = node_count;
+	p.tri_count = tri_count;
 	p.shading = rt.options.enableShading ? 1 : 0;
 	p.ao_mode = AO_NONE;
 	if (rt.options.enableAO && rt.options.aoNumSamples > 0)
 		p.ao_mode = rt.options.aoMethod == RayTracer::AmbientOcclusionMethod::UNIFORM ? AO_UNIFORM : AO_RANDOM;
 	p.ao_max_distance = kernel_float(rt.options.aoMaxDistance);
 	p.ao_dirs = ao_dirs;
+	const char *variant = std::getenv("OCRT_KERNEL_VARIANT");
+	p.variant = variant ? std::atoi(variant) : 2;
+	p.scene_regular = scene_regular ? 1 : 0;
+	p.ao_regular = (p.ao_max_distance > 0.0f && std::isfinite(p.ao_max_distance)) ? 1 : 0;
+	p.primary_below = std::nextafterf(100000.0f, 0.0f);
+	p.ao_below = std::nextafterf(p.ao_max_distance, -std::numeric_limits<float>::infinity());
 	p.tiles_x = (p.width + TILE_W - 1) / TILE_W;
 	p.part = part;
 	p.local_tile_rows = local_tile_rows_for(p.height, part);

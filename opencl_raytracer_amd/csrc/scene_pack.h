@@ -14,6 +14,7 @@ struct PackedScene {
 	std::vector<NodeRec> nodes;
 	std::vector<TriRec> tris;
 	std::vector<ShadeRec> shade;
+	bool regular = false;  // all boxes finite, |coord| <= 1e37, lo <= hi (see kernels.hip slab_hit_regular)
 };
 
 // Validates the arrays against each other (every index and skip count is
@@ -40,6 +41,7 @@ uint32_t band_tile_rows_for(unsigned int grid);
 // Number of tile rows rank `rank` owns for an image of `total_height` rows.
 uint32_t local_tile_rows_for(uint32_t total_height, const Partition &part);
 
-KernelParams make_kernel_params(const RayTracer &rt, uint32_t node_count, uint32_t ao_dirs, const Partition &part);
+KernelParams make_kernel_params(const RayTracer &rt, uint32_t node_count, uint32_t tri_count, uint32_t ao_dirs,
+                                const Partition &part, bool scene_regular);
 
 }  // namespace ocrt
