@@ -1,0 +1,17 @@
+#!/bin/bash
+# usage (on the GPU box, from the repo root): tools/pmc_collect.sh OUTDIR [prof_run args...]
+# Collects the SQ/TCC/TCP counter passes for the ray-casting kernel (one rocprofv3 run per pass).
+OUT=$1; shift
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd /tmp && export TMPDIR=/tmp
+i=0
+for C in \
+ "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
+ "SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM SQ_INSTS_BRANCH" \
+ "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
+ "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE" \
+ "FETCH_SIZE" "WRITE_SIZE" ; do
+  i=$((i+1))
+  timeout -k 10 120 rocprofv3 --pmc $C --output-format csv -d $R/$OUT/p$i -- python3 $R/tools/prof_run.py --frames 2 "$@" > $R/$OUT.p$i.log 2>&1 || echo "pass $i failed"
+done
+python3 $R/tools/pmc_summary.py $R/$OUT
