@@ -44,6 +44,12 @@ WORKLOADS = {
     "bunny_600_defaults": dict(
         mesh="bunny", bvh="longest", width=600, height=600, ss=4, ao=3, golden="bunny_600_defaults",
         label="bunny.off 600x600 CLI defaults (-s 4 -a 3)"),
+    "bunny_1080p_s4": dict(
+        mesh="bunny", bvh="longest", width=1920, height=1080, ss=4, ao=3, golden=None,
+        label="bunny.off 1920x1080 -s 4 -a 3 (2x2 supersample grid: 3840x2160 sub-pixels)"),
+    "bunny_1080p_s16": dict(
+        mesh="bunny", bvh="longest", width=1920, height=1080, ss=16, ao=3, golden=None,
+        label="bunny.off 1920x1080 -s 16 -a 3 (4x4 supersample grid: 7680x4320 sub-pixels)"),
     "bunny_1080p_s64": dict(
         mesh="bunny", bvh="longest", width=1920, height=1080, ss=64, ao=3, golden=None,
         label="bunny.off 1920x1080 -s 64 -a 3 (regular 8x8 supersample grid: 15360x8640 sub-pixels)"),

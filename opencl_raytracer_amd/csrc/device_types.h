@@ -17,17 +17,35 @@ struct NodeRec {
 };
 static_assert(sizeof(NodeRec) == 32, "NodeRec is two float4");
 
-// Per-triangle invariants of the reference's plane/parametric test (reference
-// src/intersect_kernel.cl:67-90), precomputed on the host with the SAME float
-// operations the kernel would execute, so the bits are identical: 64 bytes.
+// Compressed node, 16 bytes = ONE 128-bit gather per visit.  The box is stored
+// as six binary16 values rounded OUTWARD (lo down, hi up), i.e. a superset of
+// the exact box: a superset box can only add node visits, never remove one, and
+// every triangle is still gated by its exact box (kept in TriRec) before its
+// test, so results do not change.  `link` is the subtree
+// size for an inner node and 0x80000000 | leaf index for a leaf.
+struct CNodeRec {
+	uint16_t lo[3];
+	uint16_t hi[3];
+	uint32_t link;
+};
+static_assert(sizeof(CNodeRec) == 16, "CNodeRec is one uint4");
+constexpr uint32_t CNODE_LEAF_FLAG = 0x80000000u;
+constexpr float CNODE_MAX_COORD = 65504.0f;  // largest finite binary16
+
+// Per-triangle record, 96 bytes = six float4: the invariants of the reference's
+// plane/parametric test (reference src/intersect_kernel.cl:67-90), precomputed
+// on the host with the SAME float operations the kernel would execute (so the
+// bits are identical), followed by the leaf's exact box.
 struct TriRec {
 	float ta[3];
 	float u[3];   // tb - ta
 	float v[3];   // tc - ta
 	float n[3];   // cross(u, v)
 	float uu, uv, vv, D;  // dot(u,u), dot(u,v), dot(v,v), uv*uv - uu*vv
+	float lo[3], pad0;    // exact leaf box (reference aabbs[2i], aabbs[2i+1])
+	float hi[3], pad1;
 };
-static_assert(sizeof(TriRec) == 64, "TriRec is four float4");
+static_assert(sizeof(TriRec) == 96, "TriRec is six float4");
 
 // The three vertex normals of a leaf's triangle (replaces the faces[] ->
 // normals[] double indirection of reference src/intersect_kernel.cl:118-127).
@@ -60,8 +78,9 @@ struct KernelParams {
 	int32_t ao_mode;       // AoMode
 	float ao_max_distance; // AO_MAX_DISTANCE
 	uint32_t ao_dirs;      // UNIFORM: rays per hit sub-pixel; RANDOM: AO_NUM_SAMPLES
-	int32_t variant;       // 1 = per-lane loops, 2 = wave-scheduled traversal (default)
+	int32_t variant;       // debug: 0 = default, 2 = never use the compressed nodes
 	int32_t scene_regular; // every box finite, |coord| <= 1e37 and lo <= hi: min/max slab form allowed
+	int32_t compressed;    // CNodeRec array usable (scene_regular and |coord| <= 65504)
 	int32_t ao_regular;    // AO_MAX_DISTANCE > 0 (needed by the folded form of the slab test)
 	float primary_below;   // largest float below the primary rays' max_distance (100000.0f)
 	float ao_below;        // largest float below AO_MAX_DISTANCE

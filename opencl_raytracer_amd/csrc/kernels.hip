@@ -12,10 +12,17 @@
 //   phase 1  every lane casts its primary ray (closest hit);
 //   phase 2  hit lanes compute normal + head-light term + the AO tangent frame
 //            and are ballot-compacted into an LDS table;
-//   phase 3  the (hit, direction) pairs of the tile are dealt round-robin to
-//            all 64 lanes -- lanes that missed help -- as any-hit rays that
-//            stop at the first accepted triangle; occlusion counts are LDS atomics;
+//   phase 3  the (hit, direction) pairs of the tile form a queue that all 64
+//            lanes drain -- lanes that missed help -- as any-hit rays that stop
+//            at the first accepted triangle; occlusion counts are LDS atomics;
 //   phase 4  hit lanes fold the occlusion fraction in and store the float.
+//
+// What bounds it (profiles/r01_notes.md): the scene (12 MB) lives in L2, HBM
+// traffic is negligible; the limiter is the vector L1's tag pipeline, which
+// serves about one cache line per clock per CU and sees every lane of a
+// divergent 128-bit gather as its own line.  Hence: ONE 16-byte gather per
+// node visit (CNodeRec), and a wave-level scheduler that keeps lanes busy so
+// that fewer, fuller gathers are issued.
 #include <hip/hip_runtime.h>
 
 #include "device_types.h"
@@ -37,8 +44,17 @@ struct Hit {
 	float px, py, pz;
 };
 
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
 	return (ax * bx + ay * by) + az * bz;
+}
+
+__device__ __forceinline__ void normalize3(float &x, float &y, float &z) {
+	const float l = sqrtf(dot3(x, y, z, x, y, z));
+	x = x / l;
+	y = y / l;
+	z = z / l;
 }
 
 __device__ __forceinline__ Ray make_ray(float ox, float oy, float oz, float dx, float dy, float dz) {
@@ -51,10 +67,14 @@ __device__ __forceinline__ Ray make_ray(float ox, float oy, float oz, float dx, 
 	return r;
 }
 
-// Slab test, reference src/intersect_kernel.cl:21-61.  The reference's early
-// returns only skip work; evaluating everything and AND-ing the same
+// ---------------------------------------------------------------------------
+// Slab tests
+// ---------------------------------------------------------------------------
+
+// Exact form, reference src/intersect_kernel.cl:21-61.  The reference's early
+// returns only skip work; evaluating everything and combining the same
 // comparisons (kept in their original `a > b` polarity for NaN) is identical.
-__device__ __forceinline__ bool slab_hit(const float4 lo, const float4 hi, const Ray &r, float max_distance) {
+__device__ __forceinline__ bool slab_hit_exact(const float4 lo, const float4 hi, const Ray &r, float max_distance) {
 	const bool px = r.ix >= 0.0f, py = r.iy >= 0.0f, pz = r.iz >= 0.0f;
 	float t_min = ((px ? lo.x : hi.x) - r.ox) * r.ix;
 	float t_max = ((px ? hi.x : lo.x) - r.ox) * r.ix;
@@ -71,11 +91,113 @@ __device__ __forceinline__ bool slab_hit(const float4 lo, const float4 hi, const
 	return !miss & (t_min < max_distance) & (t_max > 0.0f);
 }
 
-// Plane hit + parametric (s,t) test, reference src/intersect_kernel.cl:65-114,
-// on the precomputed TriRec.  `x > 1.00001` (double literal) == `x > 0x3F800053`.
+// Largest magnitude for which (b - o) cannot overflow.  A ray is "regular" when
+// its origin is within it and its reciprocal direction is finite and non-zero;
+// a box is regular when it is finite, within the limit and lo <= hi (checked on
+// the host, KernelParams::scene_regular).
+constexpr float REGULAR_LIMIT = 1.0e37f;
+
+__device__ __forceinline__ bool ray_is_regular(const Ray &r) {
+	return fabsf(r.ox) <= REGULAR_LIMIT && fabsf(r.oy) <= REGULAR_LIMIT && fabsf(r.oz) <= REGULAR_LIMIT &&
+	       fabsf(r.ix) <= REGULAR_LIMIT && fabsf(r.iy) <= REGULAR_LIMIT && fabsf(r.iz) <= REGULAR_LIMIT &&
+	       r.ix != 0.0f && r.iy != 0.0f && r.iz != 0.0f;
+}
+
+// min/max form.  For a regular ray against a regular box no NaN can arise,
+// (lo-o)*inv and (hi-o)*inv are ordered by the sign of inv (IEEE rounding is
+// monotonic), and the reference's chain of early-outs reduces to
+//   max(near) <= min(far)  &&  max(near) < max_distance  &&  min(far) > 0
+// -- the same comparisons on the same values.  With below = pred(max_distance)
+// (max_distance > 0) and tiny = the smallest positive float this is
+//   max(near, tiny) <= min(far, below).
+// The same monotonicity makes the test conservative under box enlargement:
+// lo' <= lo, hi' >= hi can only widen [near, far].
+__device__ __forceinline__ bool slab_hit_regular(float lox, float loy, float loz, float hix, float hiy, float hiz,
+                                                 const Ray &r, float below) {
+	const float x0 = (lox - r.ox) * r.ix, x1 = (hix - r.ox) * r.ix;
+	const float y0 = (loy - r.oy) * r.iy, y1 = (hiy - r.oy) * r.iy;
+	const float z0 = (loz - r.oz) * r.iz, z1 = (hiz - r.oz) * r.iz;
+	const float tiny = __uint_as_float(1u);
+	const float t_near = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tiny));
+	const float t_far = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), below));
+	return t_near <= t_far;
+}
+
+// ---------------------------------------------------------------------------
+// Scene access: 128-bit loads through buffer descriptors (wave-uniform base in
+// SGPRs + 32-bit per-lane byte offset).  One instruction per 16 bytes, offsets
+// past the end return 0 instead of faulting, and -- unlike a pointer load --
+// hipcc cannot split a lane off and sink it behind the box test (it did, which
+// cost a second dependent memory round trip per node).
+// ---------------------------------------------------------------------------
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ u32x4 load_u4(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_offset) {
+	return __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int) byte_offset, 0, 0);
+}
+__device__ __forceinline__ float4 load_f4(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_offset) {
+	const u32x4 v = load_u4(rsrc, byte_offset);
+	return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+struct SceneViews {
+	__amdgpu_buffer_rsrc_t nodes;   // NodeRec[node_count]
+	__amdgpu_buffer_rsrc_t cnodes;  // CNodeRec[node_count]
+	__amdgpu_buffer_rsrc_t tris;    // TriRec[tri_count]
+};
+
+// How the T lanes advance this iteration (wave-uniform choice).
+enum StepKind { STEP_COMPRESSED, STEP_REGULAR, STEP_EXACT };
+
+// One node for a lane in state T: box hit -> next node in pre-order (a hit leaf
+// becomes pending); miss -> skip the subtree.
+template <StepKind KIND>
+__device__ __forceinline__ void node_step(const SceneViews &scene, const Ray &r, float max_distance, float below,
+                                          uint32_t &i, uint32_t &pending) {
+	if (KIND == STEP_COMPRESSED) {
+		const u32x4 c = load_u4(scene.cnodes, i * 16u);
+		// (bit_cast straight from a vector element read element 0 three times with
+		// this hipcc; go through scalars)
+		const uint32_t cx = c.x, cy = c.y, cz = c.z;
+		const f16x2 a = __builtin_bit_cast(f16x2, cx), b = __builtin_bit_cast(f16x2, cy),
+		            d = __builtin_bit_cast(f16x2, cz);
+		const bool hit =
+		    slab_hit_regular((float) a.x, (float) a.y, (float) b.x, (float) b.y, (float) d.x, (float) d.y, r, below);
+		const bool leaf = (c.w & CNODE_LEAF_FLAG) != 0u;
+		pending = (hit && leaf) ? (c.w & ~CNODE_LEAF_FLAG) : NONE;
+		i += (hit || leaf) ? 1u : c.w;
+	} else {
+		const float4 lo = load_f4(scene.nodes, i * 32u);
+		const float4 hi = load_f4(scene.nodes, i * 32u + 16u);
+		const bool hit = KIND == STEP_REGULAR ? slab_hit_regular(lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, r, below)
+		                                      : slab_hit_exact(lo, hi, r, max_distance);
+		pending = hit ? __float_as_uint(hi.w) : NONE;  // inner nodes carry NONE
+		i += hit ? 1u : __float_as_uint(lo.w);
+	}
+}
+
+// Triangle test for a pending leaf, straight-line: the leaf's exact box gate
+// (reference :189,:195 -- the leaf is a node of the walk) followed by the plane
+// hit + parametric (s,t) test (reference :65-114) on the precomputed TriRec.
+// The early returns of the reference become one accumulated predicate so that
+// all L lanes stay converged.  `x > 1.00001` (double literal) == `x > 0x3F800053`.
+struct TriResult {
+	bool accepted;
+	float s, t, distance;
+	float px, py, pz;
+};
+
 template <bool CLOSEST>
-__device__ __forceinline__ bool tri_hit(const float4 *__restrict__ tri, uint32_t leaf, const Ray &r, Hit &best) {
-	const float4 q0 = tri[0], q1 = tri[1], q2 = tri[2], q3 = tri[3];
+__device__ __forceinline__ TriResult tri_test(const SceneViews &scene, uint32_t leaf, const Ray &r, bool regular,
+                                              float below) {
+	const uint32_t base = leaf * (uint32_t) sizeof(TriRec);
+	const float4 q0 = load_f4(scene.tris, base), q1 = load_f4(scene.tris, base + 16u);
+	const float4 q2 = load_f4(scene.tris, base + 32u), q3 = load_f4(scene.tris, base + 48u);
+	const float4 b0 = load_f4(scene.tris, base + 64u), b1 = load_f4(scene.tris, base + 80u);
+	// A regular ray may have reached this leaf through its enlarged box: apply the
+	// exact one.  An irregular ray only ever walks exact boxes (STEP_EXACT).
+	const bool box_ok = !regular || slab_hit_regular(b0.x, b0.y, b0.z, b1.x, b1.y, b1.z, r, below);
 	const float tax = q0.x, tay = q0.y, taz = q0.z;
 	const float ux = q0.w, uy = q1.x, uz = q1.y;
 	const float vx = q1.z, vy = q1.w, vz = q2.x;
@@ -83,143 +205,28 @@ __device__ __forceinline__ bool tri_hit(const float4 *__restrict__ tri, uint32_t
 	const float uu = q3.x, uv = q3.y, vv = q3.z, D = q3.w;
 	const float a = -dot3(nx, ny, nz, r.ox - tax, r.oy - tay, r.oz - taz);
 	const float b = dot3(nx, ny, nz, r.dx, r.dy, r.dz);
-	if (fabsf(b) < 0.000001f)
-		return false;
 	const float rr = a / b;
-	if (rr < 0.0f)
-		return false;
 	const float ipx = r.ox + rr * r.dx, ipy = r.oy + rr * r.dy, ipz = r.oz + rr * r.dz;
 	const float wx = ipx - tax, wy = ipy - tay, wz = ipz - taz;
 	const float wu = dot3(ux, uy, uz, wx, wy, wz);
 	const float wv = dot3(wx, wy, wz, vx, vy, vz);
 	const float slack_hi = __uint_as_float(0x3F800053u);
 	const float s = (uv * wv - vv * wu) / D;
-	if (s < -0.00001f || s > slack_hi)
-		return false;
 	const float t = (uv * wu - uu * wv) / D;
-	if (t < -0.00001f || (s + t) > slack_hi)
-		return false;
+	// reject: |b| < 1e-6, r < 0, s < -1e-5, s > 1.00001, t < -1e-5, s + t > 1.00001
+	const bool reject = (fabsf(b) < 0.000001f) | (rr < 0.0f) | (s < -0.00001f) | (s > slack_hi) | (t < -0.00001f) |
+	                    ((s + t) > slack_hi);
+	TriResult out;
+	out.accepted = box_ok & !reject;
+	out.s = s;
+	out.t = t;
+	out.px = ipx; out.py = ipy; out.pz = ipz;
+	out.distance = 0.0f;
 	if (CLOSEST) {
 		const float ex = ipx - r.ox, ey = ipy - r.oy, ez = ipz - r.oz;
-		const float distance = sqrtf(dot3(ex, ey, ez, ex, ey, ez));
-		if (best.distance > distance) {
-			best.distance = distance;
-			best.leaf = leaf;
-			best.s = s;
-			best.t = t;
-			best.px = ipx; best.py = ipy; best.pz = ipz;
-		}
+		out.distance = sqrtf(dot3(ex, ey, ez, ex, ey, ez));
 	}
-	return true;
-}
-
-// Stackless pre-order walk with skip counts, reference
-// src/intersect_kernel.cl:184-213.  CLOSEST visits every overlapped leaf in
-// ascending leaf order (so the strict `>` update resolves ties exactly like the
-// reference); any-hit rays return at the first accepted triangle -- the
-// reference walks on but only ever uses the boolean (:251).
-template <bool CLOSEST>
-__device__ __forceinline__ bool traverse(const float4 *__restrict__ nodes, const float4 *__restrict__ tris,
-                                         uint32_t node_count, const Ray &r, float max_distance, Hit &best) {
-	bool found = false;
-	uint32_t i = 0;
-	while (i < node_count) {
-		const float4 lo = nodes[2 * i];
-		const float4 hi = nodes[2 * i + 1];
-		const uint32_t skip = __float_as_uint(lo.w);
-		if (slab_hit(lo, hi, r, max_distance)) {
-			if (skip == 1u) {
-				const uint32_t leaf = __float_as_uint(hi.w);
-				if (tri_hit<CLOSEST>(tris + 4 * (size_t) leaf, leaf, r, best)) {
-					if (!CLOSEST)
-						return true;
-					found = true;
-				}
-			}
-			i += 1;
-		} else {
-			i += skip;
-		}
-	}
-	return found;
-}
-
-// ---------------------------------------------------------------------------
-// Wave-scheduled traversal (kernel variant 2).
-//
-// A lane is in one of three states: T (walking nodes), L (a leaf whose box was
-// hit is pending its triangle test), I (no ray).  Instead of letting every lane
-// run its own nested loops -- where the wave pays for the longest ray and a
-// triangle test runs with a handful of live lanes -- the wave picks, per
-// iteration and with scalar ballots only, the one body worth running:
-// refill idle lanes from the tile's ray queue, run the triangle test for the L
-// lanes, or advance the T lanes by one node.  Each body is straight-line and
-// predicated, so exec-mask bookkeeping stays out of the hot loop.
-// ---------------------------------------------------------------------------
-constexpr uint32_t NONE = 0xFFFFFFFFu;
-constexpr uint32_t REFILL_MIN = 16;  // refill once this many lanes are idle ...
-constexpr uint32_t LEAF_MIN = 16;    // ... run triangle tests once this many leaves are pending
-
-// Largest magnitude for which (b - o) cannot overflow; beyond it, or for a ray
-// with an infinite or NaN reciprocal direction, the exact select-based slab test
-// is used instead of the min/max form.
-constexpr float REGULAR_LIMIT = 1.0e37f;
-
-__device__ __forceinline__ bool ray_is_regular(const Ray &r) {
-	return fabsf(r.ox) <= REGULAR_LIMIT && fabsf(r.oy) <= REGULAR_LIMIT && fabsf(r.oz) <= REGULAR_LIMIT &&
-	       fabsf(r.ix) <= REGULAR_LIMIT && fabsf(r.iy) <= REGULAR_LIMIT && fabsf(r.iz) <= REGULAR_LIMIT;
-}
-
-// min/max form of the slab test.  For a regular ray against a regular box
-// (finite, lo <= hi) no NaN can arise, (lo-o)*inv and (hi-o)*inv are ordered by
-// the sign of inv (IEEE rounding is monotonic), and the reference's chain of
-// early-outs (src/intersect_kernel.cl:21-61) reduces to
-//   max(near) <= min(far)  &&  max(near) < max_distance  &&  min(far) > 0,
-// the same comparisons on the same values.  With below = pred(max_distance) and
-// tiny = the smallest positive float, that is  max(near, tiny) <= min(far, below).
-__device__ __forceinline__ bool slab_hit_regular(const float4 lo, const float4 hi, const Ray &r, float below) {
-	const float x0 = (lo.x - r.ox) * r.ix, x1 = (hi.x - r.ox) * r.ix;
-	const float y0 = (lo.y - r.oy) * r.iy, y1 = (hi.y - r.oy) * r.iy;
-	const float z0 = (lo.z - r.oz) * r.iz, z1 = (hi.z - r.oz) * r.iz;
-	const float tiny = __uint_as_float(1u);
-	const float t_near = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tiny));
-	const float t_far = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), below));
-	return t_near <= t_far;
-}
-
-// One node for a lane in state T: box hit -> next node in pre-order (and the leaf,
-// if it is one, becomes pending); miss -> skip the subtree.  Inner nodes carry
-// leaf == NONE, so no leaf/inner branch is needed.
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-// 128-bit loads through a buffer descriptor (wave-uniform base + 32-bit per-lane
-// byte offset): one instruction per float4, out-of-range offsets return 0
-// instead of faulting, and -- unlike a plain pointer load -- the compiler cannot
-// split off the .w lane and sink it behind the box test (which it did, adding a
-// second dependent memory round trip per node).
-__device__ __forceinline__ float4 load_f4(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_offset) {
-	const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int) byte_offset, 0, 0);
-	return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
-
-// One node for a lane in state T: box hit -> next node in pre-order (and the leaf,
-// if it is one, becomes pending); miss -> skip the subtree.  Inner nodes carry
-// leaf == NONE, so no leaf/inner branch is needed.
-template <bool REGULAR>
-__device__ __forceinline__ void node_step(__amdgpu_buffer_rsrc_t nodes, const Ray &r, float max_distance,
-                                          float below, uint32_t &i, uint32_t &pending) {
-	const float4 lo = load_f4(nodes, i * 32u);
-	const float4 hi = load_f4(nodes, i * 32u + 16u);
-	const bool hit = REGULAR ? slab_hit_regular(lo, hi, r, below) : slab_hit(lo, hi, r, max_distance);
-	pending = hit ? __float_as_uint(hi.w) : NONE;
-	i += hit ? 1u : __float_as_uint(lo.w);
-}
-
-__device__ __forceinline__ void normalize3(float &x, float &y, float &z) {
-	const float l = sqrtf(dot3(x, y, z, x, y, z));
-	x = x / l;
-	y = y / l;
-	z = z / l;
+	return out;
 }
 
 // Maps a rank-local tile row to the global tile row under the band partition.
@@ -228,21 +235,6 @@ __device__ __forceinline__ uint32_t global_tile_row(const Partition &p, uint32_t
 	const uint32_t within = local_row - band_local * p.band_tile_rows;
 	return (band_local * p.nranks + p.rank) * p.band_tile_rows + within;
 }
-
-}  // namespace
-
-// LDS layout of one tile's hit table (structure of arrays, lane-major so that
-// consecutive hits sit in consecutive banks).
-struct TileShared {
-	float frame[12][64];  // origin xyz, basis_x xyz, basis_y xyz, basis_z xyz
-	unsigned int occluded[64];
-};
-
-// Waves per workgroup.  The four waves of a workgroup never talk to each other
-// (each owns a tile and a private LDS slice, synchronised with wave-local
-// fences only); grouping them just lets a CU hold 32 waves -- single-wave
-// workgroups with LDS topped out at 16 per CU on gfx950 (profiles/r01_notes.md).
-constexpr uint32_t WAVES_PER_BLOCK = 4;
 
 // Orders this wave's LDS writes before its later LDS reads.  A wave executes in
 // lockstep and the LDS unit serves one wave's requests in order, so only the
@@ -253,16 +245,43 @@ __device__ __forceinline__ void wave_lds_sync() {
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void trace_tiles_kernel(const float4 *__restrict__ nodes,
-                                                         const float4 *__restrict__ tris,
-                                                         const float4 *__restrict__ shade,
-                                                         const float4 *__restrict__ ao_table,
-                                                         float *__restrict__ image, KernelParams P,
-                                                         uint2 *__restrict__ tile_stats) {
+}  // namespace
+
+// LDS slice of one tile (one wave): the hit table, structure of arrays and
+// lane-major so that consecutive hits sit in consecutive banks.
+struct TileShared {
+	float frame[12][64];  // origin xyz, basis_x xyz, basis_y xyz, basis_z xyz
+	unsigned int occluded[64];
+};
+
+// The four waves of a workgroup never talk to each other (each owns a tile and a
+// private LDS slice, synchronised with wave-local fences only).
+constexpr uint32_t WAVES_PER_BLOCK = 4;
+
+// Wave scheduler thresholds.  A lane is in state T (walking nodes), L (a hit
+// leaf is pending its triangle test) or I (no ray).  Per iteration the wave
+// runs, chosen with scalar ballots only, ONE straight-line predicated body:
+// refill the I lanes from the tile's ray queue, test the L lanes' triangles, or
+// advance the T lanes by one node.  This keeps the wave from paying for its
+// longest ray and from running a 150-instruction triangle test for two lanes.
+constexpr uint32_t REFILL_MIN = 16;  // refill once this many lanes are idle ...
+constexpr uint32_t LEAF_MIN = 16;    // ... test triangles once this many leaves are pending
+
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void trace_tiles_kernel(
+    const float4 *__restrict__ nodes_ptr, const uint4 *__restrict__ cnodes_ptr, const float4 *__restrict__ tris_ptr,
+    const float4 *__restrict__ shade, const float4 *__restrict__ ao_table, float *__restrict__ image, KernelParams P,
+    uint2 *__restrict__ tile_stats) {
 	__shared__ TileShared shared_tiles[WAVES_PER_BLOCK];
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t wave = threadIdx.x >> 6;
 	TileShared &sh = shared_tiles[wave];
+
+	// descriptors are built from kernel arguments only, so they live in SGPRs
+	SceneViews scene;
+	scene.nodes = __builtin_amdgcn_make_buffer_rsrc((void *) nodes_ptr, 0, (int) (P.node_count * 32u), 0x00020000);
+	scene.cnodes = __builtin_amdgcn_make_buffer_rsrc((void *) cnodes_ptr, 0, (int) (P.node_count * 16u), 0x00020000);
+	scene.tris = __builtin_amdgcn_make_buffer_rsrc((void *) tris_ptr, 0,
+	                                               (int) (P.tri_count * (uint32_t) sizeof(TriRec)), 0x00020000);
 
 	// Workgroup = 2x2 tiles (16x16 sub-pixels).  Workgroups b and b+8 share an
 	// XCD and its L2 (MI355X_MICROARCH.md, dispatch is round-robin over XCDs), so
@@ -270,7 +289,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void trace_tiles_kernel(const
 	// round-robin to the 8 XCD groups, and each group walks its strips top to
 	// bottom: neighbouring workgroups of a group touch the same BVH region, while
 	// every group still sees the whole image height (cost per tile varies 30x
-	// between background and model, so contiguous image blocks would idle XCDs).
+	// between background and model, so contiguous image chunks would idle XCDs).
 	const uint32_t group = blockIdx.x & 7u, seq = blockIdx.x >> 3;
 	const uint32_t strips = (P.tiles_x + 1u) >> 1;
 	const uint32_t row_pairs = (P.local_tile_rows + 1u) >> 1;
@@ -288,23 +307,62 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void trace_tiles_kernel(const
 	const uint32_t x = tile_x * TILE_W + (lane & 7u);
 	const uint32_t y = tile_y * TILE_H + (lane >> 3);
 	const bool active = x < P.width && y < P.height;
+	const uint32_t count = P.node_count;
+	const unsigned long long lanes_below = (1ull << lane) - 1ull;
 
-	// ---- phase 1: primary ray, reference src/intersect_kernel.cl:279-295 ----
+	// ---- phase 1: primary rays (closest hit), reference :279-295 ----
 	float dx = ((float) x + 0.5f) / P.a - P.half_w;
 	float dy = -(((float) y + 0.5f) / P.a - P.half_h);
 	float dz = -1.0f;
 	normalize3(dx, dy, dz);
-	const Ray primary = make_ray(0.0f, 0.0f, 2.0f, dx, dy, dz);
+	Ray ray = make_ray(0.0f, 0.0f, 2.0f, dx, dy, dz);
+	bool regular = P.scene_regular && ray_is_regular(ray);
 	Hit best;
 	best.distance = __builtin_inff();
 	best.leaf = 0;
 	best.s = best.t = 0.0f;
 	best.px = best.py = best.pz = 0.0f;
 	bool hit = false;
-	if (active)
-		hit = traverse<true>(nodes, tris, P.node_count, primary, 100000.0f, best);
+	{
+		uint32_t i = active ? 0u : count;
+		uint32_t pending = NONE;
+		for (;;) {
+			const bool walking_lane = pending == NONE && i < count;
+			const unsigned long long walking = __ballot(walking_lane);
+			const unsigned long long leaves = __ballot(pending != NONE);
+			if (leaves != 0ull && ((uint32_t) __popcll(leaves) >= LEAF_MIN || walking == 0ull)) {
+				if (pending != NONE) {
+					const TriResult tr = tri_test<true>(scene, pending, ray, regular, P.primary_below);
+					// closest hit: strict '>' in ascending leaf order, reference :106-112
+					if (tr.accepted) {
+						hit = true;
+						if (best.distance > tr.distance) {
+							best.distance = tr.distance;
+							best.leaf = pending;
+							best.s = tr.s;
+							best.t = tr.t;
+							best.px = tr.px; best.py = tr.py; best.pz = tr.pz;
+						}
+					}
+					pending = NONE;
+				}
+				continue;
+			}
+			if (walking == 0ull)
+				break;
+			const bool all_regular = __ballot(walking_lane && !regular) == 0ull;
+			if (walking_lane) {
+				if (all_regular && P.compressed)
+					node_step<STEP_COMPRESSED>(scene, ray, 100000.0f, P.primary_below, i, pending);
+				else if (all_regular)
+					node_step<STEP_REGULAR>(scene, ray, 100000.0f, P.primary_below, i, pending);
+				else
+					node_step<STEP_EXACT>(scene, ray, 100000.0f, P.primary_below, i, pending);
+			}
+		}
+	}
 
-	// ---- phase 2: shading inputs for the hit lanes, :296-304 and :215-236 ----
+	// ---- phase 2: shading inputs for the hit lanes, reference :296-304 and :215-236 ----
 	float value = 0.0f;
 	float nx = 0.0f, ny = 0.0f, nz = 0.0f;
 	uint32_t occluded_here = 0;
@@ -321,10 +379,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void trace_tiles_kernel(const
 		if (P.shading)
 			value = fminf(fmaxf(-dot3(nx, ny, nz, dx, dy, dz), 0.0f), 1.0f);
 	}
-
 	const unsigned long long hit_mask = __ballot(hit);
 	const uint32_t hit_count = (uint32_t) __popcll(hit_mask);
-	const uint32_t slot = (uint32_t) __popcll(hit_mask & ((1ull << lane) - 1ull));
+	const uint32_t slot = (uint32_t) __popcll(hit_mask & lanes_below);
 
 	if (P.ao_mode == AO_UNIFORM && P.ao_dirs > 0 && hit_count > 0) {
 		if (hit) {
@@ -354,220 +411,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void trace_tiles_kernel(const
 		}
 		wave_lds_sync();
 
-		// ---- phase 3: any-hit AO rays, :237-255, dealt to all 64 lanes ----
-		const uint32_t total = hit_count * P.ao_dirs;
-		for (uint32_t item = lane; item < total; item += 64u) {
-			const uint32_t k = item / hit_count;
-			const uint32_t h = item - k * hit_count;
-			const float4 dir = ao_table[k];
-			const float rx = (sh.frame[3][h] * dir.x + sh.frame[6][h] * dir.y) + sh.frame[9][h] * dir.z;
-			const float ry = (sh.frame[4][h] * dir.x + sh.frame[7][h] * dir.y) + sh.frame[10][h] * dir.z;
-			const float rz = (sh.frame[5][h] * dir.x + sh.frame[8][h] * dir.y) + sh.frame[11][h] * dir.z;
-			const Ray ao = make_ray(sh.frame[0][h], sh.frame[1][h], sh.frame[2][h], rx, ry, rz);
-			Hit unused;
-			if (traverse<false>(nodes, tris, P.node_count, ao, P.ao_max_distance, unused))
-				atomicAdd(&sh.occluded[h], 1u);
-		}
-		wave_lds_sync();
-
-		// ---- phase 4: value *= 1 - hits / n, :256 and :305-307 ----
-		if (hit) {
-			const uint32_t occluded = sh.occluded[slot];
-			value *= 1.0f - ((float) occluded / (float) P.ao_dirs);
-			occluded_here = occluded;
-		}
-	}
-
-	if (active)
-		image[(size_t) y * P.width + x] = value;
-
-	// Per-tile counters (plain stores, summed on demand by the host): primary
-	// hits and occluded AO rays of this tile.
-	if (tile_stats) {
-		uint32_t occluded_sum = occluded_here;
-		for (int offset = 32; offset > 0; offset >>= 1)
-			occluded_sum += __shfl_xor(occluded_sum, offset);
-		if (lane == 0)
-			tile_stats[tile] = make_uint2(hit_count, occluded_sum);
-	}
-}
-
-// Triangle test for a pending leaf, straight-line.  Same operations and order
-// as tri_hit above (reference src/intersect_kernel.cl:65-114); the early returns
-// become one accumulated predicate so that all L lanes stay converged.
-struct TriResult {
-	bool accepted;
-	float s, t, distance;
-	float px, py, pz;
-};
-
-template <bool CLOSEST>
-__device__ __forceinline__ TriResult tri_test(__amdgpu_buffer_rsrc_t tris, uint32_t leaf, const Ray &r) {
-	const float4 q0 = load_f4(tris, leaf * 64u), q1 = load_f4(tris, leaf * 64u + 16u);
-	const float4 q2 = load_f4(tris, leaf * 64u + 32u), q3 = load_f4(tris, leaf * 64u + 48u);
-	const float tax = q0.x, tay = q0.y, taz = q0.z;
-	const float ux = q0.w, uy = q1.x, uz = q1.y;
-	const float vx = q1.z, vy = q1.w, vz = q2.x;
-	const float nx = q2.y, ny = q2.z, nz = q2.w;
-	const float uu = q3.x, uv = q3.y, vv = q3.z, D = q3.w;
-	const float a = -dot3(nx, ny, nz, r.ox - tax, r.oy - tay, r.oz - taz);
-	const float b = dot3(nx, ny, nz, r.dx, r.dy, r.dz);
-	const float rr = a / b;
-	const float ipx = r.ox + rr * r.dx, ipy = r.oy + rr * r.dy, ipz = r.oz + rr * r.dz;
-	const float wx = ipx - tax, wy = ipy - tay, wz = ipz - taz;
-	const float wu = dot3(ux, uy, uz, wx, wy, wz);
-	const float wv = dot3(wx, wy, wz, vx, vy, vz);
-	const float slack_hi = __uint_as_float(0x3F800053u);
-	const float s = (uv * wv - vv * wu) / D;
-	const float t = (uv * wu - uu * wv) / D;
-	// reject: |b| < 1e-6, r < 0, s < -1e-5, s > 1.00001, t < -1e-5, s + t > 1.00001
-	const bool reject = (fabsf(b) < 0.000001f) | (rr < 0.0f) | (s < -0.00001f) | (s > slack_hi) | (t < -0.00001f) |
-	                    ((s + t) > slack_hi);
-	TriResult out;
-	out.accepted = !reject;
-	out.s = s;
-	out.t = t;
-	out.px = ipx; out.py = ipy; out.pz = ipz;
-	out.distance = 0.0f;
-	if (CLOSEST) {
-		const float ex = ipx - r.ox, ey = ipy - r.oy, ez = ipz - r.oz;
-		out.distance = sqrtf(dot3(ex, ey, ez, ex, ey, ez));
-	}
-	return out;
-}
-
-// Variant 2 of the tile kernel: same phases as trace_tiles_kernel, rays run by
-// the wave scheduler described above.
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void trace_tiles_sched_kernel(
-    const float4 *__restrict__ nodes_ptr, const float4 *__restrict__ tris_ptr, const float4 *__restrict__ shade,
-    const float4 *__restrict__ ao_table, float *__restrict__ image, KernelParams P, uint2 *__restrict__ tile_stats) {
-	__shared__ TileShared shared_tiles[WAVES_PER_BLOCK];
-	// descriptors are built from kernel arguments only, so they live in SGPRs
-	const __amdgpu_buffer_rsrc_t nodes =
-	    __builtin_amdgcn_make_buffer_rsrc((void *) nodes_ptr, 0, (int) (P.node_count * 32u), 0x00020000);
-	const __amdgpu_buffer_rsrc_t tris =
-	    __builtin_amdgcn_make_buffer_rsrc((void *) tris_ptr, 0, (int) (P.tri_count * 64u), 0x00020000);
-	const uint32_t lane = threadIdx.x & 63u;
-	const uint32_t wave = threadIdx.x >> 6;
-	TileShared &sh = shared_tiles[wave];
-
-	// workgroup -> 2x2 tiles, strips dealt round-robin to the 8 XCD groups (see variant 1)
-	const uint32_t group = blockIdx.x & 7u, seq = blockIdx.x >> 3;
-	const uint32_t strips = (P.tiles_x + 1u) >> 1;
-	const uint32_t row_pairs = (P.local_tile_rows + 1u) >> 1;
-	const uint32_t strips_here = (strips + 7u - group) >> 3;
-	if (seq >= strips_here * row_pairs)
-		return;
-	const uint32_t strip_index = seq / row_pairs;
-	const uint32_t row_pair = seq - strip_index * row_pairs;
-	const uint32_t tile_x = 2u * (group + 8u * strip_index) + (wave & 1u);
-	const uint32_t local_row = 2u * row_pair + (wave >> 1);
-	if (tile_x >= P.tiles_x || local_row >= P.local_tile_rows)
-		return;
-	const uint32_t tile = local_row * P.tiles_x + tile_x;
-	const uint32_t tile_y = global_tile_row(P.part, local_row);
-	const uint32_t x = tile_x * TILE_W + (lane & 7u);
-	const uint32_t y = tile_y * TILE_H + (lane >> 3);
-	const bool active = x < P.width && y < P.height;
-	const uint32_t count = P.node_count;
-	const unsigned long long lanes_below = (1ull << lane) - 1ull;
-
-	// ---- phase 1: primary rays (closest hit), no refill ----
-	float dx = ((float) x + 0.5f) / P.a - P.half_w;
-	float dy = -(((float) y + 0.5f) / P.a - P.half_h);
-	float dz = -1.0f;
-	normalize3(dx, dy, dz);
-	Ray ray = make_ray(0.0f, 0.0f, 2.0f, dx, dy, dz);
-	bool regular = P.scene_regular && ray_is_regular(ray);
-	Hit best;
-	best.distance = __builtin_inff();
-	best.leaf = 0;
-	best.s = best.t = 0.0f;
-	best.px = best.py = best.pz = 0.0f;
-	bool hit = false;
-	{
-		uint32_t i = active ? 0u : count;
-		uint32_t pending = NONE;
-		for (;;) {
-			const unsigned long long walking = __ballot(pending == NONE && i < count);
-			const unsigned long long leaves = __ballot(pending != NONE);
-			if (leaves != 0ull && ((uint32_t) __popcll(leaves) >= LEAF_MIN || walking == 0ull)) {
-				if (pending != NONE) {
-					const TriResult tr = tri_test<true>(tris, pending, ray);
-					if (tr.accepted) {
-						hit = true;
-						if (best.distance > tr.distance) {
-							best.distance = tr.distance;
-							best.leaf = pending;
-							best.s = tr.s;
-							best.t = tr.t;
-							best.px = tr.px; best.py = tr.py; best.pz = tr.pz;
-						}
-					}
-					pending = NONE;
-				}
-				continue;
-			}
-			if (walking == 0ull)
-				break;
-			if (pending == NONE && i < count) {
-				if (__ballot(!regular) == 0ull)
-					node_step<true>(nodes, ray, 100000.0f, P.primary_below, i, pending);
-				else
-					node_step<false>(nodes, ray, 100000.0f, P.primary_below, i, pending);
-			}
-		}
-	}
-
-	// ---- phase 2: shading inputs for the hit lanes ----
-	float value = 0.0f;
-	float nx = 0.0f, ny = 0.0f, nz = 0.0f;
-	uint32_t occluded_here = 0;
-	if (hit) {
-		const float4 n0 = shade[3 * (size_t) best.leaf + 0];
-		const float4 n1 = shade[3 * (size_t) best.leaf + 1];
-		const float4 n2 = shade[3 * (size_t) best.leaf + 2];
-		const float b0 = 1.0f - best.s - best.t, b1 = best.s, b2 = best.t;
-		nx = (n0.x * b0 + n1.x * b1) + n2.x * b2;
-		ny = (n0.y * b0 + n1.y * b1) + n2.y * b2;
-		nz = (n0.z * b0 + n1.z * b1) + n2.z * b2;
-		normalize3(nx, ny, nz);
-		value = 1.0f;
-		if (P.shading)
-			value = fminf(fmaxf(-dot3(nx, ny, nz, dx, dy, dz), 0.0f), 1.0f);
-	}
-	const unsigned long long hit_mask = __ballot(hit);
-	const uint32_t hit_count = (uint32_t) __popcll(hit_mask);
-	const uint32_t slot = (uint32_t) __popcll(hit_mask & lanes_below);
-
-	if (P.ao_mode == AO_UNIFORM && P.ao_dirs > 0 && hit_count > 0) {
-		if (hit) {
-			const float eps = 1.0f / 100000.0f;
-			sh.frame[0][slot] = best.px + nx * eps;
-			sh.frame[1][slot] = best.py + ny * eps;
-			sh.frame[2][slot] = best.pz + nz * eps;
-			float hx = nx, hy = ny, hz = nz;
-			const float ax = fabsf(nx), ay = fabsf(ny), az = fabsf(nz);
-			if (ax <= ay && ax <= az)
-				hx = 1.0f;
-			else if (ay <= ax && ay <= az)
-				hy = 1.0f;
-			else if (az <= ax && az <= ay)
-				hz = 1.0f;
-			float bxx = hy * nz - hz * ny, bxy = hz * nx - hx * nz, bxz = hx * ny - hy * nx;
-			normalize3(bxx, bxy, bxz);
-			float bzx = bxy * nz - bxz * ny, bzy = bxz * nx - bxx * nz, bzz = bxx * ny - bxy * nx;
-			normalize3(bzx, bzy, bzz);
-			sh.frame[3][slot] = bxx; sh.frame[4][slot] = bxy; sh.frame[5][slot] = bxz;
-			sh.frame[6][slot] = nx;  sh.frame[7][slot] = ny;  sh.frame[8][slot] = nz;
-			sh.frame[9][slot] = bzx; sh.frame[10][slot] = bzy; sh.frame[11][slot] = bzz;
-			sh.occluded[slot] = 0u;
-		}
-		wave_lds_sync();
-
-		// ---- phase 3: the tile's hit_count * ao_dirs any-hit rays, queue order is
-		// direction-major so that neighbouring lanes cast the same table direction
-		// from neighbouring pixels ----
+		// ---- phase 3: the tile's hit_count * ao_dirs any-hit rays (reference
+		// :237-255).  Queue order is direction-major, so neighbouring lanes cast
+		// the same table direction from neighbouring surface points. ----
 		const uint32_t total = hit_count * P.ao_dirs;
 		uint32_t next = 0;  // wave-uniform queue head
 		uint32_t i = count;
@@ -587,6 +433,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void trace_tiles_sched_kernel
 					const uint32_t k = item / hit_count;
 					h = item - k * hit_count;
 					const float4 dir = ao_table[k];
+					// ray_dir = basis_x * xs + basis_y * ys + basis_z * zs, lane by lane
 					const float rx = (sh.frame[3][h] * dir.x + sh.frame[6][h] * dir.y) + sh.frame[9][h] * dir.z;
 					const float ry = (sh.frame[4][h] * dir.x + sh.frame[7][h] * dir.y) + sh.frame[10][h] * dir.z;
 					const float rz = (sh.frame[5][h] * dir.x + sh.frame[8][h] * dir.y) + sh.frame[11][h] * dir.z;
@@ -599,10 +446,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void trace_tiles_sched_kernel
 			}
 			if (leaves != 0ull && ((uint32_t) __popcll(leaves) >= LEAF_MIN || walking == 0ull)) {
 				if (pending != NONE) {
-					const TriResult tr = tri_test<false>(tris, pending, ray);
+					const TriResult tr = tri_test<false>(scene, pending, ray, regular, P.ao_below);
 					if (tr.accepted) {
 						atomicAdd(&sh.occluded[h], 1u);
-						i = count;  // any-hit: this ray is done
+						i = count;  // any-hit: the reference walks on but only uses the boolean (:251)
 					}
 					pending = NONE;
 				}
@@ -610,16 +457,19 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void trace_tiles_sched_kernel
 			}
 			if (walking == 0ull)
 				break;
+			const bool all_regular = __ballot(walking_lane && !regular) == 0ull;
 			if (walking_lane) {
-				if (__ballot(!regular) == 0ull)
-					node_step<true>(nodes, ray, P.ao_max_distance, P.ao_below, i, pending);
+				if (all_regular && P.compressed)
+					node_step<STEP_COMPRESSED>(scene, ray, P.ao_max_distance, P.ao_below, i, pending);
+				else if (all_regular)
+					node_step<STEP_REGULAR>(scene, ray, P.ao_max_distance, P.ao_below, i, pending);
 				else
-					node_step<false>(nodes, ray, P.ao_max_distance, P.ao_below, i, pending);
+					node_step<STEP_EXACT>(scene, ray, P.ao_max_distance, P.ao_below, i, pending);
 			}
 		}
 		wave_lds_sync();
 
-		// ---- phase 4 ----
+		// ---- phase 4: value *= 1 - hits / n, reference :256 and :305-307 ----
 		if (hit) {
 			const uint32_t occluded = sh.occluded[slot];
 			value *= 1.0f - ((float) occluded / (float) P.ao_dirs);
@@ -630,6 +480,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void trace_tiles_sched_kernel
 	if (active)
 		image[(size_t) y * P.width + x] = value;
 
+	// Per-tile counters (plain stores, summed on demand by the host): primary
+	// hits and occluded AO rays of this tile.
 	if (tile_stats) {
 		uint32_t occluded_sum = occluded_here;
 		for (int offset = 32; offset > 0; offset >>= 1)
@@ -667,21 +519,16 @@ __global__ __launch_bounds__(256) void resize_kernel(const float *__restrict__ t
 }
 
 // ---- host-callable launchers (keeps the launch syntax inside this TU) ----
-void launch_trace_tiles(const void *nodes, const void *tris, const void *shade, const void *ao_table, float *image,
-                        const KernelParams &P, void *tile_stats, void *stream) {
+void launch_trace_tiles(const void *nodes, const void *cnodes, const void *tris, const void *shade,
+                        const void *ao_table, float *image, const KernelParams &P, void *tile_stats, void *stream) {
 	const uint32_t total_tiles = P.tiles_x * P.local_tile_rows;
 	if (total_tiles == 0)
 		return;
 	const uint32_t strips = (P.tiles_x + 1u) >> 1, row_pairs = (P.local_tile_rows + 1u) >> 1;
 	const uint32_t blocks = 8u * ((strips + 7u) >> 3) * row_pairs;
-	if (P.variant == 1)
-		hipLaunchKernelGGL(trace_tiles_kernel, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, (hipStream_t) stream,
-		                   (const float4 *) nodes, (const float4 *) tris, (const float4 *) shade,
-		                   (const float4 *) ao_table, image, P, (uint2 *) tile_stats);
-	else
-		hipLaunchKernelGGL(trace_tiles_sched_kernel, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, (hipStream_t) stream,
-		                   (const float4 *) nodes, (const float4 *) tris, (const float4 *) shade,
-		                   (const float4 *) ao_table, image, P, (uint2 *) tile_stats);
+	hipLaunchKernelGGL(trace_tiles_kernel, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, (hipStream_t) stream,
+	                   (const float4 *) nodes, (const uint4 *) cnodes, (const float4 *) tris, (const float4 *) shade,
+	                   (const float4 *) ao_table, image, P, (uint2 *) tile_stats);
 }
 
 void launch_resize(const float *tmp, unsigned char *out, const KernelParams &P, uint32_t out_width, uint32_t n,
