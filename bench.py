@@ -195,31 +195,17 @@ def main():
     host.set_stream(stream.cuda_stream)
 
     # band buffers: equal-sized on every rank so the gather is one collective
-    local_rows = host.local_rows
-    max_rows = max(int(rt.partition_rows(opt, r, world).size) for r in range(world))
-    band = torch.zeros((max_rows, opt.width), dtype=torch.uint8, device=device)
-    final = torch.zeros((opt.height, opt.width), dtype=torch.uint8, device=device)
-    gather_list, src_index, dst_index = None, None, None
-    if rank == 0 and world > 1:
-        gather_list = [torch.zeros_like(band) for _ in range(world)]
-        src, dst = [], []
-        for r in range(world):
-            rows = rt.partition_rows(opt, r, world)
-            for j, g in enumerate(rows):
-                if g < opt.height:
-                    src.append(r * max_rows + j)
-                    dst.append(int(g))
-        src_index = torch.tensor(src, dtype=torch.long, device=device)
-        dst_index = torch.tensor(dst, dtype=torch.long, device=device)
+    from opencl_raytracer_amd.multi_gpu import BandLayout, gather_bands
+
+    layout = BandLayout(opt, world)
+    assert layout.local_rows(rank) == host.local_rows
+    band = torch.zeros((layout.max_rows, opt.width), dtype=torch.uint8, device=device)
+    result = {}
 
     def step():
         host.render_async()
         host.resize_into_device(band.data_ptr())
-        if world > 1:
-            dist.gather(band, gather_list, dst=0)
-            if rank == 0:
-                stacked = torch.cat(gather_list, dim=0)
-                final.index_copy_(0, dst_index, stacked.index_select(0, src_index))
+        result["final"] = gather_bands(band, layout, rank)
 
     def fence():
         torch.cuda.synchronize(device)
@@ -255,10 +241,7 @@ def main():
         total_rays, total_hits, total_occluded = my_rays, st["primary_hits"], st["ao_occluded"]
 
     if rank == 0:
-        if world == 1:
-            final_u8 = band[:opt.height].cpu().numpy()
-        else:
-            final_u8 = final.cpu().numpy()
+        final_u8 = result["final"].cpu().numpy()
         pgm_md5 = hashlib.md5(rt.pgm_bytes(final_u8)).hexdigest()
         golden_md5, counters = None, None
         if w["golden"]:
