@@ -148,11 +148,6 @@ double rt_total_kernel_ms(const rt_host *h);
 uint64_t rt_kernel_launches(const rt_host *h);
 void rt_reset_timers(rt_host *h);
 
-/* Test hooks for the node compression (binary16 bounds rounded outward): the
- * largest half <= v (toward < 0) / smallest half >= v (toward > 0), |v| <= 65504. */
-uint16_t rt_debug_half_outward(float v, int toward);
-float rt_debug_half_to_float(uint16_t h);
-
 /* OpenCLHost::printInfo, reference src/opencl_host.cc:76-119. */
 void rt_print_info(void);
 /* Number of visible HIP devices (0 without a GPU; never fails). */

@@ -121,8 +121,6 @@ _SIGNATURES = {
     "rt_total_kernel_ms": (C.c_double, [C.c_void_p]),
     "rt_kernel_launches": (C.c_uint64, [C.c_void_p]),
     "rt_reset_timers": (None, [C.c_void_p]),
-    "rt_debug_half_outward": (C.c_uint16, [C.c_float, C.c_int]),
-    "rt_debug_half_to_float": (C.c_float, [C.c_uint16]),
     "rt_print_info": (None, []),
     "rt_device_count": (C.c_int, []),
 }

@@ -323,9 +323,6 @@ void rt_reset_timers(rt_host *h) {
 		h->dev->resetTimers();
 }
 
-uint16_t rt_debug_half_outward(float v, int toward) { return ocrt::half_bits_outward(v, toward); }
-float rt_debug_half_to_float(uint16_t h) { return ocrt::half_bits_to_float(h); }
-
 void rt_print_info(void) { HipHost::printInfo(); }
 int rt_device_count(void) { return ocrt::visible_device_count(); }
 

@@ -48,7 +48,7 @@ DeviceRenderer::DeviceRenderer(const RayTracer::Options &options, int device_, u
 	, own_stream(nullptr)
 	, stream(nullptr)
 	, d_nodes(nullptr)
-	, d_cnodes(nullptr)
+	, d_wnodes(nullptr)
 	, d_tris(nullptr)
 	, d_shade(nullptr)
 	, d_ao(nullptr)
@@ -77,7 +77,7 @@ DeviceRenderer::DeviceRenderer(const RayTracer::Options &options, int device_, u
 	part.rank = rank;
 	part.nranks = nranks;
 	part.band_tile_rows = band_tile_rows_for(grid);
-	kp = make_kernel_params(rt, 0, 0, 0, part, false, false);
+	kp = make_kernel_params(rt, 0, 0, 0, part, false, false, 0.0f);
 	local_out_rows = kp.local_tile_rows * TILE_H / grid;
 	tile_count = (size_t) kp.tiles_x * kp.local_tile_rows;
 
@@ -118,7 +118,7 @@ void DeviceRenderer::useDevice() const { OCRT_HIP(hipSetDevice(device)); }
 
 void DeviceRenderer::freeScene() {
 	device_free(d_nodes);
-	device_free(d_cnodes);
+	device_free(d_wnodes);
 	device_free(d_tris);
 	device_free(d_shade);
 	device_free(d_ao);
@@ -148,27 +148,27 @@ size_t DeviceRenderer::upload(const PackedScene &scene) {
 		}
 	}
 	kp = make_kernel_params(rt, (uint32_t) scene.nodes.size(), (uint32_t) scene.tris.size(), ao_dirs, part, scene.regular,
-	                        scene.compressible);
+	                        scene.walkable, scene.origin_limit);
 	const size_t nodes_bytes = scene.nodes.size() * sizeof(NodeRec);
-	const size_t cnodes_bytes = scene.cnodes.size() * sizeof(CNodeRec);
+	const size_t wnodes_bytes = scene.wnodes.size() * sizeof(WalkNodeRec);
 	const size_t tris_bytes = scene.tris.size() * sizeof(TriRec);
 	const size_t shade_bytes = scene.shade.size() * sizeof(ShadeRec);
 	const size_t ao_bytes = table.size() * sizeof(float);
 	d_nodes = device_alloc(nodes_bytes);
-	d_cnodes = device_alloc(cnodes_bytes);
+	d_wnodes = device_alloc(wnodes_bytes);
 	d_tris = device_alloc(tris_bytes);
 	d_shade = device_alloc(shade_bytes);
 	d_ao = device_alloc(ao_bytes);
 	OCRT_HIP(hipMemcpy(d_nodes, scene.nodes.data(), nodes_bytes, hipMemcpyHostToDevice));
-	if (cnodes_bytes)
-		OCRT_HIP(hipMemcpy(d_cnodes, scene.cnodes.data(), cnodes_bytes, hipMemcpyHostToDevice));
+	if (wnodes_bytes)
+		OCRT_HIP(hipMemcpy(d_wnodes, scene.wnodes.data(), wnodes_bytes, hipMemcpyHostToDevice));
 	OCRT_HIP(hipMemcpy(d_tris, scene.tris.data(), tris_bytes, hipMemcpyHostToDevice));
 	OCRT_HIP(hipMemcpy(d_shade, scene.shade.data(), shade_bytes, hipMemcpyHostToDevice));
 	if (ao_bytes)
 		OCRT_HIP(hipMemcpy(d_ao, table.data(), ao_bytes, hipMemcpyHostToDevice));
 	OCRT_HIP(hipDeviceSynchronize());
 	scene_ready = true;
-	return nodes_bytes + cnodes_bytes + tris_bytes + shade_bytes + ao_bytes + (size_t) rt.totalWidth * rt.totalHeight * sizeof(float) +
+	return nodes_bytes + wnodes_bytes + tris_bytes + shade_bytes + ao_bytes + (size_t) rt.totalWidth * rt.totalHeight * sizeof(float) +
 	       (size_t) local_out_rows * opts.width + tile_count * sizeof(uint2);
 }
 
@@ -187,7 +187,7 @@ void DeviceRenderer::enqueueRender() {
 		ev = { a, b };
 	}
 	OCRT_HIP(hipEventRecord((hipEvent_t) ev.first, (hipStream_t) stream));
-	launch_trace_tiles(d_nodes, d_cnodes, d_tris, d_shade, d_ao, (float *) d_image, kp, d_tile_stats, stream);
+	launch_trace_tiles(d_nodes, d_wnodes, d_tris, d_shade, d_ao, (float *) d_image, kp, d_tile_stats, stream);
 	OCRT_HIP(hipGetLastError());
 	OCRT_HIP(hipEventRecord((hipEvent_t) ev.second, (hipStream_t) stream));
 	pending_events.push_back(ev);

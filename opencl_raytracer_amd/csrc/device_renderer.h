@@ -78,7 +78,7 @@ class DeviceRenderer {
 		uint32_t grid;            // supersample grid side
 		uint32_t local_out_rows;
 		void *own_stream, *stream;
-		void *d_nodes, *d_cnodes, *d_tris, *d_shade, *d_ao, *d_image, *d_u8, *d_tile_stats;
+		void *d_nodes, *d_wnodes, *d_tris, *d_shade, *d_ao, *d_image, *d_u8, *d_tile_stats;
 		size_t tile_count;
 		bool scene_ready, frame_ready;
 		std::vector<std::pair<void *, void *>> pending_events, free_events;
@@ -88,7 +88,7 @@ class DeviceRenderer {
 };
 
 // kernels.hip
-void launch_trace_tiles(const void *nodes, const void *cnodes, const void *tris, const void *shade, const void *ao_table, float *image,
+void launch_trace_tiles(const void *nodes, const void *wnodes, const void *tris, const void *shade, const void *ao_table, float *image,
                         const KernelParams &P, void *tile_stats, void *stream);
 void launch_resize(const float *tmp, unsigned char *out, const KernelParams &P, uint32_t out_width, uint32_t n,
                    uint32_t local_out_rows, void *stream);

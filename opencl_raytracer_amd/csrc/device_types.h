@@ -17,20 +17,19 @@ struct NodeRec {
 };
 static_assert(sizeof(NodeRec) == 32, "NodeRec is two float4");
 
-// Compressed node, 16 bytes = ONE 128-bit gather per visit.  The box is stored
-// as six binary16 values rounded OUTWARD (lo down, hi up), i.e. a superset of
-// the exact box: a superset box can only add node visits, never remove one, and
-// every triangle is still gated by its exact box (kept in TriRec) before its
-// test, so results do not change.  `link` is the subtree
-// size for an inner node and 0x80000000 | leaf index for a leaf.
-struct CNodeRec {
-	uint16_t lo[3];
-	uint16_t hi[3];
-	uint32_t link;
+// Walk node, 32 bytes: the node's box ENLARGED by a safety margin, laid out as
+// (lo, hi) pairs per axis so that the three fused multiply-adds of the
+// conservative slab test are packed instructions.  A superset box can only add
+// node visits, never remove one, and every triangle is still gated by its exact
+// box (kept in TriRec) before its test, so results do not change
+// (SURVEY.md 8a-0.7); kernels.hip states the error bound behind the margin.
+struct WalkNodeRec {
+	float lox, hix, loy, hiy;
+	float loz, hiz;
+	uint32_t skip;  // subtree size in nodes; 1 = leaf
+	uint32_t leaf;  // leaf index, 0xFFFFFFFF for inner nodes
 };
-static_assert(sizeof(CNodeRec) == 16, "CNodeRec is one uint4");
-constexpr uint32_t CNODE_LEAF_FLAG = 0x80000000u;
-constexpr float CNODE_MAX_COORD = 65504.0f;  // largest finite binary16
+static_assert(sizeof(WalkNodeRec) == 32, "WalkNodeRec is two float4");
 
 // Per-triangle record, 96 bytes = six float4: the invariants of the reference's
 // plane/parametric test (reference src/intersect_kernel.cl:67-90), precomputed
@@ -78,9 +77,10 @@ struct KernelParams {
 	int32_t ao_mode;       // AoMode
 	float ao_max_distance; // AO_MAX_DISTANCE
 	uint32_t ao_dirs;      // UNIFORM: rays per hit sub-pixel; RANDOM: AO_NUM_SAMPLES
-	int32_t variant;       // debug: 0 = default, 2 = never use the compressed nodes
-	int32_t scene_regular; // every box finite, |coord| <= 1e37 and lo <= hi: min/max slab form allowed
-	int32_t compressed;    // CNodeRec array usable (scene_regular and |coord| <= 65504)
+	int32_t variant;       // debug: 0 = default, 2 = never use the walk nodes (exact boxes only)
+	int32_t scene_regular; // every box finite, |coord| <= 1e37, lo <= hi, children inside parents
+	int32_t walk_ok;       // WalkNodeRec array usable (scene_regular and coordinates small enough)
+	float origin_limit;    // rays whose |origin| exceeds this use the exact boxes (margin was sized for it)
 	int32_t ao_regular;    // AO_MAX_DISTANCE > 0 (needed by the folded form of the slab test)
 	float primary_below;   // largest float below the primary rays' max_distance (100000.0f)
 	float ao_below;        // largest float below AO_MAX_DISTANCE

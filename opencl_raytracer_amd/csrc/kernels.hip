@@ -18,11 +18,13 @@
 //   phase 4  hit lanes fold the occlusion fraction in and store the float.
 //
 // What bounds it (profiles/r01_notes.md): the scene (12 MB) lives in L2, HBM
-// traffic is negligible; the limiter is the vector L1's tag pipeline, which
-// serves about one cache line per clock per CU and sees every lane of a
-// divergent 128-bit gather as its own line.  Hence: ONE 16-byte gather per
-// node visit (CNodeRec), and a wave-level scheduler that keeps lanes busy so
-// that fewer, fuller gathers are issued.
+// traffic is negligible; the vector ALU is ~80 % busy (a wave64 VALU
+// instruction holds its SIMD for four cycles) and every node visit is a
+// dependent L1/L2 round trip.  Hence: as few VALU instructions per node visit as
+// the arithmetic contract allows (a conservative, packed-FMA box test on
+// enlarged boxes for the walk; the exact test only where the reference's result
+// depends on it, i.e. at the leaves), and a wave-level scheduler that keeps the
+// lanes busy.
 #include <hip/hip_runtime.h>
 
 #include "device_types.h"
@@ -35,6 +37,7 @@ struct Ray {
 	float ox, oy, oz;
 	float dx, dy, dz;
 	float ix, iy, iz;  // 1.0f / d, hoisted out of the per-node slab test
+	float cx, cy, cz;  // -(o * inv): lets the conservative walk test be one fma per plane
 };
 
 struct Hit {
@@ -64,6 +67,9 @@ __device__ __forceinline__ Ray make_ray(float ox, float oy, float oz, float dx, 
 	r.ix = 1.0f / dx;
 	r.iy = 1.0f / dy;
 	r.iz = 1.0f / dz;
+	r.cx = -(ox * r.ix);
+	r.cy = -(oy * r.iy);
+	r.cz = -(oz * r.iz);
 	return r;
 }
 
@@ -103,6 +109,16 @@ __device__ __forceinline__ bool ray_is_regular(const Ray &r) {
 	       r.ix != 0.0f && r.iy != 0.0f && r.iz != 0.0f;
 }
 
+// May this ray use the enlarged walk boxes?  Origin within the bound the margin
+// was sized for, reciprocal direction in [2^-60, 2^100] (no overflow of o*inv,
+// no underflow of margin*inv).
+__device__ __forceinline__ bool ray_is_walkable(const Ray &r, float origin_limit) {
+	const float inv_lo = 8.6736174e-19f, inv_hi = 1.2676506e30f;
+	return fabsf(r.ox) <= origin_limit && fabsf(r.oy) <= origin_limit && fabsf(r.oz) <= origin_limit &&
+	       fabsf(r.ix) >= inv_lo && fabsf(r.ix) <= inv_hi && fabsf(r.iy) >= inv_lo && fabsf(r.iy) <= inv_hi &&
+	       fabsf(r.iz) >= inv_lo && fabsf(r.iz) <= inv_hi;
+}
+
 // min/max form.  For a regular ray against a regular box no NaN can arise,
 // (lo-o)*inv and (hi-o)*inv are ordered by the sign of inv (IEEE rounding is
 // monotonic), and the reference's chain of early-outs reduces to
@@ -131,7 +147,6 @@ __device__ __forceinline__ bool slab_hit_regular(float lox, float loy, float loz
 // cost a second dependent memory round trip per node).
 // ---------------------------------------------------------------------------
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ u32x4 load_u4(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_offset) {
 	return __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int) byte_offset, 0, 0);
@@ -142,38 +157,82 @@ __device__ __forceinline__ float4 load_f4(__amdgpu_buffer_rsrc_t rsrc, uint32_t 
 }
 
 struct SceneViews {
-	__amdgpu_buffer_rsrc_t nodes;   // NodeRec[node_count]
-	__amdgpu_buffer_rsrc_t cnodes;  // CNodeRec[node_count]
+	__amdgpu_buffer_rsrc_t nodes;   // NodeRec[node_count]      exact boxes
+	__amdgpu_buffer_rsrc_t wnodes;  // WalkNodeRec[node_count]  enlarged boxes
 	__amdgpu_buffer_rsrc_t tris;    // TriRec[tri_count]
 };
 
-// How the T lanes advance this iteration (wave-uniform choice).
-enum StepKind { STEP_COMPRESSED, STEP_REGULAR, STEP_EXACT };
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Conservative slab test of the walk: t = fma(plane, inv, -(o*inv)) per plane
+// (three packed FMAs for the six planes) on a box that the host enlarged by
+// m = 2^-19 * S on every side, S >= every |box coordinate| and |ray origin|.
+//
+// Claim: whenever the exact test (slab_hit_regular on the exact box) passes,
+// this one passes.  Per plane and for inv > 0 (inv < 0 mirrors), with u = 2^-24:
+//   here   U = fl(lo'*inv + c),  c = fl(-o*inv),  lo' <= lo - m
+//          U <= (lo - m - o)*inv + |o|*inv*u + |U|*u
+//   exact  T = fl(fl(lo - o)*inv) >= (lo - o)*inv - |lo - o|*inv*(2u + u^2)
+// so U <= T as soon as m >= u*(4|o| + 3|lo| + m) ~ 7uS, and m = 32uS.  The far
+// plane is symmetric (U >= T).  Hence [near, far] here contains the exact
+// interval and  max(near, tiny) <= min(far, below)  is implied.  Sub-normal
+// results would break the relative-error model; |inv| >= 2^-60 keeps m*inv far
+// above them.
+__device__ __forceinline__ bool slab_hit_walk(const u32x4 a, const u32x4 b, const Ray &r, float below) {
+	const f32x2 px = { __uint_as_float(a.x), __uint_as_float(a.y) };
+	const f32x2 py = { __uint_as_float(a.z), __uint_as_float(a.w) };
+	const f32x2 pz = { __uint_as_float(b.x), __uint_as_float(b.y) };
+	const f32x2 tx = __builtin_elementwise_fma(px, (f32x2){ r.ix, r.ix }, (f32x2){ r.cx, r.cx });
+	const f32x2 ty = __builtin_elementwise_fma(py, (f32x2){ r.iy, r.iy }, (f32x2){ r.cy, r.cy });
+	const f32x2 tz = __builtin_elementwise_fma(pz, (f32x2){ r.iz, r.iz }, (f32x2){ r.cz, r.cz });
+	const float tiny = __uint_as_float(1u);
+	const float t_near = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fmaxf(fminf(tz.x, tz.y), tiny));
+	const float t_far = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fminf(fmaxf(tz.x, tz.y), below));
+	return t_near <= t_far;
+}
 
 // One node for a lane in state T: box hit -> next node in pre-order (a hit leaf
-// becomes pending); miss -> skip the subtree.
-template <StepKind KIND>
-__device__ __forceinline__ void node_step(const SceneViews &scene, const Ray &r, float max_distance, float below,
-                                          uint32_t &i, uint32_t &pending) {
-	if (KIND == STEP_COMPRESSED) {
-		const u32x4 c = load_u4(scene.cnodes, i * 16u);
-		// (bit_cast straight from a vector element read element 0 three times with
-		// this hipcc; go through scalars)
-		const uint32_t cx = c.x, cy = c.y, cz = c.z;
-		const f16x2 a = __builtin_bit_cast(f16x2, cx), b = __builtin_bit_cast(f16x2, cy),
-		            d = __builtin_bit_cast(f16x2, cz);
-		const bool hit =
-		    slab_hit_regular((float) a.x, (float) a.y, (float) b.x, (float) b.y, (float) d.x, (float) d.y, r, below);
-		const bool leaf = (c.w & CNODE_LEAF_FLAG) != 0u;
-		pending = (hit && leaf) ? (c.w & ~CNODE_LEAF_FLAG) : NONE;
-		i += (hit || leaf) ? 1u : c.w;
+// becomes pending; inner nodes carry leaf == NONE); miss -> skip the subtree.
+__device__ __forceinline__ void node_step_walk(const SceneViews &scene, const Ray &r, float below, uint32_t &i,
+                                               uint32_t &pending) {
+	const u32x4 a = load_u4(scene.wnodes, i * 32u);
+	const u32x4 b = load_u4(scene.wnodes, i * 32u + 16u);
+	const bool hit = slab_hit_walk(a, b, r, below);
+	pending = hit ? b.w : NONE;
+	i += hit ? 1u : b.z;
+}
+
+template <bool REGULAR>
+__device__ __forceinline__ void node_step_exact(const SceneViews &scene, const Ray &r, float max_distance, float below,
+                                                uint32_t &i, uint32_t &pending) {
+	const float4 lo = load_f4(scene.nodes, i * 32u);
+	const float4 hi = load_f4(scene.nodes, i * 32u + 16u);
+	const bool hit = REGULAR ? slab_hit_regular(lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, r, below)
+	                         : slab_hit_exact(lo, hi, r, max_distance);
+	pending = hit ? __float_as_uint(hi.w) : NONE;
+	i += hit ? 1u : __float_as_uint(lo.w);
+}
+
+// Advances the T lanes: WALK_STEPS nodes on the enlarged boxes when every
+// walking lane may use them (the common case), else one node on the exact ones.
+template <int WALK_STEPS>
+__device__ __forceinline__ void advance_walkers(const SceneViews &scene, const Ray &r, bool walkable, bool regular,
+                                                bool walk_ok, float max_distance, float below, uint32_t count,
+                                                uint32_t &i, uint32_t &pending) {
+	bool walking_lane = pending == NONE && i < count;
+	if (walk_ok && __ballot(walking_lane && !walkable) == 0ull) {
+#pragma unroll
+		for (int step = 0; step < WALK_STEPS; ++step) {
+			if (walking_lane)
+				node_step_walk(scene, r, below, i, pending);
+			walking_lane = pending == NONE && i < count;
+		}
+	} else if (__ballot(walking_lane && !regular) == 0ull) {
+		if (walking_lane)
+			node_step_exact<true>(scene, r, max_distance, below, i, pending);
 	} else {
-		const float4 lo = load_f4(scene.nodes, i * 32u);
-		const float4 hi = load_f4(scene.nodes, i * 32u + 16u);
-		const bool hit = KIND == STEP_REGULAR ? slab_hit_regular(lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, r, below)
-		                                      : slab_hit_exact(lo, hi, r, max_distance);
-		pending = hit ? __float_as_uint(hi.w) : NONE;  // inner nodes carry NONE
-		i += hit ? 1u : __float_as_uint(lo.w);
+		if (walking_lane)
+			node_step_exact<false>(scene, r, max_distance, below, i, pending);
 	}
 }
 
@@ -196,7 +255,7 @@ __device__ __forceinline__ TriResult tri_test(const SceneViews &scene, uint32_t 
 	const float4 q2 = load_f4(scene.tris, base + 32u), q3 = load_f4(scene.tris, base + 48u);
 	const float4 b0 = load_f4(scene.tris, base + 64u), b1 = load_f4(scene.tris, base + 80u);
 	// A regular ray may have reached this leaf through its enlarged box: apply the
-	// exact one.  An irregular ray only ever walks exact boxes (STEP_EXACT).
+	// exact one.  An irregular ray only ever walks exact boxes.
 	const bool box_ok = !regular || slab_hit_regular(b0.x, b0.y, b0.z, b1.x, b1.y, b1.z, r, below);
 	const float tax = q0.x, tay = q0.y, taz = q0.z;
 	const float ux = q0.w, uy = q1.x, uz = q1.y;
@@ -267,8 +326,9 @@ constexpr uint32_t WAVES_PER_BLOCK = 4;
 constexpr uint32_t REFILL_MIN = 16;  // refill once this many lanes are idle ...
 constexpr uint32_t LEAF_MIN = 16;    // ... test triangles once this many leaves are pending
 
+template <int WALK_STEPS>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void trace_tiles_kernel(
-    const float4 *__restrict__ nodes_ptr, const uint4 *__restrict__ cnodes_ptr, const float4 *__restrict__ tris_ptr,
+    const float4 *__restrict__ nodes_ptr, const float4 *__restrict__ wnodes_ptr, const float4 *__restrict__ tris_ptr,
     const float4 *__restrict__ shade, const float4 *__restrict__ ao_table, float *__restrict__ image, KernelParams P,
     uint2 *__restrict__ tile_stats) {
 	__shared__ TileShared shared_tiles[WAVES_PER_BLOCK];
@@ -279,7 +339,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void trace_tiles_kernel(
 	// descriptors are built from kernel arguments only, so they live in SGPRs
 	SceneViews scene;
 	scene.nodes = __builtin_amdgcn_make_buffer_rsrc((void *) nodes_ptr, 0, (int) (P.node_count * 32u), 0x00020000);
-	scene.cnodes = __builtin_amdgcn_make_buffer_rsrc((void *) cnodes_ptr, 0, (int) (P.node_count * 16u), 0x00020000);
+	scene.wnodes = __builtin_amdgcn_make_buffer_rsrc((void *) wnodes_ptr, 0, (int) (P.node_count * 32u), 0x00020000);
 	scene.tris = __builtin_amdgcn_make_buffer_rsrc((void *) tris_ptr, 0,
 	                                               (int) (P.tri_count * (uint32_t) sizeof(TriRec)), 0x00020000);
 
@@ -317,6 +377,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void trace_tiles_kernel(
 	normalize3(dx, dy, dz);
 	Ray ray = make_ray(0.0f, 0.0f, 2.0f, dx, dy, dz);
 	bool regular = P.scene_regular && ray_is_regular(ray);
+	bool walkable = regular && ray_is_walkable(ray, P.origin_limit);
 	Hit best;
 	best.distance = __builtin_inff();
 	best.leaf = 0;
@@ -327,8 +388,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void trace_tiles_kernel(
 		uint32_t i = active ? 0u : count;
 		uint32_t pending = NONE;
 		for (;;) {
-			const bool walking_lane = pending == NONE && i < count;
-			const unsigned long long walking = __ballot(walking_lane);
+			const unsigned long long walking = __ballot(pending == NONE && i < count);
 			const unsigned long long leaves = __ballot(pending != NONE);
 			if (leaves != 0ull && ((uint32_t) __popcll(leaves) >= LEAF_MIN || walking == 0ull)) {
 				if (pending != NONE) {
@@ -350,15 +410,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void trace_tiles_kernel(
 			}
 			if (walking == 0ull)
 				break;
-			const bool all_regular = __ballot(walking_lane && !regular) == 0ull;
-			if (walking_lane) {
-				if (all_regular && P.compressed)
-					node_step<STEP_COMPRESSED>(scene, ray, 100000.0f, P.primary_below, i, pending);
-				else if (all_regular)
-					node_step<STEP_REGULAR>(scene, ray, 100000.0f, P.primary_below, i, pending);
-				else
-					node_step<STEP_EXACT>(scene, ray, 100000.0f, P.primary_below, i, pending);
-			}
+			advance_walkers<WALK_STEPS>(scene, ray, walkable, regular, P.walk_ok != 0, 100000.0f, P.primary_below, count, i, pending);
 		}
 	}
 
@@ -420,12 +472,14 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void trace_tiles_kernel(
 		uint32_t pending = NONE;
 		uint32_t h = 0;
 		regular = true;
+		walkable = true;
 		for (;;) {
 			const bool walking_lane = pending == NONE && i < count;
 			const unsigned long long walking = __ballot(walking_lane);
 			const unsigned long long leaves = __ballot(pending != NONE);
-			const uint32_t idle = 64u - (uint32_t) __popcll(walking) - (uint32_t) __popcll(leaves);
-			if (next < total && (idle >= REFILL_MIN || (walking | leaves) == 0ull)) {
+			const uint32_t n_leaves = (uint32_t) __popcll(leaves);
+			const uint32_t idle = 64u - (uint32_t) __popcll(walking) - n_leaves;
+			if (next < total && idle >= REFILL_MIN) {
 				const bool idle_lane = !walking_lane && pending == NONE;
 				const unsigned long long idle_mask = __ballot(idle_lane);
 				const uint32_t item = next + (uint32_t) __popcll(idle_mask & lanes_below);
@@ -439,12 +493,13 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void trace_tiles_kernel(
 					const float rz = (sh.frame[5][h] * dir.x + sh.frame[8][h] * dir.y) + sh.frame[11][h] * dir.z;
 					ray = make_ray(sh.frame[0][h], sh.frame[1][h], sh.frame[2][h], rx, ry, rz);
 					regular = P.scene_regular && P.ao_regular && ray_is_regular(ray);
+					walkable = regular && ray_is_walkable(ray, P.origin_limit);
 					i = 0u;
 				}
-				next += (uint32_t) __popcll(idle_mask);
+				next += idle;
 				continue;
 			}
-			if (leaves != 0ull && ((uint32_t) __popcll(leaves) >= LEAF_MIN || walking == 0ull)) {
+			if (n_leaves != 0u && (n_leaves >= LEAF_MIN || walking == 0ull)) {
 				if (pending != NONE) {
 					const TriResult tr = tri_test<false>(scene, pending, ray, regular, P.ao_below);
 					if (tr.accepted) {
@@ -457,15 +512,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void trace_tiles_kernel(
 			}
 			if (walking == 0ull)
 				break;
-			const bool all_regular = __ballot(walking_lane && !regular) == 0ull;
-			if (walking_lane) {
-				if (all_regular && P.compressed)
-					node_step<STEP_COMPRESSED>(scene, ray, P.ao_max_distance, P.ao_below, i, pending);
-				else if (all_regular)
-					node_step<STEP_REGULAR>(scene, ray, P.ao_max_distance, P.ao_below, i, pending);
-				else
-					node_step<STEP_EXACT>(scene, ray, P.ao_max_distance, P.ao_below, i, pending);
-			}
+			advance_walkers<WALK_STEPS>(scene, ray, walkable, regular, P.walk_ok != 0, P.ao_max_distance, P.ao_below, count, i,
+			                pending);
 		}
 		wave_lds_sync();
 
@@ -519,16 +567,24 @@ __global__ __launch_bounds__(256) void resize_kernel(const float *__restrict__ t
 }
 
 // ---- host-callable launchers (keeps the launch syntax inside this TU) ----
-void launch_trace_tiles(const void *nodes, const void *cnodes, const void *tris, const void *shade,
+void launch_trace_tiles(const void *nodes, const void *wnodes, const void *tris, const void *shade,
                         const void *ao_table, float *image, const KernelParams &P, void *tile_stats, void *stream) {
 	const uint32_t total_tiles = P.tiles_x * P.local_tile_rows;
 	if (total_tiles == 0)
 		return;
 	const uint32_t strips = (P.tiles_x + 1u) >> 1, row_pairs = (P.local_tile_rows + 1u) >> 1;
 	const uint32_t blocks = 8u * ((strips + 7u) >> 3) * row_pairs;
-	hipLaunchKernelGGL(trace_tiles_kernel, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, (hipStream_t) stream,
-	                   (const float4 *) nodes, (const uint4 *) cnodes, (const float4 *) tris, (const float4 *) shade,
-	                   (const float4 *) ao_table, image, P, (uint2 *) tile_stats);
+#define OCRT_LAUNCH(K)                                                                                              \
+	hipLaunchKernelGGL(trace_tiles_kernel<K>, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, (hipStream_t) stream,     \
+	                   (const float4 *) nodes, (const float4 *) wnodes, (const float4 *) tris, (const float4 *) shade, \
+	                   (const float4 *) ao_table, image, P, (uint2 *) tile_stats)
+	switch (P.variant) {  // debug knob OCRT_KERNEL_VARIANT: walk steps per scheduling decision
+	case 11: OCRT_LAUNCH(1); break;
+	case 14: OCRT_LAUNCH(4); break;
+	case 18: OCRT_LAUNCH(8); break;
+	default: OCRT_LAUNCH(2); break;
+	}
+#undef OCRT_LAUNCH
 }
 
 void launch_resize(const float *tmp, unsigned char *out, const KernelParams &P, uint32_t out_width, uint32_t n,

@@ -9,51 +9,6 @@
 
 namespace ocrt {
 
-float half_bits_to_float(uint16_t h) {
-	const uint32_t sign = (uint32_t) (h & 0x8000u) << 16;
-	const uint32_t exp = (h >> 10) & 0x1Fu, mant = h & 0x3FFu;
-	float magnitude;
-	if (exp == 0)
-		magnitude = std::ldexp((float) mant, -24);  // zero / subnormal
-	else if (exp == 31)
-		magnitude = mant ? std::numeric_limits<float>::quiet_NaN() : std::numeric_limits<float>::infinity();
-	else
-		magnitude = std::ldexp((float) (mant | 0x400u), (int) exp - 25);
-	return sign ? -magnitude : magnitude;
-}
-
-uint16_t half_bits_outward(float v, int toward) {
-	// Halves on a monotonic integer line: key(h) = h for h >= +0, -(h & 0x7FFF) below.
-	auto from_key = [](int key) -> uint16_t { return key >= 0 ? (uint16_t) key : (uint16_t) (0x8000u | (uint32_t) -key); };
-	// round-to-nearest first (ties do not matter, the result is corrected below)
-	const float a = std::fabs(v);
-	int magnitude;
-	if (a < 6.103515625e-05f) {  // below 2^-14: subnormal halves, spacing 2^-24
-		magnitude = (int) std::lrintf(a * 16777216.0f);
-	} else {
-		int e;
-		const float m = std::frexp(a, &e);                      // a = m * 2^e, m in [0.5, 1)
-		const int mant = (int) std::lrintf(m * 2048.0f) - 1024;  // 11 significant bits -> 10 stored
-		magnitude = ((e + 14) << 10) + mant;                    // a carry out of mant bumps the exponent
-	}
-	if (magnitude > 0x7BFF)
-		magnitude = 0x7BFF;
-	int key = std::signbit(v) ? -magnitude : magnitude;
-	// step to the correct side of v
-	if (toward < 0) {
-		while (half_bits_to_float(from_key(key)) > v)
-			--key;
-		while (key < 0x7BFF && half_bits_to_float(from_key(key + 1)) <= v)
-			++key;
-	} else {
-		while (half_bits_to_float(from_key(key)) < v)
-			++key;
-		while (key > -0x7BFF && half_bits_to_float(from_key(key - 1)) >= v)
-			--key;
-	}
-	return from_key(key);
-}
-
 PackedScene pack_scene(const std::vector<uint32_t> &faces, const std::vector<uint32_t> &nodes,
                        const std::vector<Vec3f> &aabbs, const std::vector<Vec3f> &vertices,
                        const std::vector<Vec3f> &vnormals) {
@@ -110,22 +65,52 @@ PackedScene pack_scene(const std::vector<uint32_t> &faces, const std::vector<uin
 				out.tris[out.nodes[i].leaf].hi[k] = out.nodes[i].hi[k];
 			}
 
-	// compressed copy of the nodes: only for scenes whose boxes fit binary16's range
-	out.compressible = out.regular;
-	for (size_t i = 0; i < count && out.compressible; ++i)
+	// Children inside parents?  (Always true for a built BVH; user-supplied arrays
+	// may violate it, and the conservative walk relies on it: see kernels.hip.)
+	if (out.regular) {
+		struct Open {
+			size_t end;
+			const NodeRec *box;
+		};
+		std::vector<Open> open;
+		for (size_t i = 0; i < count && out.regular; ++i) {
+			while (!open.empty() && open.back().end <= i)
+				open.pop_back();
+			const NodeRec &n = out.nodes[i];
+			if (!open.empty()) {
+				const NodeRec &parent = *open.back().box;
+				for (unsigned k = 0; k < 3; ++k)
+					if (n.lo[k] < parent.lo[k] || n.hi[k] > parent.hi[k])
+						out.regular = false;
+			}
+			if (n.skip > 1)
+				open.push_back(Open{ i + n.skip, &n });
+		}
+	}
+
+	// Walk nodes: boxes enlarged by m = 2^-19 * S, S bounding every box coordinate
+	// and every ray origin the walk accepts (camera at (0,0,2); AO origins sit on
+	// the surface).  kernels.hip shows m >= 4x the rounding error of its test.
+	float extent = 2.0f;
+	for (const NodeRec &n : out.nodes)
 		for (unsigned k = 0; k < 3; ++k)
-			if (!(std::fabs(out.nodes[i].lo[k]) <= CNODE_MAX_COORD) || !(std::fabs(out.nodes[i].hi[k]) <= CNODE_MAX_COORD))
-				out.compressible = false;
-	if (out.compressible) {
-		out.cnodes.resize(count);
+			extent = std::fmax(extent, std::fmax(std::fabs(n.lo[k]), std::fabs(n.hi[k])));
+	out.origin_limit = extent * 1.01f + 0.01f;
+	out.walkable = out.regular && out.origin_limit <= 1048576.0f;
+	if (out.walkable) {
+		const float margin = std::ldexp(out.origin_limit, -19);
+		const float inf = std::numeric_limits<float>::infinity();
+		out.wnodes.resize(count);
 		for (size_t i = 0; i < count; ++i) {
 			const NodeRec &n = out.nodes[i];
-			CNodeRec &c = out.cnodes[i];
+			WalkNodeRec &w = out.wnodes[i];
+			float *lo[3] = { &w.lox, &w.loy, &w.loz }, *hi[3] = { &w.hix, &w.hiy, &w.hiz };
 			for (unsigned k = 0; k < 3; ++k) {
-				c.lo[k] = half_bits_outward(n.lo[k], -1);
-				c.hi[k] = half_bits_outward(n.hi[k], +1);
+				*lo[k] = std::nextafter(n.lo[k] - margin, -inf);
+				*hi[k] = std::nextafter(n.hi[k] + margin, inf);
 			}
-			c.link = n.skip == 1 ? (CNODE_LEAF_FLAG | n.leaf) : n.skip;
+			w.skip = n.skip;
+			w.leaf = n.leaf;
 		}
 	}
 
@@ -221,7 +206,8 @@ uint32_t local_tile_rows_for(uint32_t total_height, const Partition &part) {
 }
 
 KernelParams make_kernel_params(const RayTracer &rt, uint32_t node_count, uint32_t tri_count, uint32_t ao_dirs,
-                                const Partition &part, bool scene_regular, bool scene_compressible) {
+                                const Partition &part, bool scene_regular, bool scene_walkable,
+                                float origin_limit) {
 	KernelParams p{};
 	p.width = rt.totalWidth;
 	p.height = rt.totalHeight;
@@ -241,7 +227,8 @@ KernelParams make_kernel_params(const RayTracer &rt, uint32_t node_count, uint32
 	const char *variant = std::getenv("OCRT_KERNEL_VARIANT");
 	p.variant = variant ? std::atoi(variant) : 0;
 	p.scene_regular = scene_regular ? 1 : 0;
-	p.compressed = (scene_compressible && p.variant != 2) ? 1 : 0;
+	p.walk_ok = (scene_walkable && p.variant != 2) ? 1 : 0;
+	p.origin_limit = origin_limit;
 	p.ao_regular = (p.ao_max_distance > 0.0f && std::isfinite(p.ao_max_distance)) ? 1 : 0;
 	p.primary_below = std::nextafterf(100000.0f, 0.0f);
 	p.ao_below = std::nextafterf(p.ao_max_distance, -std::numeric_limits<float>::infinity());

@@ -12,17 +12,13 @@ namespace ocrt {
 
 struct PackedScene {
 	std::vector<NodeRec> nodes;
-	std::vector<CNodeRec> cnodes;  // empty unless `compressible`
+	std::vector<WalkNodeRec> wnodes;  // empty unless `walkable`
 	std::vector<TriRec> tris;
 	std::vector<ShadeRec> shade;
-	bool regular = false;       // all boxes finite, |coord| <= 1e37, lo <= hi (see kernels.hip slab_hit_regular)
-	bool compressible = false;  // regular and every |coord| <= 65504: cnodes is filled
+	bool regular = false;   // boxes finite, |coord| <= 1e37, lo <= hi, every child box inside its parent's
+	bool walkable = false;  // regular and coordinates <= 2^20: wnodes is filled
+	float origin_limit = 0; // |ray origin| bound the enlargement margin was computed for
 };
-
-// binary16 bit pattern of the largest half <= v (toward = -1) or the smallest
-// half >= v (toward = +1); v must be finite with |v| <= 65504.
-uint16_t half_bits_outward(float v, int toward);
-float half_bits_to_float(uint16_t h);
 
 // Validates the arrays against each other (every index and skip count is
 // range-checked, so the kernels can never read out of bounds) and packs them.
@@ -49,6 +45,7 @@ uint32_t band_tile_rows_for(unsigned int grid);
 uint32_t local_tile_rows_for(uint32_t total_height, const Partition &part);
 
 KernelParams make_kernel_params(const RayTracer &rt, uint32_t node_count, uint32_t tri_count, uint32_t ao_dirs,
-                                const Partition &part, bool scene_regular, bool scene_compressible);
+                                const Partition &part, bool scene_regular, bool scene_walkable,
+                                float origin_limit);
 
 }  // namespace ocrt

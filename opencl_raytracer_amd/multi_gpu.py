@@ -38,8 +38,20 @@ class BandLayout:
         if np.sort(self.dst_index).tolist() != list(range(options.height)):
             raise AssertionError("band partition does not tile the image")
 
+        self._device_indices = {}
+
     def local_rows(self, rank: int) -> int:
         return int(self.rows[rank].size)
+
+    def indices_on(self, device):
+        """(src, dst) row-index tensors on `device`, uploaded once."""
+        import torch
+
+        key = str(device)
+        if key not in self._device_indices:
+            self._device_indices[key] = (torch.as_tensor(self.src_index, device=device),
+                                         torch.as_tensor(self.dst_index, device=device))
+        return self._device_indices[key]
 
 
 def gather_bands(band, layout: BandLayout, rank: int, group=None):
@@ -48,8 +60,9 @@ def gather_bands(band, layout: BandLayout, rank: int, group=None):
     import torch
     import torch.distributed as dist
 
+    src, dst = layout.indices_on(band.device)
     if layout.world == 1:
-        return band.index_select(0, torch.as_tensor(layout.src_index, device=band.device))
+        return band.index_select(0, src)
     gather_list: Optional[list] = None
     if rank == 0:
         gather_list = [torch.empty_like(band) for _ in range(layout.world)]
@@ -58,6 +71,5 @@ def gather_bands(band, layout: BandLayout, rank: int, group=None):
         return None
     stacked = torch.cat(gather_list, dim=0)
     final = torch.empty((layout.options.height, layout.options.width), dtype=band.dtype, device=band.device)
-    final.index_copy_(0, torch.as_tensor(layout.dst_index, device=band.device),
-                      stacked.index_select(0, torch.as_tensor(layout.src_index, device=band.device)))
+    final.index_copy_(0, dst, stacked.index_select(0, src))
     return final

@@ -121,22 +121,6 @@ def test_partition_rows_cover_image(rt):
             assert np.all(seen == 1), (w, h, ss, nranks)
 
 
-def test_half_outward_rounding(rt):
-    lib = rt.load_library()
-    rng = np.random.default_rng(5)
-    vals = np.concatenate([rng.standard_normal(500).astype(np.float32) * s for s in (1e-7, 1e-3, 1.0, 300.0, 20000.0)]
-                          + [np.array([0.0, -0.0, 65504.0, -65504.0, 6.1e-5, 5.96e-8, 1e-9, 0.5, 2048.5], np.float32)])
-    vals = vals[np.abs(vals) <= 65504]
-    for v in vals:
-        for toward in (-1, 1):
-            h = np.frombuffer(np.uint16(lib.rt_debug_half_outward(float(v), toward)).tobytes(), dtype=np.float16)[0]
-            f = np.float32(h)
-            if toward < 0:
-                assert f <= v and np.float32(np.nextafter(h, np.float16(np.inf))) > v
-            else:
-                assert f >= v and np.float32(np.nextafter(h, np.float16(-np.inf))) < v
-
-
 def header_symbols():
     text = open(os.path.join(ROOT, "include", "rt_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
