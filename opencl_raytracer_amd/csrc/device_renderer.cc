@@ -77,9 +77,9 @@ DeviceRenderer::DeviceRenderer(const RayTracer::Options &options, int device_, u
 	part.rank = rank;
 	part.nranks = nranks;
 	part.band_tile_rows = band_tile_rows_for(grid);
-	kp = make_kernel_params(rt, 0, 0, 0, part, false, false, 0.0f);
+	kp = make_kernel_params(rt, 0, 0, 0, part, false, false, 0.0f, 0);
 	local_out_rows = kp.local_tile_rows * TILE_H / grid;
-	tile_count = (size_t) kp.tiles_x * kp.local_tile_rows;
+	tile_count = (size_t) ((kp.tiles_x + 1) / 2) * ((kp.local_tile_rows + 1) / 2);  // macro tiles
 
 	useDevice();
 	hipStream_t s;
@@ -148,7 +148,7 @@ size_t DeviceRenderer::upload(const PackedScene &scene) {
 		}
 	}
 	kp = make_kernel_params(rt, (uint32_t) scene.nodes.size(), (uint32_t) scene.tris.size(), ao_dirs, part, scene.regular,
-	                        scene.walkable, scene.origin_limit);
+	                        scene.walkable, scene.origin_limit, scene.top_count);
 	const size_t nodes_bytes = scene.nodes.size() * sizeof(NodeRec);
 	const size_t wnodes_bytes = scene.wnodes.size() * sizeof(WalkNodeRec);
 	const size_t tris_bytes = scene.tris.size() * sizeof(TriRec);

@@ -23,13 +23,25 @@ static_assert(sizeof(NodeRec) == 32, "NodeRec is two float4");
 // node visits, never remove one, and every triangle is still gated by its exact
 // box (kept in TriRec) before its test, so results do not change
 // (SURVEY.md 8a-0.7); kernels.hip states the error bound behind the margin.
+//
+// The walk array is stored "top first": entries [0, top_count) are the nodes of
+// the first levels of the tree in pre-order (they are copied into LDS by every
+// workgroup), followed by the body of every subtree that was cut off, each body
+// contiguous and in pre-order.  `link`'s top two bits give the kind:
+//   WALK_INNER   span = number of array entries of this node's (truncated) subtree
+//   WALK_LEAF    span = 1, payload = leaf index (= triangle index in leaf order)
+//   WALK_PORTAL  a cut: payload = index of the first body entry, span = body length
 struct WalkNodeRec {
 	float lox, hix, loy, hiy;
 	float loz, hiz;
-	uint32_t skip;  // subtree size in nodes; 1 = leaf
-	uint32_t leaf;  // leaf index, 0xFFFFFFFF for inner nodes
+	uint32_t span;
+	uint32_t link;
 };
 static_assert(sizeof(WalkNodeRec) == 32, "WalkNodeRec is two float4");
+constexpr uint32_t WALK_INNER = 0u, WALK_LEAF = 1u, WALK_PORTAL = 2u;
+constexpr uint32_t WALK_KIND_SHIFT = 30u;
+constexpr uint32_t WALK_PAYLOAD_MASK = (1u << WALK_KIND_SHIFT) - 1u;
+constexpr uint32_t WALK_TOP_CAPACITY = 1024u;  // entries of the top of the tree kept in LDS (64 KB)
 
 // Per-triangle record, 96 bytes = six float4: the invariants of the reference's
 // plane/parametric test (reference src/intersect_kernel.cl:67-90), precomputed
@@ -81,6 +93,7 @@ struct KernelParams {
 	int32_t scene_regular; // every box finite, |coord| <= 1e37, lo <= hi, children inside parents
 	int32_t walk_ok;       // WalkNodeRec array usable (scene_regular and coordinates small enough)
 	float origin_limit;    // rays whose |origin| exceeds this use the exact boxes (margin was sized for it)
+	uint32_t top_count;    // walk-array entries [0, top_count) are the LDS-resident top of the tree
 	int32_t ao_regular;    // AO_MAX_DISTANCE > 0 (needed by the folded form of the slab test)
 	float primary_below;   // largest float below the primary rays' max_distance (100000.0f)
 	float ao_below;        // largest float below AO_MAX_DISTANCE
@@ -91,6 +104,8 @@ struct KernelParams {
 
 constexpr uint32_t TILE_W = 8;
 constexpr uint32_t TILE_H = 8;
+// A workgroup (16 waves) renders a macro tile of 2 x 2 tiles.
+constexpr uint32_t MACRO_TILES = 4;
 
 // Ray statistics of the last frame (summed on the host from per-tile counters).
 struct RenderStats {

@@ -8,23 +8,27 @@
 // layout, traversal order, where a value is computed) is free and is chosen
 // for the CDNA4 wave64 machine.
 //
-// Work decomposition: one 64-lane wavefront owns one 8x8 tile of sub-pixels.
-//   phase 1  every lane casts its primary ray (closest hit);
-//   phase 2  hit lanes compute normal + head-light term + the AO tangent frame
-//            and are ballot-compacted into an LDS table;
-//   phase 3  the (hit, direction) pairs of the tile form a queue that all 64
-//            lanes drain -- lanes that missed help -- as any-hit rays that stop
-//            at the first accepted triangle; occlusion counts are LDS atomics;
-//   phase 4  hit lanes fold the occlusion fraction in and store the float.
+// Work decomposition: a 1024-thread workgroup (16 waves) owns a macro tile of
+// 16x16 sub-pixels and keeps the top of the BVH (the first ~11 levels, which
+// take half of all node visits) in LDS.
+//   phase 0  all waves copy the top of the walk array into LDS;
+//   phase 1  waves 0-3 cast the primary rays of one 8x8 tile each (closest hit),
+//            hit lanes compute normal + head-light term + the AO tangent frame
+//            and append themselves to the workgroup's hit table in LDS;
+//   phase 2  the (hit, direction) pairs of the macro tile form ONE queue that
+//            all 16 waves drain as any-hit rays (they stop at the first accepted
+//            triangle); occlusion counts are LDS atomics;
+//   phase 3  one thread per hit folds the occlusion fraction in and stores the float.
 //
-// What bounds it (profiles/r01_notes.md): the scene (12 MB) lives in L2, HBM
-// traffic is negligible; the vector ALU is ~80 % busy (a wave64 VALU
-// instruction holds its SIMD for four cycles) and every node visit is a
-// dependent L1/L2 round trip.  Hence: as few VALU instructions per node visit as
-// the arithmetic contract allows (a conservative, packed-FMA box test on
-// enlarged boxes for the walk; the exact test only where the reference's result
-// depends on it, i.e. at the leaves), and a wave-level scheduler that keeps the
-// lanes busy.
+// What bounds it (profiles/r01_notes.md): the scene (12 MB) lives in L2 and HBM
+// traffic is negligible.  Every node visit is a dependent 32-byte gather; the
+// vector L1 looks up about one cache line per clock per CU and divergent lanes
+// each need their own line, so the walk is bound by L1 gather rate and latency.
+// Hence: the top of the tree in LDS (3x lower latency, separate bandwidth), as
+// few VALU instructions per visit as the arithmetic contract allows (a
+// conservative packed-FMA box test on enlarged boxes for the walk, the exact
+// test only where the reference's result depends on it: at the leaves), and a
+// wave-level scheduler that keeps the lanes busy.
 #include <hip/hip_runtime.h>
 
 #include "device_types.h"
@@ -191,48 +195,80 @@ __device__ __forceinline__ bool slab_hit_walk(const u32x4 a, const u32x4 b, cons
 	return t_near <= t_far;
 }
 
-// One node for a lane in state T: box hit -> next node in pre-order (a hit leaf
-// becomes pending; inner nodes carry leaf == NONE); miss -> skip the subtree.
-__device__ __forceinline__ void node_step_walk(const SceneViews &scene, const Ray &r, float below, uint32_t &i,
-                                               uint32_t &pending) {
-	const u32x4 a = load_u4(scene.wnodes, i * 32u);
-	const u32x4 b = load_u4(scene.wnodes, i * 32u + 16u);
+// Cursor of a walking lane.
+//   walk mode : i indexes the top-first walk array; entries below `top` are read
+//               from LDS, the rest from global memory.  While inside a cut-off
+//               body, `end` is the body's end and `ret` the top entry to resume at.
+//   exact mode: i indexes the original pre-order NodeRec array (limit = node count).
+// A lane is done when i >= limit and it is not inside a body.
+struct Cursor {
+	uint32_t i, end, ret, limit;
+};
+__device__ __forceinline__ bool cursor_alive(const Cursor &c) { return c.i < c.limit || c.end != NONE; }
+__device__ __forceinline__ void cursor_finish(Cursor &c) {
+	c.i = c.limit;
+	c.end = NONE;
+}
+
+// One node for a lane in state T on the enlarged boxes: box hit -> first child
+// (next entry; a hit leaf becomes pending; a hit portal enters its body); miss ->
+// skip the subtree.
+__device__ __forceinline__ void node_step_walk(const SceneViews &scene, const uint4 *__restrict__ top, uint32_t top_count,
+                                               const Ray &r, float below, Cursor &c, uint32_t &pending) {
+	u32x4 a, b;
+	if (c.i < top_count) {
+		const uint4 la = top[2u * c.i], lb = top[2u * c.i + 1u];
+		a = (u32x4){ la.x, la.y, la.z, la.w };
+		b = (u32x4){ lb.x, lb.y, lb.z, lb.w };
+	} else {
+		a = load_u4(scene.wnodes, c.i * 32u);
+		b = load_u4(scene.wnodes, c.i * 32u + 16u);
+	}
 	const bool hit = slab_hit_walk(a, b, r, below);
-	pending = hit ? b.w : NONE;
-	i += hit ? 1u : b.z;
+	const uint32_t span = b.z, kind = b.w >> WALK_KIND_SHIFT, payload = b.w & WALK_PAYLOAD_MASK;
+	const bool portal = kind == WALK_PORTAL;
+	pending = (hit && kind == WALK_LEAF) ? payload : NONE;
+	if (hit && portal) {
+		c.ret = c.i + 1u;
+		c.i = payload;
+		c.end = payload + span;
+	} else {
+		c.i += (hit || portal) ? 1u : span;
+	}
+	if (c.i == c.end) {
+		c.i = c.ret;
+		c.end = NONE;
+	}
 }
 
-template <bool REGULAR>
-__device__ __forceinline__ void node_step_exact(const SceneViews &scene, const Ray &r, float max_distance, float below,
-                                                uint32_t &i, uint32_t &pending) {
-	const float4 lo = load_f4(scene.nodes, i * 32u);
-	const float4 hi = load_f4(scene.nodes, i * 32u + 16u);
-	const bool hit = REGULAR ? slab_hit_regular(lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, r, below)
-	                         : slab_hit_exact(lo, hi, r, max_distance);
-	pending = hit ? __float_as_uint(hi.w) : NONE;
-	i += hit ? 1u : __float_as_uint(lo.w);
+// Same on the exact boxes with the reference's own test (irregular rays, scenes
+// without a walk array).
+__device__ __forceinline__ void node_step_exact(const SceneViews &scene, const Ray &r, float max_distance, Cursor &c,
+                                                uint32_t &pending) {
+	const float4 lo = load_f4(scene.nodes, c.i * 32u);
+	const float4 hi = load_f4(scene.nodes, c.i * 32u + 16u);
+	const bool hit = slab_hit_exact(lo, hi, r, max_distance);
+	pending = hit ? __float_as_uint(hi.w) : NONE;  // inner nodes carry NONE
+	c.i += hit ? 1u : __float_as_uint(lo.w);
 }
 
-// Advances the T lanes: WALK_STEPS nodes on the enlarged boxes when every
-// walking lane may use them (the common case), else one node on the exact ones.
+// Advances the T lanes: WALK_STEPS nodes for the lanes that walk the enlarged
+// boxes (the common case); when none of those is walking, one node for the lanes
+// on the exact boxes.
 template <int WALK_STEPS>
-__device__ __forceinline__ void advance_walkers(const SceneViews &scene, const Ray &r, bool walkable, bool regular,
-                                                bool walk_ok, float max_distance, float below, uint32_t count,
-                                                uint32_t &i, uint32_t &pending) {
-	bool walking_lane = pending == NONE && i < count;
-	if (walk_ok && __ballot(walking_lane && !walkable) == 0ull) {
+__device__ __forceinline__ void advance_walkers(const SceneViews &scene, const uint4 *__restrict__ top,
+                                                uint32_t top_count, const Ray &r, bool walkable, float max_distance,
+                                                float below, Cursor &c, uint32_t &pending) {
+	bool walking_lane = pending == NONE && cursor_alive(c);
+	if (__ballot(walking_lane && walkable) != 0ull) {
 #pragma unroll
 		for (int step = 0; step < WALK_STEPS; ++step) {
-			if (walking_lane)
-				node_step_walk(scene, r, below, i, pending);
-			walking_lane = pending == NONE && i < count;
+			if (walking_lane && walkable)
+				node_step_walk(scene, top, top_count, r, below, c, pending);
+			walking_lane = pending == NONE && cursor_alive(c);
 		}
-	} else if (__ballot(walking_lane && !regular) == 0ull) {
-		if (walking_lane)
-			node_step_exact<true>(scene, r, max_distance, below, i, pending);
-	} else {
-		if (walking_lane)
-			node_step_exact<false>(scene, r, max_distance, below, i, pending);
+	} else if (walking_lane) {
+		node_step_exact(scene, r, max_distance, c, pending);
 	}
 }
 
@@ -254,8 +290,8 @@ __device__ __forceinline__ TriResult tri_test(const SceneViews &scene, uint32_t 
 	const float4 q0 = load_f4(scene.tris, base), q1 = load_f4(scene.tris, base + 16u);
 	const float4 q2 = load_f4(scene.tris, base + 32u), q3 = load_f4(scene.tris, base + 48u);
 	const float4 b0 = load_f4(scene.tris, base + 64u), b1 = load_f4(scene.tris, base + 80u);
-	// A regular ray may have reached this leaf through its enlarged box: apply the
-	// exact one.  An irregular ray only ever walks exact boxes.
+	// A lane on the walk array may have reached this leaf through its enlarged box:
+	// apply the exact one.  A lane on the exact array already passed it.
 	const bool box_ok = !regular || slab_hit_regular(b0.x, b0.y, b0.z, b1.x, b1.y, b1.z, r, below);
 	const float tax = q0.x, tay = q0.y, taz = q0.z;
 	const float ux = q0.w, uy = q1.x, uz = q1.y;
@@ -295,46 +331,41 @@ __device__ __forceinline__ uint32_t global_tile_row(const Partition &p, uint32_t
 	return (band_local * p.nranks + p.rank) * p.band_tile_rows + within;
 }
 
-// Orders this wave's LDS writes before its later LDS reads.  A wave executes in
-// lockstep and the LDS unit serves one wave's requests in order, so only the
-// compiler must be kept from reordering across this point.
-__device__ __forceinline__ void wave_lds_sync() {
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-	__builtin_amdgcn_wave_barrier();
-	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 }  // namespace
 
-// LDS slice of one tile (one wave): the hit table, structure of arrays and
-// lane-major so that consecutive hits sit in consecutive banks.
-struct TileShared {
-	float frame[12][64];  // origin xyz, basis_x xyz, basis_y xyz, basis_z xyz
-	unsigned int occluded[64];
+// LDS of one workgroup: the top of the walk array and the macro tile's hit table
+// (structure of arrays, lane-major: consecutive hits sit in consecutive banks).
+constexpr uint32_t WAVES_PER_BLOCK = 16;
+constexpr uint32_t MACRO_PIXELS = MACRO_TILES * TILE_W * TILE_H;  // 256
+struct BlockShared {
+	uint4 top[2 * WALK_TOP_CAPACITY];  // 64 KB
+	float frame[12][MACRO_PIXELS];     // origin xyz, basis_x xyz, basis_y xyz, basis_z xyz
+	float value[MACRO_PIXELS];         // head-light term of the hit
+	unsigned int pixel[MACRO_PIXELS];  // image index of the hit
+	unsigned int occluded[MACRO_PIXELS];
+	unsigned int hit_total;
+	unsigned int queue_head;
+	unsigned int occluded_total;
 };
-
-// The four waves of a workgroup never talk to each other (each owns a tile and a
-// private LDS slice, synchronised with wave-local fences only).
-constexpr uint32_t WAVES_PER_BLOCK = 4;
+static_assert(sizeof(BlockShared) <= 81920, "two workgroups must fit the 160 KB of a CU");
 
 // Wave scheduler thresholds.  A lane is in state T (walking nodes), L (a hit
 // leaf is pending its triangle test) or I (no ray).  Per iteration the wave
 // runs, chosen with scalar ballots only, ONE straight-line predicated body:
-// refill the I lanes from the tile's ray queue, test the L lanes' triangles, or
-// advance the T lanes by one node.  This keeps the wave from paying for its
+// refill the I lanes from the macro tile's ray queue, test the L lanes'
+// triangles, or advance the T lanes.  This keeps the wave from paying for its
 // longest ray and from running a 150-instruction triangle test for two lanes.
 constexpr uint32_t REFILL_MIN = 16;  // refill once this many lanes are idle ...
 constexpr uint32_t LEAF_MIN = 16;    // ... test triangles once this many leaves are pending
 
 template <int WALK_STEPS>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void trace_tiles_kernel(
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 2) void trace_tiles_kernel(
     const float4 *__restrict__ nodes_ptr, const float4 *__restrict__ wnodes_ptr, const float4 *__restrict__ tris_ptr,
     const float4 *__restrict__ shade, const float4 *__restrict__ ao_table, float *__restrict__ image, KernelParams P,
     uint2 *__restrict__ tile_stats) {
-	__shared__ TileShared shared_tiles[WAVES_PER_BLOCK];
+	__shared__ BlockShared sh;
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t wave = threadIdx.x >> 6;
-	TileShared &sh = shared_tiles[wave];
 
 	// descriptors are built from kernel arguments only, so they live in SGPRs
 	SceneViews scene;
@@ -343,56 +374,75 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void trace_tiles_kernel(
 	scene.tris = __builtin_amdgcn_make_buffer_rsrc((void *) tris_ptr, 0,
 	                                               (int) (P.tri_count * (uint32_t) sizeof(TriRec)), 0x00020000);
 
-	// Workgroup = 2x2 tiles (16x16 sub-pixels).  Workgroups b and b+8 share an
-	// XCD and its L2 (MI355X_MICROARCH.md, dispatch is round-robin over XCDs), so
-	// the image is cut into vertical strips two tiles wide, strips are dealt
-	// round-robin to the 8 XCD groups, and each group walks its strips top to
-	// bottom: neighbouring workgroups of a group touch the same BVH region, while
-	// every group still sees the whole image height (cost per tile varies 30x
-	// between background and model, so contiguous image chunks would idle XCDs).
+	// Workgroup -> macro tile (2x2 tiles = 16x16 sub-pixels).  Workgroups b and
+	// b+8 share an XCD and its L2 (MI355X_MICROARCH.md, dispatch is round-robin
+	// over XCDs), so the image is cut into vertical strips one macro tile wide,
+	// strips are dealt round-robin to the 8 XCD groups, and each group walks its
+	// strips top to bottom: neighbouring workgroups of a group touch the same BVH
+	// region, while every group still sees the whole image height (cost per tile
+	// varies 30x between background and model, so contiguous image chunks would
+	// idle XCDs).
 	const uint32_t group = blockIdx.x & 7u, seq = blockIdx.x >> 3;
 	const uint32_t strips = (P.tiles_x + 1u) >> 1;
 	const uint32_t row_pairs = (P.local_tile_rows + 1u) >> 1;
 	const uint32_t strips_here = (strips + 7u - group) >> 3;
 	if (seq >= strips_here * row_pairs)
-		return;  // whole workgroup leaves; no workgroup-wide barrier is used below
+		return;  // whole workgroup leaves before the first barrier
 	const uint32_t strip_index = seq / row_pairs;
 	const uint32_t row_pair = seq - strip_index * row_pairs;
-	const uint32_t tile_x = 2u * (group + 8u * strip_index) + (wave & 1u);
-	const uint32_t local_row = 2u * row_pair + (wave >> 1);
-	if (tile_x >= P.tiles_x || local_row >= P.local_tile_rows)
-		return;
-	const uint32_t tile = local_row * P.tiles_x + tile_x;
-	const uint32_t tile_y = global_tile_row(P.part, local_row);
-	const uint32_t x = tile_x * TILE_W + (lane & 7u);
-	const uint32_t y = tile_y * TILE_H + (lane >> 3);
-	const bool active = x < P.width && y < P.height;
+	const uint32_t strip = group + 8u * strip_index;
+	const uint32_t macro_tile = row_pair * strips + strip;
+
+	// ---- phase 0: top of the tree -> LDS ----
+	const uint32_t top_count = P.walk_ok ? P.top_count : 0u;
+	for (uint32_t e = threadIdx.x; e < 2u * top_count; e += 64u * WAVES_PER_BLOCK) {
+		const u32x4 v = load_u4(scene.wnodes, e * 16u);
+		sh.top[e] = make_uint4(v.x, v.y, v.z, v.w);
+	}
+	if (threadIdx.x == 0) {
+		sh.hit_total = 0u;
+		sh.queue_head = 0u;
+		sh.occluded_total = 0u;
+	}
+	__syncthreads();
+
 	const uint32_t count = P.node_count;
 	const unsigned long long lanes_below = (1ull << lane) - 1ull;
+	Ray ray;
+	bool walkable;
 
-	// ---- phase 1: primary rays (closest hit), reference :279-295 ----
-	float dx = ((float) x + 0.5f) / P.a - P.half_w;
-	float dy = -(((float) y + 0.5f) / P.a - P.half_h);
-	float dz = -1.0f;
-	normalize3(dx, dy, dz);
-	Ray ray = make_ray(0.0f, 0.0f, 2.0f, dx, dy, dz);
-	bool regular = P.scene_regular && ray_is_regular(ray);
-	bool walkable = regular && ray_is_walkable(ray, P.origin_limit);
-	Hit best;
-	best.distance = __builtin_inff();
-	best.leaf = 0;
-	best.s = best.t = 0.0f;
-	best.px = best.py = best.pz = 0.0f;
-	bool hit = false;
-	{
-		uint32_t i = active ? 0u : count;
+	// ---- phase 1: primary rays (closest hit), reference :279-304, waves 0..3 ----
+	if (wave < MACRO_TILES) {
+		const uint32_t tile_x = 2u * strip + (wave & 1u);
+		const uint32_t local_row = 2u * row_pair + (wave >> 1);
+		const uint32_t tile_y = global_tile_row(P.part, local_row);
+		const uint32_t x = tile_x * TILE_W + (lane & 7u);
+		const uint32_t y = tile_y * TILE_H + (lane >> 3);
+		const bool active = tile_x < P.tiles_x && local_row < P.local_tile_rows && x < P.width && y < P.height;
+		float dx = ((float) x + 0.5f) / P.a - P.half_w;
+		float dy = -(((float) y + 0.5f) / P.a - P.half_h);
+		float dz = -1.0f;
+		normalize3(dx, dy, dz);
+		ray = make_ray(0.0f, 0.0f, 2.0f, dx, dy, dz);
+		walkable = P.walk_ok && ray_is_regular(ray) && ray_is_walkable(ray, P.origin_limit);
+		Hit best;
+		best.distance = __builtin_inff();
+		best.leaf = 0;
+		best.s = best.t = 0.0f;
+		best.px = best.py = best.pz = 0.0f;
+		bool hit = false;
+		Cursor cur;
+		cur.limit = walkable ? top_count : count;
+		cur.i = active ? 0u : cur.limit;
+		cur.end = NONE;
+		cur.ret = 0u;
 		uint32_t pending = NONE;
 		for (;;) {
-			const unsigned long long walking = __ballot(pending == NONE && i < count);
+			const unsigned long long walking = __ballot(pending == NONE && cursor_alive(cur));
 			const unsigned long long leaves = __ballot(pending != NONE);
 			if (leaves != 0ull && ((uint32_t) __popcll(leaves) >= LEAF_MIN || walking == 0ull)) {
 				if (pending != NONE) {
-					const TriResult tr = tri_test<true>(scene, pending, ray, regular, P.primary_below);
+					const TriResult tr = tri_test<true>(scene, pending, ray, walkable, P.primary_below);
 					// closest hit: strict '>' in ascending leaf order, reference :106-112
 					if (tr.accepted) {
 						hit = true;
@@ -410,33 +460,39 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void trace_tiles_kernel(
 			}
 			if (walking == 0ull)
 				break;
-			advance_walkers<WALK_STEPS>(scene, ray, walkable, regular, P.walk_ok != 0, 100000.0f, P.primary_below, count, i, pending);
+			advance_walkers<WALK_STEPS>(scene, sh.top, top_count, ray, walkable, 100000.0f, P.primary_below, cur,
+			                            pending);
 		}
-	}
 
-	// ---- phase 2: shading inputs for the hit lanes, reference :296-304 and :215-236 ----
-	float value = 0.0f;
-	float nx = 0.0f, ny = 0.0f, nz = 0.0f;
-	uint32_t occluded_here = 0;
-	if (hit) {
-		const float4 n0 = shade[3 * (size_t) best.leaf + 0];
-		const float4 n1 = shade[3 * (size_t) best.leaf + 1];
-		const float4 n2 = shade[3 * (size_t) best.leaf + 2];
-		const float b0 = 1.0f - best.s - best.t, b1 = best.s, b2 = best.t;
-		nx = (n0.x * b0 + n1.x * b1) + n2.x * b2;
-		ny = (n0.y * b0 + n1.y * b1) + n2.y * b2;
-		nz = (n0.z * b0 + n1.z * b1) + n2.z * b2;
-		normalize3(nx, ny, nz);
-		value = 1.0f;
-		if (P.shading)
-			value = fminf(fmaxf(-dot3(nx, ny, nz, dx, dy, dz), 0.0f), 1.0f);
-	}
-	const unsigned long long hit_mask = __ballot(hit);
-	const uint32_t hit_count = (uint32_t) __popcll(hit_mask);
-	const uint32_t slot = (uint32_t) __popcll(hit_mask & lanes_below);
-
-	if (P.ao_mode == AO_UNIFORM && P.ao_dirs > 0 && hit_count > 0) {
+		// shading inputs of the hit lanes, reference :296-304 and :215-236
+		float value = 0.0f;
+		float nx = 0.0f, ny = 0.0f, nz = 0.0f;
 		if (hit) {
+			const float4 n0 = shade[3 * (size_t) best.leaf + 0];
+			const float4 n1 = shade[3 * (size_t) best.leaf + 1];
+			const float4 n2 = shade[3 * (size_t) best.leaf + 2];
+			const float b0 = 1.0f - best.s - best.t, b1 = best.s, b2 = best.t;
+			nx = (n0.x * b0 + n1.x * b1) + n2.x * b2;
+			ny = (n0.y * b0 + n1.y * b1) + n2.y * b2;
+			nz = (n0.z * b0 + n1.z * b1) + n2.z * b2;
+			normalize3(nx, ny, nz);
+			value = 1.0f;
+			if (P.shading)
+				value = fminf(fmaxf(-dot3(nx, ny, nz, dx, dy, dz), 0.0f), 1.0f);
+		}
+		const bool want_ao = P.ao_mode == AO_UNIFORM && P.ao_dirs > 0;
+		// every sub-pixel without AO work is final now
+		if (active && !(hit && want_ao))
+			image[(size_t) y * P.width + x] = value;
+
+		const unsigned long long hit_mask = __ballot(hit);
+		const uint32_t hit_count = (uint32_t) __popcll(hit_mask);
+		uint32_t base = 0u;
+		if (lane == 0u && hit_count > 0u)
+			base = atomicAdd(&sh.hit_total, hit_count);
+		base = (uint32_t) __shfl((int) base, 0);
+		if (hit && want_ao) {
+			const uint32_t slot = base + (uint32_t) __popcll(hit_mask & lanes_below);
 			// p = point + normal * (1.0f / 100000.0f)
 			const float eps = 1.0f / 100000.0f;
 			sh.frame[0][slot] = best.px + nx * eps;
@@ -459,84 +515,93 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void trace_tiles_kernel(
 			sh.frame[3][slot] = bxx; sh.frame[4][slot] = bxy; sh.frame[5][slot] = bxz;
 			sh.frame[6][slot] = nx;  sh.frame[7][slot] = ny;  sh.frame[8][slot] = nz;
 			sh.frame[9][slot] = bzx; sh.frame[10][slot] = bzy; sh.frame[11][slot] = bzz;
+			sh.value[slot] = value;
+			sh.pixel[slot] = y * P.width + x;
 			sh.occluded[slot] = 0u;
 		}
-		wave_lds_sync();
+	}
+	__syncthreads();
 
-		// ---- phase 3: the tile's hit_count * ao_dirs any-hit rays (reference
-		// :237-255).  Queue order is direction-major, so neighbouring lanes cast
-		// the same table direction from neighbouring surface points. ----
-		const uint32_t total = hit_count * P.ao_dirs;
-		uint32_t next = 0;  // wave-uniform queue head
-		uint32_t i = count;
+	const uint32_t hit_total = sh.hit_total;
+	if (P.ao_mode == AO_UNIFORM && P.ao_dirs > 0 && hit_total > 0) {
+		// ---- phase 2: the macro tile's hit_total * ao_dirs any-hit rays (reference
+		// :237-255), one queue for all 16 waves.  Queue order is direction-major, so
+		// neighbouring lanes cast the same table direction from neighbouring hits. ----
+		const uint32_t total = hit_total * P.ao_dirs;
+		bool exhausted = false;  // wave-uniform: the queue has been drained
+		Cursor cur;
+		cur.limit = top_count;
+		cur.i = cur.limit;
+		cur.end = NONE;
+		cur.ret = 0u;
 		uint32_t pending = NONE;
 		uint32_t h = 0;
-		regular = true;
 		walkable = true;
 		for (;;) {
-			const bool walking_lane = pending == NONE && i < count;
+			const bool walking_lane = pending == NONE && cursor_alive(cur);
 			const unsigned long long walking = __ballot(walking_lane);
 			const unsigned long long leaves = __ballot(pending != NONE);
 			const uint32_t n_leaves = (uint32_t) __popcll(leaves);
 			const uint32_t idle = 64u - (uint32_t) __popcll(walking) - n_leaves;
-			if (next < total && idle >= REFILL_MIN) {
+			if (!exhausted && idle >= REFILL_MIN) {
 				const bool idle_lane = !walking_lane && pending == NONE;
 				const unsigned long long idle_mask = __ballot(idle_lane);
-				const uint32_t item = next + (uint32_t) __popcll(idle_mask & lanes_below);
+				uint32_t first = 0u;
+				if (lane == 0u)
+					first = atomicAdd(&sh.queue_head, idle);
+				first = (uint32_t) __shfl((int) first, 0);
+				exhausted = first + idle >= total;
+				const uint32_t item = first + (uint32_t) __popcll(idle_mask & lanes_below);
 				if (idle_lane && item < total) {
-					const uint32_t k = item / hit_count;
-					h = item - k * hit_count;
+					const uint32_t k = item / hit_total;
+					h = item - k * hit_total;
 					const float4 dir = ao_table[k];
 					// ray_dir = basis_x * xs + basis_y * ys + basis_z * zs, lane by lane
 					const float rx = (sh.frame[3][h] * dir.x + sh.frame[6][h] * dir.y) + sh.frame[9][h] * dir.z;
 					const float ry = (sh.frame[4][h] * dir.x + sh.frame[7][h] * dir.y) + sh.frame[10][h] * dir.z;
 					const float rz = (sh.frame[5][h] * dir.x + sh.frame[8][h] * dir.y) + sh.frame[11][h] * dir.z;
 					ray = make_ray(sh.frame[0][h], sh.frame[1][h], sh.frame[2][h], rx, ry, rz);
-					regular = P.scene_regular && P.ao_regular && ray_is_regular(ray);
-					walkable = regular && ray_is_walkable(ray, P.origin_limit);
-					i = 0u;
+					walkable = P.walk_ok && P.ao_regular && ray_is_regular(ray) && ray_is_walkable(ray, P.origin_limit);
+					cur.limit = walkable ? top_count : count;
+					cur.i = 0u;
+					cur.end = NONE;
 				}
-				next += idle;
 				continue;
 			}
 			if (n_leaves != 0u && (n_leaves >= LEAF_MIN || walking == 0ull)) {
 				if (pending != NONE) {
-					const TriResult tr = tri_test<false>(scene, pending, ray, regular, P.ao_below);
+					const TriResult tr = tri_test<false>(scene, pending, ray, walkable, P.ao_below);
 					if (tr.accepted) {
 						atomicAdd(&sh.occluded[h], 1u);
-						i = count;  // any-hit: the reference walks on but only uses the boolean (:251)
+						cursor_finish(cur);  // any-hit: the reference walks on but only uses the boolean (:251)
 					}
 					pending = NONE;
 				}
 				continue;
 			}
-			if (walking == 0ull)
-				break;
-			advance_walkers<WALK_STEPS>(scene, ray, walkable, regular, P.walk_ok != 0, P.ao_max_distance, P.ao_below, count, i,
-			                pending);
+			if (walking == 0ull) {
+				if (exhausted)
+					break;
+				continue;  // all lanes idle and the queue is not drained: refill next
+			}
+			advance_walkers<WALK_STEPS>(scene, sh.top, top_count, ray, walkable, P.ao_max_distance, P.ao_below, cur,
+			                            pending);
 		}
-		wave_lds_sync();
+		__syncthreads();
 
-		// ---- phase 4: value *= 1 - hits / n, reference :256 and :305-307 ----
-		if (hit) {
-			const uint32_t occluded = sh.occluded[slot];
-			value *= 1.0f - ((float) occluded / (float) P.ao_dirs);
-			occluded_here = occluded;
+		// ---- phase 3: value *= 1 - hits / n, reference :256 and :305-307 ----
+		for (uint32_t t = threadIdx.x; t < hit_total; t += 64u * WAVES_PER_BLOCK) {
+			const uint32_t occluded = sh.occluded[t];
+			image[sh.pixel[t]] = sh.value[t] * (1.0f - ((float) occluded / (float) P.ao_dirs));
+			if (tile_stats)
+				atomicAdd(&sh.occluded_total, occluded);
 		}
+		__syncthreads();
 	}
 
-	if (active)
-		image[(size_t) y * P.width + x] = value;
-
-	// Per-tile counters (plain stores, summed on demand by the host): primary
-	// hits and occluded AO rays of this tile.
-	if (tile_stats) {
-		uint32_t occluded_sum = occluded_here;
-		for (int offset = 32; offset > 0; offset >>= 1)
-			occluded_sum += __shfl_xor(occluded_sum, offset);
-		if (lane == 0)
-			tile_stats[tile] = make_uint2(hit_count, occluded_sum);
-	}
+	// Per-macro-tile counters (plain stores, summed on demand by the host).
+	if (tile_stats && threadIdx.x == 0)
+		tile_stats[macro_tile] = make_uint2(hit_total, sh.occluded_total);
 }
 
 // Supersample box filter + 8-bit quantisation on the device: one thread per
@@ -581,7 +646,6 @@ void launch_trace_tiles(const void *nodes, const void *wnodes, const void *tris,
 	switch (P.variant) {  // debug knob OCRT_KERNEL_VARIANT: walk steps per scheduling decision
 	case 11: OCRT_LAUNCH(1); break;
 	case 14: OCRT_LAUNCH(4); break;
-	case 18: OCRT_LAUNCH(8); break;
 	default: OCRT_LAUNCH(2); break;
 	}
 #undef OCRT_LAUNCH

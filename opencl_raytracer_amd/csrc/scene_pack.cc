@@ -100,18 +100,71 @@ PackedScene pack_scene(const std::vector<uint32_t> &faces, const std::vector<uin
 	if (out.walkable) {
 		const float margin = std::ldexp(out.origin_limit, -19);
 		const float inf = std::numeric_limits<float>::infinity();
+		// depth of every node, and the deepest level whose cumulative size fits the LDS top
+		std::vector<uint32_t> depth(count);
+		std::vector<size_t> per_level;
+		{
+			std::vector<size_t> ends;
+			for (size_t i = 0; i < count; ++i) {
+				while (!ends.empty() && ends.back() <= i)
+					ends.pop_back();
+				depth[i] = (uint32_t) ends.size();
+				if (per_level.size() <= depth[i])
+					per_level.resize(depth[i] + 1, 0);
+				per_level[depth[i]]++;
+				if (out.nodes[i].skip > 1)
+					ends.push_back(i + out.nodes[i].skip);
+			}
+		}
+		uint32_t cut_depth = 0;
+		for (size_t level = 0, total = 0; level < per_level.size(); ++level) {
+			total += per_level[level];
+			if (total > WALK_TOP_CAPACITY)
+				break;
+			cut_depth = (uint32_t) level;
+		}
+		// top_prefix[i] = number of top nodes among original nodes [0, i)
+		std::vector<uint32_t> top_prefix(count + 1, 0);
+		for (size_t i = 0; i < count; ++i)
+			top_prefix[i + 1] = top_prefix[i] + (depth[i] <= cut_depth ? 1u : 0u);
+		out.top_count = top_prefix[count];
 		out.wnodes.resize(count);
-		for (size_t i = 0; i < count; ++i) {
-			const NodeRec &n = out.nodes[i];
-			WalkNodeRec &w = out.wnodes[i];
+		auto fill_box = [&](WalkNodeRec &w, const NodeRec &n) {
 			float *lo[3] = { &w.lox, &w.loy, &w.loz }, *hi[3] = { &w.hix, &w.hiy, &w.hiz };
 			for (unsigned k = 0; k < 3; ++k) {
 				*lo[k] = std::nextafter(n.lo[k] - margin, -inf);
 				*hi[k] = std::nextafter(n.hi[k] + margin, inf);
 			}
-			w.skip = n.skip;
-			w.leaf = n.leaf;
+		};
+		size_t body_cursor = out.top_count;
+		for (size_t i = 0; i < count; ++i) {
+			if (depth[i] > cut_depth)
+				continue;  // copied with its portal's body below
+			const NodeRec &n = out.nodes[i];
+			WalkNodeRec &w = out.wnodes[top_prefix[i]];
+			fill_box(w, n);
+			if (n.skip == 1) {
+				w.span = 1;
+				w.link = (WALK_LEAF << WALK_KIND_SHIFT) | n.leaf;
+			} else if (depth[i] < cut_depth) {
+				w.span = top_prefix[i + n.skip] - top_prefix[i];
+				w.link = WALK_INNER << WALK_KIND_SHIFT;
+			} else {
+				// cut here: the descendants [i + 1, i + skip) form a contiguous body
+				const size_t body_len = n.skip - 1;
+				w.span = (uint32_t) body_len;
+				w.link = (WALK_PORTAL << WALK_KIND_SHIFT) | (uint32_t) body_cursor;
+				for (size_t d = i + 1; d < i + n.skip; ++d) {
+					const NodeRec &c = out.nodes[d];
+					WalkNodeRec &b = out.wnodes[body_cursor++];
+					fill_box(b, c);
+					b.span = c.skip;
+					b.link = c.skip == 1 ? ((WALK_LEAF << WALK_KIND_SHIFT) | c.leaf) : (WALK_INNER << WALK_KIND_SHIFT);
+				}
+			}
 		}
+		if (body_cursor != count)
+			throw std::logic_error("walk array construction lost nodes");
 	}
 
 	out.tris.resize(tri_count);
@@ -207,7 +260,7 @@ uint32_t local_tile_rows_for(uint32_t total_height, const Partition &part) {
 
 KernelParams make_kernel_params(const RayTracer &rt, uint32_t node_count, uint32_t tri_count, uint32_t ao_dirs,
                                 const Partition &part, bool scene_regular, bool scene_walkable,
-                                float origin_limit) {
+                                float origin_limit, uint32_t top_count) {
 	KernelParams p{};
 	p.width = rt.totalWidth;
 	p.height = rt.totalHeight;
@@ -229,6 +282,7 @@ KernelParams make_kernel_params(const RayTracer &rt, uint32_t node_count, uint32
 	p.scene_regular = scene_regular ? 1 : 0;
 	p.walk_ok = (scene_walkable && p.variant != 2) ? 1 : 0;
 	p.origin_limit = origin_limit;
+	p.top_count = top_count;
 	p.ao_regular = (p.ao_max_distance > 0.0f && std::isfinite(p.ao_max_distance)) ? 1 : 0;
 	p.primary_below = std::nextafterf(100000.0f, 0.0f);
 	p.ao_below = std::nextafterf(p.ao_max_distance, -std::numeric_limits<float>::infinity());
