@@ -54,8 +54,11 @@ DeviceRenderer::DeviceRenderer(const RayTracer::Options &options, int device_, u
 	, d_ao(nullptr)
 	, d_image(nullptr)
 	, d_u8(nullptr)
-	, d_tile_stats(nullptr)
-	, tile_count(0)
+	, d_hits(nullptr)
+	, d_occluded(nullptr)
+	, d_counters(nullptr)
+	, max_hits(0)
+	, compute_units(0)
 	, scene_ready(false)
 	, frame_ready(false)
 	, last_ms(0)
@@ -79,7 +82,9 @@ DeviceRenderer::DeviceRenderer(const RayTracer::Options &options, int device_, u
 	part.band_tile_rows = band_tile_rows_for(grid);
 	kp = make_kernel_params(rt, 0, 0, 0, part, false, false, 0.0f, 0);
 	local_out_rows = kp.local_tile_rows * TILE_H / grid;
-	tile_count = (size_t) ((kp.tiles_x + 1) / 2) * ((kp.local_tile_rows + 1) / 2);  // macro tiles
+	max_hits = (size_t) kp.local_tile_rows * TILE_H * kp.width;
+	if (max_hits >= (1ull << 32))
+		throw std::invalid_argument("image band too large for 32-bit hit indices");
 
 	useDevice();
 	hipStream_t s;
@@ -90,7 +95,14 @@ DeviceRenderer::DeviceRenderer(const RayTracer::Options &options, int device_, u
 	// is compact.
 	d_image = device_alloc((size_t) rt.totalWidth * rt.totalHeight * sizeof(float));
 	d_u8 = device_alloc((size_t) local_out_rows * opts.width);
-	d_tile_stats = device_alloc(tile_count * sizeof(uint2));
+	d_hits = device_alloc(max_hits * sizeof(HitRec));
+	d_occluded = device_alloc(max_hits * sizeof(uint32_t));
+	{
+		hipDeviceProp_t prop;
+		OCRT_HIP(hipGetDeviceProperties(&prop, device));
+		compute_units = (uint32_t) prop.multiProcessorCount;
+	}
+	d_counters = device_alloc(sizeof(FrameCounters));
 	OCRT_HIP(hipMemsetAsync(d_image, 0, (size_t) rt.totalWidth * rt.totalHeight * sizeof(float), (hipStream_t) stream));
 	OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));
 }
@@ -109,7 +121,9 @@ DeviceRenderer::~DeviceRenderer() {
 	freeScene();
 	device_free(d_image);
 	device_free(d_u8);
-	device_free(d_tile_stats);
+	device_free(d_hits);
+	device_free(d_occluded);
+	device_free(d_counters);
 	if (own_stream)
 		(void) hipStreamDestroy((hipStream_t) own_stream);
 }
@@ -169,7 +183,7 @@ size_t DeviceRenderer::upload(const PackedScene &scene) {
 	OCRT_HIP(hipDeviceSynchronize());
 	scene_ready = true;
 	return nodes_bytes + wnodes_bytes + tris_bytes + shade_bytes + ao_bytes + (size_t) rt.totalWidth * rt.totalHeight * sizeof(float) +
-	       (size_t) local_out_rows * opts.width + tile_count * sizeof(uint2);
+	       (size_t) local_out_rows * opts.width + max_hits * (sizeof(HitRec) + sizeof(uint32_t)) + sizeof(FrameCounters);
 }
 
 void DeviceRenderer::enqueueRender() {
@@ -187,7 +201,11 @@ void DeviceRenderer::enqueueRender() {
 		ev = { a, b };
 	}
 	OCRT_HIP(hipEventRecord((hipEvent_t) ev.first, (hipStream_t) stream));
-	launch_trace_tiles(d_nodes, d_wnodes, d_tris, d_shade, d_ao, (float *) d_image, kp, d_tile_stats, stream);
+	OCRT_HIP(hipMemsetAsync(d_counters, 0, sizeof(FrameCounters), (hipStream_t) stream));
+	launch_primary(d_nodes, d_wnodes, d_tris, d_shade, (float *) d_image, d_hits, d_occluded, d_counters, kp, stream);
+	OCRT_HIP(hipGetLastError());
+	launch_ao(d_nodes, d_wnodes, d_tris, d_ao, (float *) d_image, d_hits, d_occluded, d_counters, kp, (uint32_t) max_hits,
+	          compute_units, stream);
 	OCRT_HIP(hipGetLastError());
 	OCRT_HIP(hipEventRecord((hipEvent_t) ev.second, (hipStream_t) stream));
 	pending_events.push_back(ev);
@@ -254,12 +272,10 @@ RenderStats DeviceRenderer::stats() {
 	if (!frame_ready)
 		return out;
 	synchronize();
-	std::vector<uint2> tiles(tile_count);
-	OCRT_HIP(hipMemcpy(tiles.data(), d_tile_stats, tile_count * sizeof(uint2), hipMemcpyDeviceToHost));
-	for (const uint2 &t : tiles) {
-		out.primary_hits += t.x;
-		out.ao_occluded += t.y;
-	}
+	FrameCounters c{};
+	OCRT_HIP(hipMemcpy(&c, d_counters, sizeof c, hipMemcpyDeviceToHost));
+	out.primary_hits = c.primary_hits;
+	out.ao_occluded = c.occluded;
 	// Primary rays = sub-pixels of this rank's bands that lie inside the image.
 	const uint32_t tile_rows = (kp.height + TILE_H - 1) / TILE_H;
 	unsigned long long rows = 0;

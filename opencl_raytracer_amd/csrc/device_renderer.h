@@ -52,7 +52,7 @@ class DeviceRenderer {
 		void setStream(void *hip_stream);
 		void usePrivateStream();
 
-		RenderStats stats();   // sums the per-tile counters of the last frame
+		RenderStats stats();   // ray counts of the last frame (device counters)
 		float lastKernelMs() const { return last_ms; }
 		double totalKernelMs() const { return total_ms; }
 		uint64_t kernelLaunches() const { return launches; }
@@ -78,8 +78,9 @@ class DeviceRenderer {
 		uint32_t grid;            // supersample grid side
 		uint32_t local_out_rows;
 		void *own_stream, *stream;
-		void *d_nodes, *d_wnodes, *d_tris, *d_shade, *d_ao, *d_image, *d_u8, *d_tile_stats;
-		size_t tile_count;
+		void *d_nodes, *d_wnodes, *d_tris, *d_shade, *d_ao, *d_image, *d_u8, *d_hits, *d_occluded, *d_counters;
+		size_t max_hits;  // sub-pixels of this rank's bands = capacity of the hit list
+		uint32_t compute_units;
 		bool scene_ready, frame_ready;
 		std::vector<std::pair<void *, void *>> pending_events, free_events;
 		float last_ms;
@@ -88,8 +89,11 @@ class DeviceRenderer {
 };
 
 // kernels.hip
-void launch_trace_tiles(const void *nodes, const void *wnodes, const void *tris, const void *shade, const void *ao_table, float *image,
-                        const KernelParams &P, void *tile_stats, void *stream);
+void launch_primary(const void *nodes, const void *wnodes, const void *tris, const void *shade, float *image,
+                    void *hits, void *occluded_of, void *counters, const KernelParams &P, void *stream);
+void launch_ao(const void *nodes, const void *wnodes, const void *tris, const void *ao_table, float *image,
+               const void *hits, void *occluded_of, void *counters, const KernelParams &P, uint32_t max_hits,
+               uint32_t compute_units, void *stream);
 void launch_resize(const float *tmp, unsigned char *out, const KernelParams &P, uint32_t out_width, uint32_t n,
                    uint32_t local_out_rows, void *stream);
 

@@ -41,7 +41,7 @@ static_assert(sizeof(WalkNodeRec) == 32, "WalkNodeRec is two float4");
 constexpr uint32_t WALK_INNER = 0u, WALK_LEAF = 1u, WALK_PORTAL = 2u;
 constexpr uint32_t WALK_KIND_SHIFT = 30u;
 constexpr uint32_t WALK_PAYLOAD_MASK = (1u << WALK_KIND_SHIFT) - 1u;
-constexpr uint32_t WALK_TOP_CAPACITY = 1024u;  // entries of the top of the tree kept in LDS (64 KB)
+constexpr uint32_t WALK_TOP_CAPACITY = 576u;  // entries of the top of the tree kept in LDS (18 KB)
 
 // Per-triangle record, 96 bytes = six float4: the invariants of the reference's
 // plane/parametric test (reference src/intersect_kernel.cl:67-90), precomputed
@@ -93,7 +93,8 @@ struct KernelParams {
 	int32_t scene_regular; // every box finite, |coord| <= 1e37, lo <= hi, children inside parents
 	int32_t walk_ok;       // WalkNodeRec array usable (scene_regular and coordinates small enough)
 	float origin_limit;    // rays whose |origin| exceeds this use the exact boxes (margin was sized for it)
-	uint32_t top_count;    // walk-array entries [0, top_count) are the LDS-resident top of the tree
+	uint32_t top_count;    // walk-array entries [0, top_count) are the top of the tree (see WalkNodeRec)
+	uint32_t top_lds;      // how many of them the AO pass keeps in LDS (debug knob OCRT_TOP_LDS, default all)
 	int32_t ao_regular;    // AO_MAX_DISTANCE > 0 (needed by the folded form of the slab test)
 	float primary_below;   // largest float below the primary rays' max_distance (100000.0f)
 	float ao_below;        // largest float below AO_MAX_DISTANCE
@@ -104,8 +105,25 @@ struct KernelParams {
 
 constexpr uint32_t TILE_W = 8;
 constexpr uint32_t TILE_H = 8;
-// A workgroup (16 waves) renders a macro tile of 2 x 2 tiles.
-constexpr uint32_t MACRO_TILES = 4;
+// Hit record handed from the primary pass to the ambient-occlusion pass, 32 bytes:
+// (origin.xyz, head-light value), (normal.xyz, image index as bits).
+struct HitRec {
+	float ox, oy, oz, value;
+	float nx, ny, nz;
+	uint32_t pixel;
+};
+static_assert(sizeof(HitRec) == 32, "HitRec is two float4");
+
+// Device-side counters of one frame (zeroed before the primary pass).
+struct FrameCounters {
+	uint32_t hit_count;             // records in the hit list = hit sub-pixels that need AO
+	uint32_t primary_hits;          // all hit sub-pixels
+	unsigned long long queue_head;  // next unclaimed AO ray (ray index = direction * hit_count + hit)
+	unsigned long long occluded;    // occluded AO rays
+};
+
+// AO rays are claimed from the frame-wide queue in batches of this many.
+constexpr uint32_t AO_BATCH = 512;
 
 // Ray statistics of the last frame (summed on the host from per-tile counters).
 struct RenderStats {

@@ -8,17 +8,24 @@
 // layout, traversal order, where a value is computed) is free and is chosen
 // for the CDNA4 wave64 machine.
 //
-// Work decomposition: a 1024-thread workgroup (16 waves) owns a macro tile of
-// 16x16 sub-pixels and keeps the top of the BVH (the first ~11 levels, which
-// take half of all node visits) in LDS.
-//   phase 0  all waves copy the top of the walk array into LDS;
-//   phase 1  waves 0-3 cast the primary rays of one 8x8 tile each (closest hit),
-//            hit lanes compute normal + head-light term + the AO tangent frame
-//            and append themselves to the workgroup's hit table in LDS;
-//   phase 2  the (hit, direction) pairs of the macro tile form ONE queue that
-//            all 16 waves drain as any-hit rays (they stop at the first accepted
-//            triangle); occlusion counts are LDS atomics;
-//   phase 3  one thread per hit folds the occlusion fraction in and stores the float.
+// Work decomposition: two passes per frame.
+//   primary_kernel  one 64-lane wavefront per 8x8 tile of sub-pixels: closest-hit
+//                   primary rays, smooth normal and head-light term.  Sub-pixels
+//                   that need no ambient occlusion are final; every other hit is
+//                   appended (ballot-compacted per wave, one atomic per wave) to a
+//                   hit list in HBM.
+//   ao_kernel       persistent: 4 workgroups of 8 waves per CU copy the first
+//                   levels of the BVH into LDS once, then every wave claims
+//                   batches of 512 rays from ONE frame-wide queue of
+//                   (direction, hit) pairs -- direction-major, so the 64 lanes
+//                   of a wave cast the same table direction from consecutive
+//                   (= neighbouring) hits -- and traces them as any-hit rays;
+//                   occluded rays bump a per-hit counter (global atomic).
+//   resolve_kernel  one thread per hit: value * (1 - occluded / n) -> image.
+// The split exists for load balance: cost per tile varies 30x (background vs
+// model, 29 rays per hit sub-pixel), and with fused tiles the frame ended on a
+// tail of half-empty CUs.  With the compacted hit list and a single queue no
+// wave idles before the last rays of the frame are in flight.
 //
 // What bounds it (profiles/r01_notes.md): the scene (12 MB) lives in L2 and HBM
 // traffic is negligible.  Every node visit is a dependent 32-byte gather; the
@@ -213,10 +220,10 @@ __device__ __forceinline__ void cursor_finish(Cursor &c) {
 // One node for a lane in state T on the enlarged boxes: box hit -> first child
 // (next entry; a hit leaf becomes pending; a hit portal enters its body); miss ->
 // skip the subtree.
-__device__ __forceinline__ void node_step_walk(const SceneViews &scene, const uint4 *__restrict__ top, uint32_t top_count,
+__device__ __forceinline__ void node_step_walk(const SceneViews &scene, const uint4 *__restrict__ top, uint32_t top_lds,
                                                const Ray &r, float below, Cursor &c, uint32_t &pending) {
 	u32x4 a, b;
-	if (c.i < top_count) {
+	if (c.i < top_lds) {
 		const uint4 la = top[2u * c.i], lb = top[2u * c.i + 1u];
 		a = (u32x4){ la.x, la.y, la.z, la.w };
 		b = (u32x4){ lb.x, lb.y, lb.z, lb.w };
@@ -257,14 +264,14 @@ __device__ __forceinline__ void node_step_exact(const SceneViews &scene, const R
 // on the exact boxes.
 template <int WALK_STEPS>
 __device__ __forceinline__ void advance_walkers(const SceneViews &scene, const uint4 *__restrict__ top,
-                                                uint32_t top_count, const Ray &r, bool walkable, float max_distance,
+                                                uint32_t top_lds, const Ray &r, bool walkable, float max_distance,
                                                 float below, Cursor &c, uint32_t &pending) {
 	bool walking_lane = pending == NONE && cursor_alive(c);
 	if (__ballot(walking_lane && walkable) != 0ull) {
 #pragma unroll
 		for (int step = 0; step < WALK_STEPS; ++step) {
 			if (walking_lane && walkable)
-				node_step_walk(scene, top, top_count, r, below, c, pending);
+				node_step_walk(scene, top, top_lds, r, below, c, pending);
 			walking_lane = pending == NONE && cursor_alive(c);
 		}
 	} else if (walking_lane) {
@@ -333,275 +340,306 @@ __device__ __forceinline__ uint32_t global_tile_row(const Partition &p, uint32_t
 
 }  // namespace
 
-// LDS of one workgroup: the top of the walk array and the macro tile's hit table
-// (structure of arrays, lane-major: consecutive hits sit in consecutive banks).
-constexpr uint32_t WAVES_PER_BLOCK = 16;
-constexpr uint32_t MACRO_PIXELS = MACRO_TILES * TILE_W * TILE_H;  // 256
-struct BlockShared {
-	uint4 top[2 * WALK_TOP_CAPACITY];  // 64 KB
-	float frame[12][MACRO_PIXELS];     // origin xyz, basis_x xyz, basis_y xyz, basis_z xyz
-	float value[MACRO_PIXELS];         // head-light term of the hit
-	unsigned int pixel[MACRO_PIXELS];  // image index of the hit
-	unsigned int occluded[MACRO_PIXELS];
-	unsigned int hit_total;
-	unsigned int queue_head;
-	unsigned int occluded_total;
-};
-static_assert(sizeof(BlockShared) <= 81920, "two workgroups must fit the 160 KB of a CU");
-
 // Wave scheduler thresholds.  A lane is in state T (walking nodes), L (a hit
 // leaf is pending its triangle test) or I (no ray).  Per iteration the wave
 // runs, chosen with scalar ballots only, ONE straight-line predicated body:
-// refill the I lanes from the macro tile's ray queue, test the L lanes'
-// triangles, or advance the T lanes.  This keeps the wave from paying for its
-// longest ray and from running a 150-instruction triangle test for two lanes.
+// refill the I lanes from the ray queue, test the L lanes' triangles, or advance
+// the T lanes.  This keeps the wave from paying for its longest ray and from
+// running a 150-instruction triangle test for two lanes.
 constexpr uint32_t REFILL_MIN = 16;  // refill once this many lanes are idle ...
 constexpr uint32_t LEAF_MIN = 16;    // ... test triangles once this many leaves are pending
 
-template <int WALK_STEPS>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 2) void trace_tiles_kernel(
-    const float4 *__restrict__ nodes_ptr, const float4 *__restrict__ wnodes_ptr, const float4 *__restrict__ tris_ptr,
-    const float4 *__restrict__ shade, const float4 *__restrict__ ao_table, float *__restrict__ image, KernelParams P,
-    uint2 *__restrict__ tile_stats) {
-	__shared__ BlockShared sh;
-	const uint32_t lane = threadIdx.x & 63u;
-	const uint32_t wave = threadIdx.x >> 6;
-
+__device__ __forceinline__ SceneViews make_views(const float4 *nodes_ptr, const float4 *wnodes_ptr,
+                                                 const float4 *tris_ptr, const KernelParams &P) {
 	// descriptors are built from kernel arguments only, so they live in SGPRs
 	SceneViews scene;
 	scene.nodes = __builtin_amdgcn_make_buffer_rsrc((void *) nodes_ptr, 0, (int) (P.node_count * 32u), 0x00020000);
 	scene.wnodes = __builtin_amdgcn_make_buffer_rsrc((void *) wnodes_ptr, 0, (int) (P.node_count * 32u), 0x00020000);
 	scene.tris = __builtin_amdgcn_make_buffer_rsrc((void *) tris_ptr, 0,
 	                                               (int) (P.tri_count * (uint32_t) sizeof(TriRec)), 0x00020000);
+	return scene;
+}
 
-	// Workgroup -> macro tile (2x2 tiles = 16x16 sub-pixels).  Workgroups b and
-	// b+8 share an XCD and its L2 (MI355X_MICROARCH.md, dispatch is round-robin
-	// over XCDs), so the image is cut into vertical strips one macro tile wide,
-	// strips are dealt round-robin to the 8 XCD groups, and each group walks its
-	// strips top to bottom: neighbouring workgroups of a group touch the same BVH
-	// region, while every group still sees the whole image height (cost per tile
-	// varies 30x between background and model, so contiguous image chunks would
-	// idle XCDs).
+// ---------------------------------------------------------------------------
+// Pass 1: primary rays.  Four independent waves per workgroup, one tile each.
+// ---------------------------------------------------------------------------
+constexpr uint32_t PRIMARY_WAVES = 4;
+
+template <int WALK_STEPS>
+__global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
+    const float4 *__restrict__ nodes_ptr, const float4 *__restrict__ wnodes_ptr, const float4 *__restrict__ tris_ptr,
+    const float4 *__restrict__ shade, float *__restrict__ image, HitRec *__restrict__ hits,
+    uint32_t *__restrict__ occluded_of, FrameCounters *__restrict__ counters, KernelParams P) {
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t wave = threadIdx.x >> 6;
+	const SceneViews scene = make_views(nodes_ptr, wnodes_ptr, tris_ptr, P);
+
+	// Workgroup -> 2x2 tiles (16x16 sub-pixels).  Workgroups b and b+8 share an
+	// XCD and its L2 (MI355X_MICROARCH.md, dispatch is round-robin over XCDs), so
+	// the image is cut into vertical strips two tiles wide, strips are dealt
+	// round-robin to the 8 XCD groups, and each group walks its strips top to
+	// bottom: neighbouring workgroups of a group touch the same BVH region, while
+	// every group still sees the whole image height.
 	const uint32_t group = blockIdx.x & 7u, seq = blockIdx.x >> 3;
 	const uint32_t strips = (P.tiles_x + 1u) >> 1;
 	const uint32_t row_pairs = (P.local_tile_rows + 1u) >> 1;
 	const uint32_t strips_here = (strips + 7u - group) >> 3;
 	if (seq >= strips_here * row_pairs)
-		return;  // whole workgroup leaves before the first barrier
+		return;
 	const uint32_t strip_index = seq / row_pairs;
 	const uint32_t row_pair = seq - strip_index * row_pairs;
-	const uint32_t strip = group + 8u * strip_index;
-	const uint32_t macro_tile = row_pair * strips + strip;
+	const uint32_t tile_x = 2u * (group + 8u * strip_index) + (wave & 1u);
+	const uint32_t local_row = 2u * row_pair + (wave >> 1);
+	if (tile_x >= P.tiles_x || local_row >= P.local_tile_rows)
+		return;  // the waves of a workgroup never synchronise
+	const uint32_t tile_y = global_tile_row(P.part, local_row);
+	const uint32_t x = tile_x * TILE_W + (lane & 7u);
+	const uint32_t y = tile_y * TILE_H + (lane >> 3);
+	const bool active = x < P.width && y < P.height;
+	const uint32_t count = P.node_count;
+	const unsigned long long lanes_below = (1ull << lane) - 1ull;
 
-	// ---- phase 0: top of the tree -> LDS ----
-	const uint32_t top_count = P.walk_ok ? P.top_count : 0u;
-	for (uint32_t e = threadIdx.x; e < 2u * top_count; e += 64u * WAVES_PER_BLOCK) {
+	// reference src/intersect_kernel.cl:279-295
+	float dx = ((float) x + 0.5f) / P.a - P.half_w;
+	float dy = -(((float) y + 0.5f) / P.a - P.half_h);
+	float dz = -1.0f;
+	normalize3(dx, dy, dz);
+	const Ray ray = make_ray(0.0f, 0.0f, 2.0f, dx, dy, dz);
+	const bool walkable = P.walk_ok && ray_is_regular(ray) && ray_is_walkable(ray, P.origin_limit);
+	Hit best;
+	best.distance = __builtin_inff();
+	best.leaf = 0;
+	best.s = best.t = 0.0f;
+	best.px = best.py = best.pz = 0.0f;
+	bool hit = false;
+	Cursor cur;
+	cur.limit = walkable ? P.top_count : count;
+	cur.i = active ? 0u : cur.limit;
+	cur.end = NONE;
+	cur.ret = 0u;
+	uint32_t pending = NONE;
+	for (;;) {
+		const unsigned long long walking = __ballot(pending == NONE && cursor_alive(cur));
+		const unsigned long long leaves = __ballot(pending != NONE);
+		if (leaves != 0ull && ((uint32_t) __popcll(leaves) >= LEAF_MIN || walking == 0ull)) {
+			if (pending != NONE) {
+				const TriResult tr = tri_test<true>(scene, pending, ray, walkable, P.primary_below);
+				// closest hit: strict '>' in ascending leaf order, reference :106-112
+				if (tr.accepted) {
+					hit = true;
+					if (best.distance > tr.distance) {
+						best.distance = tr.distance;
+						best.leaf = pending;
+						best.s = tr.s;
+						best.t = tr.t;
+						best.px = tr.px; best.py = tr.py; best.pz = tr.pz;
+					}
+				}
+				pending = NONE;
+			}
+			continue;
+		}
+		if (walking == 0ull)
+			break;
+		advance_walkers<WALK_STEPS>(scene, nullptr, 0u, ray, walkable, 100000.0f, P.primary_below, cur, pending);
+	}
+
+	// smooth normal and head-light term, reference :296-304
+	float value = 0.0f;
+	float nx = 0.0f, ny = 0.0f, nz = 0.0f;
+	if (hit) {
+		const float4 n0 = shade[3 * (size_t) best.leaf + 0];
+		const float4 n1 = shade[3 * (size_t) best.leaf + 1];
+		const float4 n2 = shade[3 * (size_t) best.leaf + 2];
+		const float b0 = 1.0f - best.s - best.t, b1 = best.s, b2 = best.t;
+		nx = (n0.x * b0 + n1.x * b1) + n2.x * b2;
+		ny = (n0.y * b0 + n1.y * b1) + n2.y * b2;
+		nz = (n0.z * b0 + n1.z * b1) + n2.z * b2;
+		normalize3(nx, ny, nz);
+		value = 1.0f;
+		if (P.shading)
+			value = fminf(fmaxf(-dot3(nx, ny, nz, dx, dy, dz), 0.0f), 1.0f);
+	}
+	const bool want_ao = P.ao_mode == AO_UNIFORM && P.ao_dirs > 0;
+	if (active && !(hit && want_ao))
+		image[(size_t) y * P.width + x] = value;  // final already
+
+	// append the hits of this wave to the hit list: one returning atomic per wave
+	const unsigned long long hit_mask = __ballot(hit);
+	const uint32_t hit_count = (uint32_t) __popcll(hit_mask);
+	if (hit_count == 0u)
+		return;
+	uint32_t base = 0u;
+	if (lane == 0u) {
+		atomicAdd(&counters->primary_hits, hit_count);
+		if (want_ao)
+			base = atomicAdd(&counters->hit_count, hit_count);
+	}
+	base = (uint32_t) __shfl((int) base, 0);
+	if (hit && want_ao) {
+		HitRec rec;
+		rec.ox = best.px; rec.oy = best.py; rec.oz = best.pz;
+		rec.value = value;
+		rec.nx = nx; rec.ny = ny; rec.nz = nz;
+		rec.pixel = y * P.width + x;
+		const uint32_t slot = base + (uint32_t) __popcll(hit_mask & lanes_below);
+		hits[slot] = rec;
+		occluded_of[slot] = 0u;
+	}
+}
+
+// ---------------------------------------------------------------------------
+// Pass 2: ambient occlusion.  Persistent workgroups (8 waves), one ray queue.
+// ---------------------------------------------------------------------------
+constexpr uint32_t AO_WAVES = 8;
+constexpr uint32_t AO_BLOCKS_PER_CU = 4;
+
+template <int WALK_STEPS>
+__global__ __launch_bounds__(64 * AO_WAVES, AO_BLOCKS_PER_CU) void ao_kernel(
+    const float4 *__restrict__ nodes_ptr, const float4 *__restrict__ wnodes_ptr, const float4 *__restrict__ tris_ptr,
+    const float4 *__restrict__ ao_table, const HitRec *__restrict__ hits, uint32_t *__restrict__ occluded_of,
+    FrameCounters *__restrict__ counters, KernelParams P) {
+	__shared__ uint4 top[2 * WALK_TOP_CAPACITY];  // first levels of the walk array
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t hit_count = counters->hit_count;  // produced by the primary pass
+	const unsigned long long total = (unsigned long long) hit_count * P.ao_dirs;
+	if ((unsigned long long) blockIdx.x * (AO_BATCH * AO_WAVES) >= total)
+		return;  // more workgroups than batches: nothing this one could ever claim first
+	const SceneViews scene = make_views(nodes_ptr, wnodes_ptr, tris_ptr, P);
+	const uint32_t top_lds = P.walk_ok ? P.top_lds : 0u;
+	for (uint32_t e = threadIdx.x; e < 2u * top_lds; e += 64u * AO_WAVES) {
 		const u32x4 v = load_u4(scene.wnodes, e * 16u);
-		sh.top[e] = make_uint4(v.x, v.y, v.z, v.w);
+		top[e] = make_uint4(v.x, v.y, v.z, v.w);
 	}
-	if (threadIdx.x == 0) {
-		sh.hit_total = 0u;
-		sh.queue_head = 0u;
-		sh.occluded_total = 0u;
-	}
-	__syncthreads();
+	__syncthreads();  // the only workgroup-wide synchronisation: waves are independent from here on
 
 	const uint32_t count = P.node_count;
 	const unsigned long long lanes_below = (1ull << lane) - 1ull;
+	// wave-uniform: the claimed, not yet cast rays = batch_left rays starting at (direction batch_k, hit batch_h)
+	uint32_t batch_k = 0u, batch_h = 0u, batch_left = 0u;
+	bool exhausted = false;  // wave-uniform: the queue is drained
 	Ray ray;
-	bool walkable;
-
-	// ---- phase 1: primary rays (closest hit), reference :279-304, waves 0..3 ----
-	if (wave < MACRO_TILES) {
-		const uint32_t tile_x = 2u * strip + (wave & 1u);
-		const uint32_t local_row = 2u * row_pair + (wave >> 1);
-		const uint32_t tile_y = global_tile_row(P.part, local_row);
-		const uint32_t x = tile_x * TILE_W + (lane & 7u);
-		const uint32_t y = tile_y * TILE_H + (lane >> 3);
-		const bool active = tile_x < P.tiles_x && local_row < P.local_tile_rows && x < P.width && y < P.height;
-		float dx = ((float) x + 0.5f) / P.a - P.half_w;
-		float dy = -(((float) y + 0.5f) / P.a - P.half_h);
-		float dz = -1.0f;
-		normalize3(dx, dy, dz);
-		ray = make_ray(0.0f, 0.0f, 2.0f, dx, dy, dz);
-		walkable = P.walk_ok && ray_is_regular(ray) && ray_is_walkable(ray, P.origin_limit);
-		Hit best;
-		best.distance = __builtin_inff();
-		best.leaf = 0;
-		best.s = best.t = 0.0f;
-		best.px = best.py = best.pz = 0.0f;
-		bool hit = false;
-		Cursor cur;
-		cur.limit = walkable ? top_count : count;
-		cur.i = active ? 0u : cur.limit;
-		cur.end = NONE;
-		cur.ret = 0u;
-		uint32_t pending = NONE;
-		for (;;) {
-			const unsigned long long walking = __ballot(pending == NONE && cursor_alive(cur));
-			const unsigned long long leaves = __ballot(pending != NONE);
-			if (leaves != 0ull && ((uint32_t) __popcll(leaves) >= LEAF_MIN || walking == 0ull)) {
-				if (pending != NONE) {
-					const TriResult tr = tri_test<true>(scene, pending, ray, walkable, P.primary_below);
-					// closest hit: strict '>' in ascending leaf order, reference :106-112
-					if (tr.accepted) {
-						hit = true;
-						if (best.distance > tr.distance) {
-							best.distance = tr.distance;
-							best.leaf = pending;
-							best.s = tr.s;
-							best.t = tr.t;
-							best.px = tr.px; best.py = tr.py; best.pz = tr.pz;
-						}
-					}
-					pending = NONE;
+	bool walkable = true;
+	Cursor cur;
+	cur.limit = P.top_count;
+	cur.i = cur.limit;
+	cur.end = NONE;
+	cur.ret = 0u;
+	uint32_t pending = NONE;
+	uint32_t h = 0;
+	for (;;) {
+		const bool walking_lane = pending == NONE && cursor_alive(cur);
+		const unsigned long long walking = __ballot(walking_lane);
+		const unsigned long long leaves = __ballot(pending != NONE);
+		const uint32_t n_leaves = (uint32_t) __popcll(leaves);
+		const uint32_t idle = 64u - (uint32_t) __popcll(walking) - n_leaves;
+		if (!exhausted && idle >= REFILL_MIN) {
+			if (batch_left == 0u) {
+				unsigned long long claimed = 0ull;
+				if (lane == 0u)
+					claimed = atomicAdd(&counters->queue_head, (unsigned long long) AO_BATCH);
+				claimed = (unsigned long long) __shfl((long long) claimed, 0);
+				if (claimed >= total) {
+					exhausted = true;
+					continue;
 				}
-				continue;
+				// ray index = direction * hit_count + hit (the reference casts them per pixel, :237-255)
+				batch_k = (uint32_t) (claimed / hit_count);
+				batch_h = (uint32_t) (claimed - (unsigned long long) batch_k * hit_count);
+				batch_left = total - claimed < AO_BATCH ? (uint32_t) (total - claimed) : AO_BATCH;
 			}
-			if (walking == 0ull)
+			const bool idle_lane = !walking_lane && pending == NONE;
+			const unsigned long long idle_mask = __ballot(idle_lane);
+			const uint32_t rank = (uint32_t) __popcll(idle_mask & lanes_below);
+			const uint32_t take = idle < batch_left ? idle : batch_left;
+			if (idle_lane && rank < take) {
+				uint32_t k = batch_k;
+				h = batch_h + rank;
+				while (h >= hit_count) {  // the batch runs over into the next direction(s)
+					h -= hit_count;
+					++k;
+				}
+				const float4 q0 = ((const float4 *) hits)[2 * (size_t) h];
+				const float4 q1 = ((const float4 *) hits)[2 * (size_t) h + 1];
+				const float nx = q1.x, ny = q1.y, nz = q1.z;
+				// p = point + normal * (1.0f / 100000.0f), reference :215
+				const float eps = 1.0f / 100000.0f;
+				const float ox = q0.x + nx * eps, oy = q0.y + ny * eps, oz = q0.z + nz * eps;
+				// tangent frame (reference :224-236): smallest |component| of the normal replaced by 1
+				float hx = nx, hy = ny, hz = nz;
+				const float ax = fabsf(nx), ay = fabsf(ny), az = fabsf(nz);
+				if (ax <= ay && ax <= az)
+					hx = 1.0f;
+				else if (ay <= ax && ay <= az)
+					hy = 1.0f;
+				else if (az <= ax && az <= ay)
+					hz = 1.0f;
+				// basis_x = normalize(cross(h, basis_y)), basis_z = normalize(cross(basis_x, basis_y))
+				float bxx = hy * nz - hz * ny, bxy = hz * nx - hx * nz, bxz = hx * ny - hy * nx;
+				normalize3(bxx, bxy, bxz);
+				float bzx = bxy * nz - bxz * ny, bzy = bxz * nx - bxx * nz, bzz = bxx * ny - bxy * nx;
+				normalize3(bzx, bzy, bzz);
+				const float4 dir = ao_table[k];
+				// ray_dir = basis_x * xs + basis_y * ys + basis_z * zs, lane by lane
+				const float rx = (bxx * dir.x + nx * dir.y) + bzx * dir.z;
+				const float ry = (bxy * dir.x + ny * dir.y) + bzy * dir.z;
+				const float rz = (bxz * dir.x + nz * dir.y) + bzz * dir.z;
+				ray = make_ray(ox, oy, oz, rx, ry, rz);
+				walkable = P.walk_ok && P.ao_regular && ray_is_regular(ray) && ray_is_walkable(ray, P.origin_limit);
+				cur.limit = walkable ? P.top_count : count;
+				cur.i = 0u;
+				cur.end = NONE;
+			}
+			batch_left -= take;
+			batch_h += take;
+			while (batch_h >= hit_count) {
+				batch_h -= hit_count;
+				++batch_k;
+			}
+			continue;
+		}
+		if (n_leaves != 0u && (n_leaves >= LEAF_MIN || walking == 0ull)) {
+			if (pending != NONE) {
+				const TriResult tr = tri_test<false>(scene, pending, ray, walkable, P.ao_below);
+				if (tr.accepted) {
+					atomicAdd(&occluded_of[h], 1u);
+					cursor_finish(cur);  // any-hit: the reference walks on but only uses the boolean (:251)
+				}
+				pending = NONE;
+			}
+			continue;
+		}
+		if (walking == 0ull) {
+			if (exhausted)
 				break;
-			advance_walkers<WALK_STEPS>(scene, sh.top, top_count, ray, walkable, 100000.0f, P.primary_below, cur,
-			                            pending);
+			continue;  // all lanes idle and the queue is not drained: refill next
 		}
+		advance_walkers<WALK_STEPS>(scene, top, top_lds, ray, walkable, P.ao_max_distance, P.ao_below, cur, pending);
+	}
+}
 
-		// shading inputs of the hit lanes, reference :296-304 and :215-236
-		float value = 0.0f;
-		float nx = 0.0f, ny = 0.0f, nz = 0.0f;
-		if (hit) {
-			const float4 n0 = shade[3 * (size_t) best.leaf + 0];
-			const float4 n1 = shade[3 * (size_t) best.leaf + 1];
-			const float4 n2 = shade[3 * (size_t) best.leaf + 2];
-			const float b0 = 1.0f - best.s - best.t, b1 = best.s, b2 = best.t;
-			nx = (n0.x * b0 + n1.x * b1) + n2.x * b2;
-			ny = (n0.y * b0 + n1.y * b1) + n2.y * b2;
-			nz = (n0.z * b0 + n1.z * b1) + n2.z * b2;
-			normalize3(nx, ny, nz);
-			value = 1.0f;
-			if (P.shading)
-				value = fminf(fmaxf(-dot3(nx, ny, nz, dx, dy, dz), 0.0f), 1.0f);
-		}
-		const bool want_ao = P.ao_mode == AO_UNIFORM && P.ao_dirs > 0;
-		// every sub-pixel without AO work is final now
-		if (active && !(hit && want_ao))
-			image[(size_t) y * P.width + x] = value;
-
-		const unsigned long long hit_mask = __ballot(hit);
-		const uint32_t hit_count = (uint32_t) __popcll(hit_mask);
-		uint32_t base = 0u;
-		if (lane == 0u && hit_count > 0u)
-			base = atomicAdd(&sh.hit_total, hit_count);
-		base = (uint32_t) __shfl((int) base, 0);
-		if (hit && want_ao) {
-			const uint32_t slot = base + (uint32_t) __popcll(hit_mask & lanes_below);
-			// p = point + normal * (1.0f / 100000.0f)
-			const float eps = 1.0f / 100000.0f;
-			sh.frame[0][slot] = best.px + nx * eps;
-			sh.frame[1][slot] = best.py + ny * eps;
-			sh.frame[2][slot] = best.pz + nz * eps;
-			// tangent frame: the smallest |component| of the normal is replaced by 1
-			float hx = nx, hy = ny, hz = nz;
-			const float ax = fabsf(nx), ay = fabsf(ny), az = fabsf(nz);
-			if (ax <= ay && ax <= az)
-				hx = 1.0f;
-			else if (ay <= ax && ay <= az)
-				hy = 1.0f;
-			else if (az <= ax && az <= ay)
-				hz = 1.0f;
-			// basis_x = normalize(cross(h, basis_y)), basis_z = normalize(cross(basis_x, basis_y))
-			float bxx = hy * nz - hz * ny, bxy = hz * nx - hx * nz, bxz = hx * ny - hy * nx;
-			normalize3(bxx, bxy, bxz);
-			float bzx = bxy * nz - bxz * ny, bzy = bxz * nx - bxx * nz, bzz = bxx * ny - bxy * nx;
-			normalize3(bzx, bzy, bzz);
-			sh.frame[3][slot] = bxx; sh.frame[4][slot] = bxy; sh.frame[5][slot] = bxz;
-			sh.frame[6][slot] = nx;  sh.frame[7][slot] = ny;  sh.frame[8][slot] = nz;
-			sh.frame[9][slot] = bzx; sh.frame[10][slot] = bzy; sh.frame[11][slot] = bzz;
-			sh.value[slot] = value;
-			sh.pixel[slot] = y * P.width + x;
-			sh.occluded[slot] = 0u;
-		}
+// Pass 3: value *= 1 - hits / n (reference :256 and :305-307), one thread per hit.
+__global__ __launch_bounds__(256) void resolve_kernel(const HitRec *__restrict__ hits,
+                                                      const uint32_t *__restrict__ occluded_of,
+                                                      FrameCounters *__restrict__ counters, float *__restrict__ image,
+                                                      uint32_t ao_dirs) {
+	__shared__ unsigned int block_total;
+	if (threadIdx.x == 0)
+		block_total = 0u;
+	__syncthreads();
+	const uint32_t hit_count = counters->hit_count;
+	const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+	if (blockIdx.x * blockDim.x >= hit_count)
+		return;
+	if (h < hit_count) {
+		const uint32_t occluded = occluded_of[h];
+		const HitRec rec = hits[h];
+		image[rec.pixel] = rec.value * (1.0f - ((float) occluded / (float) ao_dirs));
+		atomicAdd(&block_total, occluded);
 	}
 	__syncthreads();
-
-	const uint32_t hit_total = sh.hit_total;
-	if (P.ao_mode == AO_UNIFORM && P.ao_dirs > 0 && hit_total > 0) {
-		// ---- phase 2: the macro tile's hit_total * ao_dirs any-hit rays (reference
-		// :237-255), one queue for all 16 waves.  Queue order is direction-major, so
-		// neighbouring lanes cast the same table direction from neighbouring hits. ----
-		const uint32_t total = hit_total * P.ao_dirs;
-		bool exhausted = false;  // wave-uniform: the queue has been drained
-		Cursor cur;
-		cur.limit = top_count;
-		cur.i = cur.limit;
-		cur.end = NONE;
-		cur.ret = 0u;
-		uint32_t pending = NONE;
-		uint32_t h = 0;
-		walkable = true;
-		for (;;) {
-			const bool walking_lane = pending == NONE && cursor_alive(cur);
-			const unsigned long long walking = __ballot(walking_lane);
-			const unsigned long long leaves = __ballot(pending != NONE);
-			const uint32_t n_leaves = (uint32_t) __popcll(leaves);
-			const uint32_t idle = 64u - (uint32_t) __popcll(walking) - n_leaves;
-			if (!exhausted && idle >= REFILL_MIN) {
-				const bool idle_lane = !walking_lane && pending == NONE;
-				const unsigned long long idle_mask = __ballot(idle_lane);
-				uint32_t first = 0u;
-				if (lane == 0u)
-					first = atomicAdd(&sh.queue_head, idle);
-				first = (uint32_t) __shfl((int) first, 0);
-				exhausted = first + idle >= total;
-				const uint32_t item = first + (uint32_t) __popcll(idle_mask & lanes_below);
-				if (idle_lane && item < total) {
-					const uint32_t k = item / hit_total;
-					h = item - k * hit_total;
-					const float4 dir = ao_table[k];
-					// ray_dir = basis_x * xs + basis_y * ys + basis_z * zs, lane by lane
-					const float rx = (sh.frame[3][h] * dir.x + sh.frame[6][h] * dir.y) + sh.frame[9][h] * dir.z;
-					const float ry = (sh.frame[4][h] * dir.x + sh.frame[7][h] * dir.y) + sh.frame[10][h] * dir.z;
-					const float rz = (sh.frame[5][h] * dir.x + sh.frame[8][h] * dir.y) + sh.frame[11][h] * dir.z;
-					ray = make_ray(sh.frame[0][h], sh.frame[1][h], sh.frame[2][h], rx, ry, rz);
-					walkable = P.walk_ok && P.ao_regular && ray_is_regular(ray) && ray_is_walkable(ray, P.origin_limit);
-					cur.limit = walkable ? top_count : count;
-					cur.i = 0u;
-					cur.end = NONE;
-				}
-				continue;
-			}
-			if (n_leaves != 0u && (n_leaves >= LEAF_MIN || walking == 0ull)) {
-				if (pending != NONE) {
-					const TriResult tr = tri_test<false>(scene, pending, ray, walkable, P.ao_below);
-					if (tr.accepted) {
-						atomicAdd(&sh.occluded[h], 1u);
-						cursor_finish(cur);  // any-hit: the reference walks on but only uses the boolean (:251)
-					}
-					pending = NONE;
-				}
-				continue;
-			}
-			if (walking == 0ull) {
-				if (exhausted)
-					break;
-				continue;  // all lanes idle and the queue is not drained: refill next
-			}
-			advance_walkers<WALK_STEPS>(scene, sh.top, top_count, ray, walkable, P.ao_max_distance, P.ao_below, cur,
-			                            pending);
-		}
-		__syncthreads();
-
-		// ---- phase 3: value *= 1 - hits / n, reference :256 and :305-307 ----
-		for (uint32_t t = threadIdx.x; t < hit_total; t += 64u * WAVES_PER_BLOCK) {
-			const uint32_t occluded = sh.occluded[t];
-			image[sh.pixel[t]] = sh.value[t] * (1.0f - ((float) occluded / (float) P.ao_dirs));
-			if (tile_stats)
-				atomicAdd(&sh.occluded_total, occluded);
-		}
-		__syncthreads();
-	}
-
-	// Per-macro-tile counters (plain stores, summed on demand by the host).
-	if (tile_stats && threadIdx.x == 0)
-		tile_stats[macro_tile] = make_uint2(hit_total, sh.occluded_total);
+	if (threadIdx.x == 0)
+		atomicAdd(&counters->occluded, (unsigned long long) block_total);
 }
 
 // Supersample box filter + 8-bit quantisation on the device: one thread per
@@ -632,23 +670,49 @@ __global__ __launch_bounds__(256) void resize_kernel(const float *__restrict__ t
 }
 
 // ---- host-callable launchers (keeps the launch syntax inside this TU) ----
-void launch_trace_tiles(const void *nodes, const void *wnodes, const void *tris, const void *shade,
-                        const void *ao_table, float *image, const KernelParams &P, void *tile_stats, void *stream) {
-	const uint32_t total_tiles = P.tiles_x * P.local_tile_rows;
-	if (total_tiles == 0)
+void launch_primary(const void *nodes, const void *wnodes, const void *tris, const void *shade, float *image,
+                    void *hits, void *occluded_of, void *counters, const KernelParams &P, void *stream) {
+	if (P.tiles_x * P.local_tile_rows == 0)
 		return;
 	const uint32_t strips = (P.tiles_x + 1u) >> 1, row_pairs = (P.local_tile_rows + 1u) >> 1;
 	const uint32_t blocks = 8u * ((strips + 7u) >> 3) * row_pairs;
 #define OCRT_LAUNCH(K)                                                                                              \
-	hipLaunchKernelGGL(trace_tiles_kernel<K>, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, (hipStream_t) stream,     \
+	hipLaunchKernelGGL(primary_kernel<K>, dim3(blocks), dim3(64 * PRIMARY_WAVES), 0, (hipStream_t) stream,           \
 	                   (const float4 *) nodes, (const float4 *) wnodes, (const float4 *) tris, (const float4 *) shade, \
-	                   (const float4 *) ao_table, image, P, (uint2 *) tile_stats)
+	                   image, (HitRec *) hits, (uint32_t *) occluded_of, (FrameCounters *) counters, P)
 	switch (P.variant) {  // debug knob OCRT_KERNEL_VARIANT: walk steps per scheduling decision
 	case 11: OCRT_LAUNCH(1); break;
 	case 14: OCRT_LAUNCH(4); break;
 	default: OCRT_LAUNCH(2); break;
 	}
 #undef OCRT_LAUNCH
+}
+
+void launch_ao(const void *nodes, const void *wnodes, const void *tris, const void *ao_table, float *image,
+               const void *hits, void *occluded_of, void *counters, const KernelParams &P, uint32_t max_hits,
+               uint32_t compute_units, void *stream) {
+	if (max_hits == 0 || P.ao_mode != AO_UNIFORM || P.ao_dirs == 0)
+		return;
+	// persistent grid: what the chip holds, or fewer when the frame cannot have that many batches
+	const unsigned long long max_rays = (unsigned long long) max_hits * P.ao_dirs;
+	const unsigned long long useful = (max_rays + AO_BATCH * AO_WAVES - 1) / (AO_BATCH * AO_WAVES);
+	uint32_t blocks = compute_units * AO_BLOCKS_PER_CU;
+	if (useful < blocks)
+		blocks = (uint32_t) useful;
+#define OCRT_LAUNCH(K)                                                                                            \
+	hipLaunchKernelGGL(ao_kernel<K>, dim3(blocks), dim3(64 * AO_WAVES), 0, (hipStream_t) stream,                   \
+	                   (const float4 *) nodes, (const float4 *) wnodes, (const float4 *) tris,                     \
+	                   (const float4 *) ao_table, (const HitRec *) hits, (uint32_t *) occluded_of,                 \
+	                   (FrameCounters *) counters, P)
+	switch (P.variant) {
+	case 11: OCRT_LAUNCH(1); break;
+	case 14: OCRT_LAUNCH(4); break;
+	default: OCRT_LAUNCH(2); break;
+	}
+#undef OCRT_LAUNCH
+	hipLaunchKernelGGL(resolve_kernel, dim3((max_hits + 255) / 256), dim3(256), 0, (hipStream_t) stream,
+	                   (const HitRec *) hits, (const uint32_t *) occluded_of, (FrameCounters *) counters, image,
+	                   P.ao_dirs);
 }
 
 void launch_resize(const float *tmp, unsigned char *out, const KernelParams &P, uint32_t out_width, uint32_t n,

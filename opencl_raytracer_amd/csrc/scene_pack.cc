@@ -283,6 +283,10 @@ KernelParams make_kernel_params(const RayTracer &rt, uint32_t node_count, uint32
 	p.walk_ok = (scene_walkable && p.variant != 2) ? 1 : 0;
 	p.origin_limit = origin_limit;
 	p.top_count = top_count;
+	const char *top_lds = std::getenv("OCRT_TOP_LDS");
+	p.top_lds = top_lds ? (uint32_t) std::atoi(top_lds) : top_count;
+	if (p.top_lds > top_count)
+		p.top_lds = top_count;
 	p.ao_regular = (p.ao_max_distance > 0.0f && std::isfinite(p.ao_max_distance)) ? 1 : 0;
 	p.primary_below = std::nextafterf(100000.0f, 0.0f);
 	p.ao_below = std::nextafterf(p.ao_max_distance, -std::numeric_limits<float>::infinity());
