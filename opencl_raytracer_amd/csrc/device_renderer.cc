@@ -57,6 +57,7 @@ DeviceRenderer::DeviceRenderer(const RayTracer::Options &options, int device_, u
 	, d_hits(nullptr)
 	, d_occluded(nullptr)
 	, d_counters(nullptr)
+	, d_group_offset(nullptr)
 	, max_hits(0)
 	, compute_units(0)
 	, scene_ready(false)
@@ -82,8 +83,8 @@ DeviceRenderer::DeviceRenderer(const RayTracer::Options &options, int device_, u
 	part.band_tile_rows = band_tile_rows_for(grid);
 	kp = make_kernel_params(rt, 0, 0, 0, part, false, false, 0.0f, 0);
 	local_out_rows = kp.local_tile_rows * TILE_H / grid;
-	max_hits = (size_t) kp.local_tile_rows * TILE_H * kp.width;
-	if (max_hits >= (1ull << 32))
+	max_hits = kp.group_offset[XCD_GROUPS];
+	if ((size_t) kp.local_tile_rows * TILE_H * kp.width + (1u << 20) >= (1ull << 32))
 		throw std::invalid_argument("image band too large for 32-bit hit indices");
 
 	useDevice();
@@ -103,6 +104,8 @@ DeviceRenderer::DeviceRenderer(const RayTracer::Options &options, int device_, u
 		compute_units = (uint32_t) prop.multiProcessorCount;
 	}
 	d_counters = device_alloc(sizeof(FrameCounters));
+	d_group_offset = device_alloc(sizeof kp.group_offset);
+	OCRT_HIP(hipMemcpy(d_group_offset, kp.group_offset, sizeof kp.group_offset, hipMemcpyHostToDevice));
 	OCRT_HIP(hipMemsetAsync(d_image, 0, (size_t) rt.totalWidth * rt.totalHeight * sizeof(float), (hipStream_t) stream));
 	OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));
 }
@@ -124,6 +127,7 @@ DeviceRenderer::~DeviceRenderer() {
 	device_free(d_hits);
 	device_free(d_occluded);
 	device_free(d_counters);
+	device_free(d_group_offset);
 	if (own_stream)
 		(void) hipStreamDestroy((hipStream_t) own_stream);
 }
@@ -202,10 +206,11 @@ void DeviceRenderer::enqueueRender() {
 	}
 	OCRT_HIP(hipEventRecord((hipEvent_t) ev.first, (hipStream_t) stream));
 	OCRT_HIP(hipMemsetAsync(d_counters, 0, sizeof(FrameCounters), (hipStream_t) stream));
-	launch_primary(d_nodes, d_wnodes, d_tris, d_shade, (float *) d_image, d_hits, d_occluded, d_counters, kp, stream);
+	launch_primary(d_nodes, d_wnodes, d_tris, d_shade, (float *) d_image, d_hits, d_occluded, d_counters, d_group_offset, kp,
+	               stream);
 	OCRT_HIP(hipGetLastError());
-	launch_ao(d_nodes, d_wnodes, d_tris, d_ao, (float *) d_image, d_hits, d_occluded, d_counters, kp, (uint32_t) max_hits,
-	          compute_units, stream);
+	launch_ao(d_nodes, d_wnodes, d_tris, d_ao, (float *) d_image, d_hits, d_occluded, d_counters, d_group_offset, kp,
+	          (uint32_t) max_hits, compute_units, stream);
 	OCRT_HIP(hipGetLastError());
 	OCRT_HIP(hipEventRecord((hipEvent_t) ev.second, (hipStream_t) stream));
 	pending_events.push_back(ev);

@@ -41,7 +41,7 @@ static_assert(sizeof(WalkNodeRec) == 32, "WalkNodeRec is two float4");
 constexpr uint32_t WALK_INNER = 0u, WALK_LEAF = 1u, WALK_PORTAL = 2u;
 constexpr uint32_t WALK_KIND_SHIFT = 30u;
 constexpr uint32_t WALK_PAYLOAD_MASK = (1u << WALK_KIND_SHIFT) - 1u;
-constexpr uint32_t WALK_TOP_CAPACITY = 576u;  // entries of the top of the tree kept in LDS (18 KB)
+constexpr uint32_t WALK_TOP_CAPACITY = 288u;  // entries of the top of the tree kept in LDS (9 KB)
 
 // Per-triangle record, 96 bytes = six float4: the invariants of the reference's
 // plane/parametric test (reference src/intersect_kernel.cl:67-90), precomputed
@@ -64,6 +64,8 @@ struct ShadeRec {
 	float n0[4], n1[4], n2[4];
 };
 static_assert(sizeof(ShadeRec) == 48, "ShadeRec is three float4");
+
+constexpr uint32_t XCD_GROUPS = 8;
 
 enum AoMode : int32_t { AO_NONE = 0, AO_UNIFORM = 1, AO_RANDOM = 2 };
 
@@ -95,6 +97,9 @@ struct KernelParams {
 	float origin_limit;    // rays whose |origin| exceeds this use the exact boxes (margin was sized for it)
 	uint32_t top_count;    // walk-array entries [0, top_count) are the top of the tree (see WalkNodeRec)
 	uint32_t top_lds;      // how many of them the AO pass keeps in LDS (debug knob OCRT_TOP_LDS, default all)
+	uint32_t group_offset[XCD_GROUPS + 1];  // hit-list segment of group g = [group_offset[g], group_offset[g+1])
+	uint32_t dirs_per_batch;   // an AO batch = up to 64 hits x this many directions
+	uint32_t batches_per_hits; // ceil(ao_dirs / dirs_per_batch)
 	int32_t ao_regular;    // AO_MAX_DISTANCE > 0 (needed by the folded form of the slab test)
 	float primary_below;   // largest float below the primary rays' max_distance (100000.0f)
 	float ao_below;        // largest float below AO_MAX_DISTANCE
@@ -115,15 +120,16 @@ struct HitRec {
 static_assert(sizeof(HitRec) == 32, "HitRec is two float4");
 
 // Device-side counters of one frame (zeroed before the primary pass).
+// The image's strips are dealt to 8 groups (one per XCD, see kernels.hip); each
+// group has its own segment of the hit list and its own AO batch queue, so that
+// an XCD's L2 keeps seeing the same part of the scene in both passes.
 struct FrameCounters {
-	uint32_t hit_count;             // records in the hit list = hit sub-pixels that need AO
-	uint32_t primary_hits;          // all hit sub-pixels
-	unsigned long long queue_head;  // next unclaimed AO ray (ray index = direction * hit_count + hit)
-	unsigned long long occluded;    // occluded AO rays
+	uint32_t hit_count[XCD_GROUPS];   // records in each group's hit-list segment
+	uint32_t queue_head[XCD_GROUPS];  // next unclaimed AO batch of each group
+	uint32_t primary_hits;            // all hit sub-pixels
+	uint32_t pad;
+	unsigned long long occluded;      // occluded AO rays
 };
-
-// AO rays are claimed from the frame-wide queue in batches of this many.
-constexpr uint32_t AO_BATCH = 512;
 
 // Ray statistics of the last frame (summed on the host from per-tile counters).
 struct RenderStats {

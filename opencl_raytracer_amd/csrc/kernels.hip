@@ -15,17 +15,21 @@
 //                   appended (ballot-compacted per wave, one atomic per wave) to a
 //                   hit list in HBM.
 //   ao_kernel       persistent: 4 workgroups of 8 waves per CU copy the first
-//                   levels of the BVH into LDS once, then every wave claims
-//                   batches of 512 rays from ONE frame-wide queue of
-//                   (direction, hit) pairs -- direction-major, so the 64 lanes
-//                   of a wave cast the same table direction from consecutive
-//                   (= neighbouring) hits -- and traces them as any-hit rays;
-//                   occluded rays bump a per-hit counter (global atomic).
+//                   levels of the BVH into LDS once; then every wave, on its own,
+//                   claims batches of (64 consecutive hits) x (~7 directions)
+//                   from its XCD group's queue -- stealing from the other groups
+//                   once it is empty -- rebuilds the 64 tangent frames in its LDS
+//                   slice and drains the batch's any-hit rays (direction-major:
+//                   the lanes of a wave cast one table direction from neighbouring
+//                   surface points); occlusion counts are LDS atomics, flushed to
+//                   a per-hit counter in HBM when the batch is done.
 //   resolve_kernel  one thread per hit: value * (1 - occluded / n) -> image.
 // The split exists for load balance: cost per tile varies 30x (background vs
 // model, 29 rays per hit sub-pixel), and with fused tiles the frame ended on a
-// tail of half-empty CUs.  With the compacted hit list and a single queue no
-// wave idles before the last rays of the frame are in flight.
+// tail of half-empty CUs.  After compaction every batch is full and small
+// (about 8 rays per lane), and no wave idles before the frame's last batches.
+// The hit list is segmented by XCD group so that each XCD's L2 sees the same
+// part of the scene in both passes.
 //
 // What bounds it (profiles/r01_notes.md): the scene (12 MB) lives in L2 and HBM
 // traffic is negligible.  Every node visit is a dependent 32-byte gather; the
@@ -369,7 +373,8 @@ template <int WALK_STEPS>
 __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
     const float4 *__restrict__ nodes_ptr, const float4 *__restrict__ wnodes_ptr, const float4 *__restrict__ tris_ptr,
     const float4 *__restrict__ shade, float *__restrict__ image, HitRec *__restrict__ hits,
-    uint32_t *__restrict__ occluded_of, FrameCounters *__restrict__ counters, KernelParams P) {
+    uint32_t *__restrict__ occluded_of, FrameCounters *__restrict__ counters,
+    const uint32_t *__restrict__ group_offset, KernelParams P) {
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t wave = threadIdx.x >> 6;
 	const SceneViews scene = make_views(nodes_ptr, wnodes_ptr, tris_ptr, P);
@@ -473,7 +478,7 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
 	if (lane == 0u) {
 		atomicAdd(&counters->primary_hits, hit_count);
 		if (want_ao)
-			base = atomicAdd(&counters->hit_count, hit_count);
+			base = group_offset[group] + atomicAdd(&counters->hit_count[group], hit_count);
 	}
 	base = (uint32_t) __shfl((int) base, 0);
 	if (hit && want_ao) {
@@ -489,82 +494,80 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// Pass 2: ambient occlusion.  Persistent workgroups (8 waves), one ray queue.
+// Pass 2: ambient occlusion.  Persistent workgroups; waves work independently.
 // ---------------------------------------------------------------------------
 constexpr uint32_t AO_WAVES = 8;
 constexpr uint32_t AO_BLOCKS_PER_CU = 4;
 
+// LDS slice of one wave: the tangent frames of the batch's hits (structure of
+// arrays, lane-major: consecutive hits sit in consecutive banks).
+struct WaveShared {
+	float frame[12][64];  // origin xyz, basis_x xyz, basis_y xyz, basis_z xyz
+	unsigned int occluded[64];
+};
+struct AoShared {
+	uint4 top[2 * WALK_TOP_CAPACITY];  // first levels of the walk array
+	WaveShared wave[AO_WAVES];
+};
+static_assert(sizeof(AoShared) <= 40960, "four workgroups must fit the 160 KB of a CU");
+
+// Orders this wave's LDS writes before its later LDS reads.  A wave executes in
+// lockstep and the LDS unit serves one wave's requests in order, so only the
+// compiler must be kept from reordering across this point.
+__device__ __forceinline__ void wave_lds_sync() {
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <int WALK_STEPS>
-__global__ __launch_bounds__(64 * AO_WAVES, AO_BLOCKS_PER_CU) void ao_kernel(
+__global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(4, 6))) void ao_kernel(
     const float4 *__restrict__ nodes_ptr, const float4 *__restrict__ wnodes_ptr, const float4 *__restrict__ tris_ptr,
     const float4 *__restrict__ ao_table, const HitRec *__restrict__ hits, uint32_t *__restrict__ occluded_of,
-    FrameCounters *__restrict__ counters, KernelParams P) {
-	__shared__ uint4 top[2 * WALK_TOP_CAPACITY];  // first levels of the walk array
+    FrameCounters *__restrict__ counters, const uint32_t *__restrict__ group_offset, KernelParams P) {
+	__shared__ AoShared sh;
 	const uint32_t lane = threadIdx.x & 63u;
-	const uint32_t hit_count = counters->hit_count;  // produced by the primary pass
-	const unsigned long long total = (unsigned long long) hit_count * P.ao_dirs;
-	if ((unsigned long long) blockIdx.x * (AO_BATCH * AO_WAVES) >= total)
-		return;  // more workgroups than batches: nothing this one could ever claim first
+	WaveShared &mine = sh.wave[threadIdx.x >> 6];
 	const SceneViews scene = make_views(nodes_ptr, wnodes_ptr, tris_ptr, P);
 	const uint32_t top_lds = P.walk_ok ? P.top_lds : 0u;
 	for (uint32_t e = threadIdx.x; e < 2u * top_lds; e += 64u * AO_WAVES) {
 		const u32x4 v = load_u4(scene.wnodes, e * 16u);
-		top[e] = make_uint4(v.x, v.y, v.z, v.w);
+		sh.top[e] = make_uint4(v.x, v.y, v.z, v.w);
 	}
 	__syncthreads();  // the only workgroup-wide synchronisation: waves are independent from here on
 
 	const uint32_t count = P.node_count;
 	const unsigned long long lanes_below = (1ull << lane) - 1ull;
-	// wave-uniform: the claimed, not yet cast rays = batch_left rays starting at (direction batch_k, hit batch_h)
-	uint32_t batch_k = 0u, batch_h = 0u, batch_left = 0u;
-	bool exhausted = false;  // wave-uniform: the queue is drained
-	Ray ray;
-	bool walkable = true;
-	Cursor cur;
-	cur.limit = P.top_count;
-	cur.i = cur.limit;
-	cur.end = NONE;
-	cur.ret = 0u;
-	uint32_t pending = NONE;
-	uint32_t h = 0;
-	for (;;) {
-		const bool walking_lane = pending == NONE && cursor_alive(cur);
-		const unsigned long long walking = __ballot(walking_lane);
-		const unsigned long long leaves = __ballot(pending != NONE);
-		const uint32_t n_leaves = (uint32_t) __popcll(leaves);
-		const uint32_t idle = 64u - (uint32_t) __popcll(walking) - n_leaves;
-		if (!exhausted && idle >= REFILL_MIN) {
-			if (batch_left == 0u) {
-				unsigned long long claimed = 0ull;
-				if (lane == 0u)
-					claimed = atomicAdd(&counters->queue_head, (unsigned long long) AO_BATCH);
-				claimed = (unsigned long long) __shfl((long long) claimed, 0);
-				if (claimed >= total) {
-					exhausted = true;
-					continue;
-				}
-				// ray index = direction * hit_count + hit (the reference casts them per pixel, :237-255)
-				batch_k = (uint32_t) (claimed / hit_count);
-				batch_h = (uint32_t) (claimed - (unsigned long long) batch_k * hit_count);
-				batch_left = total - claimed < AO_BATCH ? (uint32_t) (total - claimed) : AO_BATCH;
-			}
-			const bool idle_lane = !walking_lane && pending == NONE;
-			const unsigned long long idle_mask = __ballot(idle_lane);
-			const uint32_t rank = (uint32_t) __popcll(idle_mask & lanes_below);
-			const uint32_t take = idle < batch_left ? idle : batch_left;
-			if (idle_lane && rank < take) {
-				uint32_t k = batch_k;
-				h = batch_h + rank;
-				while (h >= hit_count) {  // the batch runs over into the next direction(s)
-					h -= hit_count;
-					++k;
-				}
-				const float4 q0 = ((const float4 *) hits)[2 * (size_t) h];
-				const float4 q1 = ((const float4 *) hits)[2 * (size_t) h + 1];
+	// Workgroups b and b+8 share an XCD: start with that group's queue, then help the others.
+	const uint32_t home = blockIdx.x & (XCD_GROUPS - 1u);
+	for (uint32_t turn = 0; turn < XCD_GROUPS; ++turn) {
+		const uint32_t group = (home + turn) & (XCD_GROUPS - 1u);
+		const uint32_t group_hits = counters->hit_count[group];  // produced by the primary pass
+		const uint32_t group_batches = ((group_hits + 63u) >> 6) * P.batches_per_hits;
+		for (;;) {
+			// ---- claim a batch: hits [first, first + n) of the group, directions [dir0, dir0 + n_dirs) ----
+			uint32_t batch = 0u;
+			if (lane == 0u)
+				batch = atomicAdd(&counters->queue_head[group], 1u);
+			batch = (uint32_t) __shfl((int) batch, 0);
+			if (batch >= group_batches)
+				break;
+			const uint32_t hit_block = batch / P.batches_per_hits;
+			const uint32_t dir0 = (batch - hit_block * P.batches_per_hits) * P.dirs_per_batch;
+			const uint32_t n_dirs = P.ao_dirs - dir0 < P.dirs_per_batch ? P.ao_dirs - dir0 : P.dirs_per_batch;
+			const uint32_t first = group_offset[group] + (hit_block << 6);
+			const uint32_t n = group_hits - (hit_block << 6) < 64u ? group_hits - (hit_block << 6) : 64u;
+
+			// ---- the batch's tangent frames -> this wave's LDS slice ----
+			if (lane < n) {
+				const float4 q0 = ((const float4 *) hits)[2 * (size_t) (first + lane)];
+				const float4 q1 = ((const float4 *) hits)[2 * (size_t) (first + lane) + 1];
 				const float nx = q1.x, ny = q1.y, nz = q1.z;
 				// p = point + normal * (1.0f / 100000.0f), reference :215
 				const float eps = 1.0f / 100000.0f;
-				const float ox = q0.x + nx * eps, oy = q0.y + ny * eps, oz = q0.z + nz * eps;
+				mine.frame[0][lane] = q0.x + nx * eps;
+				mine.frame[1][lane] = q0.y + ny * eps;
+				mine.frame[2][lane] = q0.z + nz * eps;
 				// tangent frame (reference :224-236): smallest |component| of the normal replaced by 1
 				float hx = nx, hy = ny, hz = nz;
 				const float ax = fabsf(nx), ay = fabsf(ny), az = fabsf(nz);
@@ -579,66 +582,104 @@ __global__ __launch_bounds__(64 * AO_WAVES, AO_BLOCKS_PER_CU) void ao_kernel(
 				normalize3(bxx, bxy, bxz);
 				float bzx = bxy * nz - bxz * ny, bzy = bxz * nx - bxx * nz, bzz = bxx * ny - bxy * nx;
 				normalize3(bzx, bzy, bzz);
-				const float4 dir = ao_table[k];
-				// ray_dir = basis_x * xs + basis_y * ys + basis_z * zs, lane by lane
-				const float rx = (bxx * dir.x + nx * dir.y) + bzx * dir.z;
-				const float ry = (bxy * dir.x + ny * dir.y) + bzy * dir.z;
-				const float rz = (bxz * dir.x + nz * dir.y) + bzz * dir.z;
-				ray = make_ray(ox, oy, oz, rx, ry, rz);
-				walkable = P.walk_ok && P.ao_regular && ray_is_regular(ray) && ray_is_walkable(ray, P.origin_limit);
-				cur.limit = walkable ? P.top_count : count;
-				cur.i = 0u;
-				cur.end = NONE;
+				mine.frame[3][lane] = bxx; mine.frame[4][lane] = bxy; mine.frame[5][lane] = bxz;
+				mine.frame[6][lane] = nx;  mine.frame[7][lane] = ny;  mine.frame[8][lane] = nz;
+				mine.frame[9][lane] = bzx; mine.frame[10][lane] = bzy; mine.frame[11][lane] = bzz;
 			}
-			batch_left -= take;
-			batch_h += take;
-			while (batch_h >= hit_count) {
-				batch_h -= hit_count;
-				++batch_k;
-			}
-			continue;
-		}
-		if (n_leaves != 0u && (n_leaves >= LEAF_MIN || walking == 0ull)) {
-			if (pending != NONE) {
-				const TriResult tr = tri_test<false>(scene, pending, ray, walkable, P.ao_below);
-				if (tr.accepted) {
-					atomicAdd(&occluded_of[h], 1u);
-					cursor_finish(cur);  // any-hit: the reference walks on but only uses the boolean (:251)
+			mine.occluded[lane] = 0u;
+			wave_lds_sync();
+
+			// ---- the batch's n * n_dirs any-hit rays (reference :237-255), direction-major ----
+			const uint32_t total = n * n_dirs;
+			uint32_t next = 0u;  // wave-uniform queue head
+			Ray ray;
+			bool walkable = true;
+			Cursor cur;
+			cur.limit = P.top_count;
+			cur.i = cur.limit;
+			cur.end = NONE;
+			cur.ret = 0u;
+			uint32_t pending = NONE;
+			uint32_t h = 0;
+			for (;;) {
+				const bool walking_lane = pending == NONE && cursor_alive(cur);
+				const unsigned long long walking = __ballot(walking_lane);
+				const unsigned long long leaves = __ballot(pending != NONE);
+				const uint32_t n_leaves = (uint32_t) __popcll(leaves);
+				const uint32_t idle = 64u - (uint32_t) __popcll(walking) - n_leaves;
+				if (next < total && idle >= REFILL_MIN) {
+					const bool idle_lane = !walking_lane && pending == NONE;
+					const unsigned long long idle_mask = __ballot(idle_lane);
+					const uint32_t item = next + (uint32_t) __popcll(idle_mask & lanes_below);
+					if (idle_lane && item < total) {
+						const uint32_t k = item / n;
+						h = item - k * n;
+						const float4 dir = ao_table[dir0 + k];
+						// ray_dir = basis_x * xs + basis_y * ys + basis_z * zs, lane by lane
+						const float rx = (mine.frame[3][h] * dir.x + mine.frame[6][h] * dir.y) + mine.frame[9][h] * dir.z;
+						const float ry = (mine.frame[4][h] * dir.x + mine.frame[7][h] * dir.y) + mine.frame[10][h] * dir.z;
+						const float rz = (mine.frame[5][h] * dir.x + mine.frame[8][h] * dir.y) + mine.frame[11][h] * dir.z;
+						ray = make_ray(mine.frame[0][h], mine.frame[1][h], mine.frame[2][h], rx, ry, rz);
+						walkable = P.walk_ok && P.ao_regular && ray_is_regular(ray) && ray_is_walkable(ray, P.origin_limit);
+						cur.limit = walkable ? P.top_count : count;
+						cur.i = 0u;
+						cur.end = NONE;
+					}
+					next += idle;
+					continue;
 				}
-				pending = NONE;
+				if (n_leaves != 0u && (n_leaves >= LEAF_MIN || walking == 0ull)) {
+					if (pending != NONE) {
+						const TriResult tr = tri_test<false>(scene, pending, ray, walkable, P.ao_below);
+						if (tr.accepted) {
+							atomicAdd(&mine.occluded[h], 1u);
+							cursor_finish(cur);  // any-hit: the reference walks on but only uses the boolean (:251)
+						}
+						pending = NONE;
+					}
+					continue;
+				}
+				if (walking == 0ull)
+					break;  // nothing walking, nothing pending, and then next >= total (idle == 64 would have refilled)
+				advance_walkers<WALK_STEPS>(scene, sh.top, top_lds, ray, walkable, P.ao_max_distance, P.ao_below, cur,
+				                            pending);
 			}
-			continue;
+			wave_lds_sync();
+			// ---- flush this batch's occlusion counts ----
+			if (lane < n) {
+				const uint32_t occluded = mine.occluded[lane];
+				if (occluded)
+					atomicAdd(&occluded_of[first + lane], occluded);
+			}
+			wave_lds_sync();
 		}
-		if (walking == 0ull) {
-			if (exhausted)
-				break;
-			continue;  // all lanes idle and the queue is not drained: refill next
-		}
-		advance_walkers<WALK_STEPS>(scene, top, top_lds, ray, walkable, P.ao_max_distance, P.ao_below, cur, pending);
 	}
 }
 
-// Pass 3: value *= 1 - hits / n (reference :256 and :305-307), one thread per hit.
+// Pass 3: value *= 1 - hits / n (reference :256 and :305-307), one thread per hit-list slot.
 __global__ __launch_bounds__(256) void resolve_kernel(const HitRec *__restrict__ hits,
                                                       const uint32_t *__restrict__ occluded_of,
                                                       FrameCounters *__restrict__ counters, float *__restrict__ image,
-                                                      uint32_t ao_dirs) {
+                                                      const uint32_t *__restrict__ group_offset, KernelParams P) {
 	__shared__ unsigned int block_total;
 	if (threadIdx.x == 0)
 		block_total = 0u;
 	__syncthreads();
-	const uint32_t hit_count = counters->hit_count;
-	const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
-	if (blockIdx.x * blockDim.x >= hit_count)
-		return;
-	if (h < hit_count) {
-		const uint32_t occluded = occluded_of[h];
-		const HitRec rec = hits[h];
-		image[rec.pixel] = rec.value * (1.0f - ((float) occluded / (float) ao_dirs));
+	const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+	// which group's segment is this slot in, and is it occupied?
+	uint32_t group = 0u;
+	for (uint32_t g = 1; g < XCD_GROUPS; ++g)
+		if (slot >= group_offset[g])
+			group = g;
+	const bool valid = slot < group_offset[XCD_GROUPS] && slot - group_offset[group] < counters->hit_count[group];
+	if (valid) {
+		const uint32_t occluded = occluded_of[slot];
+		const HitRec rec = hits[slot];
+		image[rec.pixel] = rec.value * (1.0f - ((float) occluded / (float) P.ao_dirs));
 		atomicAdd(&block_total, occluded);
 	}
 	__syncthreads();
-	if (threadIdx.x == 0)
+	if (threadIdx.x == 0 && block_total)
 		atomicAdd(&counters->occluded, (unsigned long long) block_total);
 }
 
@@ -671,7 +712,8 @@ __global__ __launch_bounds__(256) void resize_kernel(const float *__restrict__ t
 
 // ---- host-callable launchers (keeps the launch syntax inside this TU) ----
 void launch_primary(const void *nodes, const void *wnodes, const void *tris, const void *shade, float *image,
-                    void *hits, void *occluded_of, void *counters, const KernelParams &P, void *stream) {
+                    void *hits, void *occluded_of, void *counters, const void *group_offset, const KernelParams &P,
+                    void *stream) {
 	if (P.tiles_x * P.local_tile_rows == 0)
 		return;
 	const uint32_t strips = (P.tiles_x + 1u) >> 1, row_pairs = (P.local_tile_rows + 1u) >> 1;
@@ -679,7 +721,8 @@ void launch_primary(const void *nodes, const void *wnodes, const void *tris, con
 #define OCRT_LAUNCH(K)                                                                                              \
 	hipLaunchKernelGGL(primary_kernel<K>, dim3(blocks), dim3(64 * PRIMARY_WAVES), 0, (hipStream_t) stream,           \
 	                   (const float4 *) nodes, (const float4 *) wnodes, (const float4 *) tris, (const float4 *) shade, \
-	                   image, (HitRec *) hits, (uint32_t *) occluded_of, (FrameCounters *) counters, P)
+	                   image, (HitRec *) hits, (uint32_t *) occluded_of, (FrameCounters *) counters,                 \
+	                   (const uint32_t *) group_offset, P)
 	switch (P.variant) {  // debug knob OCRT_KERNEL_VARIANT: walk steps per scheduling decision
 	case 11: OCRT_LAUNCH(1); break;
 	case 14: OCRT_LAUNCH(4); break;
@@ -689,21 +732,20 @@ void launch_primary(const void *nodes, const void *wnodes, const void *tris, con
 }
 
 void launch_ao(const void *nodes, const void *wnodes, const void *tris, const void *ao_table, float *image,
-               const void *hits, void *occluded_of, void *counters, const KernelParams &P, uint32_t max_hits,
-               uint32_t compute_units, void *stream) {
+               const void *hits, void *occluded_of, void *counters, const void *group_offset, const KernelParams &P,
+               uint32_t max_hits, uint32_t compute_units, void *stream) {
 	if (max_hits == 0 || P.ao_mode != AO_UNIFORM || P.ao_dirs == 0)
 		return;
 	// persistent grid: what the chip holds, or fewer when the frame cannot have that many batches
-	const unsigned long long max_rays = (unsigned long long) max_hits * P.ao_dirs;
-	const unsigned long long useful = (max_rays + AO_BATCH * AO_WAVES - 1) / (AO_BATCH * AO_WAVES);
+	const unsigned long long max_batches = (unsigned long long) ((max_hits + 63u) / 64u) * P.batches_per_hits;
 	uint32_t blocks = compute_units * AO_BLOCKS_PER_CU;
-	if (useful < blocks)
-		blocks = (uint32_t) useful;
+	if ((max_batches + AO_WAVES - 1) / AO_WAVES < blocks)
+		blocks = (uint32_t) ((max_batches + AO_WAVES - 1) / AO_WAVES);
 #define OCRT_LAUNCH(K)                                                                                            \
 	hipLaunchKernelGGL(ao_kernel<K>, dim3(blocks), dim3(64 * AO_WAVES), 0, (hipStream_t) stream,                   \
 	                   (const float4 *) nodes, (const float4 *) wnodes, (const float4 *) tris,                     \
 	                   (const float4 *) ao_table, (const HitRec *) hits, (uint32_t *) occluded_of,                 \
-	                   (FrameCounters *) counters, P)
+	                   (FrameCounters *) counters, (const uint32_t *) group_offset, P)
 	switch (P.variant) {
 	case 11: OCRT_LAUNCH(1); break;
 	case 14: OCRT_LAUNCH(4); break;
@@ -712,7 +754,7 @@ void launch_ao(const void *nodes, const void *wnodes, const void *tris, const vo
 #undef OCRT_LAUNCH
 	hipLaunchKernelGGL(resolve_kernel, dim3((max_hits + 255) / 256), dim3(256), 0, (hipStream_t) stream,
 	                   (const HitRec *) hits, (const uint32_t *) occluded_of, (FrameCounters *) counters, image,
-	                   P.ao_dirs);
+	                   (const uint32_t *) group_offset, P);
 }
 
 void launch_resize(const float *tmp, unsigned char *out, const KernelParams &P, uint32_t out_width, uint32_t n,

@@ -293,6 +293,18 @@ KernelParams make_kernel_params(const RayTracer &rt, uint32_t node_count, uint32
 	p.tiles_x = (p.width + TILE_W - 1) / TILE_W;
 	p.part = part;
 	p.local_tile_rows = local_tile_rows_for(p.height, part);
+	// hit-list segments: group g owns the strips g, g+8, ... (two tiles wide, full band height)
+	const uint32_t strips = (p.tiles_x + 1) / 2, row_pairs = (p.local_tile_rows + 1) / 2;
+	p.group_offset[0] = 0;
+	for (uint32_t g = 0; g < XCD_GROUPS; ++g) {
+		const uint32_t strips_here = (strips + XCD_GROUPS - 1 - g) / XCD_GROUPS;
+		p.group_offset[g + 1] = p.group_offset[g] + strips_here * row_pairs * (4 * TILE_W * TILE_H);
+	}
+	// AO batches of about 8 rays per lane: 64 hits x dirs_per_batch directions
+	const char *rays_per_lane = std::getenv("OCRT_AO_RAYS_PER_LANE");  // debug knob
+	const uint32_t target = rays_per_lane ? (uint32_t) std::atoi(rays_per_lane) : 8u;
+	p.batches_per_hits = ao_dirs ? (ao_dirs + target - 1) / target : 1;
+	p.dirs_per_batch = ao_dirs ? (ao_dirs + p.batches_per_hits - 1) / p.batches_per_hits : 1;
 	return p;
 }
 
