@@ -48,7 +48,6 @@ DeviceRenderer::DeviceRenderer(const RayTracer::Options &options, int device_, u
 	, own_stream(nullptr)
 	, stream(nullptr)
 	, d_nodes(nullptr)
-	, d_wnodes(nullptr)
 	, d_tris(nullptr)
 	, d_shade(nullptr)
 	, d_ao(nullptr)
@@ -56,9 +55,10 @@ DeviceRenderer::DeviceRenderer(const RayTracer::Options &options, int device_, u
 	, d_u8(nullptr)
 	, d_hits(nullptr)
 	, d_occluded(nullptr)
+	, d_tile_hits(nullptr)
+	, d_order(nullptr)
 	, d_counters(nullptr)
-	, d_group_offset(nullptr)
-	, max_hits(0)
+	, tile_count(0)
 	, compute_units(0)
 	, scene_ready(false)
 	, frame_ready(false)
@@ -81,11 +81,9 @@ DeviceRenderer::DeviceRenderer(const RayTracer::Options &options, int device_, u
 	part.rank = rank;
 	part.nranks = nranks;
 	part.band_tile_rows = band_tile_rows_for(grid);
-	kp = make_kernel_params(rt, 0, 0, 0, part, false, false, 0.0f, 0);
+	kp = make_kernel_params(rt, 0, 0, 0, part, false);
 	local_out_rows = kp.local_tile_rows * TILE_H / grid;
-	max_hits = kp.group_offset[XCD_GROUPS];
-	if ((size_t) kp.local_tile_rows * TILE_H * kp.width + (1u << 20) >= (1ull << 32))
-		throw std::invalid_argument("image band too large for 32-bit hit indices");
+	tile_count = (size_t) kp.tiles_x * kp.local_tile_rows;
 
 	useDevice();
 	hipStream_t s;
@@ -96,16 +94,18 @@ DeviceRenderer::DeviceRenderer(const RayTracer::Options &options, int device_, u
 	// is compact.
 	d_image = device_alloc((size_t) rt.totalWidth * rt.totalHeight * sizeof(float));
 	d_u8 = device_alloc((size_t) local_out_rows * opts.width);
-	d_hits = device_alloc(max_hits * sizeof(HitRec));
-	d_occluded = device_alloc(max_hits * sizeof(uint32_t));
+	// hit list: 64 slots per tile; ordered tile lists: one segment per XCD group
+	const size_t order_slots = (size_t) ((kp.tiles_x + 1) / 2) * 2 * kp.local_tile_rows;
+	d_hits = device_alloc(tile_count * 64 * sizeof(HitRec));
+	d_occluded = device_alloc(tile_count * 64 * sizeof(uint32_t));
+	d_tile_hits = device_alloc(tile_count * sizeof(uint32_t));
+	d_order = device_alloc(order_slots * sizeof(uint32_t));
+	d_counters = device_alloc(sizeof(FrameCounters));
 	{
 		hipDeviceProp_t prop;
 		OCRT_HIP(hipGetDeviceProperties(&prop, device));
 		compute_units = (uint32_t) prop.multiProcessorCount;
 	}
-	d_counters = device_alloc(sizeof(FrameCounters));
-	d_group_offset = device_alloc(sizeof kp.group_offset);
-	OCRT_HIP(hipMemcpy(d_group_offset, kp.group_offset, sizeof kp.group_offset, hipMemcpyHostToDevice));
 	OCRT_HIP(hipMemsetAsync(d_image, 0, (size_t) rt.totalWidth * rt.totalHeight * sizeof(float), (hipStream_t) stream));
 	OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));
 }
@@ -126,8 +126,9 @@ DeviceRenderer::~DeviceRenderer() {
 	device_free(d_u8);
 	device_free(d_hits);
 	device_free(d_occluded);
+	device_free(d_tile_hits);
+	device_free(d_order);
 	device_free(d_counters);
-	device_free(d_group_offset);
 	if (own_stream)
 		(void) hipStreamDestroy((hipStream_t) own_stream);
 }
@@ -136,7 +137,6 @@ void DeviceRenderer::useDevice() const { OCRT_HIP(hipSetDevice(device)); }
 
 void DeviceRenderer::freeScene() {
 	device_free(d_nodes);
-	device_free(d_wnodes);
 	device_free(d_tris);
 	device_free(d_shade);
 	device_free(d_ao);
@@ -165,29 +165,25 @@ size_t DeviceRenderer::upload(const PackedScene &scene) {
 			    "ambient-occlusion method 'random' is not implemented on the HIP path yet (use 'uniform')");
 		}
 	}
-	kp = make_kernel_params(rt, (uint32_t) scene.nodes.size(), (uint32_t) scene.tris.size(), ao_dirs, part, scene.regular,
-	                        scene.walkable, scene.origin_limit, scene.top_count);
+	kp = make_kernel_params(rt, (uint32_t) scene.nodes.size(), (uint32_t) scene.tris.size(), ao_dirs, part, scene.regular);
 	const size_t nodes_bytes = scene.nodes.size() * sizeof(NodeRec);
-	const size_t wnodes_bytes = scene.wnodes.size() * sizeof(WalkNodeRec);
 	const size_t tris_bytes = scene.tris.size() * sizeof(TriRec);
 	const size_t shade_bytes = scene.shade.size() * sizeof(ShadeRec);
 	const size_t ao_bytes = table.size() * sizeof(float);
 	d_nodes = device_alloc(nodes_bytes);
-	d_wnodes = device_alloc(wnodes_bytes);
 	d_tris = device_alloc(tris_bytes);
 	d_shade = device_alloc(shade_bytes);
 	d_ao = device_alloc(ao_bytes);
 	OCRT_HIP(hipMemcpy(d_nodes, scene.nodes.data(), nodes_bytes, hipMemcpyHostToDevice));
-	if (wnodes_bytes)
-		OCRT_HIP(hipMemcpy(d_wnodes, scene.wnodes.data(), wnodes_bytes, hipMemcpyHostToDevice));
 	OCRT_HIP(hipMemcpy(d_tris, scene.tris.data(), tris_bytes, hipMemcpyHostToDevice));
 	OCRT_HIP(hipMemcpy(d_shade, scene.shade.data(), shade_bytes, hipMemcpyHostToDevice));
 	if (ao_bytes)
 		OCRT_HIP(hipMemcpy(d_ao, table.data(), ao_bytes, hipMemcpyHostToDevice));
 	OCRT_HIP(hipDeviceSynchronize());
 	scene_ready = true;
-	return nodes_bytes + wnodes_bytes + tris_bytes + shade_bytes + ao_bytes + (size_t) rt.totalWidth * rt.totalHeight * sizeof(float) +
-	       (size_t) local_out_rows * opts.width + max_hits * (sizeof(HitRec) + sizeof(uint32_t)) + sizeof(FrameCounters);
+	return nodes_bytes + tris_bytes + shade_bytes + ao_bytes + (size_t) rt.totalWidth * rt.totalHeight * sizeof(float) +
+	       (size_t) local_out_rows * opts.width + tile_count * (64 * (sizeof(HitRec) + sizeof(uint32_t)) + 2 * sizeof(uint32_t)) +
+	       sizeof(FrameCounters);
 }
 
 void DeviceRenderer::enqueueRender() {
@@ -206,11 +202,8 @@ void DeviceRenderer::enqueueRender() {
 	}
 	OCRT_HIP(hipEventRecord((hipEvent_t) ev.first, (hipStream_t) stream));
 	OCRT_HIP(hipMemsetAsync(d_counters, 0, sizeof(FrameCounters), (hipStream_t) stream));
-	launch_primary(d_nodes, d_wnodes, d_tris, d_shade, (float *) d_image, d_hits, d_occluded, d_counters, d_group_offset, kp,
-	               stream);
-	OCRT_HIP(hipGetLastError());
-	launch_ao(d_nodes, d_wnodes, d_tris, d_ao, (float *) d_image, d_hits, d_occluded, d_counters, d_group_offset, kp,
-	          (uint32_t) max_hits, compute_units, stream);
+	launch_frame(d_nodes, d_tris, d_shade, d_ao, (float *) d_image, d_hits, d_occluded, d_tile_hits, d_order, d_counters, kp,
+	             compute_units, stream);
 	OCRT_HIP(hipGetLastError());
 	OCRT_HIP(hipEventRecord((hipEvent_t) ev.second, (hipStream_t) stream));
 	pending_events.push_back(ev);

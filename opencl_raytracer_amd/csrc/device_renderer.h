@@ -78,8 +78,8 @@ class DeviceRenderer {
 		uint32_t grid;            // supersample grid side
 		uint32_t local_out_rows;
 		void *own_stream, *stream;
-		void *d_nodes, *d_wnodes, *d_tris, *d_shade, *d_ao, *d_image, *d_u8, *d_hits, *d_occluded, *d_counters, *d_group_offset;
-		size_t max_hits;  // sub-pixels of this rank's bands = capacity of the hit list
+		void *d_nodes, *d_tris, *d_shade, *d_ao, *d_image, *d_u8, *d_hits, *d_occluded, *d_tile_hits, *d_order, *d_counters;
+		size_t tile_count;
 		uint32_t compute_units;
 		bool scene_ready, frame_ready;
 		std::vector<std::pair<void *, void *>> pending_events, free_events;
@@ -89,12 +89,9 @@ class DeviceRenderer {
 };
 
 // kernels.hip
-void launch_primary(const void *nodes, const void *wnodes, const void *tris, const void *shade, float *image,
-                    void *hits, void *occluded_of, void *counters, const void *group_offset, const KernelParams &P,
-                    void *stream);
-void launch_ao(const void *nodes, const void *wnodes, const void *tris, const void *ao_table, float *image,
-               const void *hits, void *occluded_of, void *counters, const void *group_offset, const KernelParams &P,
-               uint32_t max_hits, uint32_t compute_units, void *stream);
+void launch_frame(const void *nodes, const void *tris, const void *shade, const void *ao_table, float *image,
+                  void *hits, void *occluded_of, void *tile_hits, void *order, void *counters, const KernelParams &P,
+                  uint32_t compute_units, void *stream);
 void launch_resize(const float *tmp, unsigned char *out, const KernelParams &P, uint32_t out_width, uint32_t n,
                    uint32_t local_out_rows, void *stream);
 

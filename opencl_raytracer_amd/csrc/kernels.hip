@@ -8,39 +8,34 @@
 // layout, traversal order, where a value is computed) is free and is chosen
 // for the CDNA4 wave64 machine.
 //
-// Work decomposition: two passes per frame.
-//   primary_kernel  one 64-lane wavefront per 8x8 tile of sub-pixels: closest-hit
-//                   primary rays, smooth normal and head-light term.  Sub-pixels
-//                   that need no ambient occlusion are final; every other hit is
-//                   appended (ballot-compacted per wave, one atomic per wave) to a
-//                   hit list in HBM.
-//   ao_kernel       persistent: 4 workgroups of 8 waves per CU copy the first
-//                   levels of the BVH into LDS once; then every wave, on its own,
-//                   claims batches of (64 consecutive hits) x (~7 directions)
-//                   from its XCD group's queue -- stealing from the other groups
-//                   once it is empty -- rebuilds the 64 tangent frames in its LDS
-//                   slice and drains the batch's any-hit rays (direction-major:
-//                   the lanes of a wave cast one table direction from neighbouring
-//                   surface points); occlusion counts are LDS atomics, flushed to
-//                   a per-hit counter in HBM when the batch is done.
-//   resolve_kernel  one thread per hit: value * (1 - occluded / n) -> image.
-// The split exists for load balance: cost per tile varies 30x (background vs
-// model, 29 rays per hit sub-pixel), and with fused tiles the frame ended on a
-// tail of half-empty CUs.  After compaction every batch is full and small
-// (about 8 rays per lane), and no wave idles before the frame's last batches.
-// The hit list is segmented by XCD group so that each XCD's L2 sees the same
-// part of the scene in both passes.
+// Work decomposition: one 64-lane wavefront per 8x8 tile of sub-pixels, in two
+// passes with a tiny ordering step between them.
+//   primary_kernel  every lane casts its primary ray (closest hit) and computes
+//                   the smooth normal and head-light term.  Sub-pixels that need
+//                   no ambient occlusion are final; the tile's other hits are
+//                   ballot-compacted into the tile's 64 slots of the hit list.
+//   order_kernel    counting sort of the non-empty tiles by hit count, heaviest
+//                   first, per XCD group.
+//   ao_kernel       persistent waves claim tiles in that order.  A wave rebuilds
+//                   the tile's tangent frames in its LDS slice and drains the
+//                   tile's (hit, direction) pairs -- direction-major, so that the
+//                   lanes cast one table direction from neighbouring surface
+//                   points -- as any-hit rays that stop at the first accepted
+//                   triangle; occlusion counts are LDS atomics; the hit lanes
+//                   then store value * (1 - occluded / n).
+// Why not one fused launch (it was, see profiles/r01_notes.md): cost per tile
+// varies 30x (background vs model, 29 rays per hit sub-pixel) and a full tile
+// keeps its wave busy for ~1/6 of the frame, so the frame used to end on a long
+// tail of half-empty CUs.  With the tiles' costs known after the primary pass,
+// longest-first claiming packs them almost perfectly.
 //
-// What bounds it (profiles/r01_notes.md): the scene (12 MB) lives in L2 and HBM
-// traffic is negligible.  Every node visit is a dependent 32-byte gather; the
-// vector L1 looks up about one cache line per clock per CU and divergent lanes
-// each need their own line, so the walk is bound by L1 gather rate and latency.
-// Hence: the top of the tree in LDS (3x lower latency, separate bandwidth), as
-// few VALU instructions per visit as the arithmetic contract allows (a
-// conservative packed-FMA box test on enlarged boxes for the walk, the exact
-// test only where the reference's result depends on it: at the leaves), and a
-// wave-level scheduler that keeps the lanes busy.
+// What bounds it: the scene (12 MB) lives in L2, HBM traffic is negligible;
+// every node visit is a dependent, lane-divergent 32-byte gather served by the
+// vector L1 at about one cache line per clock per CU, and the VALU is ~80 %
+// busy -- see profiles/r01_notes.md for the counters and the microbenchmark.
 #include <hip/hip_runtime.h>
+
+#include <cstdlib>
 
 #include "device_types.h"
 
@@ -52,7 +47,6 @@ struct Ray {
 	float ox, oy, oz;
 	float dx, dy, dz;
 	float ix, iy, iz;  // 1.0f / d, hoisted out of the per-node slab test
-	float cx, cy, cz;  // -(o * inv): lets the conservative walk test be one fma per plane
 };
 
 struct Hit {
@@ -62,17 +56,8 @@ struct Hit {
 	float px, py, pz;
 };
 
-constexpr uint32_t NONE = 0xFFFFFFFFu;
-
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
 	return (ax * bx + ay * by) + az * bz;
-}
-
-__device__ __forceinline__ void normalize3(float &x, float &y, float &z) {
-	const float l = sqrtf(dot3(x, y, z, x, y, z));
-	x = x / l;
-	y = y / l;
-	z = z / l;
 }
 
 __device__ __forceinline__ Ray make_ray(float ox, float oy, float oz, float dx, float dy, float dz) {
@@ -82,20 +67,13 @@ __device__ __forceinline__ Ray make_ray(float ox, float oy, float oz, float dx, 
 	r.ix = 1.0f / dx;
 	r.iy = 1.0f / dy;
 	r.iz = 1.0f / dz;
-	r.cx = -(ox * r.ix);
-	r.cy = -(oy * r.iy);
-	r.cz = -(oz * r.iz);
 	return r;
 }
 
-// ---------------------------------------------------------------------------
-// Slab tests
-// ---------------------------------------------------------------------------
-
-// Exact form, reference src/intersect_kernel.cl:21-61.  The reference's early
-// returns only skip work; evaluating everything and combining the same
+// Slab test, reference src/intersect_kernel.cl:21-61.  The reference's early
+// returns only skip work; evaluating everything and AND-ing the same
 // comparisons (kept in their original `a > b` polarity for NaN) is identical.
-__device__ __forceinline__ bool slab_hit_exact(const float4 lo, const float4 hi, const Ray &r, float max_distance) {
+__device__ __forceinline__ bool slab_hit(const float4 lo, const float4 hi, const Ray &r, float max_distance) {
 	const bool px = r.ix >= 0.0f, py = r.iy >= 0.0f, pz = r.iz >= 0.0f;
 	float t_min = ((px ? lo.x : hi.x) - r.ox) * r.ix;
 	float t_max = ((px ? hi.x : lo.x) - r.ox) * r.ix;
@@ -112,182 +90,97 @@ __device__ __forceinline__ bool slab_hit_exact(const float4 lo, const float4 hi,
 	return !miss & (t_min < max_distance) & (t_max > 0.0f);
 }
 
-// Largest magnitude for which (b - o) cannot overflow.  A ray is "regular" when
-// its origin is within it and its reciprocal direction is finite and non-zero;
-// a box is regular when it is finite, within the limit and lo <= hi (checked on
-// the host, KernelParams::scene_regular).
+// ---------------------------------------------------------------------------
+// Wave-scheduled traversal.
+//
+// A lane is in one of three states: T (walking nodes), L (a leaf whose box was
+// hit is pending its triangle test), I (no ray).  Instead of letting every lane
+// run its own nested loops -- where the wave pays for the longest ray and a
+// triangle test runs with a handful of live lanes -- the wave picks, per
+// iteration and with scalar ballots only, the one body worth running:
+// refill idle lanes from the tile's ray queue, run the triangle test for the L
+// lanes, or advance the T lanes by one node.  Each body is straight-line and
+// predicated, so exec-mask bookkeeping stays out of the hot loop.
+// ---------------------------------------------------------------------------
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+constexpr uint32_t REFILL_MIN = 16;  // refill once this many lanes are idle ...
+constexpr uint32_t LEAF_MIN = 16;    // ... run triangle tests once this many leaves are pending
+
+// Largest magnitude for which (b - o) cannot overflow; beyond it, or for a ray
+// with an infinite or NaN reciprocal direction, the exact select-based slab test
+// is used instead of the min/max form.
 constexpr float REGULAR_LIMIT = 1.0e37f;
 
 __device__ __forceinline__ bool ray_is_regular(const Ray &r) {
 	return fabsf(r.ox) <= REGULAR_LIMIT && fabsf(r.oy) <= REGULAR_LIMIT && fabsf(r.oz) <= REGULAR_LIMIT &&
-	       fabsf(r.ix) <= REGULAR_LIMIT && fabsf(r.iy) <= REGULAR_LIMIT && fabsf(r.iz) <= REGULAR_LIMIT &&
-	       r.ix != 0.0f && r.iy != 0.0f && r.iz != 0.0f;
+	       fabsf(r.ix) <= REGULAR_LIMIT && fabsf(r.iy) <= REGULAR_LIMIT && fabsf(r.iz) <= REGULAR_LIMIT;
 }
 
-// May this ray use the enlarged walk boxes?  Origin within the bound the margin
-// was sized for, reciprocal direction in [2^-60, 2^100] (no overflow of o*inv,
-// no underflow of margin*inv).
-__device__ __forceinline__ bool ray_is_walkable(const Ray &r, float origin_limit) {
-	const float inv_lo = 8.6736174e-19f, inv_hi = 1.2676506e30f;
-	return fabsf(r.ox) <= origin_limit && fabsf(r.oy) <= origin_limit && fabsf(r.oz) <= origin_limit &&
-	       fabsf(r.ix) >= inv_lo && fabsf(r.ix) <= inv_hi && fabsf(r.iy) >= inv_lo && fabsf(r.iy) <= inv_hi &&
-	       fabsf(r.iz) >= inv_lo && fabsf(r.iz) <= inv_hi;
-}
-
-// min/max form.  For a regular ray against a regular box no NaN can arise,
-// (lo-o)*inv and (hi-o)*inv are ordered by the sign of inv (IEEE rounding is
-// monotonic), and the reference's chain of early-outs reduces to
-//   max(near) <= min(far)  &&  max(near) < max_distance  &&  min(far) > 0
-// -- the same comparisons on the same values.  With below = pred(max_distance)
-// (max_distance > 0) and tiny = the smallest positive float this is
-//   max(near, tiny) <= min(far, below).
-// The same monotonicity makes the test conservative under box enlargement:
-// lo' <= lo, hi' >= hi can only widen [near, far].
-__device__ __forceinline__ bool slab_hit_regular(float lox, float loy, float loz, float hix, float hiy, float hiz,
-                                                 const Ray &r, float below) {
-	const float x0 = (lox - r.ox) * r.ix, x1 = (hix - r.ox) * r.ix;
-	const float y0 = (loy - r.oy) * r.iy, y1 = (hiy - r.oy) * r.iy;
-	const float z0 = (loz - r.oz) * r.iz, z1 = (hiz - r.oz) * r.iz;
+// min/max form of the slab test.  For a regular ray against a regular box
+// (finite, lo <= hi) no NaN can arise, (lo-o)*inv and (hi-o)*inv are ordered by
+// the sign of inv (IEEE rounding is monotonic), and the reference's chain of
+// early-outs (src/intersect_kernel.cl:21-61) reduces to
+//   max(near) <= min(far)  &&  max(near) < max_distance  &&  min(far) > 0,
+// the same comparisons on the same values.  With below = pred(max_distance) and
+// tiny = the smallest positive float, that is  max(near, tiny) <= min(far, below).
+__device__ __forceinline__ bool slab_hit_regular(const float4 lo, const float4 hi, const Ray &r, float below) {
+	const float x0 = (lo.x - r.ox) * r.ix, x1 = (hi.x - r.ox) * r.ix;
+	const float y0 = (lo.y - r.oy) * r.iy, y1 = (hi.y - r.oy) * r.iy;
+	const float z0 = (lo.z - r.oz) * r.iz, z1 = (hi.z - r.oz) * r.iz;
 	const float tiny = __uint_as_float(1u);
 	const float t_near = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tiny));
 	const float t_far = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), below));
 	return t_near <= t_far;
 }
 
-// ---------------------------------------------------------------------------
-// Scene access: 128-bit loads through buffer descriptors (wave-uniform base in
-// SGPRs + 32-bit per-lane byte offset).  One instruction per 16 bytes, offsets
-// past the end return 0 instead of faulting, and -- unlike a pointer load --
-// hipcc cannot split a lane off and sink it behind the box test (it did, which
-// cost a second dependent memory round trip per node).
-// ---------------------------------------------------------------------------
+// One node for a lane in state T: box hit -> next node in pre-order (and the leaf,
+// if it is one, becomes pending); miss -> skip the subtree.  Inner nodes carry
+// leaf == NONE, so no leaf/inner branch is needed.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ u32x4 load_u4(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_offset) {
-	return __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int) byte_offset, 0, 0);
-}
+// 128-bit loads through a buffer descriptor (wave-uniform base + 32-bit per-lane
+// byte offset): one instruction per float4, out-of-range offsets return 0
+// instead of faulting, and -- unlike a plain pointer load -- the compiler cannot
+// split off the .w lane and sink it behind the box test (which it did, adding a
+// second dependent memory round trip per node).
 __device__ __forceinline__ float4 load_f4(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_offset) {
-	const u32x4 v = load_u4(rsrc, byte_offset);
+	const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int) byte_offset, 0, 0);
 	return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
-struct SceneViews {
-	__amdgpu_buffer_rsrc_t nodes;   // NodeRec[node_count]      exact boxes
-	__amdgpu_buffer_rsrc_t wnodes;  // WalkNodeRec[node_count]  enlarged boxes
-	__amdgpu_buffer_rsrc_t tris;    // TriRec[tri_count]
-};
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// Conservative slab test of the walk: t = fma(plane, inv, -(o*inv)) per plane
-// (three packed FMAs for the six planes) on a box that the host enlarged by
-// m = 2^-19 * S on every side, S >= every |box coordinate| and |ray origin|.
-//
-// Claim: whenever the exact test (slab_hit_regular on the exact box) passes,
-// this one passes.  Per plane and for inv > 0 (inv < 0 mirrors), with u = 2^-24:
-//   here   U = fl(lo'*inv + c),  c = fl(-o*inv),  lo' <= lo - m
-//          U <= (lo - m - o)*inv + |o|*inv*u + |U|*u
-//   exact  T = fl(fl(lo - o)*inv) >= (lo - o)*inv - |lo - o|*inv*(2u + u^2)
-// so U <= T as soon as m >= u*(4|o| + 3|lo| + m) ~ 7uS, and m = 32uS.  The far
-// plane is symmetric (U >= T).  Hence [near, far] here contains the exact
-// interval and  max(near, tiny) <= min(far, below)  is implied.  Sub-normal
-// results would break the relative-error model; |inv| >= 2^-60 keeps m*inv far
-// above them.
-__device__ __forceinline__ bool slab_hit_walk(const u32x4 a, const u32x4 b, const Ray &r, float below) {
-	const f32x2 px = { __uint_as_float(a.x), __uint_as_float(a.y) };
-	const f32x2 py = { __uint_as_float(a.z), __uint_as_float(a.w) };
-	const f32x2 pz = { __uint_as_float(b.x), __uint_as_float(b.y) };
-	const f32x2 tx = __builtin_elementwise_fma(px, (f32x2){ r.ix, r.ix }, (f32x2){ r.cx, r.cx });
-	const f32x2 ty = __builtin_elementwise_fma(py, (f32x2){ r.iy, r.iy }, (f32x2){ r.cy, r.cy });
-	const f32x2 tz = __builtin_elementwise_fma(pz, (f32x2){ r.iz, r.iz }, (f32x2){ r.cz, r.cz });
-	const float tiny = __uint_as_float(1u);
-	const float t_near = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fmaxf(fminf(tz.x, tz.y), tiny));
-	const float t_far = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fminf(fmaxf(tz.x, tz.y), below));
-	return t_near <= t_far;
+// One node for a lane in state T: box hit -> next node in pre-order (and the leaf,
+// if it is one, becomes pending); miss -> skip the subtree.  Inner nodes carry
+// leaf == NONE, so no leaf/inner branch is needed.
+template <bool REGULAR>
+__device__ __forceinline__ void node_step(__amdgpu_buffer_rsrc_t nodes, const Ray &r, float max_distance,
+                                          float below, uint32_t &i, uint32_t &pending) {
+	const float4 lo = load_f4(nodes, i * 32u);
+	const float4 hi = load_f4(nodes, i * 32u + 16u);
+	const bool hit = REGULAR ? slab_hit_regular(lo, hi, r, below) : slab_hit(lo, hi, r, max_distance);
+	pending = hit ? __float_as_uint(hi.w) : NONE;
+	i += hit ? 1u : __float_as_uint(lo.w);
 }
 
-// Cursor of a walking lane.
-//   walk mode : i indexes the top-first walk array; entries below `top` are read
-//               from LDS, the rest from global memory.  While inside a cut-off
-//               body, `end` is the body's end and `ret` the top entry to resume at.
-//   exact mode: i indexes the original pre-order NodeRec array (limit = node count).
-// A lane is done when i >= limit and it is not inside a body.
-struct Cursor {
-	uint32_t i, end, ret, limit;
-};
-__device__ __forceinline__ bool cursor_alive(const Cursor &c) { return c.i < c.limit || c.end != NONE; }
-__device__ __forceinline__ void cursor_finish(Cursor &c) {
-	c.i = c.limit;
-	c.end = NONE;
+__device__ __forceinline__ void normalize3(float &x, float &y, float &z) {
+	const float l = sqrtf(dot3(x, y, z, x, y, z));
+	x = x / l;
+	y = y / l;
+	z = z / l;
 }
 
-// One node for a lane in state T on the enlarged boxes: box hit -> first child
-// (next entry; a hit leaf becomes pending; a hit portal enters its body); miss ->
-// skip the subtree.
-__device__ __forceinline__ void node_step_walk(const SceneViews &scene, const uint4 *__restrict__ top, uint32_t top_lds,
-                                               const Ray &r, float below, Cursor &c, uint32_t &pending) {
-	u32x4 a, b;
-	if (c.i < top_lds) {
-		const uint4 la = top[2u * c.i], lb = top[2u * c.i + 1u];
-		a = (u32x4){ la.x, la.y, la.z, la.w };
-		b = (u32x4){ lb.x, lb.y, lb.z, lb.w };
-	} else {
-		a = load_u4(scene.wnodes, c.i * 32u);
-		b = load_u4(scene.wnodes, c.i * 32u + 16u);
-	}
-	const bool hit = slab_hit_walk(a, b, r, below);
-	const uint32_t span = b.z, kind = b.w >> WALK_KIND_SHIFT, payload = b.w & WALK_PAYLOAD_MASK;
-	const bool portal = kind == WALK_PORTAL;
-	pending = (hit && kind == WALK_LEAF) ? payload : NONE;
-	if (hit && portal) {
-		c.ret = c.i + 1u;
-		c.i = payload;
-		c.end = payload + span;
-	} else {
-		c.i += (hit || portal) ? 1u : span;
-	}
-	if (c.i == c.end) {
-		c.i = c.ret;
-		c.end = NONE;
-	}
+// Maps a rank-local tile row to the global tile row under the band partition.
+__device__ __forceinline__ uint32_t global_tile_row(const Partition &p, uint32_t local_row) {
+	const uint32_t band_local = local_row / p.band_tile_rows;
+	const uint32_t within = local_row - band_local * p.band_tile_rows;
+	return (band_local * p.nranks + p.rank) * p.band_tile_rows + within;
 }
 
-// Same on the exact boxes with the reference's own test (irregular rays, scenes
-// without a walk array).
-__device__ __forceinline__ void node_step_exact(const SceneViews &scene, const Ray &r, float max_distance, Cursor &c,
-                                                uint32_t &pending) {
-	const float4 lo = load_f4(scene.nodes, c.i * 32u);
-	const float4 hi = load_f4(scene.nodes, c.i * 32u + 16u);
-	const bool hit = slab_hit_exact(lo, hi, r, max_distance);
-	pending = hit ? __float_as_uint(hi.w) : NONE;  // inner nodes carry NONE
-	c.i += hit ? 1u : __float_as_uint(lo.w);
-}
+}  // namespace
 
-// Advances the T lanes: WALK_STEPS nodes for the lanes that walk the enlarged
-// boxes (the common case); when none of those is walking, one node for the lanes
-// on the exact boxes.
-template <int WALK_STEPS>
-__device__ __forceinline__ void advance_walkers(const SceneViews &scene, const uint4 *__restrict__ top,
-                                                uint32_t top_lds, const Ray &r, bool walkable, float max_distance,
-                                                float below, Cursor &c, uint32_t &pending) {
-	bool walking_lane = pending == NONE && cursor_alive(c);
-	if (__ballot(walking_lane && walkable) != 0ull) {
-#pragma unroll
-		for (int step = 0; step < WALK_STEPS; ++step) {
-			if (walking_lane && walkable)
-				node_step_walk(scene, top, top_lds, r, below, c, pending);
-			walking_lane = pending == NONE && cursor_alive(c);
-		}
-	} else if (walking_lane) {
-		node_step_exact(scene, r, max_distance, c, pending);
-	}
-}
-
-// Triangle test for a pending leaf, straight-line: the leaf's exact box gate
-// (reference :189,:195 -- the leaf is a node of the walk) followed by the plane
-// hit + parametric (s,t) test (reference :65-114) on the precomputed TriRec.
-// The early returns of the reference become one accumulated predicate so that
-// all L lanes stay converged.  `x > 1.00001` (double literal) == `x > 0x3F800053`.
+// Triangle test for a pending leaf, straight-line.  Same operations and order
+// as the reference (src/intersect_kernel.cl:65-114) on the precomputed TriRec;
+// the early returns become one accumulated predicate so that all L lanes stay
+// converged.  `x > 1.00001` (double literal) == `x > 0x3F800053`.
 struct TriResult {
 	bool accepted;
 	float s, t, distance;
@@ -295,15 +188,9 @@ struct TriResult {
 };
 
 template <bool CLOSEST>
-__device__ __forceinline__ TriResult tri_test(const SceneViews &scene, uint32_t leaf, const Ray &r, bool regular,
-                                              float below) {
-	const uint32_t base = leaf * (uint32_t) sizeof(TriRec);
-	const float4 q0 = load_f4(scene.tris, base), q1 = load_f4(scene.tris, base + 16u);
-	const float4 q2 = load_f4(scene.tris, base + 32u), q3 = load_f4(scene.tris, base + 48u);
-	const float4 b0 = load_f4(scene.tris, base + 64u), b1 = load_f4(scene.tris, base + 80u);
-	// A lane on the walk array may have reached this leaf through its enlarged box:
-	// apply the exact one.  A lane on the exact array already passed it.
-	const bool box_ok = !regular || slab_hit_regular(b0.x, b0.y, b0.z, b1.x, b1.y, b1.z, r, below);
+__device__ __forceinline__ TriResult tri_test(__amdgpu_buffer_rsrc_t tris, uint32_t leaf, const Ray &r) {
+	const float4 q0 = load_f4(tris, leaf * 64u), q1 = load_f4(tris, leaf * 64u + 16u);
+	const float4 q2 = load_f4(tris, leaf * 64u + 32u), q3 = load_f4(tris, leaf * 64u + 48u);
 	const float tax = q0.x, tay = q0.y, taz = q0.z;
 	const float ux = q0.w, uy = q1.x, uz = q1.y;
 	const float vx = q1.z, vy = q1.w, vz = q2.x;
@@ -323,7 +210,7 @@ __device__ __forceinline__ TriResult tri_test(const SceneViews &scene, uint32_t 
 	const bool reject = (fabsf(b) < 0.000001f) | (rr < 0.0f) | (s < -0.00001f) | (s > slack_hi) | (t < -0.00001f) |
 	                    ((s + t) > slack_hi);
 	TriResult out;
-	out.accepted = box_ok & !reject;
+	out.accepted = !reject;
 	out.s = s;
 	out.t = t;
 	out.px = ipx; out.py = ipy; out.pz = ipz;
@@ -335,74 +222,78 @@ __device__ __forceinline__ TriResult tri_test(const SceneViews &scene, uint32_t 
 	return out;
 }
 
-// Maps a rank-local tile row to the global tile row under the band partition.
-__device__ __forceinline__ uint32_t global_tile_row(const Partition &p, uint32_t local_row) {
-	const uint32_t band_local = local_row / p.band_tile_rows;
-	const uint32_t within = local_row - band_local * p.band_tile_rows;
-	return (band_local * p.nranks + p.rank) * p.band_tile_rows + within;
-}
+struct SceneViews {
+	__amdgpu_buffer_rsrc_t nodes;  // NodeRec[node_count]
+	__amdgpu_buffer_rsrc_t tris;   // TriRec[tri_count]
+};
 
-}  // namespace
-
-// Wave scheduler thresholds.  A lane is in state T (walking nodes), L (a hit
-// leaf is pending its triangle test) or I (no ray).  Per iteration the wave
-// runs, chosen with scalar ballots only, ONE straight-line predicated body:
-// refill the I lanes from the ray queue, test the L lanes' triangles, or advance
-// the T lanes.  This keeps the wave from paying for its longest ray and from
-// running a 150-instruction triangle test for two lanes.
-constexpr uint32_t REFILL_MIN = 16;  // refill once this many lanes are idle ...
-constexpr uint32_t LEAF_MIN = 16;    // ... test triangles once this many leaves are pending
-
-__device__ __forceinline__ SceneViews make_views(const float4 *nodes_ptr, const float4 *wnodes_ptr,
-                                                 const float4 *tris_ptr, const KernelParams &P) {
+__device__ __forceinline__ SceneViews make_views(const float4 *nodes_ptr, const float4 *tris_ptr, const KernelParams &P) {
 	// descriptors are built from kernel arguments only, so they live in SGPRs
 	SceneViews scene;
 	scene.nodes = __builtin_amdgcn_make_buffer_rsrc((void *) nodes_ptr, 0, (int) (P.node_count * 32u), 0x00020000);
-	scene.wnodes = __builtin_amdgcn_make_buffer_rsrc((void *) wnodes_ptr, 0, (int) (P.node_count * 32u), 0x00020000);
-	scene.tris = __builtin_amdgcn_make_buffer_rsrc((void *) tris_ptr, 0,
-	                                               (int) (P.tri_count * (uint32_t) sizeof(TriRec)), 0x00020000);
+	scene.tris = __builtin_amdgcn_make_buffer_rsrc((void *) tris_ptr, 0, (int) (P.tri_count * 64u), 0x00020000);
 	return scene;
 }
+
+// Advances the lanes in state T by one node: the min/max slab form when every
+// walking lane's ray is regular (the common case), the reference's own form otherwise.
+__device__ __forceinline__ void advance_walkers(const SceneViews &scene, const Ray &r, bool regular, float max_distance,
+                                                float below, uint32_t count, uint32_t &i, uint32_t &pending) {
+	const bool walking_lane = pending == NONE && i < count;
+	const bool all_regular = __ballot(walking_lane && !regular) == 0ull;
+	if (walking_lane) {
+		if (all_regular)
+			node_step<true>(scene.nodes, r, max_distance, below, i, pending);
+		else
+			node_step<false>(scene.nodes, r, max_distance, below, i, pending);
+	}
+}
+
+// Position of this lane among the set bits of `mask` below it.
+__device__ __forceinline__ uint32_t rank_in(unsigned long long mask) {
+	return __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
+}
+
+// Tile <-> workgroup mapping shared by the passes.  A workgroup of the primary
+// pass covers 2x2 tiles (16x16 sub-pixels).  Workgroups b and b+8 share an XCD
+// and its L2 (MI355X_MICROARCH.md, dispatch is round-robin over XCDs), so the
+// image is cut into vertical strips two tiles wide, strips are dealt round-robin
+// to the 8 XCD groups, and each group walks its strips top to bottom:
+// neighbouring workgroups of a group touch the same BVH region, while every
+// group still sees the whole image height.
+__device__ __forceinline__ uint32_t group_of_tile_x(uint32_t tile_x) { return (tile_x >> 1) & (XCD_GROUPS - 1u); }
 
 // ---------------------------------------------------------------------------
 // Pass 1: primary rays.  Four independent waves per workgroup, one tile each.
 // ---------------------------------------------------------------------------
 constexpr uint32_t PRIMARY_WAVES = 4;
 
-template <int WALK_STEPS>
 __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
-    const float4 *__restrict__ nodes_ptr, const float4 *__restrict__ wnodes_ptr, const float4 *__restrict__ tris_ptr,
-    const float4 *__restrict__ shade, float *__restrict__ image, HitRec *__restrict__ hits,
-    uint32_t *__restrict__ occluded_of, FrameCounters *__restrict__ counters,
-    const uint32_t *__restrict__ group_offset, KernelParams P) {
+    const float4 *__restrict__ nodes_ptr, const float4 *__restrict__ tris_ptr, const float4 *__restrict__ shade,
+    float *__restrict__ image, HitRec *__restrict__ hits, uint32_t *__restrict__ occluded_of,
+    uint32_t *__restrict__ tile_hits, FrameCounters *__restrict__ counters, KernelParams P) {
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t wave = threadIdx.x >> 6;
-	const SceneViews scene = make_views(nodes_ptr, wnodes_ptr, tris_ptr, P);
+	const SceneViews scene = make_views(nodes_ptr, tris_ptr, P);
 
-	// Workgroup -> 2x2 tiles (16x16 sub-pixels).  Workgroups b and b+8 share an
-	// XCD and its L2 (MI355X_MICROARCH.md, dispatch is round-robin over XCDs), so
-	// the image is cut into vertical strips two tiles wide, strips are dealt
-	// round-robin to the 8 XCD groups, and each group walks its strips top to
-	// bottom: neighbouring workgroups of a group touch the same BVH region, while
-	// every group still sees the whole image height.
-	const uint32_t group = blockIdx.x & 7u, seq = blockIdx.x >> 3;
+	const uint32_t group = blockIdx.x & (XCD_GROUPS - 1u), seq = blockIdx.x >> 3;
 	const uint32_t strips = (P.tiles_x + 1u) >> 1;
 	const uint32_t row_pairs = (P.local_tile_rows + 1u) >> 1;
-	const uint32_t strips_here = (strips + 7u - group) >> 3;
+	const uint32_t strips_here = (strips + XCD_GROUPS - 1u - group) >> 3;
 	if (seq >= strips_here * row_pairs)
 		return;
 	const uint32_t strip_index = seq / row_pairs;
 	const uint32_t row_pair = seq - strip_index * row_pairs;
-	const uint32_t tile_x = 2u * (group + 8u * strip_index) + (wave & 1u);
+	const uint32_t tile_x = 2u * (group + XCD_GROUPS * strip_index) + (wave & 1u);
 	const uint32_t local_row = 2u * row_pair + (wave >> 1);
 	if (tile_x >= P.tiles_x || local_row >= P.local_tile_rows)
 		return;  // the waves of a workgroup never synchronise
+	const uint32_t tile = local_row * P.tiles_x + tile_x;
 	const uint32_t tile_y = global_tile_row(P.part, local_row);
 	const uint32_t x = tile_x * TILE_W + (lane & 7u);
 	const uint32_t y = tile_y * TILE_H + (lane >> 3);
 	const bool active = x < P.width && y < P.height;
 	const uint32_t count = P.node_count;
-	const unsigned long long lanes_below = (1ull << lane) - 1ull;
 
 	// reference src/intersect_kernel.cl:279-295
 	float dx = ((float) x + 0.5f) / P.a - P.half_w;
@@ -410,25 +301,21 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
 	float dz = -1.0f;
 	normalize3(dx, dy, dz);
 	const Ray ray = make_ray(0.0f, 0.0f, 2.0f, dx, dy, dz);
-	const bool walkable = P.walk_ok && ray_is_regular(ray) && ray_is_walkable(ray, P.origin_limit);
+	const bool regular = P.scene_regular && ray_is_regular(ray);
 	Hit best;
 	best.distance = __builtin_inff();
 	best.leaf = 0;
 	best.s = best.t = 0.0f;
 	best.px = best.py = best.pz = 0.0f;
 	bool hit = false;
-	Cursor cur;
-	cur.limit = walkable ? P.top_count : count;
-	cur.i = active ? 0u : cur.limit;
-	cur.end = NONE;
-	cur.ret = 0u;
+	uint32_t i = active ? 0u : count;
 	uint32_t pending = NONE;
 	for (;;) {
-		const unsigned long long walking = __ballot(pending == NONE && cursor_alive(cur));
+		const unsigned long long walking = __ballot(pending == NONE && i < count);
 		const unsigned long long leaves = __ballot(pending != NONE);
 		if (leaves != 0ull && ((uint32_t) __popcll(leaves) >= LEAF_MIN || walking == 0ull)) {
 			if (pending != NONE) {
-				const TriResult tr = tri_test<true>(scene, pending, ray, walkable, P.primary_below);
+				const TriResult tr = tri_test<true>(scene.tris, pending, ray);
 				// closest hit: strict '>' in ascending leaf order, reference :106-112
 				if (tr.accepted) {
 					hit = true;
@@ -446,7 +333,7 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
 		}
 		if (walking == 0ull)
 			break;
-		advance_walkers<WALK_STEPS>(scene, nullptr, 0u, ray, walkable, 100000.0f, P.primary_below, cur, pending);
+		advance_walkers(scene, ray, regular, 100000.0f, P.primary_below, count, i, pending);
 	}
 
 	// smooth normal and head-light term, reference :296-304
@@ -469,47 +356,94 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
 	if (active && !(hit && want_ao))
 		image[(size_t) y * P.width + x] = value;  // final already
 
-	// append the hits of this wave to the hit list: one returning atomic per wave
+	// the tile's hits go into the tile's own 64 slots of the hit list, compacted
 	const unsigned long long hit_mask = __ballot(hit);
 	const uint32_t hit_count = (uint32_t) __popcll(hit_mask);
-	if (hit_count == 0u)
-		return;
-	uint32_t base = 0u;
 	if (lane == 0u) {
-		atomicAdd(&counters->primary_hits, hit_count);
-		if (want_ao)
-			base = group_offset[group] + atomicAdd(&counters->hit_count[group], hit_count);
+		tile_hits[tile] = want_ao ? hit_count : 0u;
+		if (hit_count)
+			atomicAdd(&counters->primary_hits, hit_count);
 	}
-	base = (uint32_t) __shfl((int) base, 0);
 	if (hit && want_ao) {
 		HitRec rec;
 		rec.ox = best.px; rec.oy = best.py; rec.oz = best.pz;
 		rec.value = value;
 		rec.nx = nx; rec.ny = ny; rec.nz = nz;
 		rec.pixel = y * P.width + x;
-		const uint32_t slot = base + (uint32_t) __popcll(hit_mask & lanes_below);
+		const size_t slot = (size_t) tile * 64u + rank_in(hit_mask);
 		hits[slot] = rec;
 		occluded_of[slot] = 0u;
 	}
 }
 
 // ---------------------------------------------------------------------------
-// Pass 2: ambient occlusion.  Persistent workgroups; waves work independently.
+// Ordering step: per XCD group, the non-empty tiles sorted by hit count,
+// heaviest first (counting sort, one workgroup per group).
 // ---------------------------------------------------------------------------
-constexpr uint32_t AO_WAVES = 8;
-constexpr uint32_t AO_BLOCKS_PER_CU = 4;
+__global__ __launch_bounds__(1024) void order_kernel(const uint32_t *__restrict__ tile_hits,
+                                                     uint32_t *__restrict__ order, FrameCounters *__restrict__ counters,
+                                                     KernelParams P) {
+	__shared__ unsigned int bucket[65];  // tiles per hit count, then running write cursor
+	const uint32_t group = blockIdx.x;
+	const uint32_t strips = (P.tiles_x + 1u) >> 1;
+	const uint32_t strips_here = (strips + XCD_GROUPS - 1u - group) >> 3;
+	const uint32_t tiles_here = strips_here * 2u * P.local_tile_rows;  // incl. a possible column past the image
+	// this group's segment of `order` starts where the previous groups' capacity ends
+	uint32_t segment = 0u;
+	for (uint32_t g = 0; g < group; ++g)
+		segment += ((strips + XCD_GROUPS - 1u - g) >> 3) * 2u * P.local_tile_rows;
+	if (threadIdx.x < 65u)
+		bucket[threadIdx.x] = 0u;
+	__syncthreads();
+	// tile e of the group: strip (e / (2 * rows)), then row-major 2-wide
+	auto tile_of = [&](uint32_t e, uint32_t &tile) -> bool {
+		const uint32_t per_strip = 2u * P.local_tile_rows;
+		const uint32_t strip_index = e / per_strip, within = e - strip_index * per_strip;
+		const uint32_t tile_x = 2u * (group + XCD_GROUPS * strip_index) + (within & 1u);
+		const uint32_t local_row = within >> 1;
+		tile = local_row * P.tiles_x + tile_x;
+		return tile_x < P.tiles_x;
+	};
+	for (uint32_t e = threadIdx.x; e < tiles_here; e += blockDim.x) {
+		uint32_t tile;
+		if (tile_of(e, tile))
+			atomicAdd(&bucket[P.debug_no_sort ? (tile_hits[tile] ? 1u : 0u) : tile_hits[tile]], 1u);
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		// exclusive prefix over descending hit counts; empty tiles are dropped
+		uint32_t running = 0u;
+		for (int c = 64; c >= 1; --c) {
+			const uint32_t n = bucket[c];
+			bucket[c] = running;
+			running += n;
+		}
+		counters->queue[group].work_tiles = running;
+		counters->queue[group].head = 0u;
+	}
+	__syncthreads();
+	for (uint32_t e = threadIdx.x; e < tiles_here; e += blockDim.x) {
+		uint32_t tile;
+		if (tile_of(e, tile)) {
+			const uint32_t c = P.debug_no_sort ? (tile_hits[tile] ? 1u : 0u) : tile_hits[tile];
+			if (c)
+				order[segment + atomicAdd(&bucket[c], 1u)] = tile;
+		}
+	}
+}
 
-// LDS slice of one wave: the tangent frames of the batch's hits (structure of
-// arrays, lane-major: consecutive hits sit in consecutive banks).
-struct WaveShared {
+// ---------------------------------------------------------------------------
+// Pass 2: ambient occlusion.  Persistent, independent waves; one tile at a time.
+// ---------------------------------------------------------------------------
+constexpr uint32_t AO_WAVES = 4;
+constexpr uint32_t AO_BLOCKS_PER_CU = 8;
+
+// LDS slice of one wave: the tile's hit table, structure of arrays and lane-major
+// so that consecutive hits sit in consecutive banks.
+struct TileShared {
 	float frame[12][64];  // origin xyz, basis_x xyz, basis_y xyz, basis_z xyz
 	unsigned int occluded[64];
 };
-struct AoShared {
-	uint4 top[2 * WALK_TOP_CAPACITY];  // first levels of the walk array
-	WaveShared wave[AO_WAVES];
-};
-static_assert(sizeof(AoShared) <= 40960, "four workgroups must fit the 160 KB of a CU");
 
 // Orders this wave's LDS writes before its later LDS reads.  A wave executes in
 // lockstep and the LDS unit serves one wave's requests in order, so only the
@@ -520,55 +454,57 @@ __device__ __forceinline__ void wave_lds_sync() {
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int WALK_STEPS>
-__global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(4, 6))) void ao_kernel(
-    const float4 *__restrict__ nodes_ptr, const float4 *__restrict__ wnodes_ptr, const float4 *__restrict__ tris_ptr,
-    const float4 *__restrict__ ao_table, const HitRec *__restrict__ hits, uint32_t *__restrict__ occluded_of,
-    FrameCounters *__restrict__ counters, const uint32_t *__restrict__ group_offset, KernelParams P) {
-	__shared__ AoShared sh;
+__global__ __launch_bounds__(64 * AO_WAVES) void ao_kernel(
+    const float4 *__restrict__ nodes_ptr, const float4 *__restrict__ tris_ptr, const float4 *__restrict__ ao_table,
+    const HitRec *__restrict__ hits, uint32_t *__restrict__ occluded_of, const uint32_t *__restrict__ tile_hits,
+    const uint32_t *__restrict__ order, FrameCounters *__restrict__ counters, KernelParams P) {
+	__shared__ TileShared shared_tiles[AO_WAVES];
 	const uint32_t lane = threadIdx.x & 63u;
-	WaveShared &mine = sh.wave[threadIdx.x >> 6];
-	const SceneViews scene = make_views(nodes_ptr, wnodes_ptr, tris_ptr, P);
-	const uint32_t top_lds = P.walk_ok ? P.top_lds : 0u;
-	for (uint32_t e = threadIdx.x; e < 2u * top_lds; e += 64u * AO_WAVES) {
-		const u32x4 v = load_u4(scene.wnodes, e * 16u);
-		sh.top[e] = make_uint4(v.x, v.y, v.z, v.w);
-	}
-	__syncthreads();  // the only workgroup-wide synchronisation: waves are independent from here on
-
+	TileShared &sh = shared_tiles[threadIdx.x >> 6];
+	const SceneViews scene = make_views(nodes_ptr, tris_ptr, P);
 	const uint32_t count = P.node_count;
-	const unsigned long long lanes_below = (1ull << lane) - 1ull;
+	const uint32_t strips = (P.tiles_x + 1u) >> 1;
+
 	// Workgroups b and b+8 share an XCD: start with that group's queue, then help the others.
 	const uint32_t home = blockIdx.x & (XCD_GROUPS - 1u);
 	for (uint32_t turn = 0; turn < XCD_GROUPS; ++turn) {
 		const uint32_t group = (home + turn) & (XCD_GROUPS - 1u);
-		const uint32_t group_hits = counters->hit_count[group];  // produced by the primary pass
-		const uint32_t group_batches = ((group_hits + 63u) >> 6) * P.batches_per_hits;
+		uint32_t segment = 0u;
+		for (uint32_t g = 0; g < group; ++g)
+			segment += ((strips + XCD_GROUPS - 1u - g) >> 3) * 2u * P.local_tile_rows;
+		const uint32_t work_jobs = counters->queue[group].work_tiles * P.jobs_per_tile;
 		for (;;) {
-			// ---- claim a batch: hits [first, first + n) of the group, directions [dir0, dir0 + n_dirs) ----
-			uint32_t batch = 0u;
-			if (lane == 0u)
-				batch = atomicAdd(&counters->queue_head[group], 1u);
-			batch = (uint32_t) __shfl((int) batch, 0);
-			if (batch >= group_batches)
+			// look before claiming: most visits to a foreign group find its queue drained,
+			// and a plain load does not queue up behind the other waves' atomics
+			if (__hip_atomic_load(&counters->queue[group].head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= work_jobs)
 				break;
-			const uint32_t hit_block = batch / P.batches_per_hits;
-			const uint32_t dir0 = (batch - hit_block * P.batches_per_hits) * P.dirs_per_batch;
-			const uint32_t n_dirs = P.ao_dirs - dir0 < P.dirs_per_batch ? P.ao_dirs - dir0 : P.dirs_per_batch;
-			const uint32_t first = group_offset[group] + (hit_block << 6);
-			const uint32_t n = group_hits - (hit_block << 6) < 64u ? group_hits - (hit_block << 6) : 64u;
+			uint32_t claimed = 0u;
+			if (lane == 0u)
+				claimed = atomicAdd(&counters->queue[group].head, 1u);
+			claimed = (uint32_t) __shfl((int) claimed, 0);
+			if (claimed >= work_jobs)
+				break;
+			// job = (tile, direction range); the jobs of a tile are adjacent in the queue, so
+			// the waves that take them share the tile's hit records in L2
+			const uint32_t tile_index = claimed / P.jobs_per_tile;
+			const uint32_t dir0 = (claimed - tile_index * P.jobs_per_tile) * P.dirs_per_job;
+			if (dir0 >= P.ao_dirs)
+				continue;
+			const uint32_t n_dirs = P.ao_dirs - dir0 < P.dirs_per_job ? P.ao_dirs - dir0 : P.dirs_per_job;
+			const uint32_t tile = order[segment + tile_index];
+			const uint32_t hit_count = tile_hits[tile];
 
-			// ---- the batch's tangent frames -> this wave's LDS slice ----
-			if (lane < n) {
-				const float4 q0 = ((const float4 *) hits)[2 * (size_t) (first + lane)];
-				const float4 q1 = ((const float4 *) hits)[2 * (size_t) (first + lane) + 1];
+			// ---- the tile's tangent frames -> this wave's LDS slice (reference :215-236) ----
+			if (lane < hit_count) {
+				const float4 q0 = ((const float4 *) hits)[2 * ((size_t) tile * 64u + lane)];
+				const float4 q1 = ((const float4 *) hits)[2 * ((size_t) tile * 64u + lane) + 1];
 				const float nx = q1.x, ny = q1.y, nz = q1.z;
-				// p = point + normal * (1.0f / 100000.0f), reference :215
+				// p = point + normal * (1.0f / 100000.0f)
 				const float eps = 1.0f / 100000.0f;
-				mine.frame[0][lane] = q0.x + nx * eps;
-				mine.frame[1][lane] = q0.y + ny * eps;
-				mine.frame[2][lane] = q0.z + nz * eps;
-				// tangent frame (reference :224-236): smallest |component| of the normal replaced by 1
+				sh.frame[0][lane] = q0.x + nx * eps;
+				sh.frame[1][lane] = q0.y + ny * eps;
+				sh.frame[2][lane] = q0.z + nz * eps;
+				// tangent frame: the smallest |component| of the normal is replaced by 1
 				float hx = nx, hy = ny, hz = nz;
 				const float ax = fabsf(nx), ay = fabsf(ny), az = fabsf(nz);
 				if (ax <= ay && ax <= az)
@@ -582,74 +518,69 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(4
 				normalize3(bxx, bxy, bxz);
 				float bzx = bxy * nz - bxz * ny, bzy = bxz * nx - bxx * nz, bzz = bxx * ny - bxy * nx;
 				normalize3(bzx, bzy, bzz);
-				mine.frame[3][lane] = bxx; mine.frame[4][lane] = bxy; mine.frame[5][lane] = bxz;
-				mine.frame[6][lane] = nx;  mine.frame[7][lane] = ny;  mine.frame[8][lane] = nz;
-				mine.frame[9][lane] = bzx; mine.frame[10][lane] = bzy; mine.frame[11][lane] = bzz;
+				sh.frame[3][lane] = bxx; sh.frame[4][lane] = bxy; sh.frame[5][lane] = bxz;
+				sh.frame[6][lane] = nx;  sh.frame[7][lane] = ny;  sh.frame[8][lane] = nz;
+				sh.frame[9][lane] = bzx; sh.frame[10][lane] = bzy; sh.frame[11][lane] = bzz;
 			}
-			mine.occluded[lane] = 0u;
+			sh.occluded[lane] = 0u;
 			wave_lds_sync();
 
-			// ---- the batch's n * n_dirs any-hit rays (reference :237-255), direction-major ----
-			const uint32_t total = n * n_dirs;
+			// ---- the tile's hit_count * ao_dirs any-hit rays (reference :237-255).  Queue
+			// order is direction-major, so neighbouring lanes cast the same table direction
+			// from neighbouring pixels. ----
+			const uint32_t total = hit_count * n_dirs;
 			uint32_t next = 0u;  // wave-uniform queue head
-			Ray ray;
-			bool walkable = true;
-			Cursor cur;
-			cur.limit = P.top_count;
-			cur.i = cur.limit;
-			cur.end = NONE;
-			cur.ret = 0u;
+			uint32_t i = count;
 			uint32_t pending = NONE;
 			uint32_t h = 0;
+			Ray ray;
+			bool regular = true;
 			for (;;) {
-				const bool walking_lane = pending == NONE && cursor_alive(cur);
+				const bool walking_lane = pending == NONE && i < count;
 				const unsigned long long walking = __ballot(walking_lane);
 				const unsigned long long leaves = __ballot(pending != NONE);
 				const uint32_t n_leaves = (uint32_t) __popcll(leaves);
 				const uint32_t idle = 64u - (uint32_t) __popcll(walking) - n_leaves;
 				if (next < total && idle >= REFILL_MIN) {
 					const bool idle_lane = !walking_lane && pending == NONE;
-					const unsigned long long idle_mask = __ballot(idle_lane);
-					const uint32_t item = next + (uint32_t) __popcll(idle_mask & lanes_below);
+					const uint32_t item = next + rank_in(__ballot(idle_lane));
 					if (idle_lane && item < total) {
-						const uint32_t k = item / n;
-						h = item - k * n;
+						const uint32_t k = item / hit_count;
+						h = item - k * hit_count;
 						const float4 dir = ao_table[dir0 + k];
 						// ray_dir = basis_x * xs + basis_y * ys + basis_z * zs, lane by lane
-						const float rx = (mine.frame[3][h] * dir.x + mine.frame[6][h] * dir.y) + mine.frame[9][h] * dir.z;
-						const float ry = (mine.frame[4][h] * dir.x + mine.frame[7][h] * dir.y) + mine.frame[10][h] * dir.z;
-						const float rz = (mine.frame[5][h] * dir.x + mine.frame[8][h] * dir.y) + mine.frame[11][h] * dir.z;
-						ray = make_ray(mine.frame[0][h], mine.frame[1][h], mine.frame[2][h], rx, ry, rz);
-						walkable = P.walk_ok && P.ao_regular && ray_is_regular(ray) && ray_is_walkable(ray, P.origin_limit);
-						cur.limit = walkable ? P.top_count : count;
-						cur.i = 0u;
-						cur.end = NONE;
+						const float rx = (sh.frame[3][h] * dir.x + sh.frame[6][h] * dir.y) + sh.frame[9][h] * dir.z;
+						const float ry = (sh.frame[4][h] * dir.x + sh.frame[7][h] * dir.y) + sh.frame[10][h] * dir.z;
+						const float rz = (sh.frame[5][h] * dir.x + sh.frame[8][h] * dir.y) + sh.frame[11][h] * dir.z;
+						ray = make_ray(sh.frame[0][h], sh.frame[1][h], sh.frame[2][h], rx, ry, rz);
+						regular = P.scene_regular && P.ao_regular && ray_is_regular(ray);
+						i = 0u;
 					}
 					next += idle;
 					continue;
 				}
 				if (n_leaves != 0u && (n_leaves >= LEAF_MIN || walking == 0ull)) {
 					if (pending != NONE) {
-						const TriResult tr = tri_test<false>(scene, pending, ray, walkable, P.ao_below);
+						const TriResult tr = tri_test<false>(scene.tris, pending, ray);
 						if (tr.accepted) {
-							atomicAdd(&mine.occluded[h], 1u);
-							cursor_finish(cur);  // any-hit: the reference walks on but only uses the boolean (:251)
+							atomicAdd(&sh.occluded[h], 1u);
+							i = count;  // any-hit: the reference walks on but only uses the boolean (:251)
 						}
 						pending = NONE;
 					}
 					continue;
 				}
 				if (walking == 0ull)
-					break;  // nothing walking, nothing pending, and then next >= total (idle == 64 would have refilled)
-				advance_walkers<WALK_STEPS>(scene, sh.top, top_lds, ray, walkable, P.ao_max_distance, P.ao_below, cur,
-				                            pending);
+					break;
+				advance_walkers(scene, ray, regular, P.ao_max_distance, P.ao_below, count, i, pending);
 			}
 			wave_lds_sync();
-			// ---- flush this batch's occlusion counts ----
-			if (lane < n) {
-				const uint32_t occluded = mine.occluded[lane];
+
+			// ---- this job's share of the occlusion counts ----
+			if (lane < hit_count) {
+				const uint32_t occluded = sh.occluded[lane];
 				if (occluded)
-					atomicAdd(&occluded_of[first + lane], occluded);
+					atomicAdd(&occluded_of[(size_t) tile * 64u + lane], occluded);
 			}
 			wave_lds_sync();
 		}
@@ -659,24 +590,21 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(4
 // Pass 3: value *= 1 - hits / n (reference :256 and :305-307), one thread per hit-list slot.
 __global__ __launch_bounds__(256) void resolve_kernel(const HitRec *__restrict__ hits,
                                                       const uint32_t *__restrict__ occluded_of,
+                                                      const uint32_t *__restrict__ tile_hits,
                                                       FrameCounters *__restrict__ counters, float *__restrict__ image,
-                                                      const uint32_t *__restrict__ group_offset, KernelParams P) {
+                                                      uint32_t tiles, uint32_t ao_dirs) {
 	__shared__ unsigned int block_total;
 	if (threadIdx.x == 0)
 		block_total = 0u;
 	__syncthreads();
 	const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-	// which group's segment is this slot in, and is it occupied?
-	uint32_t group = 0u;
-	for (uint32_t g = 1; g < XCD_GROUPS; ++g)
-		if (slot >= group_offset[g])
-			group = g;
-	const bool valid = slot < group_offset[XCD_GROUPS] && slot - group_offset[group] < counters->hit_count[group];
-	if (valid) {
+	const uint32_t tile = slot >> 6;
+	if (tile < tiles && (slot & 63u) < tile_hits[tile]) {
 		const uint32_t occluded = occluded_of[slot];
 		const HitRec rec = hits[slot];
-		image[rec.pixel] = rec.value * (1.0f - ((float) occluded / (float) P.ao_dirs));
-		atomicAdd(&block_total, occluded);
+		image[rec.pixel] = rec.value * (1.0f - ((float) occluded / (float) ao_dirs));
+		if (occluded)
+			atomicAdd(&block_total, occluded);
 	}
 	__syncthreads();
 	if (threadIdx.x == 0 && block_total)
@@ -711,50 +639,34 @@ __global__ __launch_bounds__(256) void resize_kernel(const float *__restrict__ t
 }
 
 // ---- host-callable launchers (keeps the launch syntax inside this TU) ----
-void launch_primary(const void *nodes, const void *wnodes, const void *tris, const void *shade, float *image,
-                    void *hits, void *occluded_of, void *counters, const void *group_offset, const KernelParams &P,
-                    void *stream) {
+void launch_frame(const void *nodes, const void *tris, const void *shade, const void *ao_table, float *image,
+                  void *hits, void *occluded_of, void *tile_hits, void *order, void *counters, const KernelParams &P,
+                  uint32_t compute_units, void *stream) {
 	if (P.tiles_x * P.local_tile_rows == 0)
 		return;
+	hipStream_t s = (hipStream_t) stream;
 	const uint32_t strips = (P.tiles_x + 1u) >> 1, row_pairs = (P.local_tile_rows + 1u) >> 1;
-	const uint32_t blocks = 8u * ((strips + 7u) >> 3) * row_pairs;
-#define OCRT_LAUNCH(K)                                                                                              \
-	hipLaunchKernelGGL(primary_kernel<K>, dim3(blocks), dim3(64 * PRIMARY_WAVES), 0, (hipStream_t) stream,           \
-	                   (const float4 *) nodes, (const float4 *) wnodes, (const float4 *) tris, (const float4 *) shade, \
-	                   image, (HitRec *) hits, (uint32_t *) occluded_of, (FrameCounters *) counters,                 \
-	                   (const uint32_t *) group_offset, P)
-	switch (P.variant) {  // debug knob OCRT_KERNEL_VARIANT: walk steps per scheduling decision
-	case 11: OCRT_LAUNCH(1); break;
-	case 14: OCRT_LAUNCH(4); break;
-	default: OCRT_LAUNCH(2); break;
-	}
-#undef OCRT_LAUNCH
-}
-
-void launch_ao(const void *nodes, const void *wnodes, const void *tris, const void *ao_table, float *image,
-               const void *hits, void *occluded_of, void *counters, const void *group_offset, const KernelParams &P,
-               uint32_t max_hits, uint32_t compute_units, void *stream) {
-	if (max_hits == 0 || P.ao_mode != AO_UNIFORM || P.ao_dirs == 0)
+	const uint32_t blocks = XCD_GROUPS * ((strips + XCD_GROUPS - 1u) >> 3) * row_pairs;
+	hipLaunchKernelGGL(primary_kernel, dim3(blocks), dim3(64 * PRIMARY_WAVES), 0, s, (const float4 *) nodes,
+	                   (const float4 *) tris, (const float4 *) shade, image, (HitRec *) hits, (uint32_t *) occluded_of,
+	                   (uint32_t *) tile_hits, (FrameCounters *) counters, P);
+	if (P.ao_mode != AO_UNIFORM || P.ao_dirs == 0)
 		return;
-	// persistent grid: what the chip holds, or fewer when the frame cannot have that many batches
-	const unsigned long long max_batches = (unsigned long long) ((max_hits + 63u) / 64u) * P.batches_per_hits;
-	uint32_t blocks = compute_units * AO_BLOCKS_PER_CU;
-	if ((max_batches + AO_WAVES - 1) / AO_WAVES < blocks)
-		blocks = (uint32_t) ((max_batches + AO_WAVES - 1) / AO_WAVES);
-#define OCRT_LAUNCH(K)                                                                                            \
-	hipLaunchKernelGGL(ao_kernel<K>, dim3(blocks), dim3(64 * AO_WAVES), 0, (hipStream_t) stream,                   \
-	                   (const float4 *) nodes, (const float4 *) wnodes, (const float4 *) tris,                     \
-	                   (const float4 *) ao_table, (const HitRec *) hits, (uint32_t *) occluded_of,                 \
-	                   (FrameCounters *) counters, (const uint32_t *) group_offset, P)
-	switch (P.variant) {
-	case 11: OCRT_LAUNCH(1); break;
-	case 14: OCRT_LAUNCH(4); break;
-	default: OCRT_LAUNCH(2); break;
-	}
-#undef OCRT_LAUNCH
-	hipLaunchKernelGGL(resolve_kernel, dim3((max_hits + 255) / 256), dim3(256), 0, (hipStream_t) stream,
-	                   (const HitRec *) hits, (const uint32_t *) occluded_of, (FrameCounters *) counters, image,
-	                   (const uint32_t *) group_offset, P);
+	hipLaunchKernelGGL(order_kernel, dim3(XCD_GROUPS), dim3(1024), 0, s, (const uint32_t *) tile_hits,
+	                   (uint32_t *) order, (FrameCounters *) counters, P);
+	// persistent grid: what the chip holds, or one wave per tile when the image is small
+	const uint32_t tiles = P.tiles_x * P.local_tile_rows;
+	uint32_t ao_blocks = compute_units * AO_BLOCKS_PER_CU;
+	if (const char *env = getenv("OCRT_AO_BLOCKS"))  // debug knob
+		ao_blocks = (uint32_t) atoi(env);
+	if ((tiles + AO_WAVES - 1) / AO_WAVES < ao_blocks)
+		ao_blocks = (tiles + AO_WAVES - 1) / AO_WAVES;
+	hipLaunchKernelGGL(ao_kernel, dim3(ao_blocks), dim3(64 * AO_WAVES), 0, s, (const float4 *) nodes,
+	                   (const float4 *) tris, (const float4 *) ao_table, (const HitRec *) hits, (uint32_t *) occluded_of,
+	                   (const uint32_t *) tile_hits, (const uint32_t *) order, (FrameCounters *) counters, P);
+	hipLaunchKernelGGL(resolve_kernel, dim3((tiles * 64u + 255u) / 256u), dim3(256), 0, s, (const HitRec *) hits,
+	                   (const uint32_t *) occluded_of, (const uint32_t *) tile_hits, (FrameCounters *) counters, image,
+	                   tiles, P.ao_dirs);
 }
 
 void launch_resize(const float *tmp, unsigned char *out, const KernelParams &P, uint32_t out_width, uint32_t n,

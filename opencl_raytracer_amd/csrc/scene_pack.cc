@@ -57,115 +57,6 @@ PackedScene pack_scene(const std::vector<uint32_t> &faces, const std::vector<uin
 	}
 	if (leaf != tri_count)
 		throw std::invalid_argument("upload: leaf count differs from triangle count");
-	out.tris.resize(tri_count);
-	for (size_t i = 0; i < count; ++i)
-		if (out.nodes[i].skip == 1)
-			for (unsigned k = 0; k < 3; ++k) {
-				out.tris[out.nodes[i].leaf].lo[k] = out.nodes[i].lo[k];
-				out.tris[out.nodes[i].leaf].hi[k] = out.nodes[i].hi[k];
-			}
-
-	// Children inside parents?  (Always true for a built BVH; user-supplied arrays
-	// may violate it, and the conservative walk relies on it: see kernels.hip.)
-	if (out.regular) {
-		struct Open {
-			size_t end;
-			const NodeRec *box;
-		};
-		std::vector<Open> open;
-		for (size_t i = 0; i < count && out.regular; ++i) {
-			while (!open.empty() && open.back().end <= i)
-				open.pop_back();
-			const NodeRec &n = out.nodes[i];
-			if (!open.empty()) {
-				const NodeRec &parent = *open.back().box;
-				for (unsigned k = 0; k < 3; ++k)
-					if (n.lo[k] < parent.lo[k] || n.hi[k] > parent.hi[k])
-						out.regular = false;
-			}
-			if (n.skip > 1)
-				open.push_back(Open{ i + n.skip, &n });
-		}
-	}
-
-	// Walk nodes: boxes enlarged by m = 2^-19 * S, S bounding every box coordinate
-	// and every ray origin the walk accepts (camera at (0,0,2); AO origins sit on
-	// the surface).  kernels.hip shows m >= 4x the rounding error of its test.
-	float extent = 2.0f;
-	for (const NodeRec &n : out.nodes)
-		for (unsigned k = 0; k < 3; ++k)
-			extent = std::fmax(extent, std::fmax(std::fabs(n.lo[k]), std::fabs(n.hi[k])));
-	out.origin_limit = extent * 1.01f + 0.01f;
-	out.walkable = out.regular && out.origin_limit <= 1048576.0f;
-	if (out.walkable) {
-		const float margin = std::ldexp(out.origin_limit, -19);
-		const float inf = std::numeric_limits<float>::infinity();
-		// depth of every node, and the deepest level whose cumulative size fits the LDS top
-		std::vector<uint32_t> depth(count);
-		std::vector<size_t> per_level;
-		{
-			std::vector<size_t> ends;
-			for (size_t i = 0; i < count; ++i) {
-				while (!ends.empty() && ends.back() <= i)
-					ends.pop_back();
-				depth[i] = (uint32_t) ends.size();
-				if (per_level.size() <= depth[i])
-					per_level.resize(depth[i] + 1, 0);
-				per_level[depth[i]]++;
-				if (out.nodes[i].skip > 1)
-					ends.push_back(i + out.nodes[i].skip);
-			}
-		}
-		uint32_t cut_depth = 0;
-		for (size_t level = 0, total = 0; level < per_level.size(); ++level) {
-			total += per_level[level];
-			if (total > WALK_TOP_CAPACITY)
-				break;
-			cut_depth = (uint32_t) level;
-		}
-		// top_prefix[i] = number of top nodes among original nodes [0, i)
-		std::vector<uint32_t> top_prefix(count + 1, 0);
-		for (size_t i = 0; i < count; ++i)
-			top_prefix[i + 1] = top_prefix[i] + (depth[i] <= cut_depth ? 1u : 0u);
-		out.top_count = top_prefix[count];
-		out.wnodes.resize(count);
-		auto fill_box = [&](WalkNodeRec &w, const NodeRec &n) {
-			float *lo[3] = { &w.lox, &w.loy, &w.loz }, *hi[3] = { &w.hix, &w.hiy, &w.hiz };
-			for (unsigned k = 0; k < 3; ++k) {
-				*lo[k] = std::nextafter(n.lo[k] - margin, -inf);
-				*hi[k] = std::nextafter(n.hi[k] + margin, inf);
-			}
-		};
-		size_t body_cursor = out.top_count;
-		for (size_t i = 0; i < count; ++i) {
-			if (depth[i] > cut_depth)
-				continue;  // copied with its portal's body below
-			const NodeRec &n = out.nodes[i];
-			WalkNodeRec &w = out.wnodes[top_prefix[i]];
-			fill_box(w, n);
-			if (n.skip == 1) {
-				w.span = 1;
-				w.link = (WALK_LEAF << WALK_KIND_SHIFT) | n.leaf;
-			} else if (depth[i] < cut_depth) {
-				w.span = top_prefix[i + n.skip] - top_prefix[i];
-				w.link = WALK_INNER << WALK_KIND_SHIFT;
-			} else {
-				// cut here: the descendants [i + 1, i + skip) form a contiguous body
-				const size_t body_len = n.skip - 1;
-				w.span = (uint32_t) body_len;
-				w.link = (WALK_PORTAL << WALK_KIND_SHIFT) | (uint32_t) body_cursor;
-				for (size_t d = i + 1; d < i + n.skip; ++d) {
-					const NodeRec &c = out.nodes[d];
-					WalkNodeRec &b = out.wnodes[body_cursor++];
-					fill_box(b, c);
-					b.span = c.skip;
-					b.link = c.skip == 1 ? ((WALK_LEAF << WALK_KIND_SHIFT) | c.leaf) : (WALK_INNER << WALK_KIND_SHIFT);
-				}
-			}
-		}
-		if (body_cursor != count)
-			throw std::logic_error("walk array construction lost nodes");
-	}
 
 	out.tris.resize(tri_count);
 	out.shade.resize(tri_count);
@@ -186,7 +77,6 @@ PackedScene pack_scene(const std::vector<uint32_t> &faces, const std::vector<uin
 		r.uv = u.dot(v);
 		r.vv = v.dot(v);
 		r.D = r.uv * r.uv - r.uu * r.vv;
-		r.pad0 = r.pad1 = 0.0f;
 		ShadeRec &s = out.shade[t];
 		const Vec3f *src[3] = { &vnormals[i0], &vnormals[i1], &vnormals[i2] };
 		float *dst[3] = { s.n0, s.n1, s.n2 };
@@ -259,8 +149,7 @@ uint32_t local_tile_rows_for(uint32_t total_height, const Partition &part) {
 }
 
 KernelParams make_kernel_params(const RayTracer &rt, uint32_t node_count, uint32_t tri_count, uint32_t ao_dirs,
-                                const Partition &part, bool scene_regular, bool scene_walkable,
-                                float origin_limit, uint32_t top_count) {
+                                const Partition &part, bool scene_regular) {
 	KernelParams p{};
 	p.width = rt.totalWidth;
 	p.height = rt.totalHeight;
@@ -277,34 +166,18 @@ KernelParams make_kernel_params(const RayTracer &rt, uint32_t node_count, uint32
 		p.ao_mode = rt.options.aoMethod == RayTracer::AmbientOcclusionMethod::UNIFORM ? AO_UNIFORM : AO_RANDOM;
 	p.ao_max_distance = kernel_float(rt.options.aoMaxDistance);
 	p.ao_dirs = ao_dirs;
-	const char *variant = std::getenv("OCRT_KERNEL_VARIANT");
-	p.variant = variant ? std::atoi(variant) : 0;
 	p.scene_regular = scene_regular ? 1 : 0;
-	p.walk_ok = (scene_walkable && p.variant != 2) ? 1 : 0;
-	p.origin_limit = origin_limit;
-	p.top_count = top_count;
-	const char *top_lds = std::getenv("OCRT_TOP_LDS");
-	p.top_lds = top_lds ? (uint32_t) std::atoi(top_lds) : top_count;
-	if (p.top_lds > top_count)
-		p.top_lds = top_count;
+	p.debug_no_sort = std::getenv("OCRT_NO_SORT") ? 1 : 0;
+	const char *rays_per_lane = std::getenv("OCRT_AO_RAYS_PER_LANE");  // debug knob
+	const uint32_t target = rays_per_lane ? (uint32_t) std::atoi(rays_per_lane) : 8u;
+	p.jobs_per_tile = ao_dirs ? (ao_dirs + target - 1) / target : 1;
+	p.dirs_per_job = ao_dirs ? (ao_dirs + p.jobs_per_tile - 1) / p.jobs_per_tile : 1;
 	p.ao_regular = (p.ao_max_distance > 0.0f && std::isfinite(p.ao_max_distance)) ? 1 : 0;
 	p.primary_below = std::nextafterf(100000.0f, 0.0f);
 	p.ao_below = std::nextafterf(p.ao_max_distance, -std::numeric_limits<float>::infinity());
 	p.tiles_x = (p.width + TILE_W - 1) / TILE_W;
 	p.part = part;
 	p.local_tile_rows = local_tile_rows_for(p.height, part);
-	// hit-list segments: group g owns the strips g, g+8, ... (two tiles wide, full band height)
-	const uint32_t strips = (p.tiles_x + 1) / 2, row_pairs = (p.local_tile_rows + 1) / 2;
-	p.group_offset[0] = 0;
-	for (uint32_t g = 0; g < XCD_GROUPS; ++g) {
-		const uint32_t strips_here = (strips + XCD_GROUPS - 1 - g) / XCD_GROUPS;
-		p.group_offset[g + 1] = p.group_offset[g] + strips_here * row_pairs * (4 * TILE_W * TILE_H);
-	}
-	// AO batches of about 8 rays per lane: 64 hits x dirs_per_batch directions
-	const char *rays_per_lane = std::getenv("OCRT_AO_RAYS_PER_LANE");  // debug knob
-	const uint32_t target = rays_per_lane ? (uint32_t) std::atoi(rays_per_lane) : 8u;
-	p.batches_per_hits = ao_dirs ? (ao_dirs + target - 1) / target : 1;
-	p.dirs_per_batch = ao_dirs ? (ao_dirs + p.batches_per_hits - 1) / p.batches_per_hits : 1;
 	return p;
 }
 

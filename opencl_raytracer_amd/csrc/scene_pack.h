@@ -12,13 +12,9 @@ namespace ocrt {
 
 struct PackedScene {
 	std::vector<NodeRec> nodes;
-	std::vector<WalkNodeRec> wnodes;  // empty unless `walkable`
 	std::vector<TriRec> tris;
 	std::vector<ShadeRec> shade;
-	bool regular = false;   // boxes finite, |coord| <= 1e37, lo <= hi, every child box inside its parent's
-	bool walkable = false;  // regular and coordinates <= 2^20: wnodes is filled
-	float origin_limit = 0; // |ray origin| bound the enlargement margin was computed for
-	uint32_t top_count = 0; // wnodes[0, top_count) = top of the tree (see WalkNodeRec)
+	bool regular = false;  // all boxes finite, |coord| <= 1e37, lo <= hi (see kernels.hip slab_hit_regular)
 };
 
 // Validates the arrays against each other (every index and skip count is
@@ -46,7 +42,6 @@ uint32_t band_tile_rows_for(unsigned int grid);
 uint32_t local_tile_rows_for(uint32_t total_height, const Partition &part);
 
 KernelParams make_kernel_params(const RayTracer &rt, uint32_t node_count, uint32_t tri_count, uint32_t ao_dirs,
-                                const Partition &part, bool scene_regular, bool scene_walkable,
-                                float origin_limit, uint32_t top_count);
+                                const Partition &part, bool scene_regular);
 
 }  // namespace ocrt
