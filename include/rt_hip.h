@@ -140,11 +140,15 @@ int rt_resize_into_device(rt_host *h, void *device_u8);
 int rt_set_stream(rt_host *h, void *hip_stream);
 int rt_use_private_stream(rt_host *h);
 
-/* Ray counts of the last frame and HIP-event timing of the ray-casting kernel
- * (last launch, running total in ms and number of launches since the reset). */
+/* Ray counts of the last frame and HIP-event timing of the ray-casting passes
+ * on the launch stream (last frame, running total in ms and number of frames
+ * since the reset): *_kernel_ms covers every pass of a frame, *_ao_ms the
+ * ambient-occlusion passes (ordering + AO + resolve) alone. */
 int rt_get_stats(rt_host *h, rt_stats *out);
 float rt_last_kernel_ms(const rt_host *h);
 double rt_total_kernel_ms(const rt_host *h);
+float rt_last_ao_ms(const rt_host *h);
+double rt_total_ao_ms(const rt_host *h);
 uint64_t rt_kernel_launches(const rt_host *h);
 void rt_reset_timers(rt_host *h);
 

@@ -119,6 +119,8 @@ _SIGNATURES = {
     "rt_get_stats": (C.c_int, [C.c_void_p, C.POINTER(_Stats)]),
     "rt_last_kernel_ms": (C.c_float, [C.c_void_p]),
     "rt_total_kernel_ms": (C.c_double, [C.c_void_p]),
+    "rt_last_ao_ms": (C.c_float, [C.c_void_p]),
+    "rt_total_ao_ms": (C.c_double, [C.c_void_p]),
     "rt_kernel_launches": (C.c_uint64, [C.c_void_p]),
     "rt_reset_timers": (None, [C.c_void_p]),
     "rt_print_info": (None, []),
@@ -345,6 +347,14 @@ class Host:
     @property
     def total_kernel_ms(self) -> float:
         return float(load_library().rt_total_kernel_ms(self._h))
+
+    @property
+    def last_ao_ms(self) -> float:
+        return float(load_library().rt_last_ao_ms(self._h))
+
+    @property
+    def total_ao_ms(self) -> float:
+        return float(load_library().rt_total_ao_ms(self._h))
 
     @property
     def kernel_launches(self) -> int:

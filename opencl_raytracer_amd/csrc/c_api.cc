@@ -317,6 +317,8 @@ int rt_get_stats(rt_host *h, rt_stats *out) {
 
 float rt_last_kernel_ms(const rt_host *h) { return h ? h->dev->lastKernelMs() : 0.0f; }
 double rt_total_kernel_ms(const rt_host *h) { return h ? h->dev->totalKernelMs() : 0.0; }
+float rt_last_ao_ms(const rt_host *h) { return h ? h->dev->lastAoMs() : 0.0f; }
+double rt_total_ao_ms(const rt_host *h) { return h ? h->dev->totalAoMs() : 0.0; }
 uint64_t rt_kernel_launches(const rt_host *h) { return h ? h->dev->kernelLaunches() : 0; }
 void rt_reset_timers(rt_host *h) {
 	if (h)

@@ -63,7 +63,9 @@ DeviceRenderer::DeviceRenderer(const RayTracer::Options &options, int device_, u
 	, scene_ready(false)
 	, frame_ready(false)
 	, last_ms(0)
+	, last_ao_ms(0)
 	, total_ms(0)
+	, total_ao_ms(0)
 	, launches(0) {
 	if (nranks == 0 || rank >= nranks)
 		throw std::invalid_argument("rank must be < nranks");
@@ -115,11 +117,12 @@ DeviceRenderer::~DeviceRenderer() {
 		return;
 	if (stream)
 		(void) hipStreamSynchronize((hipStream_t) stream);
-	for (auto &pair : pending_events)
-		free_events.push_back(pair);
-	for (auto &pair : free_events) {
-		(void) hipEventDestroy((hipEvent_t) pair.first);
-		(void) hipEventDestroy((hipEvent_t) pair.second);
+	for (auto &ev : pending_events)
+		free_events.push_back(ev);
+	for (auto &ev : free_events) {
+		(void) hipEventDestroy((hipEvent_t) ev.start);
+		(void) hipEventDestroy((hipEvent_t) ev.ao_start);
+		(void) hipEventDestroy((hipEvent_t) ev.stop);
 	}
 	freeScene();
 	device_free(d_image);
@@ -190,22 +193,27 @@ void DeviceRenderer::enqueueRender() {
 	if (!scene_ready)
 		throw std::logic_error("render called before upload");
 	useDevice();
-	std::pair<void *, void *> ev;
+	FrameEvents ev;
 	if (!free_events.empty()) {
 		ev = free_events.back();
 		free_events.pop_back();
 	} else {
-		hipEvent_t a, b;
+		hipEvent_t a, b, c;
 		OCRT_HIP(hipEventCreate(&a));
 		OCRT_HIP(hipEventCreate(&b));
-		ev = { a, b };
+		OCRT_HIP(hipEventCreate(&c));
+		ev = { a, b, c };
 	}
-	OCRT_HIP(hipEventRecord((hipEvent_t) ev.first, (hipStream_t) stream));
-	OCRT_HIP(hipMemsetAsync(d_counters, 0, sizeof(FrameCounters), (hipStream_t) stream));
-	launch_frame(d_nodes, d_tris, d_shade, d_ao, (float *) d_image, d_hits, d_occluded, d_tile_hits, d_order, d_counters, kp,
-	             compute_units, stream);
+	hipStream_t s = (hipStream_t) stream;
+	OCRT_HIP(hipEventRecord((hipEvent_t) ev.start, s));
+	OCRT_HIP(hipMemsetAsync(d_counters, 0, sizeof(FrameCounters), s));
+	launch_primary(d_nodes, d_tris, d_shade, (float *) d_image, d_hits, d_occluded, d_tile_hits, d_counters, kp, stream);
 	OCRT_HIP(hipGetLastError());
-	OCRT_HIP(hipEventRecord((hipEvent_t) ev.second, (hipStream_t) stream));
+	OCRT_HIP(hipEventRecord((hipEvent_t) ev.ao_start, s));
+	launch_ao(d_nodes, d_tris, d_ao, (float *) d_image, d_hits, d_occluded, d_tile_hits, d_order, d_counters, kp,
+	          compute_units, stream);
+	OCRT_HIP(hipGetLastError());
+	OCRT_HIP(hipEventRecord((hipEvent_t) ev.stop, s));
 	pending_events.push_back(ev);
 	frame_ready = true;
 }
@@ -224,10 +232,13 @@ void DeviceRenderer::synchronize() {
 	useDevice();
 	OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));
 	for (auto &ev : pending_events) {
-		float ms = 0;
-		OCRT_HIP(hipEventElapsedTime(&ms, (hipEvent_t) ev.first, (hipEvent_t) ev.second));
+		float ms = 0, ao_ms = 0;
+		OCRT_HIP(hipEventElapsedTime(&ms, (hipEvent_t) ev.start, (hipEvent_t) ev.stop));
+		OCRT_HIP(hipEventElapsedTime(&ao_ms, (hipEvent_t) ev.ao_start, (hipEvent_t) ev.stop));
 		last_ms = ms;
+		last_ao_ms = ao_ms;
 		total_ms += ms;
+		total_ao_ms += ao_ms;
 		++launches;
 		free_events.push_back(ev);
 	}

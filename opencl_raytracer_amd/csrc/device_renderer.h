@@ -53,10 +53,12 @@ class DeviceRenderer {
 		void usePrivateStream();
 
 		RenderStats stats();   // ray counts of the last frame (device counters)
-		float lastKernelMs() const { return last_ms; }
+		float lastKernelMs() const { return last_ms; }      // all passes of the last frame
+		float lastAoMs() const { return last_ao_ms; }       // ordering + AO + resolve passes of the last frame
 		double totalKernelMs() const { return total_ms; }
+		double totalAoMs() const { return total_ao_ms; }
 		uint64_t kernelLaunches() const { return launches; }
-		void resetTimers() { total_ms = 0; launches = 0; last_ms = 0; }
+		void resetTimers() { total_ms = total_ao_ms = 0; launches = 0; last_ms = last_ao_ms = 0; }
 
 		uint32_t localRows() const { return local_out_rows; }  // output rows this rank owns
 		uint32_t width() const { return opts.width; }
@@ -82,16 +84,21 @@ class DeviceRenderer {
 		size_t tile_count;
 		uint32_t compute_units;
 		bool scene_ready, frame_ready;
-		std::vector<std::pair<void *, void *>> pending_events, free_events;
-		float last_ms;
-		double total_ms;
+		struct FrameEvents {
+			void *start, *ao_start, *stop;
+		};
+		std::vector<FrameEvents> pending_events, free_events;
+		float last_ms, last_ao_ms;
+		double total_ms, total_ao_ms;
 		uint64_t launches;
 };
 
 // kernels.hip
-void launch_frame(const void *nodes, const void *tris, const void *shade, const void *ao_table, float *image,
-                  void *hits, void *occluded_of, void *tile_hits, void *order, void *counters, const KernelParams &P,
-                  uint32_t compute_units, void *stream);
+void launch_primary(const void *nodes, const void *tris, const void *shade, float *image, void *hits,
+                    void *occluded_of, void *tile_hits, void *counters, const KernelParams &P, void *stream);
+void launch_ao(const void *nodes, const void *tris, const void *ao_table, float *image, void *hits,
+               void *occluded_of, void *tile_hits, void *order, void *counters, const KernelParams &P,
+               uint32_t compute_units, void *stream);
 void launch_resize(const float *tmp, unsigned char *out, const KernelParams &P, uint32_t out_width, uint32_t n,
                    uint32_t local_out_rows, void *stream);
 

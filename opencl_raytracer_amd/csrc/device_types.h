@@ -94,6 +94,8 @@ struct KernelParams {
 	float primary_below;   // largest float below the primary rays' max_distance (100000.0f)
 	float ao_below;        // largest float below AO_MAX_DISTANCE
 	int32_t debug_no_sort; // debug knob OCRT_NO_SORT: claim tiles in arbitrary order instead of heaviest first
+	uint32_t refill_min;    // wave scheduler: refill once this many lanes are idle (debug knob OCRT_REFILL_MIN)
+	uint32_t leaf_min;      // ... test triangles once this many leaves are pending (OCRT_LEAF_MIN)
 	uint32_t jobs_per_tile; // a tile's AO rays are split by direction range into this many jobs ...
 	uint32_t dirs_per_job;  // ... of this many table directions each (about 8 rays per lane)
 	uint32_t tiles_x;      // tiles per image row

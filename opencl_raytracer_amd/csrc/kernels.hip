@@ -103,8 +103,8 @@ __device__ __forceinline__ bool slab_hit(const float4 lo, const float4 hi, const
 // predicated, so exec-mask bookkeeping stays out of the hot loop.
 // ---------------------------------------------------------------------------
 constexpr uint32_t NONE = 0xFFFFFFFFu;
-constexpr uint32_t REFILL_MIN = 16;  // refill once this many lanes are idle ...
-constexpr uint32_t LEAF_MIN = 16;    // ... run triangle tests once this many leaves are pending
+// Thresholds (KernelParams::refill_min / leaf_min, 16 each): refill once that many
+// lanes are idle, run the triangle tests once that many leaves are pending.
 
 // Largest magnitude for which (b - o) cannot overflow; beyond it, or for a ray
 // with an infinite or NaN reciprocal direction, the exact select-based slab test
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
 	for (;;) {
 		const unsigned long long walking = __ballot(pending == NONE && i < count);
 		const unsigned long long leaves = __ballot(pending != NONE);
-		if (leaves != 0ull && ((uint32_t) __popcll(leaves) >= LEAF_MIN || walking == 0ull)) {
+		if (leaves != 0ull && ((uint32_t) __popcll(leaves) >= P.leaf_min || walking == 0ull)) {
 			if (pending != NONE) {
 				const TriResult tr = tri_test<true>(scene.tris, pending, ray);
 				// closest hit: strict '>' in ascending leaf order, reference :106-112
@@ -541,7 +541,7 @@ __global__ __launch_bounds__(64 * AO_WAVES) void ao_kernel(
 				const unsigned long long leaves = __ballot(pending != NONE);
 				const uint32_t n_leaves = (uint32_t) __popcll(leaves);
 				const uint32_t idle = 64u - (uint32_t) __popcll(walking) - n_leaves;
-				if (next < total && idle >= REFILL_MIN) {
+				if (next < total && idle >= P.refill_min) {
 					const bool idle_lane = !walking_lane && pending == NONE;
 					const uint32_t item = next + rank_in(__ballot(idle_lane));
 					if (idle_lane && item < total) {
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(64 * AO_WAVES) void ao_kernel(
 					next += idle;
 					continue;
 				}
-				if (n_leaves != 0u && (n_leaves >= LEAF_MIN || walking == 0ull)) {
+				if (n_leaves != 0u && (n_leaves >= P.leaf_min || walking == 0ull)) {
 					if (pending != NONE) {
 						const TriResult tr = tri_test<false>(scene.tris, pending, ray);
 						if (tr.accepted) {
@@ -639,9 +639,8 @@ __global__ __launch_bounds__(256) void resize_kernel(const float *__restrict__ t
 }
 
 // ---- host-callable launchers (keeps the launch syntax inside this TU) ----
-void launch_frame(const void *nodes, const void *tris, const void *shade, const void *ao_table, float *image,
-                  void *hits, void *occluded_of, void *tile_hits, void *order, void *counters, const KernelParams &P,
-                  uint32_t compute_units, void *stream) {
+void launch_primary(const void *nodes, const void *tris, const void *shade, float *image, void *hits,
+                    void *occluded_of, void *tile_hits, void *counters, const KernelParams &P, void *stream) {
 	if (P.tiles_x * P.local_tile_rows == 0)
 		return;
 	hipStream_t s = (hipStream_t) stream;
@@ -650,8 +649,14 @@ void launch_frame(const void *nodes, const void *tris, const void *shade, const 
 	hipLaunchKernelGGL(primary_kernel, dim3(blocks), dim3(64 * PRIMARY_WAVES), 0, s, (const float4 *) nodes,
 	                   (const float4 *) tris, (const float4 *) shade, image, (HitRec *) hits, (uint32_t *) occluded_of,
 	                   (uint32_t *) tile_hits, (FrameCounters *) counters, P);
-	if (P.ao_mode != AO_UNIFORM || P.ao_dirs == 0)
+}
+
+void launch_ao(const void *nodes, const void *tris, const void *ao_table, float *image, void *hits,
+               void *occluded_of, void *tile_hits, void *order, void *counters, const KernelParams &P,
+               uint32_t compute_units, void *stream) {
+	if (P.tiles_x * P.local_tile_rows == 0 || P.ao_mode != AO_UNIFORM || P.ao_dirs == 0)
 		return;
+	hipStream_t s = (hipStream_t) stream;
 	hipLaunchKernelGGL(order_kernel, dim3(XCD_GROUPS), dim3(1024), 0, s, (const uint32_t *) tile_hits,
 	                   (uint32_t *) order, (FrameCounters *) counters, P);
 	// persistent grid: what the chip holds, or one wave per tile when the image is small

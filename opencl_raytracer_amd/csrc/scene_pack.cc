@@ -168,6 +168,9 @@ KernelParams make_kernel_params(const RayTracer &rt, uint32_t node_count, uint32
 	p.ao_dirs = ao_dirs;
 	p.scene_regular = scene_regular ? 1 : 0;
 	p.debug_no_sort = std::getenv("OCRT_NO_SORT") ? 1 : 0;
+	const char *refill_min = std::getenv("OCRT_REFILL_MIN"), *leaf_min = std::getenv("OCRT_LEAF_MIN");
+	p.refill_min = refill_min ? (uint32_t) std::atoi(refill_min) : 16u;
+	p.leaf_min = leaf_min ? (uint32_t) std::atoi(leaf_min) : 16u;
 	const char *rays_per_lane = std::getenv("OCRT_AO_RAYS_PER_LANE");  // debug knob
 	const uint32_t target = rays_per_lane ? (uint32_t) std::atoi(rays_per_lane) : 8u;
 	p.jobs_per_tile = ao_dirs ? (ao_dirs + target - 1) / target : 1;
