@@ -141,3 +141,54 @@ def test_error_paths(rt, scene_for):
     host.close()
     with pytest.raises(rt.RtError):
         rt.Host(opt, 99)  # device index out of range
+
+
+def test_interior_standin_matches_oracle(rt, oracle):
+    """The closed interior scene (stand-in for the missing sibenik.off): every
+    primary ray hits, AO rays see close occluders everywhere."""
+    import orc
+    from tools.meshes import interior_path
+
+    scene = rt.Scene.load_off(interior_path()).build_bvh(0)
+    arrays = orc.SceneArrays.from_scene(scene)
+    for (w, h, ss, ao) in ((160, 90, 1, 3), (64, 36, 4, 2)):
+        opt = rt.Options.defaults(width=w, height=h, n_super_samples=ss, ao_num_samples=ao)
+        host = render_hip(rt, scene, opt)
+        ref_img, counters, _ = oracle.render(orc.params_from_options(opt), arrays)
+        assert np.array_equal(bits(host.download()), bits(ref_img))
+        assert np.array_equal(host.download_u8(), oracle.resize(ref_img, w, h, ss))
+        st = host.stats()
+        assert st["primary_hits"] == counters["primary_hits"] == opt.total_width * opt.total_height
+        assert st["ao_occluded"] == counters["ao_occluded"]
+        host.close()
+
+
+def test_render_cli_writes_the_golden_pgm(rt, golden, tmp_path):
+    """End to end through the `render` binary: same flags as the reference CLI,
+    PGM file byte-identical to the golden one."""
+    import os
+    import subprocess
+
+    from conftest import ROOT, mesh_file
+
+    exe = os.path.join(ROOT, "opencl_raytracer_amd", "bin", "render")
+    for name, extra in (("bunny_256_s1_a3", []), ("blob_128x96_s4_a3_sah", ["-r", "sah"])):
+        c = golden["renders"][name]
+        out = tmp_path / (name + ".pgm")
+        cmd = [exe, "-w", str(c["width"]), "-h", str(c["height"]), "-s", str(c["ss"]),
+               "--ambient-occlusion-samples=" + str(c["ao"]), "-d", str(c["aod"]), "-f", str(c["focal"])] + extra + \
+              [mesh_file(c["mesh"]), str(out)]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert "Rendering image" in r.stdout and "Building BVH" in r.stdout
+        assert hashlib.md5(out.read_bytes()).hexdigest() == c["pgm_md5"]
+
+
+def test_random_ao_is_rejected_loudly(rt, scene_for):
+    opt = rt.Options.defaults(width=16, height=16, n_super_samples=1, ao_method=1)
+    scene, _ = scene_for("blob", "longest")
+    host = rt.Host(opt, 0)
+    with pytest.raises(rt.RtError) as e:
+        host.upload_scene(scene)
+    assert "random" in e.value.message
+    host.close()
