@@ -164,8 +164,8 @@ size_t DeviceRenderer::upload(const PackedScene &scene) {
 			table = uniform_ao_table(opts.aoNumSamples, opts.aoAlphaMin, opts.aoAlphaMax);
 			ao_dirs = (uint32_t) (table.size() / 4);
 		} else {
-			throw std::invalid_argument(
-			    "ambient-occlusion method 'random' is not implemented on the HIP path yet (use 'uniform')");
+			// RANDOM casts the normal ray plus AO_NUM_SAMPLES + 1 random ones (reference :260-275)
+			ao_dirs = opts.aoNumSamples + 2;
 		}
 	}
 	kp = make_kernel_params(rt, (uint32_t) scene.nodes.size(), (uint32_t) scene.tris.size(), ao_dirs, part, scene.regular);
@@ -297,7 +297,7 @@ RenderStats DeviceRenderer::stats() {
 		rows += (kp.height - y0 < TILE_H) ? kp.height - y0 : TILE_H;
 	}
 	out.primary_rays = rows * kp.width;
-	out.ao_rays = kp.ao_mode == AO_UNIFORM ? out.primary_hits * kp.ao_dirs : 0;
+	out.ao_rays = kp.ao_mode != AO_NONE ? out.primary_hits * kp.ao_dirs : 0;
 	return out;
 }
 

@@ -88,7 +88,8 @@ struct KernelParams {
 	int32_t shading;       // SHADING_ENABLE
 	int32_t ao_mode;       // AoMode
 	float ao_max_distance; // AO_MAX_DISTANCE
-	uint32_t ao_dirs;      // UNIFORM: rays per hit sub-pixel; RANDOM: AO_NUM_SAMPLES
+	uint32_t ao_dirs;      // AO rays cast per hit sub-pixel (UNIFORM: table size; RANDOM: AO_NUM_SAMPLES + 2)
+	uint32_t ao_divisor;   // n of `1 - hits / n` (UNIFORM: ao_dirs; RANDOM: AO_NUM_SAMPLES + 1, reference :260-275)
 	int32_t scene_regular; // every box finite, |coord| <= 1e37 and lo <= hi: min/max slab form allowed
 	int32_t ao_regular;    // AO_MAX_DISTANCE > 0 (needed by the folded form of the slab test)
 	float primary_below;   // largest float below the primary rays' max_distance (100000.0f)

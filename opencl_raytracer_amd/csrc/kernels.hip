@@ -352,7 +352,7 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
 		if (P.shading)
 			value = fminf(fmaxf(-dot3(nx, ny, nz, dx, dy, dz), 0.0f), 1.0f);
 	}
-	const bool want_ao = P.ao_mode == AO_UNIFORM && P.ao_dirs > 0;
+	const bool want_ao = P.ao_mode != AO_NONE && P.ao_dirs > 0;
 	if (active && !(hit && want_ao))
 		image[(size_t) y * P.width + x] = value;  // final already
 
@@ -432,6 +432,28 @@ __global__ __launch_bounds__(1024) void order_kernel(const uint32_t *__restrict_
 	}
 }
 
+// xorshift128 of the RANDOM hemisphere sampler, reference src/intersect_kernel.cl:128-152.
+struct Rng {
+	uint32_t x, y, z, w;
+};
+__device__ __forceinline__ uint32_t rng_next(Rng &v) {
+	const uint32_t t = v.x ^ (v.x << 11u);
+	v.x = v.y;
+	v.y = v.z;
+	v.z = v.w;
+	return v.w = v.w ^ (v.w >> 19u) ^ (t ^ (t >> 8u));
+}
+__device__ __forceinline__ Rng rng_seed(uint32_t seed) {
+	Rng v;
+	v.x = (123456789u ^ seed) * 88675123u;
+	v.y = (362436069u ^ seed) * 123456789u;
+	v.z = (521288629u ^ seed) * 362436069u;
+	v.w = (88675123u ^ seed) * 521288629u;
+	rng_next(v);
+	return v;
+}
+__device__ __forceinline__ float rng_float(Rng &v) { return 2.32830643653869629E-10f * rng_next(v); }
+
 // ---------------------------------------------------------------------------
 // Pass 2: ambient occlusion.  Persistent, independent waves; one tile at a time.
 // ---------------------------------------------------------------------------
@@ -443,6 +465,7 @@ constexpr uint32_t AO_BLOCKS_PER_CU = 8;
 struct TileShared {
 	float frame[12][64];  // origin xyz, basis_x xyz, basis_y xyz, basis_z xyz
 	unsigned int occluded[64];
+	unsigned int pixel[64];  // RANDOM mode: the sub-pixel's image index seeds its generator
 };
 
 // Orders this wave's LDS writes before its later LDS reads.  A wave executes in
@@ -454,6 +477,9 @@ __device__ __forceinline__ void wave_lds_sync() {
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// MODE is AO_UNIFORM or AO_RANDOM: two instantiations, so that the RANDOM sampler's
+// code and registers stay out of the default path.
+template <int MODE>
 __global__ __launch_bounds__(64 * AO_WAVES) void ao_kernel(
     const float4 *__restrict__ nodes_ptr, const float4 *__restrict__ tris_ptr, const float4 *__restrict__ ao_table,
     const HitRec *__restrict__ hits, uint32_t *__restrict__ occluded_of, const uint32_t *__restrict__ tile_hits,
@@ -498,12 +524,15 @@ __global__ __launch_bounds__(64 * AO_WAVES) void ao_kernel(
 			if (lane < hit_count) {
 				const float4 q0 = ((const float4 *) hits)[2 * ((size_t) tile * 64u + lane)];
 				const float4 q1 = ((const float4 *) hits)[2 * ((size_t) tile * 64u + lane) + 1];
-				const float nx = q1.x, ny = q1.y, nz = q1.z;
+				float nx = q1.x, ny = q1.y, nz = q1.z;
 				// p = point + normal * (1.0f / 100000.0f)
 				const float eps = 1.0f / 100000.0f;
 				sh.frame[0][lane] = q0.x + nx * eps;
 				sh.frame[1][lane] = q0.y + ny * eps;
 				sh.frame[2][lane] = q0.z + nz * eps;
+				sh.pixel[lane] = __float_as_uint(q1.w);
+				if (MODE == AO_RANDOM)
+					normalize3(nx, ny, nz);  // hemisphere_sampler normalises once more, reference :155
 				// tangent frame: the smallest |component| of the normal is replaced by 1
 				float hx = nx, hy = ny, hz = nz;
 				const float ax = fabsf(nx), ay = fabsf(ny), az = fabsf(nz);
@@ -547,11 +576,43 @@ __global__ __launch_bounds__(64 * AO_WAVES) void ao_kernel(
 					if (idle_lane && item < total) {
 						const uint32_t k = item / hit_count;
 						h = item - k * hit_count;
-						const float4 dir = ao_table[dir0 + k];
+						float xs, ys, zs;
+						bool along_normal = false;
+						if (MODE == AO_UNIFORM) {
+							const float4 dir = ao_table[dir0 + k];
+							xs = dir.x; ys = dir.y; zs = dir.z;
+						} else {
+							// RANDOM (reference :153-183, :257-276): ray 0 goes along the normal, ray
+							// j >= 1 uses draws 2j-2 and 2j-1 of the sub-pixel's generator.  Device libm
+							// rounds differently from the host's: this mode is outside the bit-exact contract.
+							const uint32_t j = dir0 + k;
+							along_normal = j == 0u;
+							Rng rng = rng_seed(536870923u * sh.pixel[h]);
+							for (uint32_t skip = 1; skip < j; ++skip) {
+								rng_next(rng);
+								rng_next(rng);
+							}
+							const float xi1 = rng_float(rng);
+							const float xi2 = rng_float(rng);
+							const float theta = acosf(sqrtf(1.0f - xi1));
+							const float phi = (float) (2.0 * (double) xi2);
+							xs = sinf(theta) * cospif(phi);
+							ys = cosf(theta);
+							zs = sinf(theta) * sinpif(phi);
+						}
 						// ray_dir = basis_x * xs + basis_y * ys + basis_z * zs, lane by lane
-						const float rx = (sh.frame[3][h] * dir.x + sh.frame[6][h] * dir.y) + sh.frame[9][h] * dir.z;
-						const float ry = (sh.frame[4][h] * dir.x + sh.frame[7][h] * dir.y) + sh.frame[10][h] * dir.z;
-						const float rz = (sh.frame[5][h] * dir.x + sh.frame[8][h] * dir.y) + sh.frame[11][h] * dir.z;
+						float rx = (sh.frame[3][h] * xs + sh.frame[6][h] * ys) + sh.frame[9][h] * zs;
+						float ry = (sh.frame[4][h] * xs + sh.frame[7][h] * ys) + sh.frame[10][h] * zs;
+						float rz = (sh.frame[5][h] * xs + sh.frame[8][h] * ys) + sh.frame[11][h] * zs;
+						if (MODE == AO_RANDOM) {
+							normalize3(rx, ry, rz);
+							if (along_normal) {
+								// the un-normalised shading normal itself (:263); recover it from the origin offset
+								// is not possible exactly, so it is kept in the hit record
+								const float4 q1 = ((const float4 *) hits)[2 * ((size_t) tile * 64u + h) + 1];
+								rx = q1.x; ry = q1.y; rz = q1.z;
+							}
+						}
 						ray = make_ray(sh.frame[0][h], sh.frame[1][h], sh.frame[2][h], rx, ry, rz);
 						regular = P.scene_regular && P.ao_regular && ray_is_regular(ray);
 						i = 0u;
@@ -592,7 +653,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(const HitRec *__restrict__
                                                       const uint32_t *__restrict__ occluded_of,
                                                       const uint32_t *__restrict__ tile_hits,
                                                       FrameCounters *__restrict__ counters, float *__restrict__ image,
-                                                      uint32_t tiles, uint32_t ao_dirs) {
+                                                      uint32_t tiles, uint32_t ao_divisor) {
 	__shared__ unsigned int block_total;
 	if (threadIdx.x == 0)
 		block_total = 0u;
@@ -602,7 +663,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(const HitRec *__restrict__
 	if (tile < tiles && (slot & 63u) < tile_hits[tile]) {
 		const uint32_t occluded = occluded_of[slot];
 		const HitRec rec = hits[slot];
-		image[rec.pixel] = rec.value * (1.0f - ((float) occluded / (float) ao_dirs));
+		image[rec.pixel] = rec.value * (1.0f - ((float) occluded / (float) ao_divisor));
 		if (occluded)
 			atomicAdd(&block_total, occluded);
 	}
@@ -654,7 +715,7 @@ void launch_primary(const void *nodes, const void *tris, const void *shade, floa
 void launch_ao(const void *nodes, const void *tris, const void *ao_table, float *image, void *hits,
                void *occluded_of, void *tile_hits, void *order, void *counters, const KernelParams &P,
                uint32_t compute_units, void *stream) {
-	if (P.tiles_x * P.local_tile_rows == 0 || P.ao_mode != AO_UNIFORM || P.ao_dirs == 0)
+	if (P.tiles_x * P.local_tile_rows == 0 || P.ao_mode == AO_NONE || P.ao_dirs == 0)
 		return;
 	hipStream_t s = (hipStream_t) stream;
 	hipLaunchKernelGGL(order_kernel, dim3(XCD_GROUPS), dim3(1024), 0, s, (const uint32_t *) tile_hits,
@@ -666,12 +727,19 @@ void launch_ao(const void *nodes, const void *tris, const void *ao_table, float 
 		ao_blocks = (uint32_t) atoi(env);
 	if ((tiles + AO_WAVES - 1) / AO_WAVES < ao_blocks)
 		ao_blocks = (tiles + AO_WAVES - 1) / AO_WAVES;
-	hipLaunchKernelGGL(ao_kernel, dim3(ao_blocks), dim3(64 * AO_WAVES), 0, s, (const float4 *) nodes,
-	                   (const float4 *) tris, (const float4 *) ao_table, (const HitRec *) hits, (uint32_t *) occluded_of,
-	                   (const uint32_t *) tile_hits, (const uint32_t *) order, (FrameCounters *) counters, P);
+	if (P.ao_mode == AO_UNIFORM)
+		hipLaunchKernelGGL(ao_kernel<AO_UNIFORM>, dim3(ao_blocks), dim3(64 * AO_WAVES), 0, s, (const float4 *) nodes,
+		                   (const float4 *) tris, (const float4 *) ao_table, (const HitRec *) hits,
+		                   (uint32_t *) occluded_of, (const uint32_t *) tile_hits, (const uint32_t *) order,
+		                   (FrameCounters *) counters, P);
+	else
+		hipLaunchKernelGGL(ao_kernel<AO_RANDOM>, dim3(ao_blocks), dim3(64 * AO_WAVES), 0, s, (const float4 *) nodes,
+		                   (const float4 *) tris, (const float4 *) ao_table, (const HitRec *) hits,
+		                   (uint32_t *) occluded_of, (const uint32_t *) tile_hits, (const uint32_t *) order,
+		                   (FrameCounters *) counters, P);
 	hipLaunchKernelGGL(resolve_kernel, dim3((tiles * 64u + 255u) / 256u), dim3(256), 0, s, (const HitRec *) hits,
 	                   (const uint32_t *) occluded_of, (const uint32_t *) tile_hits, (FrameCounters *) counters, image,
-	                   tiles, P.ao_dirs);
+	                   tiles, P.ao_divisor);
 }
 
 void launch_resize(const float *tmp, unsigned char *out, const KernelParams &P, uint32_t out_width, uint32_t n,

@@ -166,6 +166,7 @@ KernelParams make_kernel_params(const RayTracer &rt, uint32_t node_count, uint32
 		p.ao_mode = rt.options.aoMethod == RayTracer::AmbientOcclusionMethod::UNIFORM ? AO_UNIFORM : AO_RANDOM;
 	p.ao_max_distance = kernel_float(rt.options.aoMaxDistance);
 	p.ao_dirs = ao_dirs;
+	p.ao_divisor = p.ao_mode == AO_RANDOM ? ao_dirs - 1 : ao_dirs;
 	p.scene_regular = scene_regular ? 1 : 0;
 	p.debug_no_sort = std::getenv("OCRT_NO_SORT") ? 1 : 0;
 	const char *refill_min = std::getenv("OCRT_REFILL_MIN"), *leaf_min = std::getenv("OCRT_LEAF_MIN");

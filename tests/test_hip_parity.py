@@ -184,11 +184,30 @@ def test_render_cli_writes_the_golden_pgm(rt, golden, tmp_path):
         assert hashlib.md5(out.read_bytes()).hexdigest() == c["pgm_md5"]
 
 
-def test_random_ao_is_rejected_loudly(rt, scene_for):
-    opt = rt.Options.defaults(width=16, height=16, n_super_samples=1, ao_method=1)
-    scene, _ = scene_for("blob", "longest")
-    host = rt.Host(opt, 0)
-    with pytest.raises(rt.RtError) as e:
-        host.upload_scene(scene)
-    assert "random" in e.value.message
+@pytest.mark.parametrize("mesh,samples", [("blob", 6), ("bunny", 16)])
+def test_random_ao_statistical_parity(rt, oracle, scene_for, mesh, samples):
+    """`-m random` (reference intersect_kernel.cl:128-183,257-276) calls acos/sin/
+    cos/cospi/sinpi on per-pixel data; device and host libm round differently, so
+    this mode is outside the bit-exact contract.  The integer
+    generator and the ray bookkeeping are exact, so: identical ray counts, and
+    8-bit images that differ only where a ray flipped between hit and miss --
+    tolerance: mean |delta| <= 0.25 grey levels, >= 97 % of the pixels identical,
+    no pixel further off than three occlusion steps."""
+    import orc
+
+    opt = rt.Options.defaults(width=160, height=120, n_super_samples=1, ao_num_samples=samples, ao_method=1,
+                              ao_max_distance=0.3)
+    scene, arrays = scene_for(mesh, "longest")
+    host = render_hip(rt, scene, opt)
+    gpu = host.download_u8().astype(np.int32)
+    st = host.stats()
+    ref_img, counters, _ = oracle.render(orc.params_from_options(opt), arrays)
+    ref = oracle.resize(ref_img, opt.width, opt.height, 1).astype(np.int32)
+    assert st["primary_hits"] == counters["primary_hits"]
+    assert st["ao_rays"] == counters["ao_rays"] == counters["primary_hits"] * (samples + 2)
+    delta = np.abs(gpu - ref)
+    assert delta.mean() <= 0.25, delta.mean()
+    assert (delta == 0).mean() >= 0.97, (delta == 0).mean()
+    assert delta.max() <= 3 * 255 // (samples + 1) + 1, delta.max()
+    assert abs(st["ao_occluded"] - counters["ao_occluded"]) <= 0.002 * counters["ao_rays"] + 8
     host.close()
