@@ -191,10 +191,17 @@ def main():
     rt.load_library()  # raises if the HIP library is missing: no fallback
     if not torch.cuda.is_available() or rt.device_count() < 1:
         sys.exit("bench.py needs a visible MI355X (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # One rank per GPU over RCCL.  Rehearsal knob for a one-GPU box: OCRT_BENCH_BACKEND=gloo maps every
+    # rank to an existing device and stages the band gather through host memory.
+    backend = os.environ.get("OCRT_BENCH_BACKEND", "nccl")
+    device_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
+    device = torch.device("cuda", device_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     w = WORKLOADS[args.workload]
     opt = workload_options(rt, w)
@@ -202,7 +209,7 @@ def main():
     scene = rt.Scene.load_off(mesh_path(w["mesh"])).build_bvh(opt.bvh_method)
     t_scene = time.perf_counter() - t0
 
-    host = rt.Host(opt, local_rank, rank, world)
+    host = rt.Host(opt, device_index, rank, world)
     host.upload_scene(scene)
     # One explicit torch stream carries the kernels, the resize and (through
     # torch.distributed's stream sync) the gather, so they are ordered.
@@ -221,7 +228,10 @@ def main():
     def step():
         host.render_async()
         host.resize_into_device(band.data_ptr())
-        result["final"] = gather_bands(band, layout, rank)
+        if world > 1 and backend != "nccl":
+            result["final"] = gather_bands(band.cpu(), layout, rank)  # rehearsal path: host-staged gather
+        else:
+            result["final"] = gather_bands(band, layout, rank)
 
     def fence():
         torch.cuda.synchronize(device)
@@ -247,10 +257,11 @@ def main():
     kernel_ms = host.total_kernel_ms / max(1, host.kernel_launches)
     ao_ms = host.total_ao_ms / max(1, host.kernel_launches)
     if world > 1:
-        t = torch.tensor([elapsed, kernel_ms, ao_ms], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed, kernel_ms, ao_ms], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms_max, ao_ms_max = float(t[0]), float(t[1]), float(t[2])
-        r = torch.tensor([my_rays, st["primary_hits"], st["ao_occluded"]], dtype=torch.int64, device=device)
+        r = torch.tensor([my_rays, st["primary_hits"], st["ao_occluded"]], dtype=torch.int64,
+                         device=device if backend == "nccl" else "cpu")
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
         total_rays, total_hits, total_occluded = (int(x) for x in r)
     else:
@@ -279,7 +290,7 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": f"{w['mesh']}.off mesh asset, fixed camera (no randomness in this path)",
             "config": {"workload": w["label"], "rays_per_frame": total_rays, "primary_hits": total_hits,
-                       "parallelism": f"image bands x{world}" + (", RCCL gather to rank 0" if world > 1 else ""),
+                       "parallelism": f"image bands x{world}" + (f", {'RCCL' if backend == 'nccl' else backend} gather to rank 0" if world > 1 else ""),
                        "pgm_md5": pgm_md5, "pgm_matches_golden": golden_md5 is not None,
                        "scene_build_s": round(t_scene, 3), "device": torch.cuda.get_device_name(device)},
         }

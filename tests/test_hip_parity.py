@@ -211,3 +211,40 @@ def test_random_ao_statistical_parity(rt, oracle, scene_for, mesh, samples):
     assert delta.max() <= 3 * 255 // (samples + 1) + 1, delta.max()
     assert abs(st["ao_occluded"] - counters["ao_occluded"]) <= 0.002 * counters["ao_rays"] + 8
     host.close()
+
+
+@pytest.mark.parametrize("damage", ["inverted_box", "nan_leaf_box", "huge_box", "inf_box", "nan_vertex"])
+def test_irregular_scene_arrays_match_oracle(rt, oracle, scene_for, damage):
+    """Scene arrays a BVH builder would never emit (inverted / NaN / infinite /
+    overflowing boxes, a NaN vertex) arrive through the upload API: the kernels
+    must then fall back to the reference's own slab test and still agree with
+    the oracle bit for bit."""
+    import orc
+
+    _, arrays = scene_for("blob", "longest")
+    nodes, aabbs, verts = arrays.nodes.copy(), arrays.aabbs.copy(), arrays.vertices.copy()
+    inner = int(np.flatnonzero(nodes > 8)[5])
+    leaf = int(np.flatnonzero(nodes == 1)[40])
+    if damage == "inverted_box":
+        aabbs[2 * inner, 0], aabbs[2 * inner + 1, 0] = aabbs[2 * inner + 1, 0], aabbs[2 * inner, 0]
+    elif damage == "nan_leaf_box":
+        aabbs[2 * leaf, 1] = np.nan
+    elif damage == "huge_box":
+        aabbs[0, :3] = -3.0e38
+        aabbs[1, :3] = 3.0e38
+    elif damage == "inf_box":
+        aabbs[0, 2] = -np.inf
+        aabbs[1, 0] = np.inf
+    elif damage == "nan_vertex":
+        verts[int(arrays.faces[3 * 17]), 1] = np.nan
+    damaged = orc.SceneArrays(arrays.faces, nodes, aabbs, verts, arrays.normals)
+    opt = rt.Options.defaults(width=96, height=64, n_super_samples=1, ao_num_samples=2, ao_max_distance=0.5)
+    host = rt.Host(opt, 0)
+    host.upload(damaged.faces, damaged.nodes, damaged.aabbs, damaged.vertices, damaged.normals)
+    host.render()
+    ref_img, counters, _ = oracle.render(orc.params_from_options(opt), damaged)
+    got = host.download()
+    same = (bits(got) == bits(ref_img)) | (np.isnan(got) & np.isnan(ref_img))
+    assert same.all(), int((~same).sum())
+    assert host.stats()["primary_hits"] == counters["primary_hits"]
+    host.close()
