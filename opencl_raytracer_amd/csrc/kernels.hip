@@ -334,6 +334,8 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
 		if (walking == 0ull)
 			break;
 		advance_walkers(scene, ray, regular, 100000.0f, P.primary_below, count, i, pending);
+		if ((uint32_t) __popcll(__ballot(pending != NONE)) < P.leaf_min)
+			advance_walkers(scene, ray, regular, 100000.0f, P.primary_below, count, i, pending);
 	}
 
 	// smooth normal and head-light term, reference :296-304
@@ -634,6 +636,9 @@ __global__ __launch_bounds__(64 * AO_WAVES) void ao_kernel(
 				if (walking == 0ull)
 					break;
 				advance_walkers(scene, ray, regular, P.ao_max_distance, P.ao_below, count, i, pending);
+				// a second node straight away while few leaves are pending: halves the scheduling overhead
+				if ((uint32_t) __popcll(__ballot(pending != NONE)) < P.leaf_min)
+					advance_walkers(scene, ray, regular, P.ao_max_distance, P.ao_below, count, i, pending);
 			}
 			wave_lds_sync();
 
