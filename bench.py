@@ -71,23 +71,6 @@ def mesh_path(name: str) -> str:
     return bunny_path() if name == "bunny" else interior_path()
 
 
-def baseline_kernel_params():
-    """(orc params, supersamples) of the default workload: lets build() prebuild
-    the matching reference-kernel object for the cpu_baseline leg."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import orc
-
-    class O:  # rt_options look-alike, so this works before the product is built
-        pass
-
-    w = WORKLOADS[DEFAULT_WORKLOAD]
-    o = O()
-    o.width, o.height, o.focal_length, o.n_super_samples = w["width"], w["height"], 1.0, w["ss"]
-    o.enable_shading, o.enable_ao, o.ao_max_distance, o.ao_num_samples = 1, int(w["ao"] != 0), 0.2, w["ao"]
-    o.ao_method, o.ao_alpha_min, o.ao_alpha_max = 0, 4, 90
-    return orc.params_from_options(o), w["ss"]
-
-
 def algorithmic_bytes(counters: dict, subpixels: int) -> dict:
     """B = 36 per node visit (4 B count + 32 B box) + 60 per
     triangle test (12 B indices + 48 B vertices) + 48 per hit primary (normals)
