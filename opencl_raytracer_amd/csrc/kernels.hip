@@ -9,20 +9,21 @@
 // for the CDNA4 wave64 machine.
 //
 // Work decomposition: one 64-lane wavefront per 8x8 tile of sub-pixels, in two
-// passes with a tiny ordering step between them.
+// passes with a tiny ordering step between them and a resolve step after.
 //   primary_kernel  every lane casts its primary ray (closest hit) and computes
 //                   the smooth normal and head-light term.  Sub-pixels that need
 //                   no ambient occlusion are final; the tile's other hits are
 //                   ballot-compacted into the tile's 64 slots of the hit list.
 //   order_kernel    counting sort of the non-empty tiles by hit count, heaviest
 //                   first, per XCD group.
-//   ao_kernel       persistent waves claim tiles in that order.  A wave rebuilds
-//                   the tile's tangent frames in its LDS slice and drains the
-//                   tile's (hit, direction) pairs -- direction-major, so that the
-//                   lanes cast one table direction from neighbouring surface
-//                   points -- as any-hit rays that stop at the first accepted
-//                   triangle; occlusion counts are LDS atomics; the hit lanes
-//                   then store value * (1 - occluded / n).
+//   ao_kernel       persistent waves claim jobs = (tile, range of table directions)
+//                   in that order.  A wave rebuilds the tile's tangent frames in
+//                   its LDS slice and drains the job's (hit, direction) pairs --
+//                   direction-major, so that the lanes cast one table direction
+//                   from neighbouring surface points -- as any-hit rays that stop
+//                   at the first accepted triangle; occlusion counts are LDS
+//                   atomics, flushed to a per-hit counter when the job is done.
+//   resolve_kernel  one thread per hit: value * (1 - occluded / n) -> image.
 // Why not one fused launch (it was, see profiles/r01_notes.md): cost per tile
 // varies 30x (background vs model, 29 rays per hit sub-pixel) and a full tile
 // keeps its wave busy for ~1/6 of the frame, so the frame used to end on a long
@@ -106,9 +107,10 @@ constexpr uint32_t NONE = 0xFFFFFFFFu;
 // Thresholds (KernelParams::refill_min / leaf_min, 16 each): refill once that many
 // lanes are idle, run the triangle tests once that many leaves are pending.
 
-// Largest magnitude for which (b - o) cannot overflow; beyond it, or for a ray
-// with an infinite or NaN reciprocal direction, the exact select-based slab test
-// is used instead of the min/max form.
+// Largest magnitude for which (b - o) cannot overflow.  A ray is "regular" when
+// its origin and its reciprocal direction are finite and within it (so no
+// inf * 0, no inf - inf); for any other ray the reference's own select-based
+// slab test is used instead of the min/max form.
 constexpr float REGULAR_LIMIT = 1.0e37f;
 
 __device__ __forceinline__ bool ray_is_regular(const Ray &r) {
@@ -133,9 +135,6 @@ __device__ __forceinline__ bool slab_hit_regular(const float4 lo, const float4 h
 	return t_near <= t_far;
 }
 
-// One node for a lane in state T: box hit -> next node in pre-order (and the leaf,
-// if it is one, becomes pending); miss -> skip the subtree.  Inner nodes carry
-// leaf == NONE, so no leaf/inner branch is needed.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // 128-bit loads through a buffer descriptor (wave-uniform base + 32-bit per-lane
@@ -261,7 +260,6 @@ __device__ __forceinline__ uint32_t rank_in(unsigned long long mask) {
 // to the 8 XCD groups, and each group walks its strips top to bottom:
 // neighbouring workgroups of a group touch the same BVH region, while every
 // group still sees the whole image height.
-__device__ __forceinline__ uint32_t group_of_tile_x(uint32_t tile_x) { return (tile_x >> 1) & (XCD_GROUPS - 1u); }
 
 // ---------------------------------------------------------------------------
 // Pass 1: primary rays.  Four independent waves per workgroup, one tile each.
