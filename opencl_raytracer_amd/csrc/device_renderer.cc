@@ -71,6 +71,8 @@ DeviceRenderer::DeviceRenderer(const RayTracer::Options &options, int device_, u
 		throw std::invalid_argument("rank must be < nranks");
 	if (opts.width == 0 || opts.height == 0 || grid == 0)
 		throw std::invalid_argument("image width, height and supersample count must be positive");
+	if ((unsigned long long) rt.totalWidth * rt.totalHeight >= (1ull << 32))
+		throw std::invalid_argument("supersampled image too large for 32-bit pixel indices");
 	const int count = visible_device_count();
 	if (count <= 0)
 		throw std::runtime_error("No device found");

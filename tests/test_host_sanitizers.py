@@ -1,0 +1,22 @@
+"""CPU: the product's host-side scene build under ASan + UBSan (GPU sanitizers are
+not available on the pool, so the sanitizers run on the CPU build only)."""
+import os
+import subprocess
+
+from conftest import ROOT, mesh_file
+
+CSRC = os.path.join(ROOT, "opencl_raytracer_amd", "csrc")
+
+
+def test_host_scene_build_under_asan_ubsan(tmp_path):
+    exe = str(tmp_path / "host_sanitize")
+    srcs = [os.path.join(ROOT, "tests", "host_sanitize.cc")] + [os.path.join(CSRC, f) for f in
+                                                               ("mesh.cc", "bvh.cc", "ray_tracer.cc", "scene_pack.cc")]
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-ffp-contract=off",
+                    "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-I", CSRC, "-o", exe] + srcs,
+                   check=True)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([exe] + [mesh_file(m) for m in ("single", "ties", "blob", "bunny")], capture_output=True,
+                       text=True, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count(" ok (") == 4
