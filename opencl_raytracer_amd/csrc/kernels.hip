@@ -94,16 +94,24 @@ __device__ __forceinline__ bool slab_hit(const float4 lo, const float4 hi, const
 // ---------------------------------------------------------------------------
 // Wave-scheduled traversal.
 //
-// A lane is in one of three states: T (walking nodes), L (a leaf whose box was
-// hit is pending its triangle test), I (no ray).  Instead of letting every lane
-// run its own nested loops -- where the wave pays for the longest ray and a
-// triangle test runs with a handful of live lanes -- the wave picks, per
-// iteration and with scalar ballots only, the one body worth running:
-// refill idle lanes from the tile's ray queue, run the triangle test for the L
-// lanes, or advance the T lanes by one node.  Each body is straight-line and
-// predicated, so exec-mask bookkeeping stays out of the hot loop.
+// A lane walks nodes (T), has hit leaves pending their triangle test (L) or has
+// no ray (I).  Instead of letting every lane run its own nested loops -- where
+// the wave pays for the longest ray and a triangle test runs with a handful of
+// live lanes -- the wave picks, per iteration and with scalar ballots only, the
+// one body worth running: refill idle lanes from the ray queue, run the triangle
+// test for the lanes with a pending leaf, or advance the walking lanes by one
+// node.  Each body is straight-line and predicated, so exec-mask bookkeeping
+// stays out of the hot loop.  A lane keeps up to TWO pending leaves (a FIFO, so
+// the reference's ascending leaf order of the tests is preserved) and goes on
+// walking while the second slot is free: lanes rarely block on a triangle test,
+// and the tests run with more lanes at once.
 // ---------------------------------------------------------------------------
 constexpr uint32_t NONE = 0xFFFFFFFFu;
+
+struct Pending {
+	uint32_t first, second;  // leaf indices in the order they were met; NONE = free
+};
+__device__ __forceinline__ bool can_walk(const Pending &p, uint32_t i, uint32_t count) { return p.second == NONE && i < count; }
 // Thresholds (KernelParams::refill_min / leaf_min, 16 each): refill once that many
 // lanes are idle, run the triangle tests once that many leaves are pending.
 
@@ -152,11 +160,14 @@ __device__ __forceinline__ float4 load_f4(__amdgpu_buffer_rsrc_t rsrc, uint32_t 
 // leaf == NONE, so no leaf/inner branch is needed.
 template <bool REGULAR>
 __device__ __forceinline__ void node_step(__amdgpu_buffer_rsrc_t nodes, const Ray &r, float max_distance,
-                                          float below, uint32_t &i, uint32_t &pending) {
+                                          float below, uint32_t &i, Pending &pending) {
 	const float4 lo = load_f4(nodes, i * 32u);
 	const float4 hi = load_f4(nodes, i * 32u + 16u);
 	const bool hit = REGULAR ? slab_hit_regular(lo, hi, r, below) : slab_hit(lo, hi, r, max_distance);
-	pending = hit ? __float_as_uint(hi.w) : NONE;
+	const uint32_t leaf = hit ? __float_as_uint(hi.w) : NONE;  // NONE unless a leaf's box was hit
+	const bool empty = pending.first == NONE;                  // (this lane walks, so `second` is free)
+	pending.second = empty ? NONE : leaf;
+	pending.first = empty ? leaf : pending.first;
 	i += hit ? 1u : __float_as_uint(lo.w);
 }
 
@@ -237,8 +248,8 @@ __device__ __forceinline__ SceneViews make_views(const float4 *nodes_ptr, const 
 // Advances the lanes in state T by one node: the min/max slab form when every
 // walking lane's ray is regular (the common case), the reference's own form otherwise.
 __device__ __forceinline__ void advance_walkers(const SceneViews &scene, const Ray &r, bool regular, float max_distance,
-                                                float below, uint32_t count, uint32_t &i, uint32_t &pending) {
-	const bool walking_lane = pending == NONE && i < count;
+                                                float below, uint32_t count, uint32_t &i, Pending &pending) {
+	const bool walking_lane = can_walk(pending, i, count);
 	const bool all_regular = __ballot(walking_lane && !regular) == 0ull;
 	if (walking_lane) {
 		if (all_regular)
@@ -307,32 +318,33 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
 	best.px = best.py = best.pz = 0.0f;
 	bool hit = false;
 	uint32_t i = active ? 0u : count;
-	uint32_t pending = NONE;
+	Pending pending = { NONE, NONE };
 	for (;;) {
-		const unsigned long long walking = __ballot(pending == NONE && i < count);
-		const unsigned long long leaves = __ballot(pending != NONE);
+		const unsigned long long walking = __ballot(can_walk(pending, i, count));
+		const unsigned long long leaves = __ballot(pending.first != NONE);
 		if (leaves != 0ull && ((uint32_t) __popcll(leaves) >= P.leaf_min || walking == 0ull)) {
-			if (pending != NONE) {
-				const TriResult tr = tri_test<true>(scene.tris, pending, ray);
+			if (pending.first != NONE) {
+				const TriResult tr = tri_test<true>(scene.tris, pending.first, ray);
 				// closest hit: strict '>' in ascending leaf order, reference :106-112
 				if (tr.accepted) {
 					hit = true;
 					if (best.distance > tr.distance) {
 						best.distance = tr.distance;
-						best.leaf = pending;
+						best.leaf = pending.first;
 						best.s = tr.s;
 						best.t = tr.t;
 						best.px = tr.px; best.py = tr.py; best.pz = tr.pz;
 					}
 				}
-				pending = NONE;
+				pending.first = pending.second;
+				pending.second = NONE;
 			}
 			continue;
 		}
 		if (walking == 0ull)
 			break;
 		advance_walkers(scene, ray, regular, 100000.0f, P.primary_below, count, i, pending);
-		if ((uint32_t) __popcll(__ballot(pending != NONE)) < P.leaf_min)
+		if ((uint32_t) __popcll(__ballot(pending.first != NONE)) < P.leaf_min)
 			advance_walkers(scene, ray, regular, 100000.0f, P.primary_below, count, i, pending);
 	}
 
@@ -560,19 +572,18 @@ __global__ __launch_bounds__(64 * AO_WAVES) void ao_kernel(
 			const uint32_t total = hit_count * n_dirs;
 			uint32_t next = 0u;  // wave-uniform queue head
 			uint32_t i = count;
-			uint32_t pending = NONE;
+			Pending pending = { NONE, NONE };
 			uint32_t h = 0;
 			Ray ray;
 			bool regular = true;
 			for (;;) {
-				const bool walking_lane = pending == NONE && i < count;
-				const unsigned long long walking = __ballot(walking_lane);
-				const unsigned long long leaves = __ballot(pending != NONE);
-				const uint32_t n_leaves = (uint32_t) __popcll(leaves);
-				const uint32_t idle = 64u - (uint32_t) __popcll(walking) - n_leaves;
+				const bool idle_lane = pending.first == NONE && !(i < count);
+				const unsigned long long walking = __ballot(can_walk(pending, i, count));
+				const uint32_t n_leaves = (uint32_t) __popcll(__ballot(pending.first != NONE));
+				const unsigned long long idle_mask = __ballot(idle_lane);
+				const uint32_t idle = (uint32_t) __popcll(idle_mask);
 				if (next < total && idle >= P.refill_min) {
-					const bool idle_lane = !walking_lane && pending == NONE;
-					const uint32_t item = next + rank_in(__ballot(idle_lane));
+					const uint32_t item = next + rank_in(idle_mask);
 					if (idle_lane && item < total) {
 						const uint32_t k = item / hit_count;
 						h = item - k * hit_count;
@@ -621,13 +632,15 @@ __global__ __launch_bounds__(64 * AO_WAVES) void ao_kernel(
 					continue;
 				}
 				if (n_leaves != 0u && (n_leaves >= P.leaf_min || walking == 0ull)) {
-					if (pending != NONE) {
-						const TriResult tr = tri_test<false>(scene.tris, pending, ray);
+					if (pending.first != NONE) {
+						const TriResult tr = tri_test<false>(scene.tris, pending.first, ray);
+						pending.first = pending.second;
+						pending.second = NONE;
 						if (tr.accepted) {
 							atomicAdd(&sh.occluded[h], 1u);
 							i = count;  // any-hit: the reference walks on but only uses the boolean (:251)
+							pending.first = NONE;
 						}
-						pending = NONE;
 					}
 					continue;
 				}
@@ -635,7 +648,7 @@ __global__ __launch_bounds__(64 * AO_WAVES) void ao_kernel(
 					break;
 				advance_walkers(scene, ray, regular, P.ao_max_distance, P.ao_below, count, i, pending);
 				// a second node straight away while few leaves are pending: halves the scheduling overhead
-				if ((uint32_t) __popcll(__ballot(pending != NONE)) < P.leaf_min)
+				if ((uint32_t) __popcll(__ballot(pending.first != NONE)) < P.leaf_min)
 					advance_walkers(scene, ray, regular, P.ao_max_distance, P.ao_below, count, i, pending);
 			}
 			wave_lds_sync();
