@@ -53,6 +53,9 @@ WORKLOADS = {
     "bunny_1080p_s64": dict(
         mesh="bunny", bvh="longest", width=1920, height=1080, ss=64, ao=3, golden=None,
         label="bunny.off 1920x1080 -s 64 -a 3 (regular 8x8 supersample grid: 15360x8640 sub-pixels)"),
+    "interior_4k_ao": dict(
+        mesh="interior", bvh="longest", width=3840, height=2160, ss=1, ao=3, golden=None,
+        label="interior stand-in for the missing sibenik.off, 3840x2160 -s 1 -a 3"),
     "interior_1080p_ao": dict(
         mesh="interior", bvh="longest", width=1920, height=1080, ss=1, ao=3, golden=None,
         label="interior stand-in for the missing sibenik.off, 1920x1080 -s 1 -a 3"),
@@ -271,7 +274,10 @@ def main():
                       else "Mrays/s; PGM bit-exact vs CPU",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": f"{w['mesh']}.off mesh asset, fixed camera (no randomness in this path)",
+            "dtype": "f32",
+            "data": ("bunny.off (the reference's mesh asset)" if w["mesh"] == "bunny" else
+                     "synthetic interior scene, stand-in for the missing sibenik.off (tools/make_interior_mesh.py)")
+                    + ", fixed camera, no randomness in this path",
             "config": {"workload": w["label"], "rays_per_frame": total_rays, "primary_hits": total_hits,
                        "parallelism": f"image bands x{world}" + (f", {'RCCL' if backend == 'nccl' else backend} gather to rank 0" if world > 1 else ""),
                        "pgm_md5": pgm_md5, "pgm_matches_golden": golden_md5 is not None,

@@ -1,0 +1,27 @@
+"""Per-rank kernel time of the band partition, measured on one GPU: renders rank 0's
+share of the frame for 1, 2, 4 and 8 ranks (what each GPU of an N-GPU run would do)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import opencl_raytracer_amd as rt  # noqa: E402
+from bench import WORKLOADS, mesh_path, workload_options  # noqa: E402
+
+w = WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "bunny_1080p_ao"]
+opt = workload_options(rt, w)
+scene = rt.Scene.load_off(mesh_path(w["mesh"])).build_bvh(opt.bvh_method)
+for n in (1, 2, 4, 8):
+    worst, worst_ao = 0.0, 0.0
+    for rank in range(n):
+        host = rt.Host(opt, 0, rank, n)
+        host.upload_scene(scene)
+        for _ in range(3):
+            host.render()
+        host.reset_timers()
+        for _ in range(10):
+            host.render_async()
+        host.sync()
+        worst = max(worst, host.total_kernel_ms / host.kernel_launches)
+        worst_ao = max(worst_ao, host.total_ao_ms / host.kernel_launches)
+        host.close()
+    print(f"{n} ranks: slowest rank {worst:.3f} ms per frame (AO passes {worst_ao:.3f} ms)")
