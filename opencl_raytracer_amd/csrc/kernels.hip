@@ -198,9 +198,8 @@ struct TriResult {
 };
 
 template <bool CLOSEST>
-__device__ __forceinline__ TriResult tri_test(__amdgpu_buffer_rsrc_t tris, uint32_t leaf, const Ray &r) {
-	const float4 q0 = load_f4(tris, leaf * 64u), q1 = load_f4(tris, leaf * 64u + 16u);
-	const float4 q2 = load_f4(tris, leaf * 64u + 32u), q3 = load_f4(tris, leaf * 64u + 48u);
+__device__ __forceinline__ TriResult tri_eval(const float4 q0, const float4 q1, const float4 q2, const float4 q3,
+                                              const Ray &r) {
 	const float tax = q0.x, tay = q0.y, taz = q0.z;
 	const float ux = q0.w, uy = q1.x, uz = q1.y;
 	const float vx = q1.z, vy = q1.w, vz = q2.x;
@@ -230,6 +229,13 @@ __device__ __forceinline__ TriResult tri_test(__amdgpu_buffer_rsrc_t tris, uint3
 		out.distance = sqrtf(dot3(ex, ey, ez, ex, ey, ez));
 	}
 	return out;
+}
+
+template <bool CLOSEST>
+__device__ __forceinline__ TriResult tri_test(__amdgpu_buffer_rsrc_t tris, uint32_t leaf, const Ray &r) {
+	const float4 q0 = load_f4(tris, leaf * 64u), q1 = load_f4(tris, leaf * 64u + 16u);
+	const float4 q2 = load_f4(tris, leaf * 64u + 32u), q3 = load_f4(tris, leaf * 64u + 48u);
+	return tri_eval<CLOSEST>(q0, q1, q2, q3, r);
 }
 
 struct SceneViews {
@@ -317,35 +323,73 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
 	best.s = best.t = 0.0f;
 	best.px = best.py = best.pz = 0.0f;
 	bool hit = false;
-	uint32_t i = active ? 0u : count;
-	Pending pending = { NONE, NONE };
-	for (;;) {
-		const unsigned long long walking = __ballot(can_walk(pending, i, count));
-		const unsigned long long leaves = __ballot(pending.first != NONE);
-		if (leaves != 0ull && ((uint32_t) __popcll(leaves) >= P.leaf_min || walking == 0ull)) {
-			if (pending.first != NONE) {
-				const TriResult tr = tri_test<true>(scene.tris, pending.first, ray);
-				// closest hit: strict '>' in ascending leaf order, reference :106-112
-				if (tr.accepted) {
-					hit = true;
-					if (best.distance > tr.distance) {
-						best.distance = tr.distance;
-						best.leaf = pending.first;
-						best.s = tr.s;
-						best.t = tr.t;
-						best.px = tr.px; best.py = tr.py; best.pz = tr.pz;
+	if (P.scene_regular && P.scene_nested && __ballot(active && !regular) == 0ull) {
+		// Shared walk: the tile's 64 rays visit the union of their nodes together.  The node
+		// index is wave-uniform, so a node (and a leaf's triangle) arrives by scalar loads and
+		// the box is tested out of SGPRs.  A lane that missed an ancestor also misses every
+		// box nested in it (the slab test is monotone in lo and hi), so each lane accepts the
+		// same triangles, in the same ascending leaf order, as on its own walk.
+		uint32_t i = 0u;
+		while (i < count) {
+			const uint32_t at = (uint32_t) __builtin_amdgcn_readfirstlane((int) i);
+			const float4 lo = nodes_ptr[2u * at], hi = nodes_ptr[2u * at + 1u];
+			uint32_t skip = __float_as_uint(lo.w), leaf = __float_as_uint(hi.w);
+			asm volatile("" : "+s"(skip), "+s"(leaf));  // keep them from the one 32-byte load, not re-fetched later
+			const bool box = slab_hit_regular(lo, hi, ray, P.primary_below) & active;  // (every lane has a valid ray)
+			if (__ballot(box) == 0ull) {
+				i = at + skip;
+				continue;
+			}
+			if (leaf != NONE) {
+				const float4 q0 = tris_ptr[4u * leaf], q1 = tris_ptr[4u * leaf + 1u];
+				const float4 q2 = tris_ptr[4u * leaf + 2u], q3 = tris_ptr[4u * leaf + 3u];
+				if (box) {
+					const TriResult tr = tri_eval<true>(q0, q1, q2, q3, ray);
+					if (tr.accepted) {
+						hit = true;
+						if (best.distance > tr.distance) {
+							best.distance = tr.distance;
+							best.leaf = leaf;
+							best.s = tr.s;
+							best.t = tr.t;
+							best.px = tr.px; best.py = tr.py; best.pz = tr.pz;
+						}
 					}
 				}
-				pending.first = pending.second;
-				pending.second = NONE;
 			}
-			continue;
+			i = at + 1u;
 		}
-		if (walking == 0ull)
-			break;
-		advance_walkers(scene, ray, regular, 100000.0f, P.primary_below, count, i, pending);
-		if ((uint32_t) __popcll(__ballot(pending.first != NONE)) < P.leaf_min)
+	} else {
+		uint32_t i = active ? 0u : count;
+		Pending pending = { NONE, NONE };
+		for (;;) {
+			const unsigned long long walking = __ballot(can_walk(pending, i, count));
+			const unsigned long long leaves = __ballot(pending.first != NONE);
+			if (leaves != 0ull && ((uint32_t) __popcll(leaves) >= P.leaf_min || walking == 0ull)) {
+				if (pending.first != NONE) {
+					const TriResult tr = tri_test<true>(scene.tris, pending.first, ray);
+					// closest hit: strict '>' in ascending leaf order, reference :106-112
+					if (tr.accepted) {
+						hit = true;
+						if (best.distance > tr.distance) {
+							best.distance = tr.distance;
+							best.leaf = pending.first;
+							best.s = tr.s;
+							best.t = tr.t;
+							best.px = tr.px; best.py = tr.py; best.pz = tr.pz;
+						}
+					}
+					pending.first = pending.second;
+					pending.second = NONE;
+				}
+				continue;
+			}
+			if (walking == 0ull)
+				break;
 			advance_walkers(scene, ray, regular, 100000.0f, P.primary_below, count, i, pending);
+			if ((uint32_t) __popcll(__ballot(pending.first != NONE)) < P.leaf_min)
+				advance_walkers(scene, ray, regular, 100000.0f, P.primary_below, count, i, pending);
+		}
 	}
 
 	// smooth normal and head-light term, reference :296-304
@@ -576,81 +620,140 @@ __global__ __launch_bounds__(64 * AO_WAVES) void ao_kernel(
 			uint32_t h = 0;
 			Ray ray;
 			bool regular = true;
-			for (;;) {
-				const bool idle_lane = pending.first == NONE && !(i < count);
-				const unsigned long long walking = __ballot(can_walk(pending, i, count));
-				const uint32_t n_leaves = (uint32_t) __popcll(__ballot(pending.first != NONE));
-				const unsigned long long idle_mask = __ballot(idle_lane);
-				const uint32_t idle = (uint32_t) __popcll(idle_mask);
-				if (next < total && idle >= P.refill_min) {
-					const uint32_t item = next + rank_in(idle_mask);
-					if (idle_lane && item < total) {
-						const uint32_t k = item / hit_count;
-						h = item - k * hit_count;
-						float xs, ys, zs;
-						bool along_normal = false;
-						if (MODE == AO_UNIFORM) {
-							const float4 dir = ao_table[dir0 + k];
-							xs = dir.x; ys = dir.y; zs = dir.z;
-						} else {
-							// RANDOM (reference :153-183, :257-276): ray 0 goes along the normal, ray
-							// j >= 1 uses draws 2j-2 and 2j-1 of the sub-pixel's generator.  Device libm
-							// rounds differently from the host's: this mode is outside the bit-exact contract.
-							const uint32_t j = dir0 + k;
-							along_normal = j == 0u;
-							Rng rng = rng_seed(536870923u * sh.pixel[h]);
-							for (uint32_t skip = 1; skip < j; ++skip) {
-								rng_next(rng);
-								rng_next(rng);
-							}
-							const float xi1 = rng_float(rng);
-							const float xi2 = rng_float(rng);
-							const float theta = acosf(sqrtf(1.0f - xi1));
-							const float phi = (float) (2.0 * (double) xi2);
-							xs = sinf(theta) * cospif(phi);
-							ys = cosf(theta);
-							zs = sinf(theta) * sinpif(phi);
-						}
-						// ray_dir = basis_x * xs + basis_y * ys + basis_z * zs, lane by lane
-						float rx = (sh.frame[3][h] * xs + sh.frame[6][h] * ys) + sh.frame[9][h] * zs;
-						float ry = (sh.frame[4][h] * xs + sh.frame[7][h] * ys) + sh.frame[10][h] * zs;
-						float rz = (sh.frame[5][h] * xs + sh.frame[8][h] * ys) + sh.frame[11][h] * zs;
-						if (MODE == AO_RANDOM) {
-							normalize3(rx, ry, rz);
-							if (along_normal) {
-								// the un-normalised shading normal itself (:263); recover it from the origin offset
-								// is not possible exactly, so it is kept in the hit record
-								const float4 q1 = ((const float4 *) hits)[2 * ((size_t) tile * 64u + h) + 1];
-								rx = q1.x; ry = q1.y; rz = q1.z;
-							}
-						}
-						ray = make_ray(sh.frame[0][h], sh.frame[1][h], sh.frame[2][h], rx, ry, rz);
-						regular = P.scene_regular && P.ao_regular && ray_is_regular(ray);
-						i = 0u;
+
+			// ray number `item` of the job -> this lane
+			auto setup_ray = [&](uint32_t item) {
+				const uint32_t k = item / hit_count;
+				h = item - k * hit_count;
+				float xs, ys, zs;
+				bool along_normal = false;
+				if (MODE == AO_UNIFORM) {
+					const float4 dir = ao_table[dir0 + k];
+					xs = dir.x; ys = dir.y; zs = dir.z;
+				} else {
+					// RANDOM (reference :153-183, :257-276): ray 0 goes along the normal, ray
+					// j >= 1 uses draws 2j-2 and 2j-1 of the sub-pixel's generator.  Device libm
+					// rounds differently from the host's: this mode is outside the bit-exact contract.
+					const uint32_t j = dir0 + k;
+					along_normal = j == 0u;
+					Rng rng = rng_seed(536870923u * sh.pixel[h]);
+					for (uint32_t skip = 1; skip < j; ++skip) {
+						rng_next(rng);
+						rng_next(rng);
 					}
-					next += idle;
-					continue;
+					const float xi1 = rng_float(rng);
+					const float xi2 = rng_float(rng);
+					const float theta = acosf(sqrtf(1.0f - xi1));
+					const float phi = (float) (2.0 * (double) xi2);
+					xs = sinf(theta) * cospif(phi);
+					ys = cosf(theta);
+					zs = sinf(theta) * sinpif(phi);
 				}
-				if (n_leaves != 0u && (n_leaves >= P.leaf_min || walking == 0ull)) {
-					if (pending.first != NONE) {
-						const TriResult tr = tri_test<false>(scene.tris, pending.first, ray);
-						pending.first = pending.second;
-						pending.second = NONE;
-						if (tr.accepted) {
-							atomicAdd(&sh.occluded[h], 1u);
-							i = count;  // any-hit: the reference walks on but only uses the boolean (:251)
-							pending.first = NONE;
-						}
+				// ray_dir = basis_x * xs + basis_y * ys + basis_z * zs, lane by lane
+				float rx = (sh.frame[3][h] * xs + sh.frame[6][h] * ys) + sh.frame[9][h] * zs;
+				float ry = (sh.frame[4][h] * xs + sh.frame[7][h] * ys) + sh.frame[10][h] * zs;
+				float rz = (sh.frame[5][h] * xs + sh.frame[8][h] * ys) + sh.frame[11][h] * zs;
+				if (MODE == AO_RANDOM) {
+					normalize3(rx, ry, rz);
+					if (along_normal) {
+						// the un-normalised shading normal itself (:263), kept in the hit record
+						const float4 q1 = ((const float4 *) hits)[2 * ((size_t) tile * 64u + h) + 1];
+						rx = q1.x; ry = q1.y; rz = q1.z;
 					}
-					continue;
 				}
-				if (walking == 0ull)
-					break;
-				advance_walkers(scene, ray, regular, P.ao_max_distance, P.ao_below, count, i, pending);
-				// a second node straight away while few leaves are pending: halves the scheduling overhead
-				if ((uint32_t) __popcll(__ballot(pending.first != NONE)) < P.leaf_min)
+				ray = make_ray(sh.frame[0][h], sh.frame[1][h], sh.frame[2][h], rx, ry, rz);
+				regular = P.scene_regular && P.ao_regular && ray_is_regular(ray);
+			};
+
+			// Every lane walks on its own; idle lanes are refilled from the job's rays while
+			// next < total.
+			auto walk_individually = [&]() {
+				for (;;) {
+					const bool idle_lane = pending.first == NONE && !(i < count);
+					const unsigned long long walking = __ballot(can_walk(pending, i, count));
+					const uint32_t n_leaves = (uint32_t) __popcll(__ballot(pending.first != NONE));
+					const unsigned long long idle_mask = __ballot(idle_lane);
+					const uint32_t idle = (uint32_t) __popcll(idle_mask);
+					if (next < total && idle >= P.refill_min) {
+						const uint32_t item = next + rank_in(idle_mask);
+						if (idle_lane && item < total) {
+							setup_ray(item);
+							i = 0u;
+						}
+						next += idle;
+						continue;
+					}
+					if (n_leaves != 0u && (n_leaves >= P.leaf_min || walking == 0ull)) {
+						if (pending.first != NONE) {
+							const TriResult tr = tri_test<false>(scene.tris, pending.first, ray);
+							pending.first = pending.second;
+							pending.second = NONE;
+							if (tr.accepted) {
+								atomicAdd(&sh.occluded[h], 1u);
+								i = count;  // any-hit: the reference walks on but only uses the boolean (:251)
+								pending.first = NONE;
+							}
+						}
+						continue;
+					}
+					if (walking == 0ull)
+						break;
 					advance_walkers(scene, ray, regular, P.ao_max_distance, P.ao_below, count, i, pending);
-			}
+					// a second node straight away while few leaves are pending: halves the scheduling overhead
+					if ((uint32_t) __popcll(__ballot(pending.first != NONE)) < P.leaf_min)
+						advance_walkers(scene, ray, regular, P.ao_max_distance, P.ao_below, count, i, pending);
+				}
+			};
+
+			// Regular, nested scenes: shared walks of 64 rays at a time (see primary_kernel) -- one
+			// wave-uniform node index, nodes and triangles by scalar loads; a lane leaves at its
+			// first accepted triangle.  Anything else walks the reference's way, lane by lane.
+			const bool packets = P.scene_regular && P.scene_nested && P.ao_regular;
+			uint32_t base = 0u;
+			do {
+				bool shared = false, alive = false;
+				if (packets) {
+					alive = base + lane < total;
+					if (alive)
+						setup_ray(base + lane);
+					base += 64u;
+					shared = __ballot(alive && !regular) == 0ull;
+					if (!shared) {
+						// a ray with an infinite or huge component: this packet goes the other way
+						next = total;
+						i = alive ? 0u : count;
+					}
+				}
+				if (!shared) {
+					walk_individually();
+					continue;
+				}
+				uint32_t at = 0u;
+				while (at < count) {
+					const float4 lo = nodes_ptr[2u * at], hi = nodes_ptr[2u * at + 1u];
+					uint32_t skip = __float_as_uint(lo.w), leaf = __float_as_uint(hi.w);
+					asm volatile("" : "+s"(skip), "+s"(leaf));  // keep them from the one 32-byte load
+					const bool box = slab_hit_regular(lo, hi, ray, P.ao_below) & alive;
+					if (__ballot(box) == 0ull) {
+						at = (uint32_t) __builtin_amdgcn_readfirstlane((int) (at + skip));
+						continue;
+					}
+					if (leaf != NONE) {
+						const float4 q0 = tris_ptr[4u * leaf], q1 = tris_ptr[4u * leaf + 1u];
+						const float4 q2 = tris_ptr[4u * leaf + 2u], q3 = tris_ptr[4u * leaf + 3u];
+						if (box) {
+							const TriResult tr = tri_eval<false>(q0, q1, q2, q3, ray);
+							if (tr.accepted) {
+								atomicAdd(&sh.occluded[h], 1u);
+								alive = false;
+							}
+						}
+						if (__ballot(alive) == 0ull)
+							break;
+					}
+					at = (uint32_t) __builtin_amdgcn_readfirstlane((int) (at + 1u));
+				}
+			} while (packets && base < total);
 			wave_lds_sync();
 
 			// ---- this job's share of the occlusion counts ----
