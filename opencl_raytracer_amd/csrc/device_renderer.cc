@@ -85,7 +85,7 @@ DeviceRenderer::DeviceRenderer(const RayTracer::Options &options, int device_, u
 	part.rank = rank;
 	part.nranks = nranks;
 	part.band_tile_rows = band_tile_rows_for(grid);
-	kp = make_kernel_params(rt, 0, 0, 0, part, false, false);
+	kp = make_kernel_params(rt, 0, 0, 0, part, nullptr);
 	local_out_rows = kp.local_tile_rows * TILE_H / grid;
 	tile_count = (size_t) kp.tiles_x * kp.local_tile_rows;
 
@@ -170,7 +170,7 @@ size_t DeviceRenderer::upload(const PackedScene &scene) {
 			ao_dirs = opts.aoNumSamples + 2;
 		}
 	}
-	kp = make_kernel_params(rt, (uint32_t) scene.nodes.size(), (uint32_t) scene.tris.size(), ao_dirs, part, scene.regular, scene.nested);
+	kp = make_kernel_params(rt, (uint32_t) scene.nodes.size(), (uint32_t) scene.tris.size(), ao_dirs, part, &scene);
 	const size_t nodes_bytes = scene.nodes.size() * sizeof(NodeRec);
 	const size_t tris_bytes = scene.tris.size() * sizeof(TriRec);
 	const size_t shade_bytes = scene.shade.size() * sizeof(ShadeRec);

@@ -92,7 +92,8 @@ struct KernelParams {
 	uint32_t ao_divisor;   // n of `1 - hits / n` (UNIFORM: ao_dirs; RANDOM: AO_NUM_SAMPLES + 1, reference :260-275)
 	int32_t scene_regular; // every box finite, |coord| <= 1e37 and lo <= hi: min/max slab form allowed
 	int32_t ao_regular;    // AO_MAX_DISTANCE > 0 (needed by the folded form of the slab test)
-	int32_t scene_nested;  // every child box lies inside its parent's box: shared (packet) walks allowed
+	int32_t scene_nested;  // every child box lies inside its parent's box: the shared walk's fast form is allowed
+	int32_t shared_walk;   // the node array is a binary tree (children partition the parent's index range)
 	float primary_below;   // largest float below the primary rays' max_distance (100000.0f)
 	float ao_below;        // largest float below AO_MAX_DISTANCE
 	int32_t debug_no_sort; // debug knob OCRT_NO_SORT: claim tiles in arbitrary order instead of heaviest first

@@ -265,6 +265,33 @@ __device__ __forceinline__ void advance_walkers(const SceneViews &scene, const R
 	}
 }
 
+// ---------------------------------------------------------------------------
+// Shared walk.  The 64 rays of a wave visit the union of their nodes together:
+// one wave-uniform node index `at`, so a node (and a leaf's triangle) arrives by
+// scalar loads and the box is tested out of SGPRs; no per-lane index, no gathers,
+// no scheduling.  Needs the node array to be a binary tree (KernelParams::shared_walk).
+//
+// Fast form (`exact` false: regular scene with nested boxes, regular rays): every
+// live lane tests every visited box.  A lane that missed an ancestor also misses
+// each box nested in it -- (lo-o)*inv and (hi-o)*inv are monotone in lo and hi, so
+// near can only grow and far only shrink -- hence a lane accepts exactly the
+// triangles of its own walk, in the same ascending leaf order.
+//
+// Exact form: each lane also keeps `mine`, the next node of its OWN walk, tests a
+// box only when at == mine, and uses the reference's select-based slab test: lane
+// by lane that is the reference walk itself, whatever the boxes and rays hold.
+// `at` never overtakes a live lane's `mine` because subtree ranges nest.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bool shared_box(bool exact, const float4 lo, const float4 hi, const Ray &ray, float max_distance,
+                                           float below, bool alive, uint32_t at, uint32_t skip, uint32_t &mine) {
+	if (!exact)
+		return slab_hit_regular(lo, hi, ray, below) & alive;
+	const bool here = alive && mine == at;
+	const bool box = here && slab_hit(lo, hi, ray, max_distance);
+	mine = here ? (box ? at + 1u : at + skip) : mine;
+	return box;
+}
+
 // Position of this lane among the set bits of `mask` below it.
 __device__ __forceinline__ uint32_t rank_in(unsigned long long mask) {
 	return __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
@@ -323,21 +350,17 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
 	best.s = best.t = 0.0f;
 	best.px = best.py = best.pz = 0.0f;
 	bool hit = false;
-	if (P.scene_regular && P.scene_nested && __ballot(active && !regular) == 0ull) {
-		// Shared walk: the tile's 64 rays visit the union of their nodes together.  The node
-		// index is wave-uniform, so a node (and a leaf's triangle) arrives by scalar loads and
-		// the box is tested out of SGPRs.  A lane that missed an ancestor also misses every
-		// box nested in it (the slab test is monotone in lo and hi), so each lane accepts the
-		// same triangles, in the same ascending leaf order, as on its own walk.
-		uint32_t i = 0u;
-		while (i < count) {
-			const uint32_t at = (uint32_t) __builtin_amdgcn_readfirstlane((int) i);
+	if (P.shared_walk) {
+		const bool exact = !(P.scene_regular && P.scene_nested) || __ballot(active && !regular) != 0ull;
+		uint32_t mine = 0u;
+		uint32_t at = 0u;
+		while (at < count) {
 			const float4 lo = nodes_ptr[2u * at], hi = nodes_ptr[2u * at + 1u];
 			uint32_t skip = __float_as_uint(lo.w), leaf = __float_as_uint(hi.w);
 			asm volatile("" : "+s"(skip), "+s"(leaf));  // keep them from the one 32-byte load, not re-fetched later
-			const bool box = slab_hit_regular(lo, hi, ray, P.primary_below) & active;  // (every lane has a valid ray)
+			const bool box = shared_box(exact, lo, hi, ray, 100000.0f, P.primary_below, active, at, skip, mine);
 			if (__ballot(box) == 0ull) {
-				i = at + skip;
+				at = (uint32_t) __builtin_amdgcn_readfirstlane((int) (at + skip));
 				continue;
 			}
 			if (leaf != NONE) {
@@ -345,6 +368,7 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
 				const float4 q2 = tris_ptr[4u * leaf + 2u], q3 = tris_ptr[4u * leaf + 3u];
 				if (box) {
 					const TriResult tr = tri_eval<true>(q0, q1, q2, q3, ray);
+					// closest hit: strict '>' in ascending leaf order, reference :106-112
 					if (tr.accepted) {
 						hit = true;
 						if (best.distance > tr.distance) {
@@ -357,7 +381,7 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
 					}
 				}
 			}
-			i = at + 1u;
+			at = (uint32_t) __builtin_amdgcn_readfirstlane((int) (at + 1u));
 		}
 	} else {
 		uint32_t i = active ? 0u : count;
@@ -535,7 +559,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 // MODE is AO_UNIFORM or AO_RANDOM: two instantiations, so that the RANDOM sampler's
 // code and registers stay out of the default path.
-template <int MODE>
+template <int MODE, bool SHARED>
 __global__ __launch_bounds__(64 * AO_WAVES) void ao_kernel(
     const float4 *__restrict__ nodes_ptr, const float4 *__restrict__ tris_ptr, const float4 *__restrict__ ao_table,
     const HitRec *__restrict__ hits, uint32_t *__restrict__ occluded_of, const uint32_t *__restrict__ tile_hits,
@@ -705,55 +729,45 @@ __global__ __launch_bounds__(64 * AO_WAVES) void ao_kernel(
 				}
 			};
 
-			// Regular, nested scenes: shared walks of 64 rays at a time (see primary_kernel) -- one
-			// wave-uniform node index, nodes and triangles by scalar loads; a lane leaves at its
-			// first accepted triangle.  Anything else walks the reference's way, lane by lane.
-			const bool packets = P.scene_regular && P.scene_nested && P.ao_regular;
-			uint32_t base = 0u;
-			do {
-				bool shared = false, alive = false;
-				if (packets) {
-					alive = base + lane < total;
+			if (!SHARED) {
+				walk_individually();
+			} else {
+				// shared walks (see shared_box) of 64 consecutive rays of the job at a time; a lane
+				// leaves at its first accepted triangle
+				const bool scene_fast = P.scene_regular && P.scene_nested && P.ao_regular;
+				for (uint32_t base = 0u; base < total; base += 64u) {
+					bool alive = base + lane < total;
 					if (alive)
 						setup_ray(base + lane);
-					base += 64u;
-					shared = __ballot(alive && !regular) == 0ull;
-					if (!shared) {
-						// a ray with an infinite or huge component: this packet goes the other way
-						next = total;
-						i = alive ? 0u : count;
-					}
-				}
-				if (!shared) {
-					walk_individually();
-					continue;
-				}
-				uint32_t at = 0u;
-				while (at < count) {
-					const float4 lo = nodes_ptr[2u * at], hi = nodes_ptr[2u * at + 1u];
-					uint32_t skip = __float_as_uint(lo.w), leaf = __float_as_uint(hi.w);
-					asm volatile("" : "+s"(skip), "+s"(leaf));  // keep them from the one 32-byte load
-					const bool box = slab_hit_regular(lo, hi, ray, P.ao_below) & alive;
-					if (__ballot(box) == 0ull) {
-						at = (uint32_t) __builtin_amdgcn_readfirstlane((int) (at + skip));
-						continue;
-					}
-					if (leaf != NONE) {
-						const float4 q0 = tris_ptr[4u * leaf], q1 = tris_ptr[4u * leaf + 1u];
-						const float4 q2 = tris_ptr[4u * leaf + 2u], q3 = tris_ptr[4u * leaf + 3u];
-						if (box) {
-							const TriResult tr = tri_eval<false>(q0, q1, q2, q3, ray);
-							if (tr.accepted) {
-								atomicAdd(&sh.occluded[h], 1u);
-								alive = false;
-							}
+					const bool exact = !scene_fast || __ballot(alive && !regular) != 0ull;
+					uint32_t mine = 0u;
+					uint32_t at = 0u;
+					while (at < count) {
+						const float4 lo = nodes_ptr[2u * at], hi = nodes_ptr[2u * at + 1u];
+						uint32_t skip = __float_as_uint(lo.w), leaf = __float_as_uint(hi.w);
+						asm volatile("" : "+s"(skip), "+s"(leaf));  // keep them from the one 32-byte load
+						const bool box = shared_box(exact, lo, hi, ray, P.ao_max_distance, P.ao_below, alive, at, skip, mine);
+						if (__ballot(box) == 0ull) {
+							at = (uint32_t) __builtin_amdgcn_readfirstlane((int) (at + skip));
+							continue;
 						}
-						if (__ballot(alive) == 0ull)
-							break;
+						if (leaf != NONE) {
+							const float4 q0 = tris_ptr[4u * leaf], q1 = tris_ptr[4u * leaf + 1u];
+							const float4 q2 = tris_ptr[4u * leaf + 2u], q3 = tris_ptr[4u * leaf + 3u];
+							if (box) {
+								const TriResult tr = tri_eval<false>(q0, q1, q2, q3, ray);
+								if (tr.accepted) {
+									atomicAdd(&sh.occluded[h], 1u);
+									alive = false;  // any-hit: the reference walks on but only uses the boolean (:251)
+								}
+							}
+							if (__ballot(alive) == 0ull)
+								break;
+						}
+						at = (uint32_t) __builtin_amdgcn_readfirstlane((int) (at + 1u));
 					}
-					at = (uint32_t) __builtin_amdgcn_readfirstlane((int) (at + 1u));
 				}
-			} while (packets && base < total);
+			}
 			wave_lds_sync();
 
 			// ---- this job's share of the occlusion counts ----
@@ -846,16 +860,22 @@ void launch_ao(const void *nodes, const void *tris, const void *ao_table, float 
 		ao_blocks = (uint32_t) atoi(env);
 	if ((tiles + AO_WAVES - 1) / AO_WAVES < ao_blocks)
 		ao_blocks = (tiles + AO_WAVES - 1) / AO_WAVES;
-	if (P.ao_mode == AO_UNIFORM)
-		hipLaunchKernelGGL(ao_kernel<AO_UNIFORM>, dim3(ao_blocks), dim3(64 * AO_WAVES), 0, s, (const float4 *) nodes,
-		                   (const float4 *) tris, (const float4 *) ao_table, (const HitRec *) hits,
-		                   (uint32_t *) occluded_of, (const uint32_t *) tile_hits, (const uint32_t *) order,
-		                   (FrameCounters *) counters, P);
-	else
-		hipLaunchKernelGGL(ao_kernel<AO_RANDOM>, dim3(ao_blocks), dim3(64 * AO_WAVES), 0, s, (const float4 *) nodes,
-		                   (const float4 *) tris, (const float4 *) ao_table, (const HitRec *) hits,
-		                   (uint32_t *) occluded_of, (const uint32_t *) tile_hits, (const uint32_t *) order,
-		                   (FrameCounters *) counters, P);
+	auto launch = [&](auto kernel) {
+		hipLaunchKernelGGL(kernel, dim3(ao_blocks), dim3(64 * AO_WAVES), 0, s, (const float4 *) nodes, (const float4 *) tris,
+		                   (const float4 *) ao_table, (const HitRec *) hits, (uint32_t *) occluded_of,
+		                   (const uint32_t *) tile_hits, (const uint32_t *) order, (FrameCounters *) counters, P);
+	};
+	if (P.ao_mode == AO_UNIFORM) {
+		if (P.shared_walk)
+			launch(ao_kernel<AO_UNIFORM, true>);
+		else
+			launch(ao_kernel<AO_UNIFORM, false>);
+	} else {
+		if (P.shared_walk)
+			launch(ao_kernel<AO_RANDOM, true>);
+		else
+			launch(ao_kernel<AO_RANDOM, false>);
+	}
 	hipLaunchKernelGGL(resolve_kernel, dim3((tiles * 64u + 255u) / 256u), dim3(256), 0, s, (const HitRec *) hits,
 	                   (const uint32_t *) occluded_of, (const uint32_t *) tile_hits, (FrameCounters *) counters, image,
 	                   tiles, P.ao_divisor);

@@ -58,16 +58,17 @@ PackedScene pack_scene(const std::vector<uint32_t> &faces, const std::vector<uin
 	if (leaf != tri_count)
 		throw std::invalid_argument("upload: leaf count differs from triangle count");
 	// children of inner node i are i+1 and i+1+skip(i+1)
+	out.binary_tree = true;
 	out.nested = true;
-	for (size_t i = 0; i < count && out.nested; ++i) {
+	for (size_t i = 0; i < count; ++i) {
 		const NodeRec &p = out.nodes[i];
 		if (p.skip == 1)
 			continue;
 		const size_t first = i + 1, second = first + out.nodes[first].skip;
-		if (second >= i + p.skip) {  // not a binary split: the walk itself is still valid, the containment claim is not checked
-			out.nested = false;
-			break;
-		}
+		// The reference finds a leaf's triangle by adding (subtree size + 1) / 2 for every subtree it
+		// skips (src/intersect_kernel.cl:191): only a full binary tree gives that a meaning.
+		if (second >= i + p.skip || second + out.nodes[second].skip != i + p.skip)
+			throw std::invalid_argument("upload: the node array is not a binary tree");
 		for (size_t c : { first, second })
 			for (unsigned k = 0; k < 3; ++k)
 				if (!(p.lo[k] <= out.nodes[c].lo[k]) || !(out.nodes[c].hi[k] <= p.hi[k]))
@@ -165,7 +166,7 @@ uint32_t local_tile_rows_for(uint32_t total_height, const Partition &part) {
 }
 
 KernelParams make_kernel_params(const RayTracer &rt, uint32_t node_count, uint32_t tri_count, uint32_t ao_dirs,
-                                const Partition &part, bool scene_regular, bool scene_nested) {
+                                const Partition &part, const PackedScene *scene) {
 	KernelParams p{};
 	p.width = rt.totalWidth;
 	p.height = rt.totalHeight;
@@ -183,8 +184,9 @@ KernelParams make_kernel_params(const RayTracer &rt, uint32_t node_count, uint32
 	p.ao_max_distance = kernel_float(rt.options.aoMaxDistance);
 	p.ao_dirs = ao_dirs;
 	p.ao_divisor = p.ao_mode == AO_RANDOM ? ao_dirs - 1 : ao_dirs;
-	p.scene_regular = scene_regular ? 1 : 0;
-	p.scene_nested = (scene_nested && !std::getenv("OCRT_NO_SHARED_WALK")) ? 1 : 0;  // debug knob
+	p.scene_regular = (scene && scene->regular) ? 1 : 0;
+	p.scene_nested = (scene && scene->nested) ? 1 : 0;
+	p.shared_walk = (scene && scene->binary_tree && !std::getenv("OCRT_NO_SHARED_WALK")) ? 1 : 0;  // (debug knob)
 	p.debug_no_sort = std::getenv("OCRT_NO_SORT") ? 1 : 0;
 	const char *refill_min = std::getenv("OCRT_REFILL_MIN"), *leaf_min = std::getenv("OCRT_LEAF_MIN");
 	p.refill_min = refill_min ? (uint32_t) std::atoi(refill_min) : 16u;

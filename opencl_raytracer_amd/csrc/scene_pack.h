@@ -15,8 +15,9 @@ struct PackedScene {
 	std::vector<TriRec> tris;
 	std::vector<ShadeRec> shade;
 	bool regular = false;  // all boxes finite, |coord| <= 1e37, lo <= hi (see kernels.hip slab_hit_regular)
-	bool nested = false;   // each inner node's box contains both children's boxes (true for any tree built by
-	                       // uniting child boxes; arbitrary uploaded arrays need not be)
+	bool binary_tree = false;  // every inner node's index range is exactly its two children's ranges
+	bool nested = false;       // ... and its box contains both children's boxes (true for any tree built by
+	                           // uniting child boxes; arbitrary uploaded arrays need not be)
 };
 
 // Validates the arrays against each other (every index and skip count is
@@ -44,6 +45,6 @@ uint32_t band_tile_rows_for(unsigned int grid);
 uint32_t local_tile_rows_for(uint32_t total_height, const Partition &part);
 
 KernelParams make_kernel_params(const RayTracer &rt, uint32_t node_count, uint32_t tri_count, uint32_t ao_dirs,
-                                const Partition &part, bool scene_regular, bool scene_nested);
+                                const Partition &part, const PackedScene *scene);
 
 }  // namespace ocrt

@@ -134,6 +134,15 @@ def test_error_paths(rt, scene_for):
     with pytest.raises(rt.RtError) as e:
         host.upload(arrays.faces, bad_nodes, arrays.aabbs, arrays.vertices, arrays.normals)
     assert e.value.code == -1
+    # an inner node with three children: the reference's triangle counter (intersect_kernel.cl:191) has no
+    # meaning on such an array, so upload refuses it
+    inner = int(np.flatnonzero(arrays.nodes > 8)[5])
+    three = arrays.nodes.copy()
+    three[[a for a in range(inner) if a + three[a] > inner]] -= 1
+    with pytest.raises(rt.RtError) as e:
+        host.upload(arrays.faces, np.delete(three, inner), np.delete(arrays.aabbs, [2 * inner, 2 * inner + 1], axis=0),
+                    arrays.vertices, arrays.normals)
+    assert e.value.code == -1 and "binary tree" in str(e.value)
     bad_faces = arrays.faces.copy()
     bad_faces[0] = 10_000_000
     with pytest.raises(rt.RtError):
@@ -213,12 +222,14 @@ def test_random_ao_statistical_parity(rt, oracle, scene_for, mesh, samples):
     host.close()
 
 
-@pytest.mark.parametrize("damage", ["inverted_box", "nan_leaf_box", "huge_box", "inf_box", "nan_vertex"])
+@pytest.mark.parametrize("damage", ["inverted_box", "nan_leaf_box", "huge_box", "inf_box", "nan_vertex",
+                                    "child_outside_parent"])
 def test_irregular_scene_arrays_match_oracle(rt, oracle, scene_for, damage):
     """Scene arrays a BVH builder would never emit (inverted / NaN / infinite /
-    overflowing boxes, a NaN vertex) arrive through the upload API: the kernels
-    must then fall back to the reference's own slab test and still agree with
-    the oracle bit for bit."""
+    overflowing boxes, a NaN vertex, a parent box that does not contain its
+    child) arrive through the upload API: the kernels must then fall back to
+    the reference's own slab test and the exact form of the shared walk and
+    still agree with the oracle bit for bit."""
     import orc
 
     _, arrays = scene_for("blob", "longest")
@@ -237,6 +248,9 @@ def test_irregular_scene_arrays_match_oracle(rt, oracle, scene_for, damage):
         aabbs[1, 0] = np.inf
     elif damage == "nan_vertex":
         verts[int(arrays.faces[3 * 17]), 1] = np.nan
+    elif damage == "child_outside_parent":
+        # finite, lo <= hi, but the node's box is now a sliver its children stick out of
+        aabbs[2 * inner + 1, 0] = aabbs[2 * inner, 0] + 1.0e-3
     damaged = orc.SceneArrays(arrays.faces, nodes, aabbs, verts, arrays.normals)
     opt = rt.Options.defaults(width=96, height=64, n_super_samples=1, ao_num_samples=2, ao_max_distance=0.5)
     host = rt.Host(opt, 0)
@@ -248,3 +262,32 @@ def test_irregular_scene_arrays_match_oracle(rt, oracle, scene_for, damage):
     assert same.all(), int((~same).sum())
     assert host.stats()["primary_hits"] == counters["primary_hits"]
     host.close()
+
+
+def test_zero_direction_components_take_the_exact_path(rt, oracle, scene_for):
+    """Odd image sizes put a sub-pixel exactly on the optical axis: dx or dy is 0, its
+    reciprocal infinite, and the packets holding such rays must use the reference's
+    select-based slab test."""
+    import orc
+
+    scene, arrays = scene_for("blob", "longest")
+    opt = rt.Options.defaults(width=97, height=65, n_super_samples=1, ao_num_samples=3)
+    host = render_hip(rt, scene, opt)
+    ref_img, counters, _ = oracle.render(orc.params_from_options(opt), arrays)
+    assert np.array_equal(bits(host.download()), bits(ref_img))
+    assert host.stats()["ao_occluded"] == counters["ao_occluded"]
+    host.close()
+
+
+@pytest.mark.parametrize("name", ["blob_128x96_s4_a3", "ties_64_s4_a3", "bunny_256_s1_a3"])
+def test_lane_by_lane_walk_still_matches(rt, golden, scene_for, name, monkeypatch):
+    """OCRT_NO_SHARED_WALK=1 selects the kernels in which every lane walks the
+    tree on its own (the first generation, kept for A/B runs)."""
+    monkeypatch.setenv("OCRT_NO_SHARED_WALK", "1")
+    case = golden["renders"][name]
+    scene, _ = scene_for(case["mesh"], case["bvh"])
+    host = render_hip(rt, scene, options_for(rt, case))
+    assert host.stats()["ao_occluded"] == case["counters"]["ao_occluded"]
+    assert hashlib.sha256(host.download().tobytes()).hexdigest() == case["float_sha256"]
+    host.close()
+
