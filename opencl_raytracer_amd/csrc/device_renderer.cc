@@ -209,6 +209,9 @@ void DeviceRenderer::enqueueRender() {
 	hipStream_t s = (hipStream_t) stream;
 	OCRT_HIP(hipEventRecord((hipEvent_t) ev.start, s));
 	OCRT_HIP(hipMemsetAsync(d_counters, 0, sizeof(FrameCounters), s));
+#ifdef OCRT_STAMPS
+	OCRT_HIP(hipMemsetAsync((char *) d_counters + offsetof(FrameCounters, stamp) + 7 * sizeof(unsigned long long), 0xFF, sizeof(unsigned long long), s));
+#endif
 	launch_primary(d_nodes, d_tris, d_shade, (float *) d_image, d_hits, d_occluded, d_tile_hits, d_counters, kp, stream);
 	OCRT_HIP(hipGetLastError());
 	OCRT_HIP(hipEventRecord((hipEvent_t) ev.ao_start, s));
@@ -287,6 +290,12 @@ RenderStats DeviceRenderer::stats() {
 	OCRT_HIP(hipMemcpy(&c, d_counters, sizeof c, hipMemcpyDeviceToHost));
 	out.primary_hits = c.primary_hits;
 	out.ao_occluded = c.occluded;
+#ifdef OCRT_STAMPS
+	std::fprintf(stderr, "AO wave-time: claim %.3f ms, frames %.3f ms, walks %.3f ms, flush %.3f ms over %llu jobs / %llu packets\n",
+	             c.stamp[0] * 1e-5, c.stamp[1] * 1e-5, c.stamp[2] * 1e-5, c.stamp[3] * 1e-5, c.stamp[4], c.stamp[5]);
+	std::fprintf(stderr, "   lifetimes sum %.3f ms, kernel span %.3f ms, last wave started %.3f ms after the first, %llu waves worked\n",
+	             c.stamp[6] * 1e-5, (c.stamp[8] - c.stamp[7]) * 1e-5, (c.stamp[9] - c.stamp[7]) * 1e-5, c.stamp[10]);
+#endif
 	// Primary rays = sub-pixels of this rank's bands that lie inside the image.
 	const uint32_t tile_rows = (kp.height + TILE_H - 1) / TILE_H;
 	unsigned long long rows = 0;

@@ -63,6 +63,9 @@ struct FrameCounters {
 	uint32_t primary_hits;        // hit sub-pixels
 	uint32_t pad;
 	unsigned long long occluded;  // occluded AO rays
+#ifdef OCRT_STAMPS
+	unsigned long long stamp[12];  // debug build: wave-time (10 ns ticks) per phase of the AO pass, jobs, packets
+#endif
 };
 
 enum AoMode : int32_t { AO_NONE = 0, AO_UNIFORM = 1, AO_RANDOM = 2 };
@@ -99,8 +102,9 @@ struct KernelParams {
 	int32_t debug_no_sort; // debug knob OCRT_NO_SORT: claim tiles in arbitrary order instead of heaviest first
 	uint32_t refill_min;    // wave scheduler: refill once this many lanes are idle (debug knob OCRT_REFILL_MIN)
 	uint32_t leaf_min;      // ... test triangles once this many leaves are pending (OCRT_LEAF_MIN)
-	uint32_t jobs_per_tile; // a tile's AO rays are split by direction range into this many jobs ...
-	uint32_t dirs_per_job;  // ... of this many table directions each (about 8 rays per lane)
+	uint32_t ao_claim_max;  // most (tile, direction) units one AO claim takes
+	uint32_t ao_guide;      // an AO claim takes 1/ao_guide of the (tile, direction) units left in its queue; the host
+	                        // sets the factor (2), launch_ao multiplies it by the waves per XCD group
 	uint32_t tiles_x;      // tiles per image row
 	uint32_t local_tile_rows;  // tile rows this rank owns
 	Partition part;

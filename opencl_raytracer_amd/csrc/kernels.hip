@@ -108,6 +108,9 @@ __device__ __forceinline__ bool slab_hit(const float4 lo, const float4 hi, const
 // ---------------------------------------------------------------------------
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 
+// The lanes' predicate as a 64-bit mask, straight from the compare (HIP's __ballot goes through an int).
+__device__ __forceinline__ unsigned long long wave_ballot(bool predicate) { return __builtin_amdgcn_ballot_w64(predicate); }
+
 struct Pending {
 	uint32_t first, second;  // leaf indices in the order they were met; NONE = free
 };
@@ -205,25 +208,34 @@ __device__ __forceinline__ TriResult tri_eval(const float4 q0, const float4 q1, 
 	const float vx = q1.z, vy = q1.w, vz = q2.x;
 	const float nx = q2.y, ny = q2.z, nz = q2.w;
 	const float uu = q3.x, uv = q3.y, vv = q3.z, D = q3.w;
+	TriResult out;
+	out.accepted = false;
+	out.s = out.t = 0.0f;
+	out.px = out.py = out.pz = 0.0f;
+	out.distance = 0.0f;
+	// reject: |b| < 1e-6, r < 0, s < -1e-5, s > 1.00001, t < -1e-5, s + t > 1.00001 -- in the
+	// reference's order; the wave stops as soon as none of its lanes is left in the running
 	const float a = -dot3(nx, ny, nz, r.ox - tax, r.oy - tay, r.oz - taz);
 	const float b = dot3(nx, ny, nz, r.dx, r.dy, r.dz);
 	const float rr = a / b;
+	bool reject = (fabsf(b) < 0.000001f) | (rr < 0.0f);
+	if (wave_ballot(!reject) == 0ull)
+		return out;
 	const float ipx = r.ox + rr * r.dx, ipy = r.oy + rr * r.dy, ipz = r.oz + rr * r.dz;
 	const float wx = ipx - tax, wy = ipy - tay, wz = ipz - taz;
 	const float wu = dot3(ux, uy, uz, wx, wy, wz);
 	const float wv = dot3(wx, wy, wz, vx, vy, vz);
 	const float slack_hi = __uint_as_float(0x3F800053u);
 	const float s = (uv * wv - vv * wu) / D;
+	reject |= (s < -0.00001f) | (s > slack_hi);
+	if (wave_ballot(!reject) == 0ull)
+		return out;
 	const float t = (uv * wu - uu * wv) / D;
-	// reject: |b| < 1e-6, r < 0, s < -1e-5, s > 1.00001, t < -1e-5, s + t > 1.00001
-	const bool reject = (fabsf(b) < 0.000001f) | (rr < 0.0f) | (s < -0.00001f) | (s > slack_hi) | (t < -0.00001f) |
-	                    ((s + t) > slack_hi);
-	TriResult out;
+	reject |= (t < -0.00001f) | ((s + t) > slack_hi);
 	out.accepted = !reject;
 	out.s = s;
 	out.t = t;
 	out.px = ipx; out.py = ipy; out.pz = ipz;
-	out.distance = 0.0f;
 	if (CLOSEST) {
 		const float ex = ipx - r.ox, ey = ipy - r.oy, ez = ipz - r.oz;
 		out.distance = sqrtf(dot3(ex, ey, ez, ex, ey, ez));
@@ -256,7 +268,7 @@ __device__ __forceinline__ SceneViews make_views(const float4 *nodes_ptr, const 
 __device__ __forceinline__ void advance_walkers(const SceneViews &scene, const Ray &r, bool regular, float max_distance,
                                                 float below, uint32_t count, uint32_t &i, Pending &pending) {
 	const bool walking_lane = can_walk(pending, i, count);
-	const bool all_regular = __ballot(walking_lane && !regular) == 0ull;
+	const bool all_regular = wave_ballot(walking_lane && !regular) == 0ull;
 	if (walking_lane) {
 		if (all_regular)
 			node_step<true>(scene.nodes, r, max_distance, below, i, pending);
@@ -290,6 +302,48 @@ __device__ __forceinline__ bool shared_box(bool exact, const float4 lo, const fl
 	const bool box = here && slab_hit(lo, hi, ray, max_distance);
 	mine = here ? (box ? at + 1u : at + skip) : mine;
 	return box;
+}
+
+// Any-hit shared walk of one packet (AO): a lane leaves at its first accepted
+// triangle and bumps *occluded (reference :251 only uses the boolean).
+template <bool EXACT>
+__device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ nodes_ptr, const float4 *__restrict__ tris_ptr,
+                                                    uint32_t count, const Ray &ray, float max_distance, float below,
+                                                    bool alive, uint32_t lane, unsigned int *occluded) {
+	uint32_t mine = 0u;
+	uint32_t at = 0u;
+	below = __builtin_canonicalizef(below);  // (once, instead of in front of every fminf)
+	// the live lanes as a scalar mask: the node steps then need no per-lane bookkeeping at all
+	unsigned long long alive_mask = wave_ballot(alive);
+	while (at < count) {
+		const float4 lo = nodes_ptr[2u * at], hi = nodes_ptr[2u * at + 1u];
+		uint32_t skip = __float_as_uint(lo.w), leaf = __float_as_uint(hi.w);
+		asm volatile("" : "+s"(skip), "+s"(leaf));  // keep them from the one 32-byte load, not re-fetched later
+		unsigned long long hit_mask;
+		if (EXACT) {
+			const bool here = alive && mine == at;
+			const bool box = here && slab_hit(lo, hi, ray, max_distance);
+			mine = here ? (box ? at + 1u : at + skip) : mine;
+			hit_mask = wave_ballot(box);
+		} else {
+			hit_mask = wave_ballot(slab_hit_regular(lo, hi, ray, below)) & alive_mask;
+		}
+		if (hit_mask != 0ull && leaf != NONE) {
+			const float4 q0 = tris_ptr[4u * leaf], q1 = tris_ptr[4u * leaf + 1u];
+			const float4 q2 = tris_ptr[4u * leaf + 2u], q3 = tris_ptr[4u * leaf + 3u];
+			if ((hit_mask >> lane) & 1ull) {
+				const TriResult tr = tri_eval<false>(q0, q1, q2, q3, ray);
+				if (tr.accepted) {
+					atomicAdd(occluded, 1u);
+					alive = false;
+				}
+			}
+			alive_mask = wave_ballot(alive);
+			if (alive_mask == 0ull)
+				break;
+		}
+		at = (uint32_t) __builtin_amdgcn_readfirstlane((int) (at + (hit_mask != 0ull ? 1u : skip)));
+	}
 }
 
 // Position of this lane among the set bits of `mask` below it.
@@ -351,7 +405,7 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
 	best.px = best.py = best.pz = 0.0f;
 	bool hit = false;
 	if (P.shared_walk) {
-		const bool exact = !(P.scene_regular && P.scene_nested) || __ballot(active && !regular) != 0ull;
+		const bool exact = !(P.scene_regular && P.scene_nested) || wave_ballot(active && !regular) != 0ull;
 		uint32_t mine = 0u;
 		uint32_t at = 0u;
 		while (at < count) {
@@ -359,7 +413,7 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
 			uint32_t skip = __float_as_uint(lo.w), leaf = __float_as_uint(hi.w);
 			asm volatile("" : "+s"(skip), "+s"(leaf));  // keep them from the one 32-byte load, not re-fetched later
 			const bool box = shared_box(exact, lo, hi, ray, 100000.0f, P.primary_below, active, at, skip, mine);
-			if (__ballot(box) == 0ull) {
+			if (wave_ballot(box) == 0ull) {
 				at = (uint32_t) __builtin_amdgcn_readfirstlane((int) (at + skip));
 				continue;
 			}
@@ -387,8 +441,8 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
 		uint32_t i = active ? 0u : count;
 		Pending pending = { NONE, NONE };
 		for (;;) {
-			const unsigned long long walking = __ballot(can_walk(pending, i, count));
-			const unsigned long long leaves = __ballot(pending.first != NONE);
+			const unsigned long long walking = wave_ballot(can_walk(pending, i, count));
+			const unsigned long long leaves = wave_ballot(pending.first != NONE);
 			if (leaves != 0ull && ((uint32_t) __popcll(leaves) >= P.leaf_min || walking == 0ull)) {
 				if (pending.first != NONE) {
 					const TriResult tr = tri_test<true>(scene.tris, pending.first, ray);
@@ -411,7 +465,7 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
 			if (walking == 0ull)
 				break;
 			advance_walkers(scene, ray, regular, 100000.0f, P.primary_below, count, i, pending);
-			if ((uint32_t) __popcll(__ballot(pending.first != NONE)) < P.leaf_min)
+			if ((uint32_t) __popcll(wave_ballot(pending.first != NONE)) < P.leaf_min)
 				advance_walkers(scene, ray, regular, 100000.0f, P.primary_below, count, i, pending);
 		}
 	}
@@ -437,7 +491,7 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
 		image[(size_t) y * P.width + x] = value;  // final already
 
 	// the tile's hits go into the tile's own 64 slots of the hit list, compacted
-	const unsigned long long hit_mask = __ballot(hit);
+	const unsigned long long hit_mask = wave_ballot(hit);
 	const uint32_t hit_count = (uint32_t) __popcll(hit_mask);
 	if (lane == 0u) {
 		tile_hits[tile] = want_ao ? hit_count : 0u;
@@ -506,8 +560,9 @@ __global__ __launch_bounds__(1024) void order_kernel(const uint32_t *__restrict_
 		uint32_t tile;
 		if (tile_of(e, tile)) {
 			const uint32_t c = P.debug_no_sort ? (tile_hits[tile] ? 1u : 0u) : tile_hits[tile];
+			// entry = tile (26 bits: at most 2^32 sub-pixels per frame) | hit count - 1 (6 bits)
 			if (c)
-				order[segment + atomicAdd(&bucket[c], 1u)] = tile;
+				order[segment + atomicAdd(&bucket[c], 1u)] = tile | ((tile_hits[tile] - 1u) << 26);
 		}
 	}
 }
@@ -559,11 +614,19 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 // MODE is AO_UNIFORM or AO_RANDOM: two instantiations, so that the RANDOM sampler's
 // code and registers stay out of the default path.
+#ifdef OCRT_STAMPS
+#define OCRT_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memrealtime()
+#define OCRT_STAMP_ADD(slot, value) stamp_acc[slot] += (unsigned long long) (value)
+#else
+#define OCRT_STAMP(var)
+#define OCRT_STAMP_ADD(slot, value)
+#endif
+
 template <int MODE, bool SHARED>
-__global__ __launch_bounds__(64 * AO_WAVES) void ao_kernel(
+__global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void ao_kernel(
     const float4 *__restrict__ nodes_ptr, const float4 *__restrict__ tris_ptr, const float4 *__restrict__ ao_table,
-    const HitRec *__restrict__ hits, uint32_t *__restrict__ occluded_of, const uint32_t *__restrict__ tile_hits,
-    const uint32_t *__restrict__ order, FrameCounters *__restrict__ counters, KernelParams P) {
+    const HitRec *__restrict__ hits, uint32_t *__restrict__ occluded_of, const uint32_t *__restrict__ order,
+    FrameCounters *__restrict__ counters, KernelParams P) {
 	__shared__ TileShared shared_tiles[AO_WAVES];
 	const uint32_t lane = threadIdx.x & 63u;
 	TileShared &sh = shared_tiles[threadIdx.x >> 6];
@@ -571,6 +634,10 @@ __global__ __launch_bounds__(64 * AO_WAVES) void ao_kernel(
 	const uint32_t count = P.node_count;
 	const uint32_t strips = (P.tiles_x + 1u) >> 1;
 
+#ifdef OCRT_STAMPS
+	unsigned long long stamp_acc[6] = { 0, 0, 0, 0, 0, 0 };
+	const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+#endif
 	// Workgroups b and b+8 share an XCD: start with that group's queue, then help the others.
 	const uint32_t home = blockIdx.x & (XCD_GROUPS - 1u);
 	for (uint32_t turn = 0; turn < XCD_GROUPS; ++turn) {
@@ -578,27 +645,40 @@ __global__ __launch_bounds__(64 * AO_WAVES) void ao_kernel(
 		uint32_t segment = 0u;
 		for (uint32_t g = 0; g < group; ++g)
 			segment += ((strips + XCD_GROUPS - 1u - g) >> 3) * 2u * P.local_tile_rows;
-		const uint32_t work_jobs = counters->queue[group].work_tiles * P.jobs_per_tile;
+		// the group's work in units of (tile, table direction), tile-major
+		const uint32_t units = counters->queue[group].work_tiles * P.ao_dirs;
 		for (;;) {
 			// look before claiming: most visits to a foreign group find its queue drained,
 			// and a plain load does not queue up behind the other waves' atomics
-			if (__hip_atomic_load(&counters->queue[group].head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= work_jobs)
+			OCRT_STAMP(t_claim);
+			const uint32_t seen = __hip_atomic_load(&counters->queue[group].head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (seen >= units)
 				break;
+			// Guided self-scheduling: a claim is 1/ao_guide of what is left (ao_guide = twice the
+			// waves of a group) -- whole tiles while there is plenty, so the per-tile set-up is
+			// paid once, single directions at the end, so the frame does not wait for a long last job.
+			uint32_t want = (units - seen) / P.ao_guide;
+			want = want < 1u ? 1u : want > P.ao_claim_max ? P.ao_claim_max : want;
 			uint32_t claimed = 0u;
 			if (lane == 0u)
-				claimed = atomicAdd(&counters->queue[group].head, 1u);
-			claimed = (uint32_t) __shfl((int) claimed, 0);
-			if (claimed >= work_jobs)
+				claimed = atomicAdd(&counters->queue[group].head, want);
+			claimed = (uint32_t) __builtin_amdgcn_readfirstlane((int) claimed);  // (lane 0 is always active here)
+			if (claimed >= units)
 				break;
-			// job = (tile, direction range); the jobs of a tile are adjacent in the queue, so
-			// the waves that take them share the tile's hit records in L2
-			const uint32_t tile_index = claimed / P.jobs_per_tile;
-			const uint32_t dir0 = (claimed - tile_index * P.jobs_per_tile) * P.dirs_per_job;
-			if (dir0 >= P.ao_dirs)
-				continue;
-			const uint32_t n_dirs = P.ao_dirs - dir0 < P.dirs_per_job ? P.ao_dirs - dir0 : P.dirs_per_job;
-			const uint32_t tile = order[segment + tile_index];
-			const uint32_t hit_count = tile_hits[tile];
+			const uint32_t claim_end = claimed + want < units ? claimed + want : units;
+			OCRT_STAMP(t_claimed);
+			OCRT_STAMP_ADD(0, t_claimed - t_claim);
+			for (uint32_t unit = claimed; unit < claim_end;) {
+			OCRT_STAMP(t_job);
+			// job = (tile, direction range); a claim that runs over a tile's last direction goes on in
+			// the next tile.  Neighbouring claims work on the same tile: its hit records are shared in L2.
+			const uint32_t tile_index = unit / P.ao_dirs;
+			const uint32_t dir0 = unit - tile_index * P.ao_dirs;
+			const uint32_t n_dirs = P.ao_dirs - dir0 < claim_end - unit ? P.ao_dirs - dir0 : claim_end - unit;
+			unit += n_dirs;
+			const uint32_t entry = order[segment + tile_index];
+			const uint32_t tile = entry & 0x03FFFFFFu;
+			const uint32_t hit_count = (entry >> 26) + 1u;
 
 			// ---- the tile's tangent frames -> this wave's LDS slice (reference :215-236) ----
 			if (lane < hit_count) {
@@ -633,6 +713,8 @@ __global__ __launch_bounds__(64 * AO_WAVES) void ao_kernel(
 			}
 			sh.occluded[lane] = 0u;
 			wave_lds_sync();
+			OCRT_STAMP(t_frames);
+			OCRT_STAMP_ADD(1, t_frames - t_job);
 
 			// ---- the tile's hit_count * ao_dirs any-hit rays (reference :237-255).  Queue
 			// order is direction-major, so neighbouring lanes cast the same table direction
@@ -646,15 +728,23 @@ __global__ __launch_bounds__(64 * AO_WAVES) void ao_kernel(
 			bool regular = true;
 
 			// ray number `item` of the job -> this lane
-			auto setup_ray = [&](uint32_t item) {
-				const uint32_t k = item / hit_count;
-				h = item - k * hit_count;
-				float xs, ys, zs;
+			// `whole` (wave-uniform): the tile is full and the 64 rays are one table direction, `shared_dir`
+			auto setup_ray = [&](uint32_t item, bool whole, const float4 shared_dir) {
+				uint32_t k;
+				float xs = shared_dir.x, ys = shared_dir.y, zs = shared_dir.z;
 				bool along_normal = false;
-				if (MODE == AO_UNIFORM) {
-					const float4 dir = ao_table[dir0 + k];
-					xs = dir.x; ys = dir.y; zs = dir.z;
+				if (whole) {
+					k = item >> 6;
+					h = item & 63u;
 				} else {
+					k = item / hit_count;
+					h = item - k * hit_count;
+					if (MODE == AO_UNIFORM) {
+						const float4 dir = ao_table[dir0 + k];
+						xs = dir.x; ys = dir.y; zs = dir.z;
+					}
+				}
+				if (MODE != AO_UNIFORM) {
 					// RANDOM (reference :153-183, :257-276): ray 0 goes along the normal, ray
 					// j >= 1 uses draws 2j-2 and 2j-1 of the sub-pixel's generator.  Device libm
 					// rounds differently from the host's: this mode is outside the bit-exact contract.
@@ -694,14 +784,14 @@ __global__ __launch_bounds__(64 * AO_WAVES) void ao_kernel(
 			auto walk_individually = [&]() {
 				for (;;) {
 					const bool idle_lane = pending.first == NONE && !(i < count);
-					const unsigned long long walking = __ballot(can_walk(pending, i, count));
-					const uint32_t n_leaves = (uint32_t) __popcll(__ballot(pending.first != NONE));
-					const unsigned long long idle_mask = __ballot(idle_lane);
+					const unsigned long long walking = wave_ballot(can_walk(pending, i, count));
+					const uint32_t n_leaves = (uint32_t) __popcll(wave_ballot(pending.first != NONE));
+					const unsigned long long idle_mask = wave_ballot(idle_lane);
 					const uint32_t idle = (uint32_t) __popcll(idle_mask);
 					if (next < total && idle >= P.refill_min) {
 						const uint32_t item = next + rank_in(idle_mask);
 						if (idle_lane && item < total) {
-							setup_ray(item);
+							setup_ray(item, false, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
 							i = 0u;
 						}
 						next += idle;
@@ -724,7 +814,7 @@ __global__ __launch_bounds__(64 * AO_WAVES) void ao_kernel(
 						break;
 					advance_walkers(scene, ray, regular, P.ao_max_distance, P.ao_below, count, i, pending);
 					// a second node straight away while few leaves are pending: halves the scheduling overhead
-					if ((uint32_t) __popcll(__ballot(pending.first != NONE)) < P.leaf_min)
+					if ((uint32_t) __popcll(wave_ballot(pending.first != NONE)) < P.leaf_min)
 						advance_walkers(scene, ray, regular, P.ao_max_distance, P.ao_below, count, i, pending);
 				}
 			};
@@ -737,38 +827,27 @@ __global__ __launch_bounds__(64 * AO_WAVES) void ao_kernel(
 				const bool scene_fast = P.scene_regular && P.scene_nested && P.ao_regular;
 				for (uint32_t base = 0u; base < total; base += 64u) {
 					bool alive = base + lane < total;
+					// a full tile's packet is one table direction: the entry comes by a scalar load
+					const bool whole = hit_count == 64u;
+					float4 shared_dir = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+					if (whole && MODE == AO_UNIFORM)
+						shared_dir = ao_table[dir0 + (base >> 6)];
 					if (alive)
-						setup_ray(base + lane);
-					const bool exact = !scene_fast || __ballot(alive && !regular) != 0ull;
-					uint32_t mine = 0u;
-					uint32_t at = 0u;
-					while (at < count) {
-						const float4 lo = nodes_ptr[2u * at], hi = nodes_ptr[2u * at + 1u];
-						uint32_t skip = __float_as_uint(lo.w), leaf = __float_as_uint(hi.w);
-						asm volatile("" : "+s"(skip), "+s"(leaf));  // keep them from the one 32-byte load
-						const bool box = shared_box(exact, lo, hi, ray, P.ao_max_distance, P.ao_below, alive, at, skip, mine);
-						if (__ballot(box) == 0ull) {
-							at = (uint32_t) __builtin_amdgcn_readfirstlane((int) (at + skip));
-							continue;
-						}
-						if (leaf != NONE) {
-							const float4 q0 = tris_ptr[4u * leaf], q1 = tris_ptr[4u * leaf + 1u];
-							const float4 q2 = tris_ptr[4u * leaf + 2u], q3 = tris_ptr[4u * leaf + 3u];
-							if (box) {
-								const TriResult tr = tri_eval<false>(q0, q1, q2, q3, ray);
-								if (tr.accepted) {
-									atomicAdd(&sh.occluded[h], 1u);
-									alive = false;  // any-hit: the reference walks on but only uses the boolean (:251)
-								}
-							}
-							if (__ballot(alive) == 0ull)
-								break;
-						}
-						at = (uint32_t) __builtin_amdgcn_readfirstlane((int) (at + 1u));
-					}
+						setup_ray(base + lane, whole, shared_dir);
+					const bool exact = !scene_fast || wave_ballot(alive && !regular) != 0ull;
+					if (exact)
+						shared_walk_any_hit<true>(nodes_ptr, tris_ptr, count, ray, P.ao_max_distance, P.ao_below, alive,
+						                          lane, &sh.occluded[h]);
+					else
+						shared_walk_any_hit<false>(nodes_ptr, tris_ptr, count, ray, P.ao_max_distance, P.ao_below, alive,
+						                           lane, &sh.occluded[h]);
 				}
 			}
 			wave_lds_sync();
+			OCRT_STAMP(t_walked);
+			OCRT_STAMP_ADD(2, t_walked - t_frames);
+			OCRT_STAMP_ADD(4, 1);
+			OCRT_STAMP_ADD(5, (total + 63u) / 64u);
 
 			// ---- this job's share of the occlusion counts ----
 			if (lane < hit_count) {
@@ -777,8 +856,25 @@ __global__ __launch_bounds__(64 * AO_WAVES) void ao_kernel(
 					atomicAdd(&occluded_of[(size_t) tile * 64u + lane], occluded);
 			}
 			wave_lds_sync();
+			OCRT_STAMP(t_flushed);
+			OCRT_STAMP_ADD(3, t_flushed - t_walked);
+			}
 		}
 	}
+#ifdef OCRT_STAMPS
+	if (lane == 0u)
+		for (int k = 0; k < 6; ++k)
+			atomicAdd(&counters->stamp[k], stamp_acc[k]);
+	if (lane == 0u) {
+		const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
+		atomicAdd(&counters->stamp[6], t_end - t_begin);               // sum of wave lifetimes
+		atomicMin(&counters->stamp[7], t_begin);                        // first start
+		atomicMax(&counters->stamp[8], t_end);                          // last end
+		atomicMax(&counters->stamp[9], t_begin);                        // last start
+		if (stamp_acc[4])
+			atomicAdd(&counters->stamp[10], 1ull);                      // waves that got any job
+	}
+#endif
 }
 
 // Pass 3: value *= 1 - hits / n (reference :256 and :305-307), one thread per hit-list slot.
@@ -846,24 +942,28 @@ void launch_primary(const void *nodes, const void *tris, const void *shade, floa
 }
 
 void launch_ao(const void *nodes, const void *tris, const void *ao_table, float *image, void *hits,
-               void *occluded_of, void *tile_hits, void *order, void *counters, const KernelParams &P,
+               void *occluded_of, void *tile_hits, void *order, void *counters, const KernelParams &params,
                uint32_t compute_units, void *stream) {
-	if (P.tiles_x * P.local_tile_rows == 0 || P.ao_mode == AO_NONE || P.ao_dirs == 0)
+	if (params.tiles_x * params.local_tile_rows == 0 || params.ao_mode == AO_NONE || params.ao_dirs == 0)
 		return;
 	hipStream_t s = (hipStream_t) stream;
 	hipLaunchKernelGGL(order_kernel, dim3(XCD_GROUPS), dim3(1024), 0, s, (const uint32_t *) tile_hits,
-	                   (uint32_t *) order, (FrameCounters *) counters, P);
-	// persistent grid: what the chip holds, or one wave per tile when the image is small
-	const uint32_t tiles = P.tiles_x * P.local_tile_rows;
+	                   (uint32_t *) order, (FrameCounters *) counters, params);
+	// persistent grid: what the chip holds, or one wave per (tile, direction) when the image is small
+	const uint32_t tiles = params.tiles_x * params.local_tile_rows;
+	const uint64_t units = (uint64_t) tiles * params.ao_dirs;
 	uint32_t ao_blocks = compute_units * AO_BLOCKS_PER_CU;
 	if (const char *env = getenv("OCRT_AO_BLOCKS"))  // debug knob
 		ao_blocks = (uint32_t) atoi(env);
-	if ((tiles + AO_WAVES - 1) / AO_WAVES < ao_blocks)
-		ao_blocks = (tiles + AO_WAVES - 1) / AO_WAVES;
+	if ((units + AO_WAVES - 1) / AO_WAVES < ao_blocks)
+		ao_blocks = (uint32_t) ((units + AO_WAVES - 1) / AO_WAVES);
+	KernelParams P = params;
+	const uint32_t waves_per_group = (ao_blocks * AO_WAVES + XCD_GROUPS - 1u) / XCD_GROUPS;
+	P.ao_guide = P.ao_guide * (waves_per_group ? waves_per_group : 1u);
 	auto launch = [&](auto kernel) {
 		hipLaunchKernelGGL(kernel, dim3(ao_blocks), dim3(64 * AO_WAVES), 0, s, (const float4 *) nodes, (const float4 *) tris,
 		                   (const float4 *) ao_table, (const HitRec *) hits, (uint32_t *) occluded_of,
-		                   (const uint32_t *) tile_hits, (const uint32_t *) order, (FrameCounters *) counters, P);
+		                   (const uint32_t *) order, (FrameCounters *) counters, P);
 	};
 	if (P.ao_mode == AO_UNIFORM) {
 		if (P.shared_walk)

@@ -191,15 +191,10 @@ KernelParams make_kernel_params(const RayTracer &rt, uint32_t node_count, uint32
 	const char *refill_min = std::getenv("OCRT_REFILL_MIN"), *leaf_min = std::getenv("OCRT_LEAF_MIN");
 	p.refill_min = refill_min ? (uint32_t) std::atoi(refill_min) : 16u;
 	p.leaf_min = leaf_min ? (uint32_t) std::atoi(leaf_min) : 16u;
-	// AO job size.  A job keeps a wave busy for (rays per lane) rounds and ends with a drain in
-	// which lanes idle, so big jobs are ~7 % cheaper per ray; but the frame should offer several
-	// jobs per resident wave (8 192 on an MI355X) or it ends on a tail of idle CUs.  Small images
-	// therefore split a tile's directions into jobs of about 8 rays per lane, large ones do not.
-	const char *rays_per_lane = std::getenv("OCRT_AO_RAYS_PER_LANE");  // debug knob
-	const uint32_t all_tiles = ((p.width + TILE_W - 1) / TILE_W) * local_tile_rows_for(p.height, part);
-	const uint32_t target = rays_per_lane ? (uint32_t) std::atoi(rays_per_lane) : (all_tiles >= 65536u ? ao_dirs : 8u);
-	p.jobs_per_tile = (ao_dirs && target) ? (ao_dirs + target - 1) / target : 1;
-	p.dirs_per_job = ao_dirs ? (ao_dirs + p.jobs_per_tile - 1) / p.jobs_per_tile : 1;
+	const char *guide = std::getenv("OCRT_AO_GUIDE");  // debug knob
+	p.ao_guide = guide && std::atoi(guide) > 0 ? (uint32_t) std::atoi(guide) : 2u;
+	const char *claim_max = std::getenv("OCRT_AO_CLAIM_MAX");  // debug knob
+	p.ao_claim_max = claim_max && std::atoi(claim_max) > 0 ? (uint32_t) std::atoi(claim_max) : 7u;
 	p.ao_regular = (p.ao_max_distance > 0.0f && std::isfinite(p.ao_max_distance)) ? 1 : 0;
 	p.primary_below = std::nextafterf(100000.0f, 0.0f);
 	p.ao_below = std::nextafterf(p.ao_max_distance, -std::numeric_limits<float>::infinity());

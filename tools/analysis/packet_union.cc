@@ -44,7 +44,7 @@ static bool tri(const TriRec &t, const R &r, float *dist, float *s_, float *t_, 
 	*s_ = s; *t_ = tt; memcpy(p, ip, sizeof ip);
 	return true;
 }
-struct Stats { unsigned long long packets = 0, rays = 0, packet_visits = 0, single_visits = 0, lane_box_hits = 0, lane_live_at_visit = 0, leaf_tests = 0, packet_leaf_visits = 0; };
+struct Stats { unsigned long long nodeath_visits = 0, max_tests_sum = 0, tests_hist[16] = {0}; unsigned long long packets = 0, rays = 0, packet_visits = 0, single_visits = 0, lane_box_hits = 0, lane_live_at_visit = 0, leaf_tests = 0, packet_leaf_visits = 0; };
 int main(int argc, char **argv) {
 	Mesh m; load_off_mesh(argv[1], &m); compute_vertex_normals(&m);
 	BVH bvh(BVH::Method::CUT_LONGEST_AXIS);
@@ -125,6 +125,18 @@ int main(int argc, char **argv) {
 						} else i += P.nodes[i].skip;
 					}
 				}
+				// shared AO walk in which nobody leaves early (leaf tests deferred to the end)
+				{
+					int tests[64] = { 0 };
+					for (size_t i = 0; i < N;) {
+						sa.nodeath_visits++;
+						int hits = 0;
+						for (int l = 0; l < nh; ++l) if (slab(P.nodes[i], ar[l], 0.2f)) { ++hits; if (P.nodes[i].skip == 1) tests[l]++; }
+						if (hits) ++i; else i += P.nodes[i].skip;
+					}
+					int mx = 0; for (int l = 0; l < nh; ++l) { mx = tests[l] > mx ? tests[l] : mx; sa.tests_hist[tests[l] > 15 ? 15 : tests[l]]++; }
+					sa.max_tests_sum += mx;
+				}
 				// shared AO walk; a lane leaves the packet at its first accepted triangle
 				sa.packets++;
 				int live = nh;
@@ -144,7 +156,7 @@ int main(int argc, char **argv) {
 #pragma omp critical
 		{
 			Stats *d[2] = { &prim, &ao }; Stats *s[2] = { &sp, &sa };
-			for (int k = 0; k < 2; ++k) { d[k]->packets += s[k]->packets; d[k]->rays += s[k]->rays; d[k]->packet_visits += s[k]->packet_visits; d[k]->single_visits += s[k]->single_visits; d[k]->lane_box_hits += s[k]->lane_box_hits; d[k]->lane_live_at_visit += s[k]->lane_live_at_visit; d[k]->leaf_tests += s[k]->leaf_tests; d[k]->packet_leaf_visits += s[k]->packet_leaf_visits; }
+			for (int k = 0; k < 2; ++k) { d[k]->packets += s[k]->packets; d[k]->rays += s[k]->rays; d[k]->packet_visits += s[k]->packet_visits; d[k]->single_visits += s[k]->single_visits; d[k]->lane_box_hits += s[k]->lane_box_hits; d[k]->lane_live_at_visit += s[k]->lane_live_at_visit; d[k]->leaf_tests += s[k]->leaf_tests; d[k]->packet_leaf_visits += s[k]->packet_leaf_visits; d[k]->nodeath_visits += s[k]->nodeath_visits; d[k]->max_tests_sum += s[k]->max_tests_sum; for (int q = 0; q < 16; ++q) d[k]->tests_hist[q] += s[k]->tests_hist[q]; }
 		}
 	}
 	const char *name[2] = { "primary", "AO" }; Stats *st[2] = { &prim, &ao };
@@ -153,5 +165,10 @@ int main(int argc, char **argv) {
 		printf("%-8s packets %llu rays/packet %.1f | single walk: %.1f visits/ray, %.2f leaf tests/ray | shared walk: %.1f visits/packet (%.1f leaves), %.1f%% of live lanes hit the box\n",
 		       name[k], s.packets, (double) s.rays / s.packets, (double) s.single_visits / s.rays, (double) s.leaf_tests / s.rays,
 		       (double) s.packet_visits / s.packets, (double) s.packet_leaf_visits / s.packets, 100.0 * s.lane_box_hits / s.lane_live_at_visit);
+		if (s.nodeath_visits) {
+			printf("         nobody leaves early: %.1f visits/packet, max leaf tests of a lane %.2f on average; lanes by #tests:", (double) s.nodeath_visits / s.packets, (double) s.max_tests_sum / s.packets);
+			for (int q = 0; q < 16; ++q) printf(" %.1f%%", 100.0 * s.tests_hist[q] / s.rays);
+			printf("\n");
+		}
 	}
 }

@@ -9,7 +9,7 @@ from collections import defaultdict
 
 def main():
     root = sys.argv[1]
-    want = sys.argv[2] if len(sys.argv) > 2 else "trace"
+    want = sys.argv[2] if len(sys.argv) > 2 else "ocrt::"
     acc = defaultdict(lambda: defaultdict(list))
     for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
         with open(path) as f:
