@@ -304,31 +304,90 @@ __device__ __forceinline__ bool shared_box(bool exact, const float4 lo, const fl
 	return box;
 }
 
+// The node steps of the fast form, hand-scheduled: from byte offset `at` on, walks
+// until some live lane hits a LEAF's box (returns its mask and the leaf; `at` stays
+// on that leaf) or the walk is over (returns 0).  Same operations as
+// slab_hit_regular -- (lo - o) * inv, (hi - o) * inv, min/max, max(.., tiny),
+// min(.., below), near <= far -- on a node fetched by one scalar load into
+// s[56:63] (temporaries v56-v62; only scalar outputs, so that the compiler knows the
+// results to be wave-uniform); per node 23 vector and 9 scalar instructions.  The compiler's own
+// version of this loop needs about 25 + 20: the walk is bound by instruction issue.
+__device__ __forceinline__ unsigned long long walk_to_leaf(const float4 *nodes_ptr, uint32_t &at, uint32_t end, const Ray &ray,
+                                                           float below, unsigned long long alive_mask, uint32_t &leaf) {
+	unsigned long long hit_mask;
+	// (the scalar operands are wave-uniform by construction; say so to the compiler)
+	at = (uint32_t) __builtin_amdgcn_readfirstlane((int) at);
+	end = (uint32_t) __builtin_amdgcn_readfirstlane((int) end);
+	below = __uint_as_float((uint32_t) __builtin_amdgcn_readfirstlane((int) __float_as_uint(below)));
+	alive_mask = ((unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (alive_mask >> 32)) << 32) |
+	             (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) alive_mask);
+	asm volatile(
+	    ".Lwalk_node_%=:\n\t"
+	    "s_load_dwordx8 s[56:63], %[base], %[at]\n\t"
+	    "s_waitcnt lgkmcnt(0)\n\t"
+	    "v_sub_f32 v56, s56, %[ox]\n\t"
+	    "v_sub_f32 v57, s60, %[ox]\n\t"
+	    "v_sub_f32 v58, s57, %[oy]\n\t"
+	    "v_sub_f32 v59, s61, %[oy]\n\t"
+	    "v_sub_f32 v60, s58, %[oz]\n\t"
+	    "v_sub_f32 v61, s62, %[oz]\n\t"
+	    "v_mul_f32 v56, %[ix], v56\n\t"
+	    "v_mul_f32 v57, %[ix], v57\n\t"
+	    "v_mul_f32 v58, %[iy], v58\n\t"
+	    "v_mul_f32 v59, %[iy], v59\n\t"
+	    "v_mul_f32 v60, %[iz], v60\n\t"
+	    "v_mul_f32 v61, %[iz], v61\n\t"
+	    "v_min_f32 v62, v56, v57\n\t"
+	    "v_max_f32 v56, v56, v57\n\t"
+	    "v_min_f32 v57, v58, v59\n\t"
+	    "v_max_f32 v58, v58, v59\n\t"
+	    "v_min_f32 v59, v60, v61\n\t"
+	    "v_max_f32 v60, v60, v61\n\t"
+	    "v_max_f32 v59, 1, v59\n\t"          // tiny = bit pattern 1
+	    "v_min_f32 v60, %[below], v60\n\t"
+	    "v_max3_f32 v62, v62, v57, v59\n\t"
+	    "v_min3_f32 v56, v56, v58, v60\n\t"
+	    "v_cmp_le_f32 vcc, v62, v56\n\t"
+	    "s_and_b64 %[hit], vcc, %[alive]\n\t"
+	    "s_cmp_lg_u64 %[hit], 0\n\t"
+	    "s_cbranch_scc1 .Lwalk_hit_%=\n\t"
+	    "s_lshl_b32 s59, s59, 5\n\t"            // nobody: skip the subtree
+	    "s_add_u32 %[at], %[at], s59\n\t"
+	    "s_cmp_lt_u32 %[at], %[end]\n\t"
+	    "s_cbranch_scc1 .Lwalk_node_%=\n\t"
+	    "s_branch .Lwalk_out_%=\n"
+	    ".Lwalk_hit_%=:\n\t"
+	    "s_cmp_lg_u32 s63, -1\n\t"
+	    "s_cbranch_scc1 .Lwalk_out_%=\n\t"      // a leaf: hand it to the caller
+	    "s_add_u32 %[at], %[at], 32\n\t"        // an inner node: its first child is next
+	    "s_cmp_lt_u32 %[at], %[end]\n\t"
+	    "s_cbranch_scc1 .Lwalk_node_%=\n\t"
+	    "s_mov_b64 %[hit], 0\n"
+	    ".Lwalk_out_%=:\n\t"
+	    "s_mov_b32 %[leaf], s63\n\t"
+	    : [at] "+s"(at), [hit] "=&s"(hit_mask), [leaf] "=&s"(leaf)
+	    : [base] "s"(nodes_ptr), [end] "s"(end), [alive] "s"(alive_mask), [below] "s"(below), [ox] "v"(ray.ox), [oy] "v"(ray.oy),
+	      [oz] "v"(ray.oz), [ix] "v"(ray.ix), [iy] "v"(ray.iy), [iz] "v"(ray.iz)
+	    : "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "vcc", "scc");
+	return hit_mask;
+}
+
 // Any-hit shared walk of one packet (AO): a lane leaves at its first accepted
 // triangle and bumps *occluded (reference :251 only uses the boolean).
 template <bool EXACT>
-__device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ nodes_ptr, const float4 *__restrict__ tris_ptr,
-                                                    uint32_t count, const Ray &ray, float max_distance, float below,
+__device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ nodes_ptr, __amdgpu_buffer_rsrc_t nodes_rsrc,
+                                                    const float4 *__restrict__ tris_ptr, uint32_t count, const Ray &ray, float max_distance, float below,
                                                     bool alive, uint32_t lane, unsigned int *occluded) {
-	uint32_t mine = 0u;
-	uint32_t at = 0u;
-	below = __builtin_canonicalizef(below);  // (once, instead of in front of every fminf)
 	// the live lanes as a scalar mask: the node steps then need no per-lane bookkeeping at all
 	unsigned long long alive_mask = wave_ballot(alive);
-	while (at < count) {
-		const float4 lo = nodes_ptr[2u * at], hi = nodes_ptr[2u * at + 1u];
-		uint32_t skip = __float_as_uint(lo.w), leaf = __float_as_uint(hi.w);
-		asm volatile("" : "+s"(skip), "+s"(leaf));  // keep them from the one 32-byte load, not re-fetched later
-		unsigned long long hit_mask;
-		if (EXACT) {
-			const bool here = alive && mine == at;
-			const bool box = here && slab_hit(lo, hi, ray, max_distance);
-			mine = here ? (box ? at + 1u : at + skip) : mine;
-			hit_mask = wave_ballot(box);
-		} else {
-			hit_mask = wave_ballot(slab_hit_regular(lo, hi, ray, below)) & alive_mask;
-		}
-		if (hit_mask != 0ull && leaf != NONE) {
+	if (!EXACT) {
+		uint32_t at = 0u;  // byte offset of the node (count < 2^27, checked at upload)
+		const uint32_t end = count * 32u;
+		while (alive_mask != 0ull && at < end) {
+			uint32_t leaf;
+			const unsigned long long hit_mask = walk_to_leaf(nodes_ptr, at, end, ray, below, alive_mask, leaf);
+			if (hit_mask == 0ull)
+				break;
 			const float4 q0 = tris_ptr[4u * leaf], q1 = tris_ptr[4u * leaf + 1u];
 			const float4 q2 = tris_ptr[4u * leaf + 2u], q3 = tris_ptr[4u * leaf + 3u];
 			if ((hit_mask >> lane) & 1ull) {
@@ -339,7 +398,33 @@ __device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ n
 				}
 			}
 			alive_mask = wave_ballot(alive);
-			if (alive_mask == 0ull)
+			at += 32u;
+		}
+		return;
+	}
+	uint32_t mine = 0u;
+	uint32_t at = 0u;
+	while (at < count) {
+		// (through the buffer descriptor: with plain pointer loads here as well the compiler moves the
+		// node pointer into VGPRs and cannot hand it to walk_to_leaf's scalar operand)
+		const float4 lo = load_f4(nodes_rsrc, at * 32u), hi = load_f4(nodes_rsrc, at * 32u + 16u);
+		const uint32_t skip = (uint32_t) __builtin_amdgcn_readfirstlane((int) __float_as_uint(lo.w));
+		const uint32_t leaf = (uint32_t) __builtin_amdgcn_readfirstlane((int) __float_as_uint(hi.w));
+		const bool here = alive && mine == at;
+		const bool box = here && slab_hit(lo, hi, ray, max_distance);
+		mine = here ? (box ? at + 1u : at + skip) : mine;
+		const unsigned long long hit_mask = wave_ballot(box);
+		if (hit_mask != 0ull && leaf != NONE) {
+			const float4 q0 = tris_ptr[4u * leaf], q1 = tris_ptr[4u * leaf + 1u];
+			const float4 q2 = tris_ptr[4u * leaf + 2u], q3 = tris_ptr[4u * leaf + 3u];
+			if (box) {
+				const TriResult tr = tri_eval<false>(q0, q1, q2, q3, ray);
+				if (tr.accepted) {
+					atomicAdd(occluded, 1u);
+					alive = false;
+				}
+			}
+			if (wave_ballot(alive) == 0ull)
 				break;
 		}
 		at = (uint32_t) __builtin_amdgcn_readfirstlane((int) (at + (hit_mask != 0ull ? 1u : skip)));
@@ -836,10 +921,10 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 						setup_ray(base + lane, whole, shared_dir);
 					const bool exact = !scene_fast || wave_ballot(alive && !regular) != 0ull;
 					if (exact)
-						shared_walk_any_hit<true>(nodes_ptr, tris_ptr, count, ray, P.ao_max_distance, P.ao_below, alive,
+						shared_walk_any_hit<true>(nodes_ptr, scene.nodes, tris_ptr, count, ray, P.ao_max_distance, P.ao_below, alive,
 						                          lane, &sh.occluded[h]);
 					else
-						shared_walk_any_hit<false>(nodes_ptr, tris_ptr, count, ray, P.ao_max_distance, P.ao_below, alive,
+						shared_walk_any_hit<false>(nodes_ptr, scene.nodes, tris_ptr, count, ray, P.ao_max_distance, P.ao_below, alive,
 						                           lane, &sh.occluded[h]);
 				}
 			}
