@@ -175,7 +175,9 @@ size_t DeviceRenderer::upload(const PackedScene &scene) {
 	const size_t tris_bytes = scene.tris.size() * sizeof(TriRec);
 	const size_t shade_bytes = scene.shade.size() * sizeof(ShadeRec);
 	const size_t ao_bytes = table.size() * sizeof(float);
-	d_nodes = device_alloc(nodes_bytes);
+	// one node of zero padding: the shared walk fetches a node together with its successor
+	d_nodes = device_alloc(nodes_bytes + sizeof(NodeRec));
+	OCRT_HIP(hipMemset((char *) d_nodes + nodes_bytes, 0, sizeof(NodeRec)));
 	d_tris = device_alloc(tris_bytes);
 	d_shade = device_alloc(shade_bytes);
 	d_ao = device_alloc(ao_bytes);

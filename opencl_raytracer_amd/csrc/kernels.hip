@@ -307,68 +307,106 @@ __device__ __forceinline__ bool shared_box(bool exact, const float4 lo, const fl
 // The node steps of the fast form, hand-scheduled: from byte offset `at` on, walks
 // until some live lane hits a LEAF's box (returns its mask and the leaf; `at` stays
 // on that leaf) or the walk is over (returns 0).  Same operations as
-// slab_hit_regular -- (lo - o) * inv, (hi - o) * inv, min/max, max(.., tiny),
-// min(.., below), near <= far -- on a node fetched by one scalar load into
-// s[56:63] (temporaries v56-v62; only scalar outputs, so that the compiler knows the
-// results to be wave-uniform); per node 23 vector and 9 scalar instructions.  The compiler's own
-// version of this loop needs about 25 + 20: the walk is bound by instruction issue.
+// slab_hit_regular -- (lo - o) * inv, (hi - o) * inv, min/max, max(.., tiny = bit
+// pattern 1), min(.., below), near <= far.  One 64-byte scalar load fetches the node
+// and its pre-order successor (the node array carries one node of padding): when a
+// lane hits an inner node, its first child is tested straight from s[56:63] without
+// another trip to memory.  Per node 23 vector and ~8 scalar instructions; the
+// compiler's own version of this loop needs about 25 + 20, and the walk is bound by
+// instruction issue and the latency of that load.  Temporaries v56-v62; only scalar
+// outputs, so that the compiler knows the results to be wave-uniform.
 __device__ __forceinline__ unsigned long long walk_to_leaf(const float4 *nodes_ptr, uint32_t &at, uint32_t end, const Ray &ray,
                                                            float below, unsigned long long alive_mask, uint32_t &leaf) {
 	unsigned long long hit_mask;
-	// (the scalar operands are wave-uniform by construction; say so to the compiler)
-	at = (uint32_t) __builtin_amdgcn_readfirstlane((int) at);
-	end = (uint32_t) __builtin_amdgcn_readfirstlane((int) end);
-	below = __uint_as_float((uint32_t) __builtin_amdgcn_readfirstlane((int) __float_as_uint(below)));
-	alive_mask = ((unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (alive_mask >> 32)) << 32) |
-	             (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) alive_mask);
 	asm volatile(
-	    ".Lwalk_node_%=:\n\t"
-	    "s_load_dwordx8 s[56:63], %[base], %[at]\n\t"
-	    "s_waitcnt lgkmcnt(0)\n\t"
-	    "v_sub_f32 v56, s56, %[ox]\n\t"
-	    "v_sub_f32 v57, s60, %[ox]\n\t"
-	    "v_sub_f32 v58, s57, %[oy]\n\t"
-	    "v_sub_f32 v59, s61, %[oy]\n\t"
-	    "v_sub_f32 v60, s58, %[oz]\n\t"
-	    "v_sub_f32 v61, s62, %[oz]\n\t"
-	    "v_mul_f32 v56, %[ix], v56\n\t"
-	    "v_mul_f32 v57, %[ix], v57\n\t"
-	    "v_mul_f32 v58, %[iy], v58\n\t"
-	    "v_mul_f32 v59, %[iy], v59\n\t"
-	    "v_mul_f32 v60, %[iz], v60\n\t"
-	    "v_mul_f32 v61, %[iz], v61\n\t"
-	    "v_min_f32 v62, v56, v57\n\t"
-	    "v_max_f32 v56, v56, v57\n\t"
-	    "v_min_f32 v57, v58, v59\n\t"
-	    "v_max_f32 v58, v58, v59\n\t"
-	    "v_min_f32 v59, v60, v61\n\t"
-	    "v_max_f32 v60, v60, v61\n\t"
-	    "v_max_f32 v59, 1, v59\n\t"          // tiny = bit pattern 1
-	    "v_min_f32 v60, %[below], v60\n\t"
-	    "v_max3_f32 v62, v62, v57, v59\n\t"
-	    "v_min3_f32 v56, v56, v58, v60\n\t"
-	    "v_cmp_le_f32 vcc, v62, v56\n\t"
-	    "s_and_b64 %[hit], vcc, %[alive]\n\t"
-	    "s_cmp_lg_u64 %[hit], 0\n\t"
-	    "s_cbranch_scc1 .Lwalk_hit_%=\n\t"
-	    "s_lshl_b32 s59, s59, 5\n\t"            // nobody: skip the subtree
-	    "s_add_u32 %[at], %[at], s59\n\t"
-	    "s_cmp_lt_u32 %[at], %[end]\n\t"
-	    "s_cbranch_scc1 .Lwalk_node_%=\n\t"
-	    "s_branch .Lwalk_out_%=\n"
-	    ".Lwalk_hit_%=:\n\t"
-	    "s_cmp_lg_u32 s63, -1\n\t"
-	    "s_cbranch_scc1 .Lwalk_out_%=\n\t"      // a leaf: hand it to the caller
-	    "s_add_u32 %[at], %[at], 32\n\t"        // an inner node: its first child is next
-	    "s_cmp_lt_u32 %[at], %[end]\n\t"
-	    "s_cbranch_scc1 .Lwalk_node_%=\n\t"
-	    "s_mov_b64 %[hit], 0\n"
-	    ".Lwalk_out_%=:\n\t"
-	    "s_mov_b32 %[leaf], s63\n\t"
+	    ".Lwalk_node_%=:\n"
+	    "\ts_load_dwordx16 s[48:63], %[base], %[at]\n"
+	    "\ts_waitcnt lgkmcnt(0)\n"
+	    "\tv_sub_f32 v56, s48, %[ox]\n"
+	    "\tv_sub_f32 v57, s52, %[ox]\n"
+	    "\tv_sub_f32 v58, s49, %[oy]\n"
+	    "\tv_sub_f32 v59, s53, %[oy]\n"
+	    "\tv_sub_f32 v60, s50, %[oz]\n"
+	    "\tv_sub_f32 v61, s54, %[oz]\n"
+	    "\tv_mul_f32 v56, %[ix], v56\n"
+	    "\tv_mul_f32 v57, %[ix], v57\n"
+	    "\tv_mul_f32 v58, %[iy], v58\n"
+	    "\tv_mul_f32 v59, %[iy], v59\n"
+	    "\tv_mul_f32 v60, %[iz], v60\n"
+	    "\tv_mul_f32 v61, %[iz], v61\n"
+	    "\tv_min_f32 v62, v56, v57\n"
+	    "\tv_max_f32 v56, v56, v57\n"
+	    "\tv_min_f32 v57, v58, v59\n"
+	    "\tv_max_f32 v58, v58, v59\n"
+	    "\tv_min_f32 v59, v60, v61\n"
+	    "\tv_max_f32 v60, v60, v61\n"
+	    "\tv_max_f32 v59, 1, v59\n"
+	    "\tv_min_f32 v60, %[below], v60\n"
+	    "\tv_max3_f32 v62, v62, v57, v59\n"
+	    "\tv_min3_f32 v56, v56, v58, v60\n"
+	    "\tv_cmp_le_f32 vcc, v62, v56\n"
+	    "\ts_and_b64 %[hit], vcc, %[alive]\n"
+	    "\ts_cmp_lg_u64 %[hit], 0\n"
+	    "\ts_cbranch_scc1 .Lwalk_hit_a_%=\n"
+	    "\ts_lshl_b32 s51, s51, 5\n"
+	    "\ts_add_u32 %[at], %[at], s51\n"
+	    "\ts_cmp_lt_u32 %[at], %[end]\n"
+	    "\ts_cbranch_scc1 .Lwalk_node_%=\n"
+	    "\ts_branch .Lwalk_out_%=\n"
+	    ".Lwalk_hit_a_%=:\n"
+	    "\ts_cmp_lg_u32 s55, -1\n"
+	    "\ts_cbranch_scc1 .Lwalk_leaf_a_%=\n"
+	    "\ts_add_u32 %[at], %[at], 32\n"
+	    "\tv_sub_f32 v56, s56, %[ox]\n"
+	    "\tv_sub_f32 v57, s60, %[ox]\n"
+	    "\tv_sub_f32 v58, s57, %[oy]\n"
+	    "\tv_sub_f32 v59, s61, %[oy]\n"
+	    "\tv_sub_f32 v60, s58, %[oz]\n"
+	    "\tv_sub_f32 v61, s62, %[oz]\n"
+	    "\tv_mul_f32 v56, %[ix], v56\n"
+	    "\tv_mul_f32 v57, %[ix], v57\n"
+	    "\tv_mul_f32 v58, %[iy], v58\n"
+	    "\tv_mul_f32 v59, %[iy], v59\n"
+	    "\tv_mul_f32 v60, %[iz], v60\n"
+	    "\tv_mul_f32 v61, %[iz], v61\n"
+	    "\tv_min_f32 v62, v56, v57\n"
+	    "\tv_max_f32 v56, v56, v57\n"
+	    "\tv_min_f32 v57, v58, v59\n"
+	    "\tv_max_f32 v58, v58, v59\n"
+	    "\tv_min_f32 v59, v60, v61\n"
+	    "\tv_max_f32 v60, v60, v61\n"
+	    "\tv_max_f32 v59, 1, v59\n"
+	    "\tv_min_f32 v60, %[below], v60\n"
+	    "\tv_max3_f32 v62, v62, v57, v59\n"
+	    "\tv_min3_f32 v56, v56, v58, v60\n"
+	    "\tv_cmp_le_f32 vcc, v62, v56\n"
+	    "\ts_and_b64 %[hit], vcc, %[alive]\n"
+	    "\ts_cmp_lg_u64 %[hit], 0\n"
+	    "\ts_cbranch_scc1 .Lwalk_hit_b_%=\n"
+	    "\ts_lshl_b32 s59, s59, 5\n"
+	    "\ts_add_u32 %[at], %[at], s59\n"
+	    "\ts_cmp_lt_u32 %[at], %[end]\n"
+	    "\ts_cbranch_scc1 .Lwalk_node_%=\n"
+	    "\ts_branch .Lwalk_out_%=\n"
+	    ".Lwalk_hit_b_%=:\n"
+	    "\ts_cmp_lg_u32 s63, -1\n"
+	    "\ts_cbranch_scc1 .Lwalk_leaf_b_%=\n"
+	    "\ts_add_u32 %[at], %[at], 32\n"
+	    "\ts_cmp_lt_u32 %[at], %[end]\n"
+	    "\ts_cbranch_scc1 .Lwalk_node_%=\n"
+	    "\ts_mov_b64 %[hit], 0\n"
+	    "\ts_branch .Lwalk_out_%=\n"
+	    ".Lwalk_leaf_a_%=:\n"
+	    "\ts_mov_b32 %[leaf], s55\n"
+	    "\ts_branch .Lwalk_out_%=\n"
+	    ".Lwalk_leaf_b_%=:\n"
+	    "\ts_mov_b32 %[leaf], s63\n"
+	    ".Lwalk_out_%=:\n"
 	    : [at] "+s"(at), [hit] "=&s"(hit_mask), [leaf] "=&s"(leaf)
 	    : [base] "s"(nodes_ptr), [end] "s"(end), [alive] "s"(alive_mask), [below] "s"(below), [ox] "v"(ray.ox), [oy] "v"(ray.oy),
 	      [oz] "v"(ray.oz), [ix] "v"(ray.ix), [iy] "v"(ray.iy), [iz] "v"(ray.iz)
-	    : "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "vcc", "scc");
+	    : "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "v56",
+	      "v57", "v58", "v59", "v60", "v61", "v62", "vcc", "scc");
 	return hit_mask;
 }
 
@@ -491,36 +529,50 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
 	bool hit = false;
 	if (P.shared_walk) {
 		const bool exact = !(P.scene_regular && P.scene_nested) || wave_ballot(active && !regular) != 0ull;
-		uint32_t mine = 0u;
-		uint32_t at = 0u;
-		while (at < count) {
-			const float4 lo = nodes_ptr[2u * at], hi = nodes_ptr[2u * at + 1u];
-			uint32_t skip = __float_as_uint(lo.w), leaf = __float_as_uint(hi.w);
-			asm volatile("" : "+s"(skip), "+s"(leaf));  // keep them from the one 32-byte load, not re-fetched later
-			const bool box = shared_box(exact, lo, hi, ray, 100000.0f, P.primary_below, active, at, skip, mine);
-			if (wave_ballot(box) == 0ull) {
-				at = (uint32_t) __builtin_amdgcn_readfirstlane((int) (at + skip));
-				continue;
-			}
-			if (leaf != NONE) {
-				const float4 q0 = tris_ptr[4u * leaf], q1 = tris_ptr[4u * leaf + 1u];
-				const float4 q2 = tris_ptr[4u * leaf + 2u], q3 = tris_ptr[4u * leaf + 3u];
-				if (box) {
-					const TriResult tr = tri_eval<true>(q0, q1, q2, q3, ray);
-					// closest hit: strict '>' in ascending leaf order, reference :106-112
-					if (tr.accepted) {
-						hit = true;
-						if (best.distance > tr.distance) {
-							best.distance = tr.distance;
-							best.leaf = leaf;
-							best.s = tr.s;
-							best.t = tr.t;
-							best.px = tr.px; best.py = tr.py; best.pz = tr.pz;
-						}
+		// closest hit: strict '>' in ascending leaf order, reference :106-112
+		auto leaf_test = [&](uint32_t leaf, bool box) {
+			const float4 q0 = tris_ptr[4u * leaf], q1 = tris_ptr[4u * leaf + 1u];
+			const float4 q2 = tris_ptr[4u * leaf + 2u], q3 = tris_ptr[4u * leaf + 3u];
+			if (box) {
+				const TriResult tr = tri_eval<true>(q0, q1, q2, q3, ray);
+				if (tr.accepted) {
+					hit = true;
+					if (best.distance > tr.distance) {
+						best.distance = tr.distance;
+						best.leaf = leaf;
+						best.s = tr.s;
+						best.t = tr.t;
+						best.px = tr.px; best.py = tr.py; best.pz = tr.pz;
 					}
 				}
 			}
-			at = (uint32_t) __builtin_amdgcn_readfirstlane((int) (at + 1u));
+		};
+		if (!exact) {
+			const unsigned long long alive_mask = wave_ballot(active);
+			const uint32_t end = count * 32u;
+			uint32_t at = 0u;  // byte offset
+			while (alive_mask != 0ull && at < end) {
+				uint32_t leaf;
+				const unsigned long long hit_mask = walk_to_leaf(nodes_ptr, at, end, ray, P.primary_below, alive_mask, leaf);
+				if (hit_mask == 0ull)
+					break;
+				leaf_test(leaf, (hit_mask >> lane) & 1ull);
+				at += 32u;
+			}
+		} else {
+			uint32_t mine = 0u;
+			uint32_t at = 0u;
+			while (at < count) {
+				// (through the buffer descriptor, see shared_walk_any_hit)
+				const float4 lo = load_f4(scene.nodes, at * 32u), hi = load_f4(scene.nodes, at * 32u + 16u);
+				const uint32_t skip = (uint32_t) __builtin_amdgcn_readfirstlane((int) __float_as_uint(lo.w));
+				const uint32_t leaf = (uint32_t) __builtin_amdgcn_readfirstlane((int) __float_as_uint(hi.w));
+				const bool box = shared_box(true, lo, hi, ray, 100000.0f, P.primary_below, active, at, skip, mine);
+				const bool any = wave_ballot(box) != 0ull;
+				if (any && leaf != NONE)
+					leaf_test(leaf, box);
+				at = (uint32_t) __builtin_amdgcn_readfirstlane((int) (at + (any ? 1u : skip)));
+			}
 		}
 	} else {
 		uint32_t i = active ? 0u : count;
