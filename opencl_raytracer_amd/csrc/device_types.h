@@ -102,7 +102,8 @@ struct KernelParams {
 	int32_t debug_no_sort; // debug knob OCRT_NO_SORT: claim tiles in arbitrary order instead of heaviest first
 	uint32_t refill_min;    // wave scheduler: refill once this many lanes are idle (debug knob OCRT_REFILL_MIN)
 	uint32_t leaf_min;      // ... test triangles once this many leaves are pending (OCRT_LEAF_MIN)
-	uint32_t ao_claim_max;  // most (tile, direction) units one AO claim takes
+	uint32_t ao_claim_max;  // most (tile, direction) units one AO claim takes; 0 = a twelfth of a wave's share, 4 .. ao_dirs
+	uint32_t ao_claim_div;  // (set by launch_ao: 12 x the waves per XCD group)
 	uint32_t ao_guide;      // an AO claim takes 1/ao_guide of the (tile, direction) units left in its queue; the host
 	                        // sets the factor (2), launch_ao multiplies it by the waves per XCD group
 	uint32_t tiles_x;      // tiles per image row

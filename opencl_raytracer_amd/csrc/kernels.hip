@@ -784,6 +784,12 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 			segment += ((strips + XCD_GROUPS - 1u - g) >> 3) * 2u * P.local_tile_rows;
 		// the group's work in units of (tile, table direction), tile-major
 		const uint32_t units = counters->queue[group].work_tiles * P.ao_dirs;
+		// largest claim: small enough for about a dozen claims per wave, so that the waves finish together
+		uint32_t claim_max = P.ao_claim_max;
+		if (claim_max == 0u) {
+			claim_max = units / P.ao_claim_div;
+			claim_max = claim_max < 4u ? 4u : claim_max > P.ao_dirs ? P.ao_dirs : claim_max;
+		}
 		for (;;) {
 			// look before claiming: most visits to a foreign group find its queue drained,
 			// and a plain load does not queue up behind the other waves' atomics
@@ -795,7 +801,7 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 			// waves of a group) -- whole tiles while there is plenty, so the per-tile set-up is
 			// paid once, single directions at the end, so the frame does not wait for a long last job.
 			uint32_t want = (units - seen) / P.ao_guide;
-			want = want < 1u ? 1u : want > P.ao_claim_max ? P.ao_claim_max : want;
+			want = want < 1u ? 1u : want > claim_max ? claim_max : want;
 			uint32_t claimed = 0u;
 			if (lane == 0u)
 				claimed = atomicAdd(&counters->queue[group].head, want);
@@ -1097,6 +1103,7 @@ void launch_ao(const void *nodes, const void *tris, const void *ao_table, float 
 	KernelParams P = params;
 	const uint32_t waves_per_group = (ao_blocks * AO_WAVES + XCD_GROUPS - 1u) / XCD_GROUPS;
 	P.ao_guide = P.ao_guide * (waves_per_group ? waves_per_group : 1u);
+	P.ao_claim_div = 12u * (waves_per_group ? waves_per_group : 1u);
 	auto launch = [&](auto kernel) {
 		hipLaunchKernelGGL(kernel, dim3(ao_blocks), dim3(64 * AO_WAVES), 0, s, (const float4 *) nodes, (const float4 *) tris,
 		                   (const float4 *) ao_table, (const HitRec *) hits, (uint32_t *) occluded_of,
