@@ -185,7 +185,7 @@ KernelParams make_kernel_params(const RayTracer &rt, uint32_t node_count, uint32
 	p.ao_dirs = ao_dirs;
 	p.ao_divisor = p.ao_mode == AO_RANDOM ? ao_dirs - 1 : ao_dirs;
 	p.scene_regular = (scene && scene->regular) ? 1 : 0;
-	p.scene_nested = (scene && scene->nested) ? 1 : 0;
+	p.scene_nested = (scene && scene->nested && !std::getenv("OCRT_FORCE_EXACT_WALK")) ? 1 : 0;  // (debug knob)
 	p.shared_walk = (scene && scene->binary_tree && !std::getenv("OCRT_NO_SHARED_WALK")) ? 1 : 0;  // (debug knob)
 	p.debug_no_sort = std::getenv("OCRT_NO_SORT") ? 1 : 0;
 	const char *refill_min = std::getenv("OCRT_REFILL_MIN"), *leaf_min = std::getenv("OCRT_LEAF_MIN");
