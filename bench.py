@@ -309,8 +309,9 @@ def main():
                 "frame_kernels_ms": round(kernel_ms_max, 4),
                 "frame_algorithmic_GBps": round(parts["frame"] / world / (kernel_ms_max * 1e-3) / 1e9, 1),
                 "note": "algorithmic bytes = REFERENCE traversal (36 B/node visit + 60 B/triangle test [+ 48 B/hit + "
-                        "4 B/sub-pixel for the primary pass]); the 12 MB scene is L2-resident, so the kernel is bound "
-                        "by L1 gather rate and latency, not by HBM: frac > 1 is possible (DESIGN.md)",
+                        "4 B/sub-pixel for the primary pass]); the 12 MB scene is cache-resident, so the kernel is "
+                        "bound by vector-instruction issue and scalar-load latency, not by HBM: frac > 1 is possible "
+                        "(DESIGN.md)",
             }
         else:
             out["roofline"] = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,

@@ -16,24 +16,29 @@
 //                   ballot-compacted into the tile's 64 slots of the hit list.
 //   order_kernel    counting sort of the non-empty tiles by hit count, heaviest
 //                   first, per XCD group.
-//   ao_kernel       persistent waves claim jobs = (tile, range of table directions)
-//                   in that order.  A wave rebuilds the tile's tangent frames in
-//                   its LDS slice and drains the job's (hit, direction) pairs --
-//                   direction-major, so that the lanes cast one table direction
-//                   from neighbouring surface points -- as any-hit rays that stop
-//                   at the first accepted triangle; occlusion counts are LDS
-//                   atomics, flushed to a per-hit counter when the job is done.
+//   ao_kernel       persistent waves claim runs of (tile, table direction) units in
+//                   that order.  A wave rebuilds the tile's tangent frames in its
+//                   LDS slice and casts one packet of 64 any-hit rays per
+//                   direction -- one table direction from the tile's neighbouring
+//                   surface points -- that stop at the first accepted triangle;
+//                   occlusion counts are LDS atomics, flushed to a per-hit counter
+//                   when the claim is done.
 //   resolve_kernel  one thread per hit: value * (1 - occluded / n) -> image.
 // Why not one fused launch (it was, see profiles/r01_notes.md): cost per tile
-// varies 30x (background vs model, 29 rays per hit sub-pixel) and a full tile
-// keeps its wave busy for ~1/6 of the frame, so the frame used to end on a long
-// tail of half-empty CUs.  With the tiles' costs known after the primary pass,
-// longest-first claiming packs them almost perfectly.
+// varies 30x (background vs model, 29 rays per hit sub-pixel), so the frame used
+// to end on a long tail of half-empty CUs.  With the tiles' costs known after the
+// primary pass, longest-first claiming packs them almost perfectly.
 //
-// What bounds it: the scene (12 MB) lives in L2, HBM traffic is negligible;
-// every node visit is a dependent, lane-divergent 32-byte gather served by the
-// vector L1 at about one cache line per clock per CU, and the VALU is ~80 %
-// busy -- see profiles/r01_notes.md for the counters and the microbenchmark.
+// How rays walk the tree: the 64 rays of a wave share ONE node index ("shared
+// walk", see shared_box / walk_to_leaf below) -- nodes and triangles arrive by
+// scalar loads, boxes are tested out of SGPRs, nothing diverges and nothing is
+// gathered.  The first generation, in which every lane walked on its own under a
+// wave scheduler, is still here (OCRT_NO_SHARED_WALK=1) for A/B runs.
+//
+// What bounds it: the scene (12 MB) is cache-resident, HBM traffic is negligible;
+// the walk is bound by vector-instruction issue (23 per node and packet) and the
+// latency of the one scalar load per node -- see DESIGN.md section 5 and
+// profiles/r01_notes.md for the counters and the microbenchmarks.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
