@@ -297,6 +297,15 @@ RenderStats DeviceRenderer::stats() {
 	             c.stamp[0] * 1e-5, c.stamp[1] * 1e-5, c.stamp[2] * 1e-5, c.stamp[3] * 1e-5, c.stamp[4], c.stamp[5]);
 	std::fprintf(stderr, "   lifetimes sum %.3f ms, kernel span %.3f ms, last wave started %.3f ms after the first, %llu waves worked\n",
 	             c.stamp[6] * 1e-5, (c.stamp[8] - c.stamp[7]) * 1e-5, (c.stamp[9] - c.stamp[7]) * 1e-5, c.stamp[10]);
+	std::fprintf(stderr, "   waves by their longest job (0.02 ms buckets):");
+	for (int k = 0; k < 32; ++k)
+		if (c.stamp[12 + k])
+			std::fprintf(stderr, " %.2f:%llu", k * 0.02, c.stamp[12 + k]);
+	std::fprintf(stderr, "\n   waves by time from their last claim to their end (0.05 ms buckets):");
+	for (int k = 0; k < 32; ++k)
+		if (c.stamp[12 + 32 + k])
+			std::fprintf(stderr, " %.2f:%llu", k * 0.05, c.stamp[12 + 32 + k]);
+	std::fprintf(stderr, "\n");
 #endif
 	// Primary rays = sub-pixels of this rank's bands that lie inside the image.
 	const uint32_t tile_rows = (kp.height + TILE_H - 1) / TILE_H;

@@ -64,7 +64,7 @@ struct FrameCounters {
 	uint32_t pad;
 	unsigned long long occluded;  // occluded AO rays
 #ifdef OCRT_STAMPS
-	unsigned long long stamp[12];  // debug build: wave-time (10 ns ticks) per phase of the AO pass, jobs, packets
+	unsigned long long stamp[12 + 64];  // [12..75]: waves by lifetime, 0.1 ms buckets  // debug build: wave-time (10 ns ticks) per phase of the AO pass, jobs, packets
 #endif
 };
 
@@ -102,6 +102,8 @@ struct KernelParams {
 	int32_t debug_no_sort; // debug knob OCRT_NO_SORT: claim tiles in arbitrary order instead of heaviest first
 	uint32_t refill_min;    // wave scheduler: refill once this many lanes are idle (debug knob OCRT_REFILL_MIN)
 	uint32_t leaf_min;      // ... test triangles once this many leaves are pending (OCRT_LEAF_MIN)
+	uint32_t heavy_div;     // the ordering step moves the costliest 1/heavy_div of a group's tiles to the front
+	uint32_t cost_shift;    // AO cost classes are (leaf stops of the primary walk x fill) >> cost_shift
 	uint32_t ao_claim_max;  // most (tile, direction) units one AO claim takes; 0 = a twelfth of a wave's share, 4 .. ao_dirs
 	uint32_t ao_claim_div;  // (set by launch_ao: 12 x the waves per XCD group)
 	uint32_t ao_guide;      // an AO claim takes 1/ao_guide of the (tile, direction) units left in its queue; the host

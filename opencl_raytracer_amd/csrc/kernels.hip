@@ -14,7 +14,7 @@
 //                   the smooth normal and head-light term.  Sub-pixels that need
 //                   no ambient occlusion are final; the tile's other hits are
 //                   ballot-compacted into the tile's 64 slots of the hit list.
-//   order_kernel    counting sort of the non-empty tiles by hit count, heaviest
+//   order_kernel    counting sort of the non-empty tiles by AO cost class, heaviest
 //                   first, per XCD group.
 //   ao_kernel       persistent waves claim runs of (tile, table direction) units in
 //                   that order.  A wave rebuilds the tile's tangent frames in its
@@ -532,6 +532,7 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
 	best.s = best.t = 0.0f;
 	best.px = best.py = best.pz = 0.0f;
 	bool hit = false;
+	uint32_t leaf_stops = 0u;  // leaves the tile's shared walk stopped at: how dense the geometry is along these rays
 	if (P.shared_walk) {
 		const bool exact = !(P.scene_regular && P.scene_nested) || wave_ballot(active && !regular) != 0ull;
 		// closest hit: strict '>' in ascending leaf order, reference :106-112
@@ -562,6 +563,7 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
 				if (hit_mask == 0ull)
 					break;
 				leaf_test(leaf, (hit_mask >> lane) & 1ull);
+				++leaf_stops;
 				at += 32u;
 			}
 		} else {
@@ -574,8 +576,10 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
 				const uint32_t leaf = (uint32_t) __builtin_amdgcn_readfirstlane((int) __float_as_uint(hi.w));
 				const bool box = shared_box(true, lo, hi, ray, 100000.0f, P.primary_below, active, at, skip, mine);
 				const bool any = wave_ballot(box) != 0ull;
-				if (any && leaf != NONE)
+				if (any && leaf != NONE) {
 					leaf_test(leaf, box);
+					++leaf_stops;
+				}
 				at = (uint32_t) __builtin_amdgcn_readfirstlane((int) (at + (any ? 1u : skip)));
 			}
 		}
@@ -636,7 +640,13 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
 	const unsigned long long hit_mask = wave_ballot(hit);
 	const uint32_t hit_count = (uint32_t) __popcll(hit_mask);
 	if (lane == 0u) {
-		tile_hits[tile] = want_ao ? hit_count : 0u;
+		// hit count, and above it the tile's AO cost class 1..64 for the ordering step: its 28 AO packets
+		// walk about as far as the primary packet did (correlation 0.8-0.9, tools/analysis/packet_union.cc),
+		// scaled by how full the packets will be.  The hit count alone does not predict the cost at all.
+		uint32_t cost = P.shared_walk ? (leaf_stops * hit_count + 63u) / 64u : hit_count;
+		cost = (cost >> P.cost_shift) + 1u;  // coarse classes: within a class the tiles keep their spatial order
+		cost = cost > 64u ? 64u : cost;
+		tile_hits[tile] = (want_ao && hit_count) ? (hit_count | (cost << 8)) : 0u;
 		if (hit_count)
 			atomicAdd(&counters->primary_hits, hit_count);
 	}
@@ -653,14 +663,17 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// Ordering step: per XCD group, the non-empty tiles sorted by hit count,
-// heaviest first (counting sort, one workgroup per group).
+// Ordering step: per XCD group, the non-empty tiles sorted by their AO cost class
+// (primary_kernel), heaviest first (counting sort, one workgroup per group).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void order_kernel(const uint32_t *__restrict__ tile_hits,
                                                      uint32_t *__restrict__ order, FrameCounters *__restrict__ counters,
                                                      KernelParams P) {
-	__shared__ unsigned int bucket[65];  // tiles per hit count, then running write cursor
+	__shared__ unsigned int bucket[65];     // tiles per cost class, then the heavy classes' write cursors
+	__shared__ unsigned int wave_light[16];  // light tiles per wave of the current chunk
+	__shared__ unsigned int heavy_from, light_base;
 	const uint32_t group = blockIdx.x;
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	const uint32_t strips = (P.tiles_x + 1u) >> 1;
 	const uint32_t strips_here = (strips + XCD_GROUPS - 1u - group) >> 3;
 	const uint32_t tiles_here = strips_here * 2u * P.local_tile_rows;  // incl. a possible column past the image
@@ -671,41 +684,74 @@ __global__ __launch_bounds__(1024) void order_kernel(const uint32_t *__restrict_
 	if (threadIdx.x < 65u)
 		bucket[threadIdx.x] = 0u;
 	__syncthreads();
-	// tile e of the group: strip (e / (2 * rows)), then row-major 2-wide
-	auto tile_of = [&](uint32_t e, uint32_t &tile) -> bool {
+	// tile e of the group: strip (e / (2 * rows)), then row-major 2-wide; returns its cost class (0: no work)
+	auto class_of = [&](uint32_t e, uint32_t &tile) -> uint32_t {
+		if (e >= tiles_here)
+			return 0u;
 		const uint32_t per_strip = 2u * P.local_tile_rows;
 		const uint32_t strip_index = e / per_strip, within = e - strip_index * per_strip;
 		const uint32_t tile_x = 2u * (group + XCD_GROUPS * strip_index) + (within & 1u);
 		const uint32_t local_row = within >> 1;
 		tile = local_row * P.tiles_x + tile_x;
-		return tile_x < P.tiles_x;
+		if (tile_x >= P.tiles_x)
+			return 0u;
+		const uint32_t packed = tile_hits[tile];
+		return P.debug_no_sort ? (packed ? 1u : 0u) : packed >> 8;
 	};
 	for (uint32_t e = threadIdx.x; e < tiles_here; e += blockDim.x) {
 		uint32_t tile;
-		if (tile_of(e, tile))
-			atomicAdd(&bucket[P.debug_no_sort ? (tile_hits[tile] ? 1u : 0u) : tile_hits[tile]], 1u);
+		const uint32_t c = class_of(e, tile);
+		if (c)
+			atomicAdd(&bucket[c], 1u);
 	}
 	__syncthreads();
 	if (threadIdx.x == 0) {
-		// exclusive prefix over descending hit counts; empty tiles are dropped
+		uint32_t total = 0u;
+		for (int c = 1; c <= 64; ++c)
+			total += bucket[c];
+		// The heavy classes -- the costliest tiles, at most 1/heavy_div (8) of them -- go first, costliest first, so
+		// that no long job starts late; everything else keeps its spatial order (cache locality).
+		uint32_t heavy = 0u;
+		int from = 65;
+		while (from > 2 && heavy + bucket[from - 1] <= total / P.heavy_div) {
+			--from;
+			heavy += bucket[from];
+		}
 		uint32_t running = 0u;
-		for (int c = 64; c >= 1; --c) {
+		for (int c = 64; c >= from; --c) {
 			const uint32_t n = bucket[c];
 			bucket[c] = running;
 			running += n;
 		}
-		counters->queue[group].work_tiles = running;
+		heavy_from = (uint32_t) from;
+		light_base = heavy;
+		counters->queue[group].work_tiles = total;
 		counters->queue[group].head = 0u;
 	}
 	__syncthreads();
-	for (uint32_t e = threadIdx.x; e < tiles_here; e += blockDim.x) {
-		uint32_t tile;
-		if (tile_of(e, tile)) {
-			const uint32_t c = P.debug_no_sort ? (tile_hits[tile] ? 1u : 0u) : tile_hits[tile];
-			// entry = tile (26 bits: at most 2^32 sub-pixels per frame) | hit count - 1 (6 bits)
-			if (c)
-				order[segment + atomicAdd(&bucket[c], 1u)] = tile | ((tile_hits[tile] - 1u) << 26);
+	const uint32_t first_heavy = heavy_from;
+	uint32_t light_cursor = light_base;
+	for (uint32_t chunk = 0; chunk < tiles_here; chunk += blockDim.x) {
+		uint32_t tile = 0u;
+		const uint32_t c = class_of(chunk + threadIdx.x, tile);
+		// entry = tile (26 bits: at most 2^32 sub-pixels per frame) | hit count - 1 (6 bits)
+		const uint32_t entry = c ? (tile | (((tile_hits[tile] & 0xFFu) - 1u) << 26)) : 0u;
+		const bool light = c != 0u && c < first_heavy;
+		const unsigned long long light_mask = wave_ballot(light);
+		if (lane == 0u)
+			wave_light[wave] = (uint32_t) __popcll(light_mask);
+		__syncthreads();
+		uint32_t before = 0u, all = 0u;
+		for (uint32_t w = 0; w < 16u; ++w) {
+			before += w < wave ? wave_light[w] : 0u;
+			all += wave_light[w];
 		}
+		if (light)
+			order[segment + light_cursor + before + rank_in(light_mask)] = entry;
+		else if (c)
+			order[segment + atomicAdd(&bucket[c], 1u)] = entry;
+		light_cursor += all;
+		__syncthreads();
 	}
 }
 
@@ -779,6 +825,7 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 #ifdef OCRT_STAMPS
 	unsigned long long stamp_acc[6] = { 0, 0, 0, 0, 0, 0 };
 	const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+	unsigned long long t_last_claim = t_begin, last_units = 0, max_job = 0;
 #endif
 	// Workgroups b and b+8 share an XCD: start with that group's queue, then help the others.
 	const uint32_t home = blockIdx.x & (XCD_GROUPS - 1u);
@@ -816,6 +863,9 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 			const uint32_t claim_end = claimed + want < units ? claimed + want : units;
 			OCRT_STAMP(t_claimed);
 			OCRT_STAMP_ADD(0, t_claimed - t_claim);
+#ifdef OCRT_STAMPS
+			t_last_claim = t_claimed; last_units = claim_end - claimed;
+#endif
 			for (uint32_t unit = claimed; unit < claim_end;) {
 			OCRT_STAMP(t_job);
 			// job = (tile, direction range); a claim that runs over a tile's last direction goes on in
@@ -1006,6 +1056,9 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 			wave_lds_sync();
 			OCRT_STAMP(t_flushed);
 			OCRT_STAMP_ADD(3, t_flushed - t_walked);
+#ifdef OCRT_STAMPS
+			if (t_flushed - t_job > max_job) max_job = t_flushed - t_job;
+#endif
 			}
 		}
 	}
@@ -1016,6 +1069,10 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 	if (lane == 0u) {
 		const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
 		atomicAdd(&counters->stamp[6], t_end - t_begin);               // sum of wave lifetimes
+		atomicAdd(&counters->stamp[11], (t_end - t_last_claim));  // sum over waves: last claim -> end
+		atomicMax(&counters->stamp[10 + 0], 0ull);
+		{ unsigned long long b2 = (t_end - t_last_claim) / 5000ull; atomicAdd(&counters->stamp[12 + 32 + (b2 > 31 ? 31 : b2)], 1ull); }
+		{ unsigned long long bucket = max_job / 2000ull; if (bucket > 31) bucket = 31; atomicAdd(&counters->stamp[12 + (bucket > 63 ? 63 : bucket)], 1ull); }
 		atomicMin(&counters->stamp[7], t_begin);                        // first start
 		atomicMax(&counters->stamp[8], t_end);                          // last end
 		atomicMax(&counters->stamp[9], t_begin);                        // last start
@@ -1037,7 +1094,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(const HitRec *__restrict__
 	__syncthreads();
 	const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t tile = slot >> 6;
-	if (tile < tiles && (slot & 63u) < tile_hits[tile]) {
+	if (tile < tiles && (slot & 63u) < (tile_hits[tile] & 0xFFu)) {
 		const uint32_t occluded = occluded_of[slot];
 		const HitRec rec = hits[slot];
 		image[rec.pixel] = rec.value * (1.0f - ((float) occluded / (float) ao_divisor));

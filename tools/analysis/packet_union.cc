@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <algorithm>
 #include "bvh.h"
 #include "mesh.h"
 #include "scene_pack.h"
@@ -58,6 +59,7 @@ int main(int argc, char **argv) {
 	const int ND = (int) table.size() / 4;
 	const float a = 1.0f * (W > H ? W : H);
 	Stats prim, ao;
+	std::vector<double> tile_prim, tile_prim_leaves, tile_ao, tile_hits_v;
 #pragma omp parallel
 	{
 		Stats sp, sa;
@@ -93,6 +95,7 @@ int main(int argc, char **argv) {
 			}
 			// shared primary walk
 			sp.packets++;
+			unsigned long long pv0 = sp.packet_visits, pl0 = sp.packet_leaf_visits, av0 = sa.packet_visits;
 			for (size_t i = 0; i < N;) {
 				sp.packet_visits++;
 				int hits = 0;
@@ -100,6 +103,7 @@ int main(int argc, char **argv) {
 				sp.lane_box_hits += hits; sp.lane_live_at_visit += 64;
 				if (hits) { if (P.nodes[i].skip == 1) sp.packet_leaf_visits++; ++i; } else i += P.nodes[i].skip;
 			}
+			const double my_prim = (double) (sp.packet_visits - pv0), my_leaves = (double) (sp.packet_leaf_visits - pl0);
 			if (!nh) continue;
 			for (int q = 0; q < ND; ++q) {
 				R ar[64];
@@ -152,6 +156,8 @@ int main(int argc, char **argv) {
 					if (hits) { if (P.nodes[i].skip == 1) sa.packet_leaf_visits++; ++i; } else i += P.nodes[i].skip;
 				}
 			}
+#pragma omp critical
+			{ tile_prim.push_back(my_prim); tile_prim_leaves.push_back(my_leaves); tile_ao.push_back((double) (sa.packet_visits - av0)); tile_hits_v.push_back(nh); }
 		}
 #pragma omp critical
 		{
@@ -159,6 +165,9 @@ int main(int argc, char **argv) {
 			for (int k = 0; k < 2; ++k) { d[k]->packets += s[k]->packets; d[k]->rays += s[k]->rays; d[k]->packet_visits += s[k]->packet_visits; d[k]->single_visits += s[k]->single_visits; d[k]->lane_box_hits += s[k]->lane_box_hits; d[k]->lane_live_at_visit += s[k]->lane_live_at_visit; d[k]->leaf_tests += s[k]->leaf_tests; d[k]->packet_leaf_visits += s[k]->packet_leaf_visits; d[k]->nodeath_visits += s[k]->nodeath_visits; d[k]->max_tests_sum += s[k]->max_tests_sum; for (int q = 0; q < 16; ++q) d[k]->tests_hist[q] += s[k]->tests_hist[q]; }
 		}
 	}
+	auto corr = [](const std::vector<double> &x, const std::vector<double> &y) { double mx = 0, my = 0; size_t n = x.size(); for (size_t i = 0; i < n; ++i) { mx += x[i]; my += y[i]; } mx /= n; my /= n; double sxy = 0, sxx = 0, syy = 0; for (size_t i = 0; i < n; ++i) { sxy += (x[i] - mx) * (y[i] - my); sxx += (x[i] - mx) * (x[i] - mx); syy += (y[i] - my) * (y[i] - my); } return sxy / sqrt(sxx * syy); };
+	if (!tile_ao.size()) return 0;
+	{ std::vector<double> sorted = tile_ao; std::sort(sorted.begin(), sorted.end()); size_t n = sorted.size(); printf("per hit tile: AO union visits (28 packets) median %.0f, p90 %.0f, p99 %.0f, max %.0f; corr with primary union visits %.2f, with primary leaf visits %.2f, with hit count %.2f\n", sorted[n / 2], sorted[n * 9 / 10], sorted[n * 99 / 100], sorted[n - 1], corr(tile_prim, tile_ao), corr(tile_prim_leaves, tile_ao), corr(tile_hits_v, tile_ao)); }
 	const char *name[2] = { "primary", "AO" }; Stats *st[2] = { &prim, &ao };
 	for (int k = 0; k < 2; ++k) {
 		Stats &s = *st[k];
