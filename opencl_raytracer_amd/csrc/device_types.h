@@ -102,6 +102,7 @@ struct KernelParams {
 	int32_t debug_no_sort; // debug knob OCRT_NO_SORT: claim tiles in arbitrary order instead of heaviest first
 	uint32_t refill_min;    // wave scheduler: refill once this many lanes are idle (debug knob OCRT_REFILL_MIN)
 	uint32_t leaf_min;      // ... test triangles once this many leaves are pending (OCRT_LEAF_MIN)
+	uint32_t batch_below;   // AO: a leaf hit by fewer lanes than this has its triangle tests deferred and batched
 	uint32_t heavy_div;     // the ordering step moves the costliest 1/heavy_div of a group's tiles to the front
 	uint32_t cost_shift;    // AO cost classes are (leaf stops of the primary walk x fill) >> cost_shift
 	uint32_t ao_claim_max;  // most (tile, direction) units one AO claim takes; 0 = a twelfth of a wave's share, 4 .. ao_dirs

@@ -113,6 +113,20 @@ __device__ __forceinline__ bool slab_hit(const float4 lo, const float4 hi, const
 // ---------------------------------------------------------------------------
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 
+// Orders this wave's LDS writes before its later LDS reads.  A wave executes in
+// lockstep and the LDS unit serves one wave's requests in order, so only the
+// compiler must be kept from reordering across this point.
+__device__ __forceinline__ void wave_lds_sync() {
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Position of this lane among the set bits of `mask` below it.
+__device__ __forceinline__ uint32_t rank_in(unsigned long long mask) {
+	return __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
+}
+
 // The lanes' predicate as a 64-bit mask, straight from the compare (HIP's __ballot goes through an int).
 __device__ __forceinline__ unsigned long long wave_ballot(bool predicate) { return __builtin_amdgcn_ballot_w64(predicate); }
 
@@ -415,34 +429,238 @@ __device__ __forceinline__ unsigned long long walk_to_leaf(const float4 *nodes_p
 	return hit_mask;
 }
 
+// The any-hit (AO) variant of walk_to_leaf: at a leaf hit by fewer than `batch_below`
+// lanes it does not stop but appends the (lane, leaf) pairs to the wave's list in LDS
+// (entry = leaf | lane << 26 at index waiting + rank of the lane among the hitters)
+// and walks on -- a leaf stop costs a trip out of this loop, a triangle load and a
+// node reload, and there are 11 of them per packet at one sample per pixel.
+// Returns 0: walk over; 1: `leaf` is hit by many lanes (`hit`), test it now, `at` is
+// on it; 2: 64 or more pairs are waiting, run a batch, `at` is on the leaf appended last.
+// Scratch: s[42:63], v56-v62.
+__device__ __forceinline__ uint32_t walk_collect(const float4 *nodes_ptr, uint32_t &at, uint32_t end, const Ray &ray, float below,
+                                                 unsigned long long alive_mask, unsigned long long &hit_mask, uint32_t &leaf,
+                                                 uint32_t &waiting, uint32_t list_lds_address, uint32_t lane_tag,
+                                                 uint32_t batch_below) {
+	uint32_t status;
+	asm volatile(
+	    ".Lcollect_node_%=:\n"
+	    "\ts_load_dwordx16 s[48:63], %[base], %[at]\n"
+	    "\ts_waitcnt lgkmcnt(0)\n"
+	    "\tv_sub_f32 v56, s48, %[ox]\n"
+	    "\tv_sub_f32 v57, s52, %[ox]\n"
+	    "\tv_sub_f32 v58, s49, %[oy]\n"
+	    "\tv_sub_f32 v59, s53, %[oy]\n"
+	    "\tv_sub_f32 v60, s50, %[oz]\n"
+	    "\tv_sub_f32 v61, s54, %[oz]\n"
+	    "\tv_mul_f32 v56, %[ix], v56\n"
+	    "\tv_mul_f32 v57, %[ix], v57\n"
+	    "\tv_mul_f32 v58, %[iy], v58\n"
+	    "\tv_mul_f32 v59, %[iy], v59\n"
+	    "\tv_mul_f32 v60, %[iz], v60\n"
+	    "\tv_mul_f32 v61, %[iz], v61\n"
+	    "\tv_min_f32 v62, v56, v57\n"
+	    "\tv_max_f32 v56, v56, v57\n"
+	    "\tv_min_f32 v57, v58, v59\n"
+	    "\tv_max_f32 v58, v58, v59\n"
+	    "\tv_min_f32 v59, v60, v61\n"
+	    "\tv_max_f32 v60, v60, v61\n"
+	    "\tv_max_f32 v59, 1, v59\n"
+	    "\tv_min_f32 v60, %[below], v60\n"
+	    "\tv_max3_f32 v62, v62, v57, v59\n"
+	    "\tv_min3_f32 v56, v56, v58, v60\n"
+	    "\tv_cmp_le_f32 vcc, v62, v56\n"
+	    "\ts_and_b64 s[44:45], vcc, %[alive]\n"
+	    "\ts_cmp_lg_u64 s[44:45], 0\n"
+	    "\ts_cbranch_scc1 .Lcollect_hit_a_%=\n"
+	    "\ts_lshl_b32 s51, s51, 5\n"
+	    "\ts_add_u32 %[at], %[at], s51\n"
+	    "\ts_cmp_lt_u32 %[at], %[end]\n"
+	    "\ts_cbranch_scc1 .Lcollect_node_%=\n"
+	    "\ts_branch .Lcollect_over_%=\n"
+	    ".Lcollect_hit_a_%=:\n"
+	    "\ts_cmp_lg_u32 s55, -1\n"
+	    "\ts_cbranch_scc1 .Lcollect_leaf_a_%=\n"
+	    ".Lcollect_next_b_%=:\n"
+	    "\ts_add_u32 %[at], %[at], 32\n"
+	    "\ts_cmp_lt_u32 %[at], %[end]\n"
+	    "\ts_cbranch_scc0 .Lcollect_over_%=\n"
+	    "\tv_sub_f32 v56, s56, %[ox]\n"
+	    "\tv_sub_f32 v57, s60, %[ox]\n"
+	    "\tv_sub_f32 v58, s57, %[oy]\n"
+	    "\tv_sub_f32 v59, s61, %[oy]\n"
+	    "\tv_sub_f32 v60, s58, %[oz]\n"
+	    "\tv_sub_f32 v61, s62, %[oz]\n"
+	    "\tv_mul_f32 v56, %[ix], v56\n"
+	    "\tv_mul_f32 v57, %[ix], v57\n"
+	    "\tv_mul_f32 v58, %[iy], v58\n"
+	    "\tv_mul_f32 v59, %[iy], v59\n"
+	    "\tv_mul_f32 v60, %[iz], v60\n"
+	    "\tv_mul_f32 v61, %[iz], v61\n"
+	    "\tv_min_f32 v62, v56, v57\n"
+	    "\tv_max_f32 v56, v56, v57\n"
+	    "\tv_min_f32 v57, v58, v59\n"
+	    "\tv_max_f32 v58, v58, v59\n"
+	    "\tv_min_f32 v59, v60, v61\n"
+	    "\tv_max_f32 v60, v60, v61\n"
+	    "\tv_max_f32 v59, 1, v59\n"
+	    "\tv_min_f32 v60, %[below], v60\n"
+	    "\tv_max3_f32 v62, v62, v57, v59\n"
+	    "\tv_min3_f32 v56, v56, v58, v60\n"
+	    "\tv_cmp_le_f32 vcc, v62, v56\n"
+	    "\ts_and_b64 s[44:45], vcc, %[alive]\n"
+	    "\ts_cmp_lg_u64 s[44:45], 0\n"
+	    "\ts_cbranch_scc1 .Lcollect_hit_b_%=\n"
+	    "\ts_lshl_b32 s59, s59, 5\n"
+	    "\ts_add_u32 %[at], %[at], s59\n"
+	    "\ts_cmp_lt_u32 %[at], %[end]\n"
+	    "\ts_cbranch_scc1 .Lcollect_node_%=\n"
+	    "\ts_branch .Lcollect_over_%=\n"
+	    ".Lcollect_hit_b_%=:\n"
+	    "\ts_cmp_lg_u32 s63, -1\n"
+	    "\ts_cbranch_scc1 .Lcollect_leaf_b_%=\n"
+	    ".Lcollect_next_a_%=:\n"
+	    "\ts_add_u32 %[at], %[at], 32\n"
+	    "\ts_cmp_lt_u32 %[at], %[end]\n"
+	    "\ts_cbranch_scc1 .Lcollect_node_%=\n"
+	    "\ts_branch .Lcollect_over_%=\n"
+	    ".Lcollect_leaf_a_%=:\n"
+	    "\ts_bcnt1_i32_b64 s46, s[44:45]\n"
+	    "\ts_cmp_ge_u32 s46, %[batch_below]\n"
+	    "\ts_cbranch_scc1 .Lcollect_now_a_%=\n"
+	    "\tv_mbcnt_lo_u32_b32 v56, s44, 0\n"
+	    "\tv_mbcnt_hi_u32_b32 v56, s45, v56\n"
+	    "\tv_add_u32 v56, %[waiting], v56\n"
+	    "\tv_lshl_add_u32 v56, v56, 2, %[list]\n"
+	    "\tv_or_b32 v57, s55, %[tag]\n"
+	    "\ts_mov_b64 s[42:43], exec\n"
+	    "\ts_mov_b64 exec, s[44:45]\n"
+	    "\tds_write_b32 v56, v57\n"
+	    "\ts_mov_b64 exec, s[42:43]\n"
+	    "\ts_add_u32 %[waiting], %[waiting], s46\n"
+	    "\ts_cmp_ge_u32 %[waiting], 64\n"
+	    "\ts_cbranch_scc1 .Lcollect_full_%=\n"
+	    "\ts_branch .Lcollect_next_b_%=\n"
+	    ".Lcollect_now_a_%=:\n"
+	    "\ts_mov_b32 %[leaf], s55\n"
+	    "\ts_branch .Lcollect_now_%=\n"
+	    ".Lcollect_leaf_b_%=:\n"
+	    "\ts_bcnt1_i32_b64 s46, s[44:45]\n"
+	    "\ts_cmp_ge_u32 s46, %[batch_below]\n"
+	    "\ts_cbranch_scc1 .Lcollect_now_b_%=\n"
+	    "\tv_mbcnt_lo_u32_b32 v56, s44, 0\n"
+	    "\tv_mbcnt_hi_u32_b32 v56, s45, v56\n"
+	    "\tv_add_u32 v56, %[waiting], v56\n"
+	    "\tv_lshl_add_u32 v56, v56, 2, %[list]\n"
+	    "\tv_or_b32 v57, s63, %[tag]\n"
+	    "\ts_mov_b64 s[42:43], exec\n"
+	    "\ts_mov_b64 exec, s[44:45]\n"
+	    "\tds_write_b32 v56, v57\n"
+	    "\ts_mov_b64 exec, s[42:43]\n"
+	    "\ts_add_u32 %[waiting], %[waiting], s46\n"
+	    "\ts_cmp_ge_u32 %[waiting], 64\n"
+	    "\ts_cbranch_scc1 .Lcollect_full_%=\n"
+	    "\ts_branch .Lcollect_next_a_%=\n"
+	    ".Lcollect_now_b_%=:\n"
+	    "\ts_mov_b32 %[leaf], s63\n"
+	    ".Lcollect_now_%=:\n"
+	    "\ts_mov_b64 %[hit], s[44:45]\n"
+	    "\ts_mov_b32 %[status], 1\n"
+	    "\ts_branch .Lcollect_out_%=\n"
+	    ".Lcollect_full_%=:\n"
+	    "\ts_mov_b32 %[status], 2\n"
+	    "\ts_branch .Lcollect_out_%=\n"
+	    ".Lcollect_over_%=:\n"
+	    "\ts_mov_b32 %[status], 0\n"
+	    ".Lcollect_out_%=:\n"
+	    : [at] "+s"(at), [waiting] "+s"(waiting), [hit] "=&s"(hit_mask), [leaf] "=&s"(leaf), [status] "=&s"(status)
+	    : [base] "s"(nodes_ptr), [end] "s"(end), [alive] "s"(alive_mask), [below] "s"(below), [batch_below] "s"(batch_below),
+	      [list] "v"(list_lds_address), [tag] "v"(lane_tag), [ox] "v"(ray.ox), [oy] "v"(ray.oy), [oz] "v"(ray.oz), [ix] "v"(ray.ix),
+	      [iy] "v"(ray.iy), [iz] "v"(ray.iz)
+	    : "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59",
+	      "s60", "s61", "s62", "s63", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "vcc", "scc", "memory");
+	return status;
+}
+
+// Triangle tests of an any-hit packet waiting to be run 64 at a time (LDS, one per wave).
+struct LeafBatch {
+	unsigned int entry[128];       // leaf | owning lane << 26; up to 63 waiting + 64 appended at one leaf
+	unsigned int occluded_bits[2];  // lanes whose ray was found occluded by the batch just run
+};
+
 // Any-hit shared walk of one packet (AO): a lane leaves at its first accepted
 // triangle and bumps *occluded (reference :251 only uses the boolean).
 template <bool EXACT>
 __device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ nodes_ptr, __amdgpu_buffer_rsrc_t nodes_rsrc,
-                                                    const float4 *__restrict__ tris_ptr, uint32_t count, const Ray &ray, float max_distance, float below,
-                                                    bool alive, uint32_t lane, unsigned int *occluded) {
+                                                    const float4 *__restrict__ tris_ptr, __amdgpu_buffer_rsrc_t tris_rsrc, uint32_t count,
+                                                    const Ray &ray, float max_distance, float below, bool alive, uint32_t lane,
+                                                    unsigned int *occluded, LeafBatch &batch, uint32_t batch_below) {
 	// the live lanes as a scalar mask: the node steps then need no per-lane bookkeeping at all
 	unsigned long long alive_mask = wave_ballot(alive);
 	if (!EXACT) {
+		// The triangle tests are not run where the walk meets them -- a leaf is hit by 15 of the 64
+		// rays on average -- but collected as (ray, leaf) pairs and run 64 at a time, each lane taking
+		// ANY pair: it fetches that ray from its owner (cross-lane reads) and the triangle by a
+		// gather.  An any-hit ray only needs "some accepted triangle", so neither the order of the
+		// tests nor who computes them matters, and every test is the same arithmetic on the same
+		// operands as before.  A ray found occluded leaves the walk after the batch instead of at
+		// the leaf, which only lets it ride along a little longer.
+		uint32_t waiting = 0u;  // pairs in batch.entry (wave-uniform)
+		auto run_batch = [&](uint32_t n) {
+			wave_lds_sync();
+			const uint32_t pair = batch.entry[lane < n ? lane : 0u];
+			const int owner = (int) (pair >> 26);
+			Ray theirs;
+			theirs.ox = __shfl(ray.ox, owner); theirs.oy = __shfl(ray.oy, owner); theirs.oz = __shfl(ray.oz, owner);
+			theirs.dx = __shfl(ray.dx, owner); theirs.dy = __shfl(ray.dy, owner); theirs.dz = __shfl(ray.dz, owner);
+			theirs.ix = theirs.iy = theirs.iz = 0.0f;  // (the triangle test does not use them)
+			if (lane < n) {
+				const TriResult tr = tri_test<false>(tris_rsrc, pair & 0x03FFFFFFu, theirs);
+				if (tr.accepted)
+					atomicOr(&batch.occluded_bits[owner >> 5], 1u << (owner & 31));
+			}
+			wave_lds_sync();
+			const uint32_t bits = batch.occluded_bits[lane >> 5];
+			if (alive && ((bits >> (lane & 31u)) & 1u)) {
+				atomicAdd(occluded, 1u);  // once per ray, however many of its pairs were accepted
+				alive = false;
+			}
+			wave_lds_sync();
+			if (lane < 2u)
+				batch.occluded_bits[lane] = 0u;
+			alive_mask = wave_ballot(alive);
+		};
 		uint32_t at = 0u;  // byte offset of the node (count < 2^27, checked at upload)
 		const uint32_t end = count * 32u;
+		const uint32_t list_lds_address = (uint32_t) (uintptr_t) &batch.entry[0];  // (low half of the flat address)
 		while (alive_mask != 0ull && at < end) {
-			uint32_t leaf;
-			const unsigned long long hit_mask = walk_to_leaf(nodes_ptr, at, end, ray, below, alive_mask, leaf);
-			if (hit_mask == 0ull)
+			uint32_t leaf = 0u;
+			unsigned long long hit_mask = 0ull;
+			const uint32_t status = walk_collect(nodes_ptr, at, end, ray, below, alive_mask, hit_mask, leaf, waiting,
+			                                     list_lds_address, lane << 26, batch_below);
+			if (status == 0u)
 				break;
-			const float4 q0 = tris_ptr[4u * leaf], q1 = tris_ptr[4u * leaf + 1u];
-			const float4 q2 = tris_ptr[4u * leaf + 2u], q3 = tris_ptr[4u * leaf + 3u];
-			if ((hit_mask >> lane) & 1ull) {
-				const TriResult tr = tri_eval<false>(q0, q1, q2, q3, ray);
-				if (tr.accepted) {
-					atomicAdd(occluded, 1u);
-					alive = false;
+			if (status == 1u) {
+				// enough of the packet is at this leaf: test it here, the triangle out of SGPRs
+				const float4 q0 = tris_ptr[4u * leaf], q1 = tris_ptr[4u * leaf + 1u];
+				const float4 q2 = tris_ptr[4u * leaf + 2u], q3 = tris_ptr[4u * leaf + 3u];
+				if ((hit_mask >> lane) & 1ull) {
+					const TriResult tr = tri_eval<false>(q0, q1, q2, q3, ray);
+					if (tr.accepted) {
+						atomicAdd(occluded, 1u);
+						alive = false;
+					}
 				}
+				alive_mask = wave_ballot(alive);
+			} else {
+				run_batch(64u);
+				waiting -= 64u;
+				if (lane < waiting)  // the pairs beyond the batch move to the front
+					batch.entry[lane] = batch.entry[64u + lane];
 			}
-			alive_mask = wave_ballot(alive);
 			at += 32u;
 		}
+		if (waiting != 0u)
+			run_batch(waiting);
 		return;
 	}
 	uint32_t mine = 0u;
@@ -474,10 +692,6 @@ __device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ n
 	}
 }
 
-// Position of this lane among the set bits of `mask` below it.
-__device__ __forceinline__ uint32_t rank_in(unsigned long long mask) {
-	return __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
-}
 
 // Tile <-> workgroup mapping shared by the passes.  A workgroup of the primary
 // pass covers 2x2 tiles (16x16 sub-pixels).  Workgroups b and b+8 share an XCD
@@ -789,16 +1003,9 @@ struct TileShared {
 	float frame[12][64];  // origin xyz, basis_x xyz, basis_y xyz, basis_z xyz
 	unsigned int occluded[64];
 	unsigned int pixel[64];  // RANDOM mode: the sub-pixel's image index seeds its generator
+	LeafBatch batch;
 };
 
-// Orders this wave's LDS writes before its later LDS reads.  A wave executes in
-// lockstep and the LDS unit serves one wave's requests in order, so only the
-// compiler must be kept from reordering across this point.
-__device__ __forceinline__ void wave_lds_sync() {
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-	__builtin_amdgcn_wave_barrier();
-	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 // MODE is AO_UNIFORM or AO_RANDOM: two instantiations, so that the RANDOM sampler's
 // code and registers stay out of the default path.
@@ -910,6 +1117,8 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 				sh.frame[9][lane] = bzx; sh.frame[10][lane] = bzy; sh.frame[11][lane] = bzz;
 			}
 			sh.occluded[lane] = 0u;
+			if (lane < 2u)
+				sh.batch.occluded_bits[lane] = 0u;
 			wave_lds_sync();
 			OCRT_STAMP(t_frames);
 			OCRT_STAMP_ADD(1, t_frames - t_job);
@@ -1034,11 +1243,11 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 						setup_ray(base + lane, whole, shared_dir);
 					const bool exact = !scene_fast || wave_ballot(alive && !regular) != 0ull;
 					if (exact)
-						shared_walk_any_hit<true>(nodes_ptr, scene.nodes, tris_ptr, count, ray, P.ao_max_distance, P.ao_below, alive,
-						                          lane, &sh.occluded[h]);
+						shared_walk_any_hit<true>(nodes_ptr, scene.nodes, tris_ptr, scene.tris, count, ray, P.ao_max_distance,
+						                          P.ao_below, alive, lane, &sh.occluded[h], sh.batch, P.batch_below);
 					else
-						shared_walk_any_hit<false>(nodes_ptr, scene.nodes, tris_ptr, count, ray, P.ao_max_distance, P.ao_below, alive,
-						                           lane, &sh.occluded[h]);
+						shared_walk_any_hit<false>(nodes_ptr, scene.nodes, tris_ptr, scene.tris, count, ray, P.ao_max_distance,
+						                           P.ao_below, alive, lane, &sh.occluded[h], sh.batch, P.batch_below);
 				}
 			}
 			wave_lds_sync();

@@ -196,6 +196,8 @@ KernelParams make_kernel_params(const RayTracer &rt, uint32_t node_count, uint32
 	const char *claim_max = std::getenv("OCRT_AO_CLAIM_MAX");  // debug knob
 	p.ao_claim_max = claim_max && std::atoi(claim_max) > 0 ? (uint32_t) std::atoi(claim_max) : 0u;
 	p.ao_claim_div = 1u;
+	const char *batch_below = std::getenv("OCRT_BATCH_BELOW");  // debug knob
+	p.batch_below = batch_below ? (uint32_t) std::atoi(batch_below) : 32u;
 	const char *heavy_div = std::getenv("OCRT_HEAVY_DIV");  // debug knob
 	p.heavy_div = heavy_div && std::atoi(heavy_div) > 0 ? (uint32_t) std::atoi(heavy_div) : 8u;
 	const char *cost_shift = std::getenv("OCRT_COST_SHIFT");  // debug knob
