@@ -291,3 +291,26 @@ def test_lane_by_lane_walk_still_matches(rt, golden, scene_for, name, monkeypatc
     assert hashlib.sha256(host.download().tobytes()).hexdigest() == case["float_sha256"]
     host.close()
 
+
+@pytest.mark.parametrize("knobs", [
+    {"OCRT_BATCH_BELOW": "0"},          # every leaf tested on the spot
+    {"OCRT_BATCH_BELOW": "65"},         # every triangle test deferred and batched
+    {"OCRT_AO_CLAIM_MAX": "1"},         # one direction per claim
+    {"OCRT_AO_CLAIM_MAX": "28", "OCRT_AO_GUIDE": "1000"},
+    {"OCRT_HEAVY_DIV": "1"},            # everything ordered by cost class
+    {"OCRT_HEAVY_DIV": "1000000", "OCRT_NO_SORT": "1"},
+    {"OCRT_FORCE_EXACT_WALK": "1"},     # per-lane cursors + select-based slab test in every packet
+    {"OCRT_AO_BLOCKS": "3"},            # three workgroups do the whole AO pass
+])
+def test_scheduling_knobs_do_not_change_the_image(rt, golden, scene_for, knobs, monkeypatch):
+    """Claim sizes, tile order, batching thresholds and the form of the walk only change who does what when."""
+    for key, value in knobs.items():
+        monkeypatch.setenv(key, value)
+    for name in ("bunny_256_s1_a3", "bunny_101x77_s9_a2", "ties_64_s4_a3"):
+        case = golden["renders"][name]
+        scene, _ = scene_for(case["mesh"], case["bvh"])
+        host = render_hip(rt, scene, options_for(rt, case))
+        assert hashlib.sha256(host.download().tobytes()).hexdigest() == case["float_sha256"], (name, knobs)
+        assert host.stats()["ao_occluded"] == case["counters"]["ao_occluded"]
+        host.close()
+
