@@ -295,16 +295,12 @@ RenderStats DeviceRenderer::stats() {
 #ifdef OCRT_STAMPS
 	std::fprintf(stderr, "AO wave-time: claim %.3f ms, frames %.3f ms, walks %.3f ms, flush %.3f ms over %llu jobs / %llu packets\n",
 	             c.stamp[0] * 1e-5, c.stamp[1] * 1e-5, c.stamp[2] * 1e-5, c.stamp[3] * 1e-5, c.stamp[4], c.stamp[5]);
-	std::fprintf(stderr, "   lifetimes sum %.3f ms, kernel span %.3f ms, last wave started %.3f ms after the first, %llu waves worked\n",
-	             c.stamp[6] * 1e-5, (c.stamp[8] - c.stamp[7]) * 1e-5, (c.stamp[9] - c.stamp[7]) * 1e-5, c.stamp[10]);
-	std::fprintf(stderr, "   waves by their longest job (0.02 ms buckets):");
+	std::fprintf(stderr, "   wave lifetimes sum %.3f ms, kernel span %.3f ms, %llu waves worked\n", c.stamp[6] * 1e-5,
+	             (c.stamp[8] - c.stamp[7]) * 1e-5, c.stamp[9]);
+	std::fprintf(stderr, "   waves by time from their last claim to their end (0.05 ms buckets):");
 	for (int k = 0; k < 32; ++k)
-		if (c.stamp[12 + k])
-			std::fprintf(stderr, " %.2f:%llu", k * 0.02, c.stamp[12 + k]);
-	std::fprintf(stderr, "\n   waves by time from their last claim to their end (0.05 ms buckets):");
-	for (int k = 0; k < 32; ++k)
-		if (c.stamp[12 + 32 + k])
-			std::fprintf(stderr, " %.2f:%llu", k * 0.05, c.stamp[12 + 32 + k]);
+		if (c.stamp[10 + k])
+			std::fprintf(stderr, " %.2f:%llu", k * 0.05, c.stamp[10 + k]);
 	std::fprintf(stderr, "\n");
 #endif
 	// Primary rays = sub-pixels of this rank's bands that lie inside the image.

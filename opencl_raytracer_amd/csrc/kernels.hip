@@ -1032,7 +1032,7 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 #ifdef OCRT_STAMPS
 	unsigned long long stamp_acc[6] = { 0, 0, 0, 0, 0, 0 };
 	const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
-	unsigned long long t_last_claim = t_begin, last_units = 0, max_job = 0;
+	unsigned long long t_last_claim = t_begin;
 #endif
 	// Workgroups b and b+8 share an XCD: start with that group's queue, then help the others.
 	const uint32_t home = blockIdx.x & (XCD_GROUPS - 1u);
@@ -1056,8 +1056,8 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 			const uint32_t seen = __hip_atomic_load(&counters->queue[group].head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			if (seen >= units)
 				break;
-			// Guided self-scheduling: a claim is 1/ao_guide of what is left (ao_guide = twice the
-			// waves of a group) -- whole tiles while there is plenty, so the per-tile set-up is
+			// Guided self-scheduling: a claim is 1/ao_guide of what is left (ao_guide = the waves
+			// of a group) -- whole tiles while there is plenty, so the per-tile set-up is
 			// paid once, single directions at the end, so the frame does not wait for a long last job.
 			uint32_t want = (units - seen) / P.ao_guide;
 			want = want < 1u ? 1u : want > claim_max ? claim_max : want;
@@ -1071,222 +1071,215 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 			OCRT_STAMP(t_claimed);
 			OCRT_STAMP_ADD(0, t_claimed - t_claim);
 #ifdef OCRT_STAMPS
-			t_last_claim = t_claimed; last_units = claim_end - claimed;
+			t_last_claim = t_claimed;
 #endif
 			for (uint32_t unit = claimed; unit < claim_end;) {
-			OCRT_STAMP(t_job);
-			// job = (tile, direction range); a claim that runs over a tile's last direction goes on in
-			// the next tile.  Neighbouring claims work on the same tile: its hit records are shared in L2.
-			const uint32_t tile_index = unit / P.ao_dirs;
-			const uint32_t dir0 = unit - tile_index * P.ao_dirs;
-			const uint32_t n_dirs = P.ao_dirs - dir0 < claim_end - unit ? P.ao_dirs - dir0 : claim_end - unit;
-			unit += n_dirs;
-			const uint32_t entry = order[segment + tile_index];
-			const uint32_t tile = entry & 0x03FFFFFFu;
-			const uint32_t hit_count = (entry >> 26) + 1u;
+				OCRT_STAMP(t_job);
+				// job = (tile, direction range); a claim that runs over a tile's last direction goes on in
+				// the next tile.  Neighbouring claims work on the same tile: its hit records are shared in L2.
+				const uint32_t tile_index = unit / P.ao_dirs;
+				const uint32_t dir0 = unit - tile_index * P.ao_dirs;
+				const uint32_t n_dirs = P.ao_dirs - dir0 < claim_end - unit ? P.ao_dirs - dir0 : claim_end - unit;
+				unit += n_dirs;
+				const uint32_t entry = order[segment + tile_index];
+				const uint32_t tile = entry & 0x03FFFFFFu;
+				const uint32_t hit_count = (entry >> 26) + 1u;
 
-			// ---- the tile's tangent frames -> this wave's LDS slice (reference :215-236) ----
-			if (lane < hit_count) {
-				const float4 q0 = ((const float4 *) hits)[2 * ((size_t) tile * 64u + lane)];
-				const float4 q1 = ((const float4 *) hits)[2 * ((size_t) tile * 64u + lane) + 1];
-				float nx = q1.x, ny = q1.y, nz = q1.z;
-				// p = point + normal * (1.0f / 100000.0f)
-				const float eps = 1.0f / 100000.0f;
-				sh.frame[0][lane] = q0.x + nx * eps;
-				sh.frame[1][lane] = q0.y + ny * eps;
-				sh.frame[2][lane] = q0.z + nz * eps;
-				sh.pixel[lane] = __float_as_uint(q1.w);
-				if (MODE == AO_RANDOM)
-					normalize3(nx, ny, nz);  // hemisphere_sampler normalises once more, reference :155
-				// tangent frame: the smallest |component| of the normal is replaced by 1
-				float hx = nx, hy = ny, hz = nz;
-				const float ax = fabsf(nx), ay = fabsf(ny), az = fabsf(nz);
-				if (ax <= ay && ax <= az)
-					hx = 1.0f;
-				else if (ay <= ax && ay <= az)
-					hy = 1.0f;
-				else if (az <= ax && az <= ay)
-					hz = 1.0f;
-				// basis_x = normalize(cross(h, basis_y)), basis_z = normalize(cross(basis_x, basis_y))
-				float bxx = hy * nz - hz * ny, bxy = hz * nx - hx * nz, bxz = hx * ny - hy * nx;
-				normalize3(bxx, bxy, bxz);
-				float bzx = bxy * nz - bxz * ny, bzy = bxz * nx - bxx * nz, bzz = bxx * ny - bxy * nx;
-				normalize3(bzx, bzy, bzz);
-				sh.frame[3][lane] = bxx; sh.frame[4][lane] = bxy; sh.frame[5][lane] = bxz;
-				sh.frame[6][lane] = nx;  sh.frame[7][lane] = ny;  sh.frame[8][lane] = nz;
-				sh.frame[9][lane] = bzx; sh.frame[10][lane] = bzy; sh.frame[11][lane] = bzz;
-			}
-			sh.occluded[lane] = 0u;
-			if (lane < 2u)
-				sh.batch.occluded_bits[lane] = 0u;
-			wave_lds_sync();
-			OCRT_STAMP(t_frames);
-			OCRT_STAMP_ADD(1, t_frames - t_job);
-
-			// ---- the tile's hit_count * ao_dirs any-hit rays (reference :237-255).  Queue
-			// order is direction-major, so neighbouring lanes cast the same table direction
-			// from neighbouring pixels. ----
-			const uint32_t total = hit_count * n_dirs;
-			uint32_t next = 0u;  // wave-uniform queue head
-			uint32_t i = count;
-			Pending pending = { NONE, NONE };
-			uint32_t h = 0;
-			Ray ray;
-			bool regular = true;
-
-			// ray number `item` of the job -> this lane
-			// `whole` (wave-uniform): the tile is full and the 64 rays are one table direction, `shared_dir`
-			auto setup_ray = [&](uint32_t item, bool whole, const float4 shared_dir) {
-				uint32_t k;
-				float xs = shared_dir.x, ys = shared_dir.y, zs = shared_dir.z;
-				bool along_normal = false;
-				if (whole) {
-					k = item >> 6;
-					h = item & 63u;
-				} else {
-					k = item / hit_count;
-					h = item - k * hit_count;
-					if (MODE == AO_UNIFORM) {
-						const float4 dir = ao_table[dir0 + k];
-						xs = dir.x; ys = dir.y; zs = dir.z;
-					}
+				// ---- the tile's tangent frames -> this wave's LDS slice (reference :215-236) ----
+				if (lane < hit_count) {
+					const float4 q0 = ((const float4 *) hits)[2 * ((size_t) tile * 64u + lane)];
+					const float4 q1 = ((const float4 *) hits)[2 * ((size_t) tile * 64u + lane) + 1];
+					float nx = q1.x, ny = q1.y, nz = q1.z;
+					// p = point + normal * (1.0f / 100000.0f)
+					const float eps = 1.0f / 100000.0f;
+					sh.frame[0][lane] = q0.x + nx * eps;
+					sh.frame[1][lane] = q0.y + ny * eps;
+					sh.frame[2][lane] = q0.z + nz * eps;
+					sh.pixel[lane] = __float_as_uint(q1.w);
+					if (MODE == AO_RANDOM)
+						normalize3(nx, ny, nz);  // hemisphere_sampler normalises once more, reference :155
+					// tangent frame: the smallest |component| of the normal is replaced by 1
+					float hx = nx, hy = ny, hz = nz;
+					const float ax = fabsf(nx), ay = fabsf(ny), az = fabsf(nz);
+					if (ax <= ay && ax <= az)
+						hx = 1.0f;
+					else if (ay <= ax && ay <= az)
+						hy = 1.0f;
+					else if (az <= ax && az <= ay)
+						hz = 1.0f;
+					// basis_x = normalize(cross(h, basis_y)), basis_z = normalize(cross(basis_x, basis_y))
+					float bxx = hy * nz - hz * ny, bxy = hz * nx - hx * nz, bxz = hx * ny - hy * nx;
+					normalize3(bxx, bxy, bxz);
+					float bzx = bxy * nz - bxz * ny, bzy = bxz * nx - bxx * nz, bzz = bxx * ny - bxy * nx;
+					normalize3(bzx, bzy, bzz);
+					sh.frame[3][lane] = bxx; sh.frame[4][lane] = bxy; sh.frame[5][lane] = bxz;
+					sh.frame[6][lane] = nx;  sh.frame[7][lane] = ny;  sh.frame[8][lane] = nz;
+					sh.frame[9][lane] = bzx; sh.frame[10][lane] = bzy; sh.frame[11][lane] = bzz;
 				}
-				if (MODE != AO_UNIFORM) {
-					// RANDOM (reference :153-183, :257-276): ray 0 goes along the normal, ray
-					// j >= 1 uses draws 2j-2 and 2j-1 of the sub-pixel's generator.  Device libm
-					// rounds differently from the host's: this mode is outside the bit-exact contract.
-					const uint32_t j = dir0 + k;
-					along_normal = j == 0u;
-					Rng rng = rng_seed(536870923u * sh.pixel[h]);
-					for (uint32_t skip = 1; skip < j; ++skip) {
-						rng_next(rng);
-						rng_next(rng);
-					}
-					const float xi1 = rng_float(rng);
-					const float xi2 = rng_float(rng);
-					const float theta = acosf(sqrtf(1.0f - xi1));
-					const float phi = (float) (2.0 * (double) xi2);
-					xs = sinf(theta) * cospif(phi);
-					ys = cosf(theta);
-					zs = sinf(theta) * sinpif(phi);
-				}
-				// ray_dir = basis_x * xs + basis_y * ys + basis_z * zs, lane by lane
-				float rx = (sh.frame[3][h] * xs + sh.frame[6][h] * ys) + sh.frame[9][h] * zs;
-				float ry = (sh.frame[4][h] * xs + sh.frame[7][h] * ys) + sh.frame[10][h] * zs;
-				float rz = (sh.frame[5][h] * xs + sh.frame[8][h] * ys) + sh.frame[11][h] * zs;
-				if (MODE == AO_RANDOM) {
-					normalize3(rx, ry, rz);
-					if (along_normal) {
-						// the un-normalised shading normal itself (:263), kept in the hit record
-						const float4 q1 = ((const float4 *) hits)[2 * ((size_t) tile * 64u + h) + 1];
-						rx = q1.x; ry = q1.y; rz = q1.z;
-					}
-				}
-				ray = make_ray(sh.frame[0][h], sh.frame[1][h], sh.frame[2][h], rx, ry, rz);
-				regular = P.scene_regular && P.ao_regular && ray_is_regular(ray);
-			};
+				sh.occluded[lane] = 0u;
+				if (lane < 2u)
+					sh.batch.occluded_bits[lane] = 0u;
+				wave_lds_sync();
+				OCRT_STAMP(t_frames);
+				OCRT_STAMP_ADD(1, t_frames - t_job);
 
-			// Every lane walks on its own; idle lanes are refilled from the job's rays while
-			// next < total.
-			auto walk_individually = [&]() {
-				for (;;) {
-					const bool idle_lane = pending.first == NONE && !(i < count);
-					const unsigned long long walking = wave_ballot(can_walk(pending, i, count));
-					const uint32_t n_leaves = (uint32_t) __popcll(wave_ballot(pending.first != NONE));
-					const unsigned long long idle_mask = wave_ballot(idle_lane);
-					const uint32_t idle = (uint32_t) __popcll(idle_mask);
-					if (next < total && idle >= P.refill_min) {
-						const uint32_t item = next + rank_in(idle_mask);
-						if (idle_lane && item < total) {
-							setup_ray(item, false, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
-							i = 0u;
+				// ---- the tile's hit_count * ao_dirs any-hit rays (reference :237-255).  Queue
+				// order is direction-major, so neighbouring lanes cast the same table direction
+				// from neighbouring pixels. ----
+				const uint32_t total = hit_count * n_dirs;
+				uint32_t next = 0u;  // wave-uniform queue head
+				uint32_t i = count;
+				Pending pending = { NONE, NONE };
+				uint32_t h = 0;
+				Ray ray;
+				bool regular = true;
+
+				// ray number `item` of the job -> this lane
+				// `whole` (wave-uniform): the tile is full and the 64 rays are one table direction, `shared_dir`
+				auto setup_ray = [&](uint32_t item, bool whole, const float4 shared_dir) {
+					uint32_t k;
+					float xs = shared_dir.x, ys = shared_dir.y, zs = shared_dir.z;
+					bool along_normal = false;
+					if (whole) {
+						k = item >> 6;
+						h = item & 63u;
+					} else {
+						k = item / hit_count;
+						h = item - k * hit_count;
+						if (MODE == AO_UNIFORM) {
+							const float4 dir = ao_table[dir0 + k];
+							xs = dir.x; ys = dir.y; zs = dir.z;
 						}
-						next += idle;
-						continue;
 					}
-					if (n_leaves != 0u && (n_leaves >= P.leaf_min || walking == 0ull)) {
-						if (pending.first != NONE) {
-							const TriResult tr = tri_test<false>(scene.tris, pending.first, ray);
-							pending.first = pending.second;
-							pending.second = NONE;
-							if (tr.accepted) {
-								atomicAdd(&sh.occluded[h], 1u);
-								i = count;  // any-hit: the reference walks on but only uses the boolean (:251)
-								pending.first = NONE;
+					if (MODE != AO_UNIFORM) {
+						// RANDOM (reference :153-183, :257-276): ray 0 goes along the normal, ray
+						// j >= 1 uses draws 2j-2 and 2j-1 of the sub-pixel's generator.  Device libm
+						// rounds differently from the host's: this mode is outside the bit-exact contract.
+						const uint32_t j = dir0 + k;
+						along_normal = j == 0u;
+						Rng rng = rng_seed(536870923u * sh.pixel[h]);
+						for (uint32_t skip = 1; skip < j; ++skip) {
+							rng_next(rng);
+							rng_next(rng);
+						}
+						const float xi1 = rng_float(rng);
+						const float xi2 = rng_float(rng);
+						const float theta = acosf(sqrtf(1.0f - xi1));
+						const float phi = (float) (2.0 * (double) xi2);
+						xs = sinf(theta) * cospif(phi);
+						ys = cosf(theta);
+						zs = sinf(theta) * sinpif(phi);
+					}
+					// ray_dir = basis_x * xs + basis_y * ys + basis_z * zs, lane by lane
+					float rx = (sh.frame[3][h] * xs + sh.frame[6][h] * ys) + sh.frame[9][h] * zs;
+					float ry = (sh.frame[4][h] * xs + sh.frame[7][h] * ys) + sh.frame[10][h] * zs;
+					float rz = (sh.frame[5][h] * xs + sh.frame[8][h] * ys) + sh.frame[11][h] * zs;
+					if (MODE == AO_RANDOM) {
+						normalize3(rx, ry, rz);
+						if (along_normal) {
+							// the un-normalised shading normal itself (:263), kept in the hit record
+							const float4 q1 = ((const float4 *) hits)[2 * ((size_t) tile * 64u + h) + 1];
+							rx = q1.x; ry = q1.y; rz = q1.z;
+						}
+					}
+					ray = make_ray(sh.frame[0][h], sh.frame[1][h], sh.frame[2][h], rx, ry, rz);
+					regular = P.scene_regular && P.ao_regular && ray_is_regular(ray);
+				};
+
+				// Every lane walks on its own; idle lanes are refilled from the job's rays while
+				// next < total.
+				auto walk_individually = [&]() {
+					for (;;) {
+						const bool idle_lane = pending.first == NONE && !(i < count);
+						const unsigned long long walking = wave_ballot(can_walk(pending, i, count));
+						const uint32_t n_leaves = (uint32_t) __popcll(wave_ballot(pending.first != NONE));
+						const unsigned long long idle_mask = wave_ballot(idle_lane);
+						const uint32_t idle = (uint32_t) __popcll(idle_mask);
+						if (next < total && idle >= P.refill_min) {
+							const uint32_t item = next + rank_in(idle_mask);
+							if (idle_lane && item < total) {
+								setup_ray(item, false, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+								i = 0u;
 							}
+							next += idle;
+							continue;
 						}
-						continue;
-					}
-					if (walking == 0ull)
-						break;
-					advance_walkers(scene, ray, regular, P.ao_max_distance, P.ao_below, count, i, pending);
-					// a second node straight away while few leaves are pending: halves the scheduling overhead
-					if ((uint32_t) __popcll(wave_ballot(pending.first != NONE)) < P.leaf_min)
+						if (n_leaves != 0u && (n_leaves >= P.leaf_min || walking == 0ull)) {
+							if (pending.first != NONE) {
+								const TriResult tr = tri_test<false>(scene.tris, pending.first, ray);
+								pending.first = pending.second;
+								pending.second = NONE;
+								if (tr.accepted) {
+									atomicAdd(&sh.occluded[h], 1u);
+									i = count;  // any-hit: the reference walks on but only uses the boolean (:251)
+									pending.first = NONE;
+								}
+							}
+							continue;
+						}
+						if (walking == 0ull)
+							break;
 						advance_walkers(scene, ray, regular, P.ao_max_distance, P.ao_below, count, i, pending);
-				}
-			};
+						// a second node straight away while few leaves are pending: halves the scheduling overhead
+						if ((uint32_t) __popcll(wave_ballot(pending.first != NONE)) < P.leaf_min)
+							advance_walkers(scene, ray, regular, P.ao_max_distance, P.ao_below, count, i, pending);
+					}
+				};
 
-			if (!SHARED) {
-				walk_individually();
-			} else {
-				// shared walks (see shared_box) of 64 consecutive rays of the job at a time; a lane
-				// leaves at its first accepted triangle
-				const bool scene_fast = P.scene_regular && P.scene_nested && P.ao_regular;
-				for (uint32_t base = 0u; base < total; base += 64u) {
-					bool alive = base + lane < total;
-					// a full tile's packet is one table direction: the entry comes by a scalar load
-					const bool whole = hit_count == 64u;
-					float4 shared_dir = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-					if (whole && MODE == AO_UNIFORM)
-						shared_dir = ao_table[dir0 + (base >> 6)];
-					if (alive)
-						setup_ray(base + lane, whole, shared_dir);
-					const bool exact = !scene_fast || wave_ballot(alive && !regular) != 0ull;
-					if (exact)
-						shared_walk_any_hit<true>(nodes_ptr, scene.nodes, tris_ptr, scene.tris, count, ray, P.ao_max_distance,
-						                          P.ao_below, alive, lane, &sh.occluded[h], sh.batch, P.batch_below);
-					else
-						shared_walk_any_hit<false>(nodes_ptr, scene.nodes, tris_ptr, scene.tris, count, ray, P.ao_max_distance,
-						                           P.ao_below, alive, lane, &sh.occluded[h], sh.batch, P.batch_below);
+				if (!SHARED) {
+					walk_individually();
+				} else {
+					// shared walks (see shared_box) of 64 consecutive rays of the job at a time; a lane
+					// leaves at its first accepted triangle
+					const bool scene_fast = P.scene_regular && P.scene_nested && P.ao_regular;
+					for (uint32_t base = 0u; base < total; base += 64u) {
+						bool alive = base + lane < total;
+						// a full tile's packet is one table direction: the entry comes by a scalar load
+						const bool whole = hit_count == 64u;
+						float4 shared_dir = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+						if (whole && MODE == AO_UNIFORM)
+							shared_dir = ao_table[dir0 + (base >> 6)];
+						if (alive)
+							setup_ray(base + lane, whole, shared_dir);
+						const bool exact = !scene_fast || wave_ballot(alive && !regular) != 0ull;
+						if (exact)
+							shared_walk_any_hit<true>(nodes_ptr, scene.nodes, tris_ptr, scene.tris, count, ray, P.ao_max_distance,
+							                          P.ao_below, alive, lane, &sh.occluded[h], sh.batch, P.batch_below);
+						else
+							shared_walk_any_hit<false>(nodes_ptr, scene.nodes, tris_ptr, scene.tris, count, ray, P.ao_max_distance,
+							                           P.ao_below, alive, lane, &sh.occluded[h], sh.batch, P.batch_below);
+					}
 				}
-			}
-			wave_lds_sync();
-			OCRT_STAMP(t_walked);
-			OCRT_STAMP_ADD(2, t_walked - t_frames);
-			OCRT_STAMP_ADD(4, 1);
-			OCRT_STAMP_ADD(5, (total + 63u) / 64u);
+				wave_lds_sync();
+				OCRT_STAMP(t_walked);
+				OCRT_STAMP_ADD(2, t_walked - t_frames);
+				OCRT_STAMP_ADD(4, 1);
+				OCRT_STAMP_ADD(5, (total + 63u) / 64u);
 
-			// ---- this job's share of the occlusion counts ----
-			if (lane < hit_count) {
-				const uint32_t occluded = sh.occluded[lane];
-				if (occluded)
-					atomicAdd(&occluded_of[(size_t) tile * 64u + lane], occluded);
-			}
-			wave_lds_sync();
-			OCRT_STAMP(t_flushed);
-			OCRT_STAMP_ADD(3, t_flushed - t_walked);
-#ifdef OCRT_STAMPS
-			if (t_flushed - t_job > max_job) max_job = t_flushed - t_job;
-#endif
+				// ---- this job's share of the occlusion counts ----
+				if (lane < hit_count) {
+					const uint32_t occluded = sh.occluded[lane];
+					if (occluded)
+						atomicAdd(&occluded_of[(size_t) tile * 64u + lane], occluded);
+				}
+				wave_lds_sync();
+				OCRT_STAMP(t_flushed);
+				OCRT_STAMP_ADD(3, t_flushed - t_walked);
 			}
 		}
 	}
 #ifdef OCRT_STAMPS
-	if (lane == 0u)
-		for (int k = 0; k < 6; ++k)
-			atomicAdd(&counters->stamp[k], stamp_acc[k]);
 	if (lane == 0u) {
 		const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
-		atomicAdd(&counters->stamp[6], t_end - t_begin);               // sum of wave lifetimes
-		atomicAdd(&counters->stamp[11], (t_end - t_last_claim));  // sum over waves: last claim -> end
-		atomicMax(&counters->stamp[10 + 0], 0ull);
-		{ unsigned long long b2 = (t_end - t_last_claim) / 5000ull; atomicAdd(&counters->stamp[12 + 32 + (b2 > 31 ? 31 : b2)], 1ull); }
-		{ unsigned long long bucket = max_job / 2000ull; if (bucket > 31) bucket = 31; atomicAdd(&counters->stamp[12 + (bucket > 63 ? 63 : bucket)], 1ull); }
-		atomicMin(&counters->stamp[7], t_begin);                        // first start
-		atomicMax(&counters->stamp[8], t_end);                          // last end
-		atomicMax(&counters->stamp[9], t_begin);                        // last start
+		for (int k = 0; k < 6; ++k)
+			atomicAdd(&counters->stamp[k], stamp_acc[k]);           // claim, frames, walks, flush (10 ns ticks); jobs, packets
+		atomicAdd(&counters->stamp[6], t_end - t_begin);            // sum of wave lifetimes
+		atomicMin(&counters->stamp[7], t_begin);                     // first start
+		atomicMax(&counters->stamp[8], t_end);                       // last end
 		if (stamp_acc[4])
-			atomicAdd(&counters->stamp[10], 1ull);                      // waves that got any job
+			atomicAdd(&counters->stamp[9], 1ull);                    // waves that got any work
+		const unsigned long long idle_bucket = (t_end - t_last_claim) / 5000ull;  // last claim -> end, 0.05 ms buckets
+		atomicAdd(&counters->stamp[10 + (idle_bucket > 31 ? 31 : idle_bucket)], 1ull);
 	}
 #endif
 }
