@@ -858,7 +858,7 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
 		// walk about as far as the primary packet did (correlation 0.8-0.9, tools/analysis/packet_union.cc),
 		// scaled by how full the packets will be.  The hit count alone does not predict the cost at all.
 		uint32_t cost = P.shared_walk ? (leaf_stops * hit_count + 63u) / 64u : hit_count;
-		cost = (cost >> P.cost_shift) + 1u;  // coarse classes: within a class the tiles keep their spatial order
+		cost = cost < 1u ? 1u : cost;
 		cost = cost > 64u ? 64u : cost;
 		tile_hits[tile] = (want_ao && hit_count) ? (hit_count | (cost << 8)) : 0u;
 		if (hit_count)
@@ -877,15 +877,15 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// Ordering step: per XCD group, the non-empty tiles sorted by their AO cost class
-// (primary_kernel), heaviest first (counting sort, one workgroup per group).
+// Ordering step: per XCD group, blocks of 64 neighbouring tiles sorted by their AO
+// cost (sum of the tiles' cost classes from primary_kernel), costliest first; the
+// tiles of a block stay together and in spatial order (counting sort, one workgroup
+// per group, one wave per block).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void order_kernel(const uint32_t *__restrict__ tile_hits,
                                                      uint32_t *__restrict__ order, FrameCounters *__restrict__ counters,
                                                      KernelParams P) {
-	__shared__ unsigned int bucket[65];     // tiles per cost class, then the heavy classes' write cursors
-	__shared__ unsigned int wave_light[16];  // light tiles per wave of the current chunk
-	__shared__ unsigned int heavy_from, light_base;
+	__shared__ unsigned int bucket[65];  // non-empty tiles per key, then the keys' write cursors
 	const uint32_t group = blockIdx.x;
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	const uint32_t strips = (P.tiles_x + 1u) >> 1;
@@ -909,63 +909,53 @@ __global__ __launch_bounds__(1024) void order_kernel(const uint32_t *__restrict_
 		tile = local_row * P.tiles_x + tile_x;
 		if (tile_x >= P.tiles_x)
 			return 0u;
-		const uint32_t packed = tile_hits[tile];
-		return P.debug_no_sort ? (packed ? 1u : 0u) : packed >> 8;
+		return tile_hits[tile] >> 8;
 	};
-	for (uint32_t e = threadIdx.x; e < tiles_here; e += blockDim.x) {
-		uint32_t tile;
-		const uint32_t c = class_of(e, tile);
-		if (c)
-			atomicAdd(&bucket[c], 1u);
+	// One wave per block of 64 spatially consecutive tiles (2 wide, 32 high).  key: the block's cost, 1..64.
+	const uint32_t n_blocks = (tiles_here + 63u) >> 6;
+	auto block_key = [&](uint32_t block, uint32_t &tile, uint32_t &cls, unsigned long long &work_mask) -> uint32_t {
+		cls = class_of(block * 64u + lane, tile);
+		work_mask = wave_ballot(cls != 0u);
+		uint32_t cost = cls;
+		for (int offset = 32; offset >= 1; offset >>= 1)
+			cost += (uint32_t) __shfl_xor((int) cost, offset);
+		const uint32_t key = P.debug_no_sort ? 1u : 1u + (cost >> P.cost_shift);
+		return key > 64u ? 64u : key;
+	};
+	for (uint32_t block = wave; block < n_blocks; block += 16u) {
+		uint32_t tile = 0u, cls;
+		unsigned long long work_mask;
+		const uint32_t key = block_key(block, tile, cls, work_mask);
+		if (lane == 0u && work_mask != 0ull)
+			atomicAdd(&bucket[key], (uint32_t) __popcll(work_mask));
 	}
 	__syncthreads();
 	if (threadIdx.x == 0) {
-		uint32_t total = 0u;
-		for (int c = 1; c <= 64; ++c)
-			total += bucket[c];
-		// The heavy classes -- the costliest tiles, at most 1/heavy_div (8) of them -- go first, costliest first, so
-		// that no long job starts late; everything else keeps its spatial order (cache locality).
-		uint32_t heavy = 0u;
-		int from = 65;
-		while (from > 2 && heavy + bucket[from - 1] <= total / P.heavy_div) {
-			--from;
-			heavy += bucket[from];
-		}
+		// exclusive prefix over descending keys: costly regions first, so that the frame ends on short claims
 		uint32_t running = 0u;
-		for (int c = 64; c >= from; --c) {
-			const uint32_t n = bucket[c];
-			bucket[c] = running;
+		for (int k = 64; k >= 1; --k) {
+			const uint32_t n = bucket[k];
+			bucket[k] = running;
 			running += n;
 		}
-		heavy_from = (uint32_t) from;
-		light_base = heavy;
-		counters->queue[group].work_tiles = total;
+		counters->queue[group].work_tiles = running;
 		counters->queue[group].head = 0u;
 	}
 	__syncthreads();
-	const uint32_t first_heavy = heavy_from;
-	uint32_t light_cursor = light_base;
-	for (uint32_t chunk = 0; chunk < tiles_here; chunk += blockDim.x) {
-		uint32_t tile = 0u;
-		const uint32_t c = class_of(chunk + threadIdx.x, tile);
-		// entry = tile (26 bits: at most 2^32 sub-pixels per frame) | hit count - 1 (6 bits)
-		const uint32_t entry = c ? (tile | (((tile_hits[tile] & 0xFFu) - 1u) << 26)) : 0u;
-		const bool light = c != 0u && c < first_heavy;
-		const unsigned long long light_mask = wave_ballot(light);
+	for (uint32_t block = wave; block < n_blocks; block += 16u) {
+		uint32_t tile = 0u, cls;
+		unsigned long long work_mask;
+		const uint32_t key = block_key(block, tile, cls, work_mask);
+		if (work_mask == 0ull)
+			continue;
+		uint32_t base = 0u;
 		if (lane == 0u)
-			wave_light[wave] = (uint32_t) __popcll(light_mask);
-		__syncthreads();
-		uint32_t before = 0u, all = 0u;
-		for (uint32_t w = 0; w < 16u; ++w) {
-			before += w < wave ? wave_light[w] : 0u;
-			all += wave_light[w];
-		}
-		if (light)
-			order[segment + light_cursor + before + rank_in(light_mask)] = entry;
-		else if (c)
-			order[segment + atomicAdd(&bucket[c], 1u)] = entry;
-		light_cursor += all;
-		__syncthreads();
+			base = atomicAdd(&bucket[key], (uint32_t) __popcll(work_mask));
+		base = (uint32_t) __builtin_amdgcn_readfirstlane((int) base);
+		// entry = tile (26 bits: at most 2^32 sub-pixels per frame) | hit count - 1 (6 bits); inside a block
+		// the tiles keep their spatial order
+		if (cls)
+			order[segment + base + rank_in(work_mask)] = tile | (((tile_hits[tile] & 0xFFu) - 1u) << 26);
 	}
 }
 

@@ -198,10 +198,8 @@ KernelParams make_kernel_params(const RayTracer &rt, uint32_t node_count, uint32
 	p.ao_claim_div = 1u;
 	const char *batch_below = std::getenv("OCRT_BATCH_BELOW");  // debug knob
 	p.batch_below = batch_below ? (uint32_t) std::atoi(batch_below) : 32u;
-	const char *heavy_div = std::getenv("OCRT_HEAVY_DIV");  // debug knob
-	p.heavy_div = heavy_div && std::atoi(heavy_div) > 0 ? (uint32_t) std::atoi(heavy_div) : 8u;
 	const char *cost_shift = std::getenv("OCRT_COST_SHIFT");  // debug knob
-	p.cost_shift = cost_shift ? (uint32_t) std::atoi(cost_shift) & 31u : 0u;
+	p.cost_shift = cost_shift ? (uint32_t) std::atoi(cost_shift) & 31u : 5u;
 	p.ao_regular = (p.ao_max_distance > 0.0f && std::isfinite(p.ao_max_distance)) ? 1 : 0;
 	p.primary_below = std::nextafterf(100000.0f, 0.0f);
 	p.ao_below = std::nextafterf(p.ao_max_distance, -std::numeric_limits<float>::infinity());

@@ -297,8 +297,8 @@ def test_lane_by_lane_walk_still_matches(rt, golden, scene_for, name, monkeypatc
     {"OCRT_BATCH_BELOW": "65"},         # every triangle test deferred and batched
     {"OCRT_AO_CLAIM_MAX": "1"},         # one direction per claim
     {"OCRT_AO_CLAIM_MAX": "28", "OCRT_AO_GUIDE": "1000"},
-    {"OCRT_HEAVY_DIV": "1"},            # everything ordered by cost class
-    {"OCRT_HEAVY_DIV": "1000000", "OCRT_NO_SORT": "1"},
+    {"OCRT_COST_SHIFT": "0"},           # finest ordering keys
+    {"OCRT_NO_SORT": "1"},              # blocks in spatial order
     {"OCRT_FORCE_EXACT_WALK": "1"},     # per-lane cursors + select-based slab test in every packet
     {"OCRT_AO_BLOCKS": "3"},            # three workgroups do the whole AO pass
 ])
