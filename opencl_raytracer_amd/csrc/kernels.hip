@@ -429,6 +429,16 @@ __device__ __forceinline__ unsigned long long walk_to_leaf(const float4 *nodes_p
 	return hit_mask;
 }
 
+// A node record by one scalar load (asm for the same reason as in walk_to_leaf: a plain load through
+// nodes_ptr next to that loop makes the compiler keep the pointer in VGPRs).
+typedef unsigned int u32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ u32x8 scalar_load_node(const float4 *nodes_ptr, uint32_t at) {
+	u32x8 r;
+	const uint32_t offset = at * 32u;
+	asm volatile("s_load_dwordx8 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(r) : "s"(nodes_ptr), "s"(offset));
+	return r;
+}
+
 // The any-hit (AO) variant of walk_to_leaf: at a leaf hit by fewer than `batch_below`
 // lanes it does not stop but appends the (lane, leaf) pairs to the wave's list in LDS
 // (entry = leaf | lane << 26 at index waiting + rank of the lane among the hitters)
@@ -590,7 +600,7 @@ struct LeafBatch {
 // Any-hit shared walk of one packet (AO): a lane leaves at its first accepted
 // triangle and bumps *occluded (reference :251 only uses the boolean).
 template <bool EXACT>
-__device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ nodes_ptr, __amdgpu_buffer_rsrc_t nodes_rsrc,
+__device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ nodes_ptr,
                                                     const float4 *__restrict__ tris_ptr, __amdgpu_buffer_rsrc_t tris_rsrc, uint32_t count,
                                                     const Ray &ray, float max_distance, float below, bool alive, uint32_t lane,
                                                     unsigned int *occluded, LeafBatch &batch, uint32_t batch_below) {
@@ -666,11 +676,10 @@ __device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ n
 	uint32_t mine = 0u;
 	uint32_t at = 0u;
 	while (at < count) {
-		// (through the buffer descriptor: with plain pointer loads here as well the compiler moves the
-		// node pointer into VGPRs and cannot hand it to walk_to_leaf's scalar operand)
-		const float4 lo = load_f4(nodes_rsrc, at * 32u), hi = load_f4(nodes_rsrc, at * 32u + 16u);
-		const uint32_t skip = (uint32_t) __builtin_amdgcn_readfirstlane((int) __float_as_uint(lo.w));
-		const uint32_t leaf = (uint32_t) __builtin_amdgcn_readfirstlane((int) __float_as_uint(hi.w));
+		const u32x8 node = scalar_load_node(nodes_ptr, at);
+		const float4 lo = make_float4(__uint_as_float(node[0]), __uint_as_float(node[1]), __uint_as_float(node[2]), 0.0f);
+		const float4 hi = make_float4(__uint_as_float(node[4]), __uint_as_float(node[5]), __uint_as_float(node[6]), 0.0f);
+		const uint32_t skip = node[3], leaf = node[7];
 		const bool here = alive && mine == at;
 		const bool box = here && slab_hit(lo, hi, ray, max_distance);
 		mine = here ? (box ? at + 1u : at + skip) : mine;
@@ -784,10 +793,10 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
 			uint32_t mine = 0u;
 			uint32_t at = 0u;
 			while (at < count) {
-				// (through the buffer descriptor, see shared_walk_any_hit)
-				const float4 lo = load_f4(scene.nodes, at * 32u), hi = load_f4(scene.nodes, at * 32u + 16u);
-				const uint32_t skip = (uint32_t) __builtin_amdgcn_readfirstlane((int) __float_as_uint(lo.w));
-				const uint32_t leaf = (uint32_t) __builtin_amdgcn_readfirstlane((int) __float_as_uint(hi.w));
+				const u32x8 node = scalar_load_node(nodes_ptr, at);
+				const float4 lo = make_float4(__uint_as_float(node[0]), __uint_as_float(node[1]), __uint_as_float(node[2]), 0.0f);
+				const float4 hi = make_float4(__uint_as_float(node[4]), __uint_as_float(node[5]), __uint_as_float(node[6]), 0.0f);
+				const uint32_t skip = node[3], leaf = node[7];
 				const bool box = shared_box(true, lo, hi, ray, 100000.0f, P.primary_below, active, at, skip, mine);
 				const bool any = wave_ballot(box) != 0ull;
 				if (any && leaf != NONE) {
@@ -1233,10 +1242,10 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 							setup_ray(base + lane, whole, shared_dir);
 						const bool exact = !scene_fast || wave_ballot(alive && !regular) != 0ull;
 						if (exact)
-							shared_walk_any_hit<true>(nodes_ptr, scene.nodes, tris_ptr, scene.tris, count, ray, P.ao_max_distance,
+							shared_walk_any_hit<true>(nodes_ptr, tris_ptr, scene.tris, count, ray, P.ao_max_distance,
 							                          P.ao_below, alive, lane, &sh.occluded[h], sh.batch, P.batch_below);
 						else
-							shared_walk_any_hit<false>(nodes_ptr, scene.nodes, tris_ptr, scene.tris, count, ray, P.ao_max_distance,
+							shared_walk_any_hit<false>(nodes_ptr, tris_ptr, scene.tris, count, ray, P.ao_max_distance,
 							                           P.ao_below, alive, lane, &sh.occluded[h], sh.batch, P.batch_below);
 					}
 				}
