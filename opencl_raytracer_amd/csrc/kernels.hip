@@ -148,6 +148,22 @@ __device__ __forceinline__ bool ray_is_regular(const Ray &r) {
 	       fabsf(r.ix) <= REGULAR_LIMIT && fabsf(r.iy) <= REGULAR_LIMIT && fabsf(r.iz) <= REGULAR_LIMIT;
 }
 
+// What the shared walk's fast form needs of a ray: a finite origin within the limit
+// and reciprocal directions that are numbers (infinite is fine -- a zero direction
+// component -- as long as not all three are).  Its slab test picks near and far by
+// the sign of the reciprocal like the reference's does (`inv >= 0 ? lo : hi`), so
+// (b - o) * inf behaves there exactly as in the reference: -inf / +inf order
+// themselves, and the NaN of 0 * inf is dropped by maxNum / minNum here as it is
+// dropped by the reference's `t_min > ty_max` comparisons and fmax / fmin updates.
+// With all three reciprocals infinite nothing would be left to compare (the
+// reference then rejects on `NaN < max_distance`), hence the exclusion.
+__device__ __forceinline__ bool ray_is_selectable(const Ray &r) {
+	const bool origin_ok = fabsf(r.ox) <= REGULAR_LIMIT && fabsf(r.oy) <= REGULAR_LIMIT && fabsf(r.oz) <= REGULAR_LIMIT;
+	const bool numbers = r.ix == r.ix && r.iy == r.iy && r.iz == r.iz;
+	const bool some_finite = fabsf(r.ix) <= REGULAR_LIMIT || fabsf(r.iy) <= REGULAR_LIMIT || fabsf(r.iz) <= REGULAR_LIMIT;
+	return origin_ok && numbers && some_finite;
+}
+
 // min/max form of the slab test.  For a regular ray against a regular box
 // (finite, lo <= hi) no NaN can arise, (lo-o)*inv and (hi-o)*inv are ordered by
 // the sign of inv (IEEE rounding is monotonic), and the reference's chain of
@@ -323,6 +339,19 @@ __device__ __forceinline__ bool shared_box(bool exact, const float4 lo, const fl
 	return box;
 }
 
+// Per packet: which lanes have a reciprocal direction >= 0 on each axis (the reference's
+// `inv >= 0 ? lo : hi` choice of the near plane, made once instead of at every node).
+struct SignMasks {
+	unsigned long long x, y, z;
+};
+__device__ __forceinline__ SignMasks sign_masks(const Ray &r) {
+	SignMasks m;
+	m.x = wave_ballot(r.ix >= 0.0f);
+	m.y = wave_ballot(r.iy >= 0.0f);
+	m.z = wave_ballot(r.iz >= 0.0f);
+	return m;
+}
+
 // The node steps of the fast form, hand-scheduled: from byte offset `at` on, walks
 // until some live lane hits a LEAF's box (returns its mask and the leaf; `at` stays
 // on that leaf) or the walk is over (returns 0).  Same operations as
@@ -335,7 +364,8 @@ __device__ __forceinline__ bool shared_box(bool exact, const float4 lo, const fl
 // instruction issue and the latency of that load.  Temporaries v56-v62; only scalar
 // outputs, so that the compiler knows the results to be wave-uniform.
 __device__ __forceinline__ unsigned long long walk_to_leaf(const float4 *nodes_ptr, uint32_t &at, uint32_t end, const Ray &ray,
-                                                           float below, unsigned long long alive_mask, uint32_t &leaf) {
+                                                           const SignMasks &sign, float below, unsigned long long alive_mask,
+                                                           uint32_t &leaf) {
 	unsigned long long hit_mask;
 	asm volatile(
 	    ".Lwalk_node_%=:\n"
@@ -353,12 +383,12 @@ __device__ __forceinline__ unsigned long long walk_to_leaf(const float4 *nodes_p
 	    "\tv_mul_f32 v59, %[iy], v59\n"
 	    "\tv_mul_f32 v60, %[iz], v60\n"
 	    "\tv_mul_f32 v61, %[iz], v61\n"
-	    "\tv_min_f32 v62, v56, v57\n"
-	    "\tv_max_f32 v56, v56, v57\n"
-	    "\tv_min_f32 v57, v58, v59\n"
-	    "\tv_max_f32 v58, v58, v59\n"
-	    "\tv_min_f32 v59, v60, v61\n"
-	    "\tv_max_f32 v60, v60, v61\n"
+	    "\tv_cndmask_b32 v62, v57, v56, %[px]\n"
+	    "\tv_cndmask_b32 v56, v56, v57, %[px]\n"
+	    "\tv_cndmask_b32 v57, v59, v58, %[py]\n"
+	    "\tv_cndmask_b32 v58, v58, v59, %[py]\n"
+	    "\tv_cndmask_b32 v59, v61, v60, %[pz]\n"
+	    "\tv_cndmask_b32 v60, v60, v61, %[pz]\n"
 	    "\tv_max_f32 v59, 1, v59\n"
 	    "\tv_min_f32 v60, %[below], v60\n"
 	    "\tv_max3_f32 v62, v62, v57, v59\n"
@@ -388,12 +418,12 @@ __device__ __forceinline__ unsigned long long walk_to_leaf(const float4 *nodes_p
 	    "\tv_mul_f32 v59, %[iy], v59\n"
 	    "\tv_mul_f32 v60, %[iz], v60\n"
 	    "\tv_mul_f32 v61, %[iz], v61\n"
-	    "\tv_min_f32 v62, v56, v57\n"
-	    "\tv_max_f32 v56, v56, v57\n"
-	    "\tv_min_f32 v57, v58, v59\n"
-	    "\tv_max_f32 v58, v58, v59\n"
-	    "\tv_min_f32 v59, v60, v61\n"
-	    "\tv_max_f32 v60, v60, v61\n"
+	    "\tv_cndmask_b32 v62, v57, v56, %[px]\n"
+	    "\tv_cndmask_b32 v56, v56, v57, %[px]\n"
+	    "\tv_cndmask_b32 v57, v59, v58, %[py]\n"
+	    "\tv_cndmask_b32 v58, v58, v59, %[py]\n"
+	    "\tv_cndmask_b32 v59, v61, v60, %[pz]\n"
+	    "\tv_cndmask_b32 v60, v60, v61, %[pz]\n"
 	    "\tv_max_f32 v59, 1, v59\n"
 	    "\tv_min_f32 v60, %[below], v60\n"
 	    "\tv_max3_f32 v62, v62, v57, v59\n"
@@ -422,8 +452,8 @@ __device__ __forceinline__ unsigned long long walk_to_leaf(const float4 *nodes_p
 	    "\ts_mov_b32 %[leaf], s63\n"
 	    ".Lwalk_out_%=:\n"
 	    : [at] "+s"(at), [hit] "=&s"(hit_mask), [leaf] "=&s"(leaf)
-	    : [base] "s"(nodes_ptr), [end] "s"(end), [alive] "s"(alive_mask), [below] "s"(below), [ox] "v"(ray.ox), [oy] "v"(ray.oy),
-	      [oz] "v"(ray.oz), [ix] "v"(ray.ix), [iy] "v"(ray.iy), [iz] "v"(ray.iz)
+	    : [base] "s"(nodes_ptr), [end] "s"(end), [alive] "s"(alive_mask), [below] "s"(below), [px] "s"(sign.x), [py] "s"(sign.y), [pz] "s"(sign.z),
+	      [ox] "v"(ray.ox), [oy] "v"(ray.oy), [oz] "v"(ray.oz), [ix] "v"(ray.ix), [iy] "v"(ray.iy), [iz] "v"(ray.iz)
 	    : "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "v56",
 	      "v57", "v58", "v59", "v60", "v61", "v62", "vcc", "scc");
 	return hit_mask;
@@ -447,7 +477,8 @@ __device__ __forceinline__ u32x8 scalar_load_node(const float4 *nodes_ptr, uint3
 // Returns 0: walk over; 1: `leaf` is hit by many lanes (`hit`), test it now, `at` is
 // on it; 2: 64 or more pairs are waiting, run a batch, `at` is on the leaf appended last.
 // Scratch: s[42:63], v56-v62.
-__device__ __forceinline__ uint32_t walk_collect(const float4 *nodes_ptr, uint32_t &at, uint32_t end, const Ray &ray, float below,
+__device__ __forceinline__ uint32_t walk_collect(const float4 *nodes_ptr, uint32_t &at, uint32_t end, const Ray &ray,
+                                                 const SignMasks &sign, float below,
                                                  unsigned long long alive_mask, unsigned long long &hit_mask, uint32_t &leaf,
                                                  uint32_t &waiting, uint32_t list_lds_address, uint32_t lane_tag,
                                                  uint32_t batch_below) {
@@ -468,12 +499,12 @@ __device__ __forceinline__ uint32_t walk_collect(const float4 *nodes_ptr, uint32
 	    "\tv_mul_f32 v59, %[iy], v59\n"
 	    "\tv_mul_f32 v60, %[iz], v60\n"
 	    "\tv_mul_f32 v61, %[iz], v61\n"
-	    "\tv_min_f32 v62, v56, v57\n"
-	    "\tv_max_f32 v56, v56, v57\n"
-	    "\tv_min_f32 v57, v58, v59\n"
-	    "\tv_max_f32 v58, v58, v59\n"
-	    "\tv_min_f32 v59, v60, v61\n"
-	    "\tv_max_f32 v60, v60, v61\n"
+	    "\tv_cndmask_b32 v62, v57, v56, %[px]\n"
+	    "\tv_cndmask_b32 v56, v56, v57, %[px]\n"
+	    "\tv_cndmask_b32 v57, v59, v58, %[py]\n"
+	    "\tv_cndmask_b32 v58, v58, v59, %[py]\n"
+	    "\tv_cndmask_b32 v59, v61, v60, %[pz]\n"
+	    "\tv_cndmask_b32 v60, v60, v61, %[pz]\n"
 	    "\tv_max_f32 v59, 1, v59\n"
 	    "\tv_min_f32 v60, %[below], v60\n"
 	    "\tv_max3_f32 v62, v62, v57, v59\n"
@@ -506,12 +537,12 @@ __device__ __forceinline__ uint32_t walk_collect(const float4 *nodes_ptr, uint32
 	    "\tv_mul_f32 v59, %[iy], v59\n"
 	    "\tv_mul_f32 v60, %[iz], v60\n"
 	    "\tv_mul_f32 v61, %[iz], v61\n"
-	    "\tv_min_f32 v62, v56, v57\n"
-	    "\tv_max_f32 v56, v56, v57\n"
-	    "\tv_min_f32 v57, v58, v59\n"
-	    "\tv_max_f32 v58, v58, v59\n"
-	    "\tv_min_f32 v59, v60, v61\n"
-	    "\tv_max_f32 v60, v60, v61\n"
+	    "\tv_cndmask_b32 v62, v57, v56, %[px]\n"
+	    "\tv_cndmask_b32 v56, v56, v57, %[px]\n"
+	    "\tv_cndmask_b32 v57, v59, v58, %[py]\n"
+	    "\tv_cndmask_b32 v58, v58, v59, %[py]\n"
+	    "\tv_cndmask_b32 v59, v61, v60, %[pz]\n"
+	    "\tv_cndmask_b32 v60, v60, v61, %[pz]\n"
 	    "\tv_max_f32 v59, 1, v59\n"
 	    "\tv_min_f32 v60, %[below], v60\n"
 	    "\tv_max3_f32 v62, v62, v57, v59\n"
@@ -584,8 +615,8 @@ __device__ __forceinline__ uint32_t walk_collect(const float4 *nodes_ptr, uint32
 	    ".Lcollect_out_%=:\n"
 	    : [at] "+s"(at), [waiting] "+s"(waiting), [hit] "=&s"(hit_mask), [leaf] "=&s"(leaf), [status] "=&s"(status)
 	    : [base] "s"(nodes_ptr), [end] "s"(end), [alive] "s"(alive_mask), [below] "s"(below), [batch_below] "s"(batch_below),
-	      [list] "v"(list_lds_address), [tag] "v"(lane_tag), [ox] "v"(ray.ox), [oy] "v"(ray.oy), [oz] "v"(ray.oz), [ix] "v"(ray.ix),
-	      [iy] "v"(ray.iy), [iz] "v"(ray.iz)
+	      [px] "s"(sign.x), [py] "s"(sign.y), [pz] "s"(sign.z), [list] "v"(list_lds_address), [tag] "v"(lane_tag), [ox] "v"(ray.ox),
+	      [oy] "v"(ray.oy), [oz] "v"(ray.oz), [ix] "v"(ray.ix), [iy] "v"(ray.iy), [iz] "v"(ray.iz)
 	    : "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59",
 	      "s60", "s61", "s62", "s63", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "vcc", "scc", "memory");
 	return status;
@@ -642,10 +673,11 @@ __device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ n
 		uint32_t at = 0u;  // byte offset of the node (count < 2^27, checked at upload)
 		const uint32_t end = count * 32u;
 		const uint32_t list_lds_address = (uint32_t) (uintptr_t) &batch.entry[0];  // (low half of the flat address)
+		const SignMasks sign = sign_masks(ray);
 		while (alive_mask != 0ull && at < end) {
 			uint32_t leaf = 0u;
 			unsigned long long hit_mask = 0ull;
-			const uint32_t status = walk_collect(nodes_ptr, at, end, ray, below, alive_mask, hit_mask, leaf, waiting,
+			const uint32_t status = walk_collect(nodes_ptr, at, end, ray, sign, below, alive_mask, hit_mask, leaf, waiting,
 			                                     list_lds_address, lane << 26, batch_below);
 			if (status == 0u)
 				break;
@@ -757,7 +789,7 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
 	bool hit = false;
 	uint32_t leaf_stops = 0u;  // leaves the tile's shared walk stopped at: how dense the geometry is along these rays
 	if (P.shared_walk) {
-		const bool exact = !(P.scene_regular && P.scene_nested) || wave_ballot(active && !regular) != 0ull;
+		const bool exact = !(P.scene_regular && P.scene_nested) || wave_ballot(active && !ray_is_selectable(ray)) != 0ull;
 		// closest hit: strict '>' in ascending leaf order, reference :106-112
 		auto leaf_test = [&](uint32_t leaf, bool box) {
 			const float4 q0 = tris_ptr[4u * leaf], q1 = tris_ptr[4u * leaf + 1u];
@@ -778,11 +810,12 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
 		};
 		if (!exact) {
 			const unsigned long long alive_mask = wave_ballot(active);
+			const SignMasks sign = sign_masks(ray);
 			const uint32_t end = count * 32u;
 			uint32_t at = 0u;  // byte offset
 			while (alive_mask != 0ull && at < end) {
 				uint32_t leaf;
-				const unsigned long long hit_mask = walk_to_leaf(nodes_ptr, at, end, ray, P.primary_below, alive_mask, leaf);
+				const unsigned long long hit_mask = walk_to_leaf(nodes_ptr, at, end, ray, sign, P.primary_below, alive_mask, leaf);
 				if (hit_mask == 0ull)
 					break;
 				leaf_test(leaf, (hit_mask >> lane) & 1ull);
@@ -1240,7 +1273,7 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 							shared_dir = ao_table[dir0 + (base >> 6)];
 						if (alive)
 							setup_ray(base + lane, whole, shared_dir);
-						const bool exact = !scene_fast || wave_ballot(alive && !regular) != 0ull;
+						const bool exact = !scene_fast || wave_ballot(alive && !ray_is_selectable(ray)) != 0ull;
 						if (exact)
 							shared_walk_any_hit<true>(nodes_ptr, tris_ptr, scene.tris, count, ray, P.ao_max_distance,
 							                          P.ao_below, alive, lane, &sh.occluded[h], sh.batch, P.batch_below);
