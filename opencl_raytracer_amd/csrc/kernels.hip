@@ -30,7 +30,7 @@
 // primary pass, longest-first claiming packs them almost perfectly.
 //
 // How rays walk the tree: the 64 rays of a wave share ONE node index ("shared
-// walk", see shared_box / walk_to_leaf below) -- nodes and triangles arrive by
+// walk", see shared_box / walk_collect below) -- nodes and triangles arrive by
 // scalar loads, boxes are tested out of SGPRs, nothing diverges and nothing is
 // gathered.  The first generation, in which every lane walked on its own under a
 // wave scheduler, is still here (OCRT_NO_SHARED_WALK=1) for A/B runs.
@@ -352,114 +352,7 @@ __device__ __forceinline__ SignMasks sign_masks(const Ray &r) {
 	return m;
 }
 
-// The node steps of the fast form, hand-scheduled: from byte offset `at` on, walks
-// until some live lane hits a LEAF's box (returns its mask and the leaf; `at` stays
-// on that leaf) or the walk is over (returns 0).  Same operations as
-// slab_hit_regular -- (lo - o) * inv, (hi - o) * inv, min/max, max(.., tiny = bit
-// pattern 1), min(.., below), near <= far.  One 64-byte scalar load fetches the node
-// and its pre-order successor (the node array carries one node of padding): when a
-// lane hits an inner node, its first child is tested straight from s[56:63] without
-// another trip to memory.  Per node 23 vector and ~8 scalar instructions; the
-// compiler's own version of this loop needs about 25 + 20, and the walk is bound by
-// instruction issue and the latency of that load.  Temporaries v56-v62; only scalar
-// outputs, so that the compiler knows the results to be wave-uniform.
-__device__ __forceinline__ unsigned long long walk_to_leaf(const float4 *nodes_ptr, uint32_t &at, uint32_t end, const Ray &ray,
-                                                           const SignMasks &sign, float below, unsigned long long alive_mask,
-                                                           uint32_t &leaf) {
-	unsigned long long hit_mask;
-	asm volatile(
-	    ".Lwalk_node_%=:\n"
-	    "\ts_load_dwordx16 s[48:63], %[base], %[at]\n"
-	    "\ts_waitcnt lgkmcnt(0)\n"
-	    "\tv_sub_f32 v56, s48, %[ox]\n"
-	    "\tv_sub_f32 v57, s52, %[ox]\n"
-	    "\tv_sub_f32 v58, s49, %[oy]\n"
-	    "\tv_sub_f32 v59, s53, %[oy]\n"
-	    "\tv_sub_f32 v60, s50, %[oz]\n"
-	    "\tv_sub_f32 v61, s54, %[oz]\n"
-	    "\tv_mul_f32 v56, %[ix], v56\n"
-	    "\tv_mul_f32 v57, %[ix], v57\n"
-	    "\tv_mul_f32 v58, %[iy], v58\n"
-	    "\tv_mul_f32 v59, %[iy], v59\n"
-	    "\tv_mul_f32 v60, %[iz], v60\n"
-	    "\tv_mul_f32 v61, %[iz], v61\n"
-	    "\tv_cndmask_b32 v62, v57, v56, %[px]\n"
-	    "\tv_cndmask_b32 v56, v56, v57, %[px]\n"
-	    "\tv_cndmask_b32 v57, v59, v58, %[py]\n"
-	    "\tv_cndmask_b32 v58, v58, v59, %[py]\n"
-	    "\tv_cndmask_b32 v59, v61, v60, %[pz]\n"
-	    "\tv_cndmask_b32 v60, v60, v61, %[pz]\n"
-	    "\tv_max_f32 v59, 1, v59\n"
-	    "\tv_min_f32 v60, %[below], v60\n"
-	    "\tv_max3_f32 v62, v62, v57, v59\n"
-	    "\tv_min3_f32 v56, v56, v58, v60\n"
-	    "\tv_cmp_le_f32 vcc, v62, v56\n"
-	    "\ts_and_b64 %[hit], vcc, %[alive]\n"
-	    "\ts_cmp_lg_u64 %[hit], 0\n"
-	    "\ts_cbranch_scc1 .Lwalk_hit_a_%=\n"
-	    "\ts_lshl_b32 s51, s51, 5\n"
-	    "\ts_add_u32 %[at], %[at], s51\n"
-	    "\ts_cmp_lt_u32 %[at], %[end]\n"
-	    "\ts_cbranch_scc1 .Lwalk_node_%=\n"
-	    "\ts_branch .Lwalk_out_%=\n"
-	    ".Lwalk_hit_a_%=:\n"
-	    "\ts_cmp_lg_u32 s55, -1\n"
-	    "\ts_cbranch_scc1 .Lwalk_leaf_a_%=\n"
-	    "\ts_add_u32 %[at], %[at], 32\n"
-	    "\tv_sub_f32 v56, s56, %[ox]\n"
-	    "\tv_sub_f32 v57, s60, %[ox]\n"
-	    "\tv_sub_f32 v58, s57, %[oy]\n"
-	    "\tv_sub_f32 v59, s61, %[oy]\n"
-	    "\tv_sub_f32 v60, s58, %[oz]\n"
-	    "\tv_sub_f32 v61, s62, %[oz]\n"
-	    "\tv_mul_f32 v56, %[ix], v56\n"
-	    "\tv_mul_f32 v57, %[ix], v57\n"
-	    "\tv_mul_f32 v58, %[iy], v58\n"
-	    "\tv_mul_f32 v59, %[iy], v59\n"
-	    "\tv_mul_f32 v60, %[iz], v60\n"
-	    "\tv_mul_f32 v61, %[iz], v61\n"
-	    "\tv_cndmask_b32 v62, v57, v56, %[px]\n"
-	    "\tv_cndmask_b32 v56, v56, v57, %[px]\n"
-	    "\tv_cndmask_b32 v57, v59, v58, %[py]\n"
-	    "\tv_cndmask_b32 v58, v58, v59, %[py]\n"
-	    "\tv_cndmask_b32 v59, v61, v60, %[pz]\n"
-	    "\tv_cndmask_b32 v60, v60, v61, %[pz]\n"
-	    "\tv_max_f32 v59, 1, v59\n"
-	    "\tv_min_f32 v60, %[below], v60\n"
-	    "\tv_max3_f32 v62, v62, v57, v59\n"
-	    "\tv_min3_f32 v56, v56, v58, v60\n"
-	    "\tv_cmp_le_f32 vcc, v62, v56\n"
-	    "\ts_and_b64 %[hit], vcc, %[alive]\n"
-	    "\ts_cmp_lg_u64 %[hit], 0\n"
-	    "\ts_cbranch_scc1 .Lwalk_hit_b_%=\n"
-	    "\ts_lshl_b32 s59, s59, 5\n"
-	    "\ts_add_u32 %[at], %[at], s59\n"
-	    "\ts_cmp_lt_u32 %[at], %[end]\n"
-	    "\ts_cbranch_scc1 .Lwalk_node_%=\n"
-	    "\ts_branch .Lwalk_out_%=\n"
-	    ".Lwalk_hit_b_%=:\n"
-	    "\ts_cmp_lg_u32 s63, -1\n"
-	    "\ts_cbranch_scc1 .Lwalk_leaf_b_%=\n"
-	    "\ts_add_u32 %[at], %[at], 32\n"
-	    "\ts_cmp_lt_u32 %[at], %[end]\n"
-	    "\ts_cbranch_scc1 .Lwalk_node_%=\n"
-	    "\ts_mov_b64 %[hit], 0\n"
-	    "\ts_branch .Lwalk_out_%=\n"
-	    ".Lwalk_leaf_a_%=:\n"
-	    "\ts_mov_b32 %[leaf], s55\n"
-	    "\ts_branch .Lwalk_out_%=\n"
-	    ".Lwalk_leaf_b_%=:\n"
-	    "\ts_mov_b32 %[leaf], s63\n"
-	    ".Lwalk_out_%=:\n"
-	    : [at] "+s"(at), [hit] "=&s"(hit_mask), [leaf] "=&s"(leaf)
-	    : [base] "s"(nodes_ptr), [end] "s"(end), [alive] "s"(alive_mask), [below] "s"(below), [px] "s"(sign.x), [py] "s"(sign.y), [pz] "s"(sign.z),
-	      [ox] "v"(ray.ox), [oy] "v"(ray.oy), [oz] "v"(ray.oz), [ix] "v"(ray.ix), [iy] "v"(ray.iy), [iz] "v"(ray.iz)
-	    : "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "v56",
-	      "v57", "v58", "v59", "v60", "v61", "v62", "vcc", "scc");
-	return hit_mask;
-}
-
-// A node record by one scalar load (asm for the same reason as in walk_to_leaf: a plain load through
+// A node record by one scalar load (asm for the reason given at walk_collect: a plain load through
 // nodes_ptr next to that loop makes the compiler keep the pointer in VGPRs).
 typedef unsigned int u32x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ u32x8 scalar_load_node(const float4 *nodes_ptr, uint32_t at) {
@@ -469,14 +362,26 @@ __device__ __forceinline__ u32x8 scalar_load_node(const float4 *nodes_ptr, uint3
 	return r;
 }
 
-// The any-hit (AO) variant of walk_to_leaf: at a leaf hit by fewer than `batch_below`
-// lanes it does not stop but appends the (lane, leaf) pairs to the wave's list in LDS
-// (entry = leaf | lane << 26 at index waiting + rank of the lane among the hitters)
-// and walks on -- a leaf stop costs a trip out of this loop, a triangle load and a
-// node reload, and there are 11 of them per packet at one sample per pixel.
+// The node steps of the fast form, hand-scheduled.  From byte offset `at` on it walks the
+// packet through the tree: per node the slab test of the reference on values fetched by a
+// scalar load -- (lo - o) * inv, (hi - o) * inv, near/far picked by the sign of inv,
+// max(.., tiny = bit pattern 1), min(.., below), near <= far -- and a scalar decision:
+// some live lane hit -> first child, nobody -> skip the subtree.  One 64-byte load
+// fetches a node and its pre-order successor (the node array carries one node of
+// padding): after a hit on an inner node its first child is tested straight from
+// s[56:63].  Per node 23 vector and ~8 scalar instructions; the compiler's own version of
+// this loop needs about 25 + 20, and the walk is bound by instruction issue and the
+// latency of that load.
+// At a leaf hit by fewer than `batch_below` lanes it does not stop but appends the
+// (lane, leaf) pairs to the wave's list in LDS (entry = leaf | lane << 26 at index
+// waiting + rank of the lane among the hitters) and walks on -- a leaf stop costs a trip
+// out of this loop, a triangle load and a node reload, and there are 11 of them per AO
+// packet at one sample per pixel.
 // Returns 0: walk over; 1: `leaf` is hit by many lanes (`hit`), test it now, `at` is
 // on it; 2: 64 or more pairs are waiting, run a batch, `at` is on the leaf appended last.
-// Scratch: s[42:63], v56-v62.
+// Scratch: s[42:63], v56-v62; only scalar outputs, so that the compiler knows the results
+// to be wave-uniform.  nodes_ptr must not be dereferenced by plain loads elsewhere in the
+// same kernel: the compiler then keeps it in VGPRs and cannot hand it to this operand.
 __device__ __forceinline__ uint32_t walk_collect(const float4 *nodes_ptr, uint32_t &at, uint32_t end, const Ray &ray,
                                                  const SignMasks &sign, float below,
                                                  unsigned long long alive_mask, unsigned long long &hit_mask, uint32_t &leaf,
@@ -628,6 +533,19 @@ struct LeafBatch {
 	unsigned int occluded_bits[2];  // lanes whose ray was found occluded by the batch just run
 };
 
+// The same for a closest-hit packet (primary rays).  The reference keeps the first hit in
+// leaf order among the nearest (`best.distance > distance`, strict): that is the minimum of
+// (distance, leaf) in lexicographic order, so the tests may run in any order and on any lane
+// if each ray's minimum of key = distance bits << 32 | leaf is kept -- here by LDS atomics.
+// The winner's barycentrics and hit point are recomputed by the ray's own lane at the end.
+struct ClosestBatch {
+	unsigned int entry[128];
+	unsigned long long best_key[64];
+	unsigned int hit_bits[2];  // rays with an accepted triangle, whatever its distance (reference :108-113)
+};
+constexpr unsigned long long KEY_NONE = ~0ull;
+constexpr uint32_t INF_BITS = 0x7F800000u;
+
 // Any-hit shared walk of one packet (AO): a lane leaves at its first accepted
 // triangle and bumps *occluded (reference :251 only uses the boolean).
 template <bool EXACT>
@@ -751,6 +669,7 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
     const float4 *__restrict__ nodes_ptr, const float4 *__restrict__ tris_ptr, const float4 *__restrict__ shade,
     float *__restrict__ image, HitRec *__restrict__ hits, uint32_t *__restrict__ occluded_of,
     uint32_t *__restrict__ tile_hits, FrameCounters *__restrict__ counters, KernelParams P) {
+	__shared__ ClosestBatch closest_batches[PRIMARY_WAVES];
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t wave = threadIdx.x >> 6;
 	const SceneViews scene = make_views(nodes_ptr, tris_ptr, P);
@@ -809,19 +728,82 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
 			}
 		};
 		if (!exact) {
+			// Leaves hit by few lanes are collected and tested 64 pairs at a time (see ClosestBatch).
+			ClosestBatch &cb = closest_batches[wave];
+			cb.best_key[lane] = KEY_NONE;
+			if (lane < 2u)
+				cb.hit_bits[lane] = 0u;
+			unsigned long long my_key = KEY_NONE;  // from the leaves tested on the spot
+			uint32_t waiting = 0u, pairs = 0u;
+			auto key_of = [](float distance, uint32_t leaf) {
+				return ((unsigned long long) __float_as_uint(distance) << 32) | leaf;
+			};
+			auto run_batch = [&](uint32_t n) {
+				wave_lds_sync();
+				const uint32_t pair = cb.entry[lane < n ? lane : 0u];
+				const int owner = (int) (pair >> 26);
+				Ray theirs = ray;  // (all primary rays start at the eye)
+				theirs.dx = __shfl(ray.dx, owner); theirs.dy = __shfl(ray.dy, owner); theirs.dz = __shfl(ray.dz, owner);
+				if (lane < n) {
+					const uint32_t leaf = pair & 0x03FFFFFFu;
+					const TriResult tr = tri_test<true>(scene.tris, leaf, theirs);
+					if (tr.accepted) {
+						atomicMin(&cb.best_key[owner], key_of(tr.distance, leaf));
+						atomicOr(&cb.hit_bits[owner >> 5], 1u << (owner & 31));
+					}
+				}
+				pairs += n;
+			};
 			const unsigned long long alive_mask = wave_ballot(active);
 			const SignMasks sign = sign_masks(ray);
+			const uint32_t list_lds_address = (uint32_t) (uintptr_t) &cb.entry[0];  // (low half of the flat address)
 			const uint32_t end = count * 32u;
 			uint32_t at = 0u;  // byte offset
 			while (alive_mask != 0ull && at < end) {
-				uint32_t leaf;
-				const unsigned long long hit_mask = walk_to_leaf(nodes_ptr, at, end, ray, sign, P.primary_below, alive_mask, leaf);
-				if (hit_mask == 0ull)
+				uint32_t leaf = 0u;
+				unsigned long long hit_mask = 0ull;
+				const uint32_t status = walk_collect(nodes_ptr, at, end, ray, sign, P.primary_below, alive_mask, hit_mask, leaf, waiting,
+				                                     list_lds_address, lane << 26, P.batch_below);
+				if (status == 0u)
 					break;
-				leaf_test(leaf, (hit_mask >> lane) & 1ull);
-				++leaf_stops;
+				if (status == 1u) {
+					const float4 q0 = tris_ptr[4u * leaf], q1 = tris_ptr[4u * leaf + 1u];
+					const float4 q2 = tris_ptr[4u * leaf + 2u], q3 = tris_ptr[4u * leaf + 3u];
+					if ((hit_mask >> lane) & 1ull) {
+						const TriResult tr = tri_eval<true>(q0, q1, q2, q3, ray);
+						if (tr.accepted) {
+							hit = true;
+							const unsigned long long key = key_of(tr.distance, leaf);
+							my_key = key < my_key ? key : my_key;
+						}
+					}
+					pairs += (uint32_t) __popcll(hit_mask);
+				} else {
+					run_batch(64u);
+					waiting -= 64u;
+					if (lane < waiting)  // the pairs beyond the batch move to the front
+						cb.entry[lane] = cb.entry[64u + lane];
+				}
 				at += 32u;
 			}
+			if (waiting != 0u)
+				run_batch(waiting);
+			wave_lds_sync();
+			const unsigned long long batched = cb.best_key[lane];
+			const unsigned long long key = batched < my_key ? batched : my_key;
+			hit = hit || ((cb.hit_bits[lane >> 5] >> (lane & 31u)) & 1u);
+			// the nearest hit's barycentrics and position: the same test once more, on the ray's own lane.  (A
+			// distance of +inf or NaN never satisfies the reference's `best.distance > distance`: `best` stays as it is.)
+			if (hit && (uint32_t) (key >> 32) < INF_BITS) {
+				const uint32_t leaf = (uint32_t) key;
+				const TriResult tr = tri_test<true>(scene.tris, leaf, ray);
+				best.distance = tr.distance;
+				best.leaf = leaf;
+				best.s = tr.s;
+				best.t = tr.t;
+				best.px = tr.px; best.py = tr.py; best.pz = tr.pz;
+			}
+			leaf_stops = pairs >> 4;  // (a leaf stop involves some 16 lanes)
 		} else {
 			uint32_t mine = 0u;
 			uint32_t at = 0u;
