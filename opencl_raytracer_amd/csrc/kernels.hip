@@ -377,6 +377,7 @@ __device__ __forceinline__ u32x8 scalar_load_node(const float4 *nodes_ptr, uint3
 // waiting + rank of the lane among the hitters) and walks on -- a leaf stop costs a trip
 // out of this loop, a triangle load and a node reload, and there are 11 of them per AO
 // packet at one sample per pixel.
+// `leaf_stops` counts the leaves some lane hit.
 // Returns 0: walk over; 1: `leaf` is hit by many lanes (`hit`), test it now, `at` is
 // on it; 2: 64 or more pairs are waiting, run a batch, `at` is on the leaf appended last.
 // Scratch: s[42:63], v56-v62; only scalar outputs, so that the compiler knows the results
@@ -385,8 +386,8 @@ __device__ __forceinline__ u32x8 scalar_load_node(const float4 *nodes_ptr, uint3
 __device__ __forceinline__ uint32_t walk_collect(const float4 *nodes_ptr, uint32_t &at, uint32_t end, const Ray &ray,
                                                  const SignMasks &sign, float below,
                                                  unsigned long long alive_mask, unsigned long long &hit_mask, uint32_t &leaf,
-                                                 uint32_t &waiting, uint32_t list_lds_address, uint32_t lane_tag,
-                                                 uint32_t batch_below) {
+                                                 uint32_t &waiting, uint32_t &leaf_stops, uint32_t list_lds_address,
+                                                 uint32_t lane_tag, uint32_t batch_below) {
 	uint32_t status;
 	asm volatile(
 	    ".Lcollect_node_%=:\n"
@@ -471,6 +472,7 @@ __device__ __forceinline__ uint32_t walk_collect(const float4 *nodes_ptr, uint32
 	    "\ts_branch .Lcollect_over_%=\n"
 	    ".Lcollect_leaf_a_%=:\n"
 	    "\ts_bcnt1_i32_b64 s46, s[44:45]\n"
+	    "\ts_add_u32 %[stops], %[stops], 1\n"
 	    "\ts_cmp_ge_u32 s46, %[batch_below]\n"
 	    "\ts_cbranch_scc1 .Lcollect_now_a_%=\n"
 	    "\tv_mbcnt_lo_u32_b32 v56, s44, 0\n"
@@ -491,6 +493,7 @@ __device__ __forceinline__ uint32_t walk_collect(const float4 *nodes_ptr, uint32
 	    "\ts_branch .Lcollect_now_%=\n"
 	    ".Lcollect_leaf_b_%=:\n"
 	    "\ts_bcnt1_i32_b64 s46, s[44:45]\n"
+	    "\ts_add_u32 %[stops], %[stops], 1\n"
 	    "\ts_cmp_ge_u32 s46, %[batch_below]\n"
 	    "\ts_cbranch_scc1 .Lcollect_now_b_%=\n"
 	    "\tv_mbcnt_lo_u32_b32 v56, s44, 0\n"
@@ -518,7 +521,8 @@ __device__ __forceinline__ uint32_t walk_collect(const float4 *nodes_ptr, uint32
 	    ".Lcollect_over_%=:\n"
 	    "\ts_mov_b32 %[status], 0\n"
 	    ".Lcollect_out_%=:\n"
-	    : [at] "+s"(at), [waiting] "+s"(waiting), [hit] "=&s"(hit_mask), [leaf] "=&s"(leaf), [status] "=&s"(status)
+	    : [at] "+s"(at), [waiting] "+s"(waiting), [stops] "+s"(leaf_stops), [hit] "=&s"(hit_mask), [leaf] "=&s"(leaf),
+	      [status] "=&s"(status)
 	    : [base] "s"(nodes_ptr), [end] "s"(end), [alive] "s"(alive_mask), [below] "s"(below), [batch_below] "s"(batch_below),
 	      [px] "s"(sign.x), [py] "s"(sign.y), [pz] "s"(sign.z), [list] "v"(list_lds_address), [tag] "v"(lane_tag), [ox] "v"(ray.ox),
 	      [oy] "v"(ray.oy), [oz] "v"(ray.oz), [ix] "v"(ray.ix), [iy] "v"(ray.iy), [iz] "v"(ray.iz)
@@ -564,6 +568,7 @@ __device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ n
 		// operands as before.  A ray found occluded leaves the walk after the batch instead of at
 		// the leaf, which only lets it ride along a little longer.
 		uint32_t waiting = 0u;  // pairs in batch.entry (wave-uniform)
+		uint32_t leaf_stops = 0u;  // (not used by this pass)
 		auto run_batch = [&](uint32_t n) {
 			wave_lds_sync();
 			const uint32_t pair = batch.entry[lane < n ? lane : 0u];
@@ -596,7 +601,7 @@ __device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ n
 			uint32_t leaf = 0u;
 			unsigned long long hit_mask = 0ull;
 			const uint32_t status = walk_collect(nodes_ptr, at, end, ray, sign, below, alive_mask, hit_mask, leaf, waiting,
-			                                     list_lds_address, lane << 26, batch_below);
+			                                     leaf_stops, list_lds_address, lane << 26, batch_below);
 			if (status == 0u)
 				break;
 			if (status == 1u) {
@@ -734,7 +739,7 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
 			if (lane < 2u)
 				cb.hit_bits[lane] = 0u;
 			unsigned long long my_key = KEY_NONE;  // from the leaves tested on the spot
-			uint32_t waiting = 0u, pairs = 0u;
+			uint32_t waiting = 0u;
 			auto key_of = [](float distance, uint32_t leaf) {
 				return ((unsigned long long) __float_as_uint(distance) << 32) | leaf;
 			};
@@ -752,7 +757,6 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
 						atomicOr(&cb.hit_bits[owner >> 5], 1u << (owner & 31));
 					}
 				}
-				pairs += n;
 			};
 			const unsigned long long alive_mask = wave_ballot(active);
 			const SignMasks sign = sign_masks(ray);
@@ -763,7 +767,7 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
 				uint32_t leaf = 0u;
 				unsigned long long hit_mask = 0ull;
 				const uint32_t status = walk_collect(nodes_ptr, at, end, ray, sign, P.primary_below, alive_mask, hit_mask, leaf, waiting,
-				                                     list_lds_address, lane << 26, P.batch_below);
+				                                     leaf_stops, list_lds_address, lane << 26, P.batch_below);
 				if (status == 0u)
 					break;
 				if (status == 1u) {
@@ -777,7 +781,6 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
 							my_key = key < my_key ? key : my_key;
 						}
 					}
-					pairs += (uint32_t) __popcll(hit_mask);
 				} else {
 					run_batch(64u);
 					waiting -= 64u;
@@ -803,7 +806,6 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
 				best.t = tr.t;
 				best.px = tr.px; best.py = tr.py; best.pz = tr.pz;
 			}
-			leaf_stops = pairs >> 4;  // (a leaf stop involves some 16 lanes)
 		} else {
 			uint32_t mine = 0u;
 			uint32_t at = 0u;
@@ -879,9 +881,10 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
 	const uint32_t hit_count = (uint32_t) __popcll(hit_mask);
 	if (lane == 0u) {
 		// hit count, and above it the tile's AO cost class 1..64 for the ordering step: its 28 AO packets
-		// walk about as far as the primary packet did (correlation 0.8-0.9, tools/analysis/packet_union.cc),
-		// scaled by how full the packets will be.  The hit count alone does not predict the cost at all.
-		uint32_t cost = P.shared_walk ? (leaf_stops * hit_count + 63u) / 64u : hit_count;
+		// walk about as far as the primary packet did (correlation 0.8-0.9, tools/analysis/packet_union.cc).
+		// The hit count does not predict the cost at all: a sparse tile's packets mix several directions
+		// and walk as many nodes as a full tile's.
+		uint32_t cost = P.shared_walk ? leaf_stops : hit_count;
 		cost = cost < 1u ? 1u : cost;
 		cost = cost > 64u ? 64u : cost;
 		tile_hits[tile] = (want_ao && hit_count) ? (hit_count | (cost << 8)) : 0u;
