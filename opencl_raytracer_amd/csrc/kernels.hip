@@ -62,6 +62,14 @@ struct Hit {
 	float px, py, pz;
 };
 
+// The reference keeps, among the nearest accepted triangles, the first in ITS leaf order
+// (`best.distance > distance`, strict, src/intersect_kernel.cl:107).  The tree walked here
+// may list the leaves in another order (walk_tree.h), so the tie is decided by the leaf
+// number itself.  (`best` starts at distance +inf: a hit at +inf or NaN never replaces it.)
+__device__ __forceinline__ bool nearer(float distance, uint32_t leaf, const Hit &best) {
+	return best.distance > distance || (best.distance == distance && leaf < best.leaf && distance < __builtin_inff());
+}
+
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
 	return (ax * bx + ay * by) + az * bz;
 }
@@ -714,7 +722,7 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
 	uint32_t leaf_stops = 0u;  // leaves the tile's shared walk stopped at: how dense the geometry is along these rays
 	if (P.shared_walk) {
 		const bool exact = !(P.scene_regular && P.scene_nested) || wave_ballot(active && !ray_is_selectable(ray)) != 0ull;
-		// closest hit: strict '>' in ascending leaf order, reference :106-112
+		// closest hit = minimum of (distance, reference leaf), see nearer(); reference :106-112
 		auto leaf_test = [&](uint32_t leaf, bool box) {
 			const float4 q0 = tris_ptr[4u * leaf], q1 = tris_ptr[4u * leaf + 1u];
 			const float4 q2 = tris_ptr[4u * leaf + 2u], q3 = tris_ptr[4u * leaf + 3u];
@@ -722,7 +730,7 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
 				const TriResult tr = tri_eval<true>(q0, q1, q2, q3, ray);
 				if (tr.accepted) {
 					hit = true;
-					if (best.distance > tr.distance) {
+					if (nearer(tr.distance, leaf, best)) {
 						best.distance = tr.distance;
 						best.leaf = leaf;
 						best.s = tr.s;
@@ -832,10 +840,10 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
 			if (leaves != 0ull && ((uint32_t) __popcll(leaves) >= P.leaf_min || walking == 0ull)) {
 				if (pending.first != NONE) {
 					const TriResult tr = tri_test<true>(scene.tris, pending.first, ray);
-					// closest hit: strict '>' in ascending leaf order, reference :106-112
+					// closest hit = minimum of (distance, reference leaf), see nearer(); reference :106-112
 					if (tr.accepted) {
 						hit = true;
-						if (best.distance > tr.distance) {
+						if (nearer(tr.distance, pending.first, best)) {
 							best.distance = tr.distance;
 							best.leaf = pending.first;
 							best.s = tr.s;

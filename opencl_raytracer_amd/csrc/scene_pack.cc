@@ -1,5 +1,7 @@
 #include "scene_pack.h"
 
+#include "walk_tree.h"
+
 #include <cmath>
 #include <cstdlib>
 #include <limits>
@@ -73,6 +75,14 @@ PackedScene pack_scene(const std::vector<uint32_t> &faces, const std::vector<uin
 			for (unsigned k = 0; k < 3; ++k)
 				if (!(p.lo[k] <= out.nodes[c].lo[k]) || !(out.nodes[c].hi[k] <= p.hi[k]))
 					out.nested = false;
+	}
+
+	// The walk may use any tree over the same leaves (walk_tree.h): take a binned-SAH one when it is cheaper
+	// than what was uploaded.  (Damaged arrays keep their tree: the exact form of the walk follows it.)
+	if (out.regular && out.nested && !std::getenv("OCRT_KEEP_TREE")) {  // (debug knob)
+		std::vector<NodeRec> rebuilt = rebuild_walk_tree(out.nodes);
+		if (rebuilt.size() == out.nodes.size() && tree_cost(rebuilt) < tree_cost(out.nodes))
+			out.nodes.swap(rebuilt);
 	}
 
 	out.tris.resize(tri_count);

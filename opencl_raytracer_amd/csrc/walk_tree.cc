@@ -1,0 +1,222 @@
+#include "walk_tree.h"
+
+#include <algorithm>
+#include <cmath>
+#include <future>
+#include <limits>
+
+namespace ocrt {
+
+namespace {
+
+struct Box {
+	float lo[3], hi[3];
+	void reset() {
+		for (int k = 0; k < 3; ++k) {
+			lo[k] = std::numeric_limits<float>::infinity();
+			hi[k] = -std::numeric_limits<float>::infinity();
+		}
+	}
+	void grow(const float *l, const float *h) {
+		for (int k = 0; k < 3; ++k) {
+			lo[k] = std::fmin(lo[k], l[k]);
+			hi[k] = std::fmax(hi[k], h[k]);
+		}
+	}
+	double area() const {
+		const double dx = (double) hi[0] - lo[0], dy = (double) hi[1] - lo[1], dz = (double) hi[2] - lo[2];
+		return dx < 0.0 ? 0.0 : 2.0 * (dx * dy + dy * dz + dz * dx);
+	}
+};
+
+struct Leaf {
+	float lo[3], hi[3];
+	float centre[3];
+	uint32_t index;  // the reference's leaf number
+};
+
+constexpr int BINS = 16;
+
+struct Builder {
+	std::vector<Leaf> leaves;
+	std::vector<NodeRec> out;  // 2n - 1 nodes: a subtree over m leaves occupies exactly 2m - 1 consecutive slots
+
+	// Writes the subtree over leaves[begin, end) in pre-order from slot `at` on and returns its box.
+	// The two halves of the top levels are built by separate threads (their slots are known in advance).
+	Box build(size_t begin, size_t end, size_t at, int depth) {
+		Box box;
+		if (end - begin == 1) {
+			const Leaf &l = leaves[begin];
+			box.reset();
+			box.grow(l.lo, l.hi);
+			for (int k = 0; k < 3; ++k) {
+				out[at].lo[k] = l.lo[k];
+				out[at].hi[k] = l.hi[k];
+			}
+			out[at].skip = 1;
+			out[at].leaf = l.index;
+			return box;
+		}
+		// (a run of lopsided splits must not exhaust the stack: halve by index from depth 48 on)
+		const size_t mid = depth < 48 ? split(begin, end) : begin + (end - begin) / 2;
+		const size_t left_at = at + 1, right_at = at + 1 + (2 * (mid - begin) - 1);
+		Box left, right;
+		if (depth < 4 && end - begin > 4096) {
+			std::future<Box> other = std::async(std::launch::async, [&] { return build(begin, mid, left_at, depth + 1); });
+			right = build(mid, end, right_at, depth + 1);
+			left = other.get();
+		} else {
+			left = build(begin, mid, left_at, depth + 1);
+			right = build(mid, end, right_at, depth + 1);
+		}
+		box = left;
+		box.grow(right.lo, right.hi);
+		for (int k = 0; k < 3; ++k) {
+			out[at].lo[k] = box.lo[k];
+			out[at].hi[k] = box.hi[k];
+		}
+		out[at].skip = (uint32_t) (2 * (end - begin) - 1);
+		out[at].leaf = 0xFFFFFFFFu;
+		return box;
+	}
+
+	// Partitions leaves[begin, end) at the cheapest of the 3 x 15 bin boundaries; equal halves by
+	// index when the centres do not separate.
+	size_t split(size_t begin, size_t end) {
+		float c_lo[3], c_hi[3];
+		for (int k = 0; k < 3; ++k) {
+			c_lo[k] = std::numeric_limits<float>::infinity();
+			c_hi[k] = -std::numeric_limits<float>::infinity();
+		}
+		for (size_t i = begin; i < end; ++i)
+			for (int k = 0; k < 3; ++k) {
+				c_lo[k] = std::fmin(c_lo[k], leaves[i].centre[k]);
+				c_hi[k] = std::fmax(c_hi[k], leaves[i].centre[k]);
+			}
+		// A leaf more than half as large as the whole node (a ground plane under a small model) would
+		// drag every box it stays in up to its own size; centre-based bins cannot set it apart and the
+		// greedy cost does not see far enough to want to.  It gets a node of its own.
+		if (end - begin > 2) {
+			Box all;
+			all.reset();
+			double largest = -1.0;
+			size_t giant = begin;
+			for (size_t i = begin; i < end; ++i) {
+				all.grow(leaves[i].lo, leaves[i].hi);
+				Box one;
+				one.reset();
+				one.grow(leaves[i].lo, leaves[i].hi);
+				const double a = one.area();
+				if (a > largest) {
+					largest = a;
+					giant = i;
+				}
+			}
+			if (largest >= 0.5 * all.area()) {
+				std::swap(leaves[begin], leaves[giant]);
+				return begin + 1;
+			}
+		}
+		double best_cost = std::numeric_limits<double>::infinity();
+		int best_axis = -1, best_bin = 0;
+		float best_scale = 0.0f;
+		for (int axis = 0; axis < 3; ++axis) {
+			const float extent = c_hi[axis] - c_lo[axis];
+			if (!(extent > 0.0f) || !std::isfinite(extent))
+				continue;
+			const float scale = (float) BINS / extent;
+			Box bin_box[BINS];
+			size_t bin_count[BINS] = { 0 };
+			for (Box &b : bin_box)
+				b.reset();
+			for (size_t i = begin; i < end; ++i) {
+				const int b = bin_of(leaves[i].centre[axis], c_lo[axis], scale);
+				bin_box[b].grow(leaves[i].lo, leaves[i].hi);
+				++bin_count[b];
+			}
+			double right_area[BINS];
+			size_t right_count[BINS];
+			Box sweep;
+			sweep.reset();
+			size_t n = 0;
+			for (int b = BINS - 1; b >= 1; --b) {
+				if (bin_count[b])
+					sweep.grow(bin_box[b].lo, bin_box[b].hi);
+				n += bin_count[b];
+				right_area[b] = sweep.area();
+				right_count[b] = n;
+			}
+			sweep.reset();
+			n = 0;
+			for (int b = 1; b < BINS; ++b) {  // split between bins b-1 and b
+				if (bin_count[b - 1])
+					sweep.grow(bin_box[b - 1].lo, bin_box[b - 1].hi);
+				n += bin_count[b - 1];
+				if (n == 0 || right_count[b] == 0)
+					continue;
+				const double cost = sweep.area() * (double) n + right_area[b] * (double) right_count[b];
+				if (cost < best_cost) {
+					best_cost = cost;
+					best_axis = axis;
+					best_bin = b;
+					best_scale = scale;
+				}
+			}
+		}
+		if (best_axis < 0)
+			return begin + (end - begin) / 2;
+		const float origin = c_lo[best_axis];
+		const auto middle = std::partition(leaves.begin() + (long) begin, leaves.begin() + (long) end, [&](const Leaf &l) {
+			return bin_of(l.centre[best_axis], origin, best_scale) < best_bin;
+		});
+		const size_t mid = (size_t) (middle - leaves.begin());
+		return (mid == begin || mid == end) ? begin + (end - begin) / 2 : mid;
+	}
+
+	static int bin_of(float centre, float origin, float scale) {
+		const int b = (int) ((centre - origin) * scale);
+		return b < 0 ? 0 : b >= BINS ? BINS - 1 : b;
+	}
+};
+
+}  // namespace
+
+double tree_cost(const std::vector<NodeRec> &nodes) {
+	if (nodes.empty())
+		return 0.0;
+	auto area = [](const NodeRec &n) {
+		const double dx = (double) n.hi[0] - n.lo[0], dy = (double) n.hi[1] - n.lo[1], dz = (double) n.hi[2] - n.lo[2];
+		return 2.0 * (dx * dy + dy * dz + dz * dx);
+	};
+	const double root = area(nodes[0]);
+	if (!(root > 0.0) || !std::isfinite(root))
+		return std::numeric_limits<double>::infinity();
+	double sum = 0.0;
+	for (const NodeRec &n : nodes)
+		sum += area(n);
+	return sum / root;
+}
+
+std::vector<NodeRec> rebuild_walk_tree(const std::vector<NodeRec> &packed) {
+	Builder b;
+	b.leaves.reserve((packed.size() + 1) / 2);
+	for (const NodeRec &n : packed) {
+		if (n.skip != 1)
+			continue;
+		Leaf l;
+		for (int k = 0; k < 3; ++k) {
+			l.lo[k] = n.lo[k];
+			l.hi[k] = n.hi[k];
+			l.centre[k] = 0.5f * n.lo[k] + 0.5f * n.hi[k];
+		}
+		l.index = n.leaf;
+		b.leaves.push_back(l);
+	}
+	if (b.leaves.empty())
+		return {};
+	b.out.resize(2 * b.leaves.size() - 1);
+	b.build(0, b.leaves.size(), 0, 0);
+	return std::move(b.out);
+}
+
+}  // namespace ocrt

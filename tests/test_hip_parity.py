@@ -301,6 +301,8 @@ def test_lane_by_lane_walk_still_matches(rt, golden, scene_for, name, monkeypatc
     {"OCRT_NO_SORT": "1"},              # blocks in spatial order
     {"OCRT_FORCE_EXACT_WALK": "1"},     # per-lane cursors + select-based slab test in every packet
     {"OCRT_AO_BLOCKS": "3"},            # three workgroups do the whole AO pass
+    {"OCRT_KEEP_TREE": "1"},            # walk the uploaded tree instead of the rebuilt one
+    {"OCRT_KEEP_TREE": "1", "OCRT_NO_SHARED_WALK": "1"},
 ])
 def test_scheduling_knobs_do_not_change_the_image(rt, golden, scene_for, knobs, monkeypatch):
     """Claim sizes, tile order, batching thresholds and the form of the walk only change who does what when."""

@@ -11,7 +11,7 @@ CSRC = os.path.join(ROOT, "opencl_raytracer_amd", "csrc")
 def test_host_scene_build_under_asan_ubsan(tmp_path):
     exe = str(tmp_path / "host_sanitize")
     srcs = [os.path.join(ROOT, "tests", "host_sanitize.cc")] + [os.path.join(CSRC, f) for f in
-                                                               ("mesh.cc", "bvh.cc", "ray_tracer.cc", "scene_pack.cc")]
+                                                               ("mesh.cc", "bvh.cc", "ray_tracer.cc", "scene_pack.cc", "walk_tree.cc")]
     subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-ffp-contract=off",
                     "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-I", CSRC, "-o", exe] + srcs,
                    check=True)

@@ -3,7 +3,7 @@
 // hits its box) compared with the rays' individual walks?  Primary packets = the 64
 // sub-pixels of a tile; AO packets = one table direction from all hit points of a tile.
 //   g++ -O2 -fopenmp -I opencl_raytracer_amd/csrc tools/analysis/packet_union.cc \
-//       opencl_raytracer_amd/csrc/{mesh,bvh,scene_pack,ray_tracer}.cc -o /tmp/packet_union
+//       opencl_raytracer_amd/csrc/{mesh,bvh,scene_pack,walk_tree,ray_tracer}.cc -o /tmp/packet_union
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>

@@ -3,7 +3,7 @@
 // scene and a plain skip-list walk (AO rays stop at the first accepted triangle,
 // like the GPU kernel).  Used to size the LDS-resident top of the tree.
 //   g++ -O2 -fopenmp -I opencl_raytracer_amd/csrc tools/analysis/visit_hist.cc \
-//       opencl_raytracer_amd/csrc/{mesh,bvh,scene_pack,ray_tracer}.cc -o /tmp/visit_hist
+//       opencl_raytracer_amd/csrc/{mesh,bvh,scene_pack,walk_tree,ray_tracer}.cc -o /tmp/visit_hist
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
