@@ -80,8 +80,8 @@ PackedScene pack_scene(const std::vector<uint32_t> &faces, const std::vector<uin
 	// The walk may use any tree over the same leaves (walk_tree.h): take a binned-SAH one when it is cheaper
 	// than what was uploaded.  (Damaged arrays keep their tree: the exact form of the walk follows it.)
 	if (out.regular && out.nested && !std::getenv("OCRT_KEEP_TREE")) {  // (debug knob)
-		std::vector<NodeRec> rebuilt = rebuild_walk_tree(out.nodes);
-		if (rebuilt.size() == out.nodes.size() && tree_cost(rebuilt) < tree_cost(out.nodes))
+		std::vector<NodeRec> rebuilt = contract_walk_tree(rebuild_walk_tree(out.nodes), 0.5);
+		if (!rebuilt.empty() && tree_cost(rebuilt) < tree_cost(out.nodes))
 			out.nodes.swap(rebuilt);
 	}
 

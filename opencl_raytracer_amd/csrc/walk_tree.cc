@@ -181,20 +181,62 @@ struct Builder {
 
 }  // namespace
 
+namespace {
+double node_area(const NodeRec &n) {
+	const double dx = (double) n.hi[0] - n.lo[0], dy = (double) n.hi[1] - n.lo[1], dz = (double) n.hi[2] - n.lo[2];
+	return 2.0 * (dx * dy + dy * dz + dz * dx);
+}
+}  // namespace
+
 double tree_cost(const std::vector<NodeRec> &nodes) {
 	if (nodes.empty())
 		return 0.0;
-	auto area = [](const NodeRec &n) {
-		const double dx = (double) n.hi[0] - n.lo[0], dy = (double) n.hi[1] - n.lo[1], dz = (double) n.hi[2] - n.lo[2];
-		return 2.0 * (dx * dy + dy * dz + dz * dx);
-	};
-	const double root = area(nodes[0]);
+	const double root = node_area(nodes[0]);
 	if (!(root > 0.0) || !std::isfinite(root))
 		return std::numeric_limits<double>::infinity();
-	double sum = 0.0;
-	for (const NodeRec &n : nodes)
-		sum += area(n);
+	struct Open {
+		size_t end;
+		double area;
+	};
+	std::vector<Open> parents;
+	double sum = root;  // the root itself
+	for (size_t i = 0; i < nodes.size(); ++i) {
+		while (!parents.empty() && parents.back().end <= i)
+			parents.pop_back();
+		if (!parents.empty())
+			sum += parents.back().area;
+		if (nodes[i].skip > 1)
+			parents.push_back({ i + nodes[i].skip, node_area(nodes[i]) });
+	}
 	return sum / root;
+}
+
+std::vector<NodeRec> contract_walk_tree(const std::vector<NodeRec> &nodes, double threshold) {
+	struct Open {
+		size_t end;  // first input index past the subtree
+		size_t at;   // where the node went in the output
+		double area;
+	};
+	std::vector<NodeRec> out;
+	out.reserve(nodes.size());
+	std::vector<Open> parents;
+	auto close = [&](size_t upto) {
+		while (!parents.empty() && parents.back().end <= upto) {
+			out[parents.back().at].skip = (uint32_t) (out.size() - parents.back().at);
+			parents.pop_back();
+		}
+	};
+	for (size_t i = 0; i < nodes.size(); ++i) {
+		close(i);
+		const NodeRec &n = nodes[i];
+		if (n.skip > 1 && !parents.empty() && node_area(n) > threshold * parents.back().area)
+			continue;  // its children now answer to its parent
+		out.push_back(n);
+		if (n.skip > 1)
+			parents.push_back({ i + n.skip, out.size() - 1, node_area(n) });
+	}
+	close(nodes.size());
+	return out;
 }
 
 std::vector<NodeRec> rebuild_walk_tree(const std::vector<NodeRec> &packed) {

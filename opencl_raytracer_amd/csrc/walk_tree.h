@@ -14,9 +14,16 @@
 
 namespace ocrt {
 
-// Surface-area cost of a packed tree: sum over all nodes of area(node) / area(root),
-// the expected number of box tests of a random ray that hits the root.
+// Surface-area cost of a packed tree (any arity): a node's box is tested when its parent's box
+// was hit, so a random ray that hits the root tests 1 + sum over the other nodes of
+// area(parent) / area(root) boxes.
 double tree_cost(const std::vector<NodeRec> &nodes);
+
+// Removes inner nodes that are hit too often to be worth testing: with p = area(node) /
+// area(parent), keeping a node with two children costs 1 + 2p tests per ray through the parent,
+// dropping it (its children become the parent's) costs 2 -- drop it when p > threshold (0.5).
+// The skip list does not care how many children a node has.
+std::vector<NodeRec> contract_walk_tree(const std::vector<NodeRec> &nodes, double threshold);
 
 // Binned-SAH tree (16 bins per axis, one leaf per node of `leaves`) over the leaf
 // records of `packed` -- same boxes, same leaf indices --, pre-order skip list like

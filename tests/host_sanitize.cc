@@ -24,7 +24,12 @@ int main(int argc, char **argv) {
 			bvh.buildBVH(mesh);
 			const std::vector<uint32_t> sorted = sort_faces_by_leaf_order(mesh, bvh);
 			const ocrt::PackedScene packed = ocrt::pack_scene(sorted, bvh.nodes, bvh.aabbs, mesh.vertices, mesh.vnormals);
-			if (packed.nodes.size() != bvh.nodes.size() || packed.tris.size() != mesh.faces.size() / 3)
+			// (the walked tree may have fewer inner nodes than the uploaded one, never fewer leaves)
+			size_t leaves = 0;
+			for (const ocrt::NodeRec &n : packed.nodes)
+				leaves += n.skip == 1;
+			if (packed.nodes.size() > bvh.nodes.size() || leaves != mesh.faces.size() / 3 ||
+			    packed.nodes[0].skip != packed.nodes.size() || packed.tris.size() != mesh.faces.size() / 3)
 				throw std::logic_error("packed sizes");
 			// a malformed array must be rejected, not read out of bounds
 			std::vector<uint32_t> bad = bvh.nodes;
