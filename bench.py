@@ -291,10 +291,12 @@ def main():
             cpu, _ = cpu_baseline(opt, scene, final_u8, w)
             if counters is None and cpu is not None:
                 pass
-        traffic = None
+        traffic, valu_insts = None, None
         try:  # HBM bytes per AO launch from the PMC passes of profiles/ (collected separately)
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-                traffic = json.load(f).get(args.workload) if world == 1 else None
+                pmc = json.load(f)
+            traffic = pmc.get(args.workload) if world == 1 else None
+            valu_insts = pmc.get(args.workload + "_valu_insts") if world == 1 else None
         except OSError:
             pass
         has_ao = bool(opt.enable_ao)
@@ -311,6 +313,11 @@ def main():
                 "kernel_ms": round(dominant_ms, 4), "algorithmic_bytes_per_launch": int(bytes_per_launch),
                 "frame_kernels_ms": round(kernel_ms_max, 4),
                 "frame_algorithmic_GBps": round(parts["frame"] / world / (kernel_ms_max * 1e-3) / 1e9, 1),
+                # what actually bounds the kernel: vector-instruction issue (instruction count from the PMC pass, launch
+                # time measured live; ceiling measured by tools/microbench/valu_rate.hip on the slab test's instruction mix)
+                "valu_issue": None if not (valu_insts and has_ao) else {
+                    "achieved": round(valu_insts / (dominant_ms * 1e-3 * 2.4e9 * 1024), 3), "ceiling": 0.42,
+                    "unit": "wave64 VALU instr/clk/SIMD (1024 SIMDs, 2.4 GHz)", "insts_per_launch": int(valu_insts)},
                 "note": "algorithmic bytes = REFERENCE traversal (36 B/node visit + 60 B/triangle test [+ 48 B/hit + "
                         "4 B/sub-pixel for the primary pass]); the 12 MB scene is cache-resident, so the kernel is "
                         "bound by vector-instruction issue and scalar-load latency, not by HBM: frac > 1 is possible "
