@@ -301,7 +301,8 @@ RenderStats DeviceRenderer::stats() {
 	for (int k = 0; k < 32; ++k)
 		if (c.stamp[10 + k])
 			std::fprintf(stderr, " %.2f:%llu", k * 0.05, c.stamp[10 + k]);
-	std::fprintf(stderr, "\n");
+	std::fprintf(stderr, "\n   of the walks: node loop %.3f ms in %llu entries, batches %.3f ms in %llu batches, %llu leaf stops\n",
+	             c.stamp[42] * 1e-5, c.stamp[44], c.stamp[43] * 1e-5, c.stamp[45], c.stamp[46]);
 #endif
 	// Primary rays = sub-pixels of this rank's bands that lie inside the image.
 	const uint32_t tile_rows = (kp.height + TILE_H - 1) / TILE_H;

@@ -64,7 +64,7 @@ struct FrameCounters {
 	uint32_t pad;
 	unsigned long long occluded;  // occluded AO rays
 #ifdef OCRT_STAMPS
-	unsigned long long stamp[10 + 32];  // debug build: wave-time (10 ns ticks) per phase of the AO pass, jobs, packets
+	unsigned long long stamp[10 + 32 + 5];  // debug build: wave-time (10 ns ticks) per phase of the AO pass, jobs, packets
 #endif
 };
 

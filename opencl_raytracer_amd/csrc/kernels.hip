@@ -564,7 +564,9 @@ template <bool EXACT>
 __device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ nodes_ptr,
                                                     const float4 *__restrict__ tris_ptr, __amdgpu_buffer_rsrc_t tris_rsrc, uint32_t count,
                                                     const Ray &ray, float max_distance, float below, bool alive, uint32_t lane,
-                                                    unsigned int *occluded, LeafBatch &batch, uint32_t batch_below) {
+                                                    unsigned int *occluded, LeafBatch &batch, uint32_t batch_below,
+                                                    unsigned long long *prof) {
+	(void) prof;  // (-DOCRT_STAMPS builds: time in the node loop / in batches, loop entries, batches, leaf stops)
 	// the live lanes as a scalar mask: the node steps then need no per-lane bookkeeping at all
 	unsigned long long alive_mask = wave_ballot(alive);
 	if (!EXACT) {
@@ -578,6 +580,9 @@ __device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ n
 		uint32_t waiting = 0u;  // pairs in batch.entry (wave-uniform)
 		uint32_t leaf_stops = 0u;  // (not used by this pass)
 		auto run_batch = [&](uint32_t n) {
+#ifdef OCRT_STAMPS
+			const unsigned long long tb0 = __builtin_amdgcn_s_memrealtime();
+#endif
 			wave_lds_sync();
 			const uint32_t pair = batch.entry[lane < n ? lane : 0u];
 			const int owner = (int) (pair >> 26);
@@ -600,6 +605,10 @@ __device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ n
 			if (lane < 2u)
 				batch.occluded_bits[lane] = 0u;
 			alive_mask = wave_ballot(alive);
+#ifdef OCRT_STAMPS
+			prof[1] += __builtin_amdgcn_s_memrealtime() - tb0;
+			prof[3] += 1;
+#endif
 		};
 		uint32_t at = 0u;  // byte offset of the node (count < 2^27, checked at upload)
 		const uint32_t end = count * 32u;
@@ -608,8 +617,15 @@ __device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ n
 		while (alive_mask != 0ull && at < end) {
 			uint32_t leaf = 0u;
 			unsigned long long hit_mask = 0ull;
+#ifdef OCRT_STAMPS
+			const unsigned long long tw0 = __builtin_amdgcn_s_memrealtime();
+#endif
 			const uint32_t status = walk_collect(nodes_ptr, at, end, ray, sign, below, alive_mask, hit_mask, leaf, waiting,
 			                                     leaf_stops, list_lds_address, lane << 26, batch_below);
+#ifdef OCRT_STAMPS
+			prof[0] += __builtin_amdgcn_s_memrealtime() - tw0;
+			prof[2] += 1;
+#endif
 			if (status == 0u)
 				break;
 			if (status == 1u) {
@@ -634,6 +650,9 @@ __device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ n
 		}
 		if (waiting != 0u)
 			run_batch(waiting);
+#ifdef OCRT_STAMPS
+		prof[4] += leaf_stops;
+#endif
 		return;
 	}
 	uint32_t mine = 0u;
@@ -1054,10 +1073,15 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 	const uint32_t count = P.node_count;
 	const uint32_t strips = (P.tiles_x + 1u) >> 1;
 
+#ifndef OCRT_STAMPS
+	unsigned long long *walk_prof = nullptr;
+#endif
 #ifdef OCRT_STAMPS
 	unsigned long long stamp_acc[6] = { 0, 0, 0, 0, 0, 0 };
 	const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
 	unsigned long long t_last_claim = t_begin;
+	unsigned long long walk_prof_store[5] = { 0, 0, 0, 0, 0 };
+	unsigned long long *walk_prof = walk_prof_store;
 #endif
 	// Workgroups b and b+8 share an XCD: start with that group's queue, then help the others.
 	const uint32_t home = blockIdx.x & (XCD_GROUPS - 1u);
@@ -1269,10 +1293,10 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 						const bool exact = !scene_fast || wave_ballot(alive && !ray_is_selectable(ray)) != 0ull;
 						if (exact)
 							shared_walk_any_hit<true>(nodes_ptr, tris_ptr, scene.tris, count, ray, P.ao_max_distance,
-							                          P.ao_below, alive, lane, &sh.occluded[h], sh.batch, P.batch_below);
+							                          P.ao_below, alive, lane, &sh.occluded[h], sh.batch, P.batch_below, walk_prof);
 						else
 							shared_walk_any_hit<false>(nodes_ptr, tris_ptr, scene.tris, count, ray, P.ao_max_distance,
-							                           P.ao_below, alive, lane, &sh.occluded[h], sh.batch, P.batch_below);
+							                           P.ao_below, alive, lane, &sh.occluded[h], sh.batch, P.batch_below, walk_prof);
 					}
 				}
 				wave_lds_sync();
@@ -1303,6 +1327,8 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 		atomicMax(&counters->stamp[8], t_end);                       // last end
 		if (stamp_acc[4])
 			atomicAdd(&counters->stamp[9], 1ull);                    // waves that got any work
+		for (int k = 0; k < 5; ++k)
+			atomicAdd(&counters->stamp[42 + k], walk_prof_store[k]);  // time in the node loop, in batches; loop entries, batches, leaf stops
 		const unsigned long long idle_bucket = (t_end - t_last_claim) / 5000ull;  // last claim -> end, 0.05 ms buckets
 		atomicAdd(&counters->stamp[10 + (idle_bucket > 31 ? 31 : idle_bucket)], 1ull);
 	}
