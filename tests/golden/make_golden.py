@@ -35,11 +35,15 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import orc  # noqa: E402
-from tools.meshes import bunny_path  # noqa: E402
+from tools.meshes import bunny_path, interior_path  # noqa: E402
 
 
 def mesh_file(name: str) -> str:
-    return bunny_path() if name == "bunny" else os.path.join(HERE, "meshes", name + ".off")
+    if name == "bunny":
+        return bunny_path()
+    if name == "interior":  # generated, labelled stand-in for the missing sibenik.off; its arrays are pinned under "scenes"
+        return interior_path()
+    return os.path.join(HERE, "meshes", name + ".off")
 
 
 def case(name, mesh, bvh="longest", width=64, height=64, ss=1, ao=3, aod=0.2, focal=1.0, shading=1, amin=4, amax=90,
@@ -70,6 +74,11 @@ CASES = [
     case("ties_64_s4_a3", "ties", width=64, height=64, ss=4, ao=3, aod=1.0),
     case("ties_5x3_s1_a1", "ties", width=5, height=3, ao=1, aod=2.0, dump=True),
     case("single_32_s1_a3", "single", width=32, height=32, ao=3, dump=True),
+    # BASELINE.json configs 3-5 at full size (digests only): interior stand-in 1080p and 4K, bunny with 64 samples
+    # per pixel (regular 8x8 grid: 15360x8640 sub-pixels, 2.2 G rays)
+    case("interior_1080p_s1_a3", "interior", width=1920, height=1080, ao=3),
+    case("interior_4k_s1_a3", "interior", width=3840, height=2160, ao=3),
+    case("bunny_1080p_s64_a3", "bunny", width=1920, height=1080, ss=64, ao=3),
 ]
 
 
@@ -95,7 +104,7 @@ class Opt:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full-sah", action="store_true", help="also run the reference's O(n^2) SAH on the full bunny (~6 min)")
-    ap.add_argument("--only", default=None)
+    ap.add_argument("--only", default=None, help="comma-separated substrings of the case names to (re)generate")
     args = ap.parse_args()
     if not orc.reference_available():
         sys.exit("reference tree not present: goldens can only be regenerated in the build container")
@@ -121,14 +130,14 @@ def main():
             "vertices": sha(v), "vnormals": sha(n), "faces": sha(f), "nodes": sha(nodes), "aabbs": sha(aabbs),
             "triangles": sha(tris), "sorted_faces": sha(sorted_faces),
         }
-        if mesh != "bunny":
+        if mesh not in ("bunny", "interior"):
             np.savez_compressed(os.path.join(HERE, f"scene_{mesh}_{bvh}.npz"), vertices=v, vnormals=n, faces=f,
                                 nodes=nodes, aabbs=aabbs, triangles=tris, sorted_faces=sorted_faces)
         print(f"scene {mesh}/{bvh}: {nodes.size} nodes ({time.time() - t0:.1f}s)", flush=True)
 
     # ---- renders ----
     for c in CASES:
-        if args.only and args.only not in c["name"]:
+        if args.only and not any(part in c["name"] for part in args.only.split(",")):
             continue
         t0 = time.time()
         opt = Opt(c)

@@ -205,6 +205,56 @@ def ref_kernel(p: OrcParams, n_super_samples: int, build: bool = True) -> Option
     return lib
 
 
+# ---- the reference kernel compiled for the MI355X itself (oracle/Makefile: ref-kernel-gfx950) ----
+GFX950_MODES = ("default", "strict", "ieee_dot", "ieee_cross", "ieee_normalize", "ieee_length", "ieee_geom", "ieee_all")
+
+
+def ref_kernel_gfx950_path(p: OrcParams, n_super_samples: int, mode: str) -> str:
+    tag = hashlib.sha1(kernel_defs(p, n_super_samples).encode()).hexdigest()[:16]
+    return os.path.join(REF_DIR, f"ref_kernel_{tag}_{mode}.co")
+
+
+def ref_kernel_gfx950(p: OrcParams, n_super_samples: int, mode: str, build: bool = True) -> Optional[str]:
+    """Path of the gfx950 code object of the reference kernel for this macro set and
+    floating-point mode; built on demand where the reference tree is present."""
+    path = ref_kernel_gfx950_path(p, n_super_samples, mode)
+    if not os.path.exists(path):
+        if not (build and reference_available()):
+            return None
+        tag = os.path.basename(path)[len("ref_kernel_"):-len(f"_{mode}.co")]
+        subprocess.run(["make", "-s", "-C", ORACLE_DIR, "ref-kernel-gfx950", f"TAG={tag}", f"MODE={mode}",
+                        f"DEFS={kernel_defs(p, n_super_samples)}"], check=True, stdout=subprocess.DEVNULL)
+    return path
+
+
+class RefGpu:
+    """oracle/libref_launch.so: loads such a code object and launches `intersect` on cuda:0."""
+
+    def __init__(self):
+        path = os.path.join(ORACLE_DIR, "libref_launch.so")
+        if not os.path.exists(path):
+            subprocess.run(["make", "-s", "-C", ORACLE_DIR, "ref-launch"], check=True)
+        lib = C.CDLL(path)
+        lib.refgpu_last_error.restype = C.c_char_p
+        lib.refgpu_run.restype = C.c_int
+        lib.refgpu_run.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                   C.c_size_t, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                   C.c_int, C.POINTER(C.c_float)]
+        self.lib = lib
+
+    def render(self, code_object: str, p: OrcParams, scene: SceneArrays, block=(16, 16), repeats: int = 0):
+        """Returns (float image, average kernel ms over `repeats` launches or None)."""
+        image = np.zeros((p.height, p.width), dtype=np.float32)
+        ms = C.c_float(0.0)
+        rc = self.lib.refgpu_run(os.fsencode(code_object), scene.faces.ctypes.data, scene.faces.size,
+                                 scene.nodes.ctypes.data, scene.nodes.size, scene.aabbs.ctypes.data,
+                                 scene.vertices.ctypes.data, scene.vertices.shape[0], scene.normals.ctypes.data,
+                                 image.ctypes.data, p.width, p.height, block[0], block[1], repeats, C.byref(ms))
+        if rc != 0:
+            raise RuntimeError("reference kernel on the GPU: " + self.lib.refgpu_last_error().decode())
+        return image, (float(ms.value) if repeats > 0 else None)
+
+
 def ref_render(lib: C.CDLL, p: OrcParams, scene: SceneArrays, rows=None, nthreads: int = 0):
     image = np.zeros((p.height, p.width), dtype=np.float32)
     y0, y1 = (0, p.height) if rows is None else rows

@@ -1,0 +1,112 @@
+"""The reference's OWN kernel on the MI355X, linked against ROCm's real OpenCL builtin
+library, against the oracle (pin the oracle with a real builtin library).
+
+oracle/Makefile (ref-kernel-gfx950) compiles the unmodified reference
+src/intersect_kernel.cl for amdgcn gfx950 with ROCm's clang; the clang driver links
+opencl.bc / ocml.bc / ockl.bc itself -- nothing stands in for a builtin.  The code objects
+are built in the build container (they need /root/reference), live under oracle/_ref/
+(git-ignored, they travel to the GPU box like the other _ref outputs) and are launched
+here through oracle/libref_launch.so (HIP module API).
+
+What an OpenCL implementation's `dot`, `cross`, `normalize`, `length`, `/` and `sqrt`
+round to is implementation-defined (OpenCL 1.2 section 7.4); ROCm's library uses fused
+multiply-adds in dot/cross and `v * rsqrt(dot(v, v))` for normalize.  So bit-identity with
+the IEEE definitions the contract fixes is not expected of the
+`default` and `strict` builds; this file MEASURES the distance (float words, 8-bit
+pixels, grey levels) per build mode and per builtin, asserts what must hold exactly --
+the reference's control flow and formulas, compiled by a different backend for the GPU
+itself and with only the geometric builtins pinned to the IEEE definitions (`ieee_geom` /
+`ieee_all`), reproduce the oracle bit for bit -- and writes the table to
+gpurun_out/refkernel_gfx950.json (committed under profiles/).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, bits, options_for
+
+pytestmark = pytest.mark.gpu
+
+# golden cases whose NDRange the reference's 16 x 16 work-groups divide ...
+CASES_16 = ["bunny_256_s1_a0", "bunny_256_s1_a3", "blob_128x96_s4_a3", "ties_64_s4_a3", "bunny_600_defaults"]
+# ... and the headline frame, whose height 1080 they do not divide: launched with 16 x 8 work-groups
+CASES_OTHER = {"bunny_1080p_s1_a0": (16, 8), "bunny_1080p_s1_a3": (16, 8)}
+ALL_CASES = CASES_16 + sorted(CASES_OTHER)
+
+REPORT = {}
+
+
+def _report_path():
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    return os.path.join(out, "refkernel_gfx950.json")
+
+
+@pytest.fixture(scope="module")
+def refgpu():
+    import orc
+
+    if not os.path.exists(os.path.join(orc.ORACLE_DIR, "libref_launch.so")):
+        pytest.skip("oracle/libref_launch.so not built")
+    return orc.RefGpu()
+
+
+def _compare(oracle, opt, ref_img, gpu_img):
+    ref_u8 = oracle.resize(ref_img, opt.width, opt.height, opt.n_super_samples).astype(np.int32)
+    gpu_u8 = oracle.resize(gpu_img, opt.width, opt.height, opt.n_super_samples).astype(np.int32)
+    delta = np.abs(ref_u8 - gpu_u8)
+    hit_flip = int(np.count_nonzero((ref_img == 0.0) != (gpu_img == 0.0)))
+    return {
+        "float_words": int(ref_img.size), "float_words_differ": int(np.count_nonzero(bits(ref_img) != bits(gpu_img))),
+        "max_abs_float_delta": float(np.max(np.abs(ref_img.astype(np.float64) - gpu_img.astype(np.float64)))),
+        "hit_miss_flips": hit_flip, "pixels": int(ref_u8.size), "pixels_differ": int(np.count_nonzero(delta)),
+        "pixels_differ_by_more_than_1": int(np.count_nonzero(delta > 1)), "max_grey_delta": int(delta.max()),
+    }
+
+
+@pytest.mark.parametrize("name", ALL_CASES)
+def test_reference_kernel_on_gfx950_vs_oracle(rt, oracle, golden, scene_for, refgpu, name):
+    import orc
+
+    c = golden["renders"][name]
+    opt = options_for(rt, c)
+    p = orc.params_from_options(opt)
+    _, arrays = scene_for(c["mesh"], c["bvh"])
+    block = CASES_OTHER.get(name, (16, 16))
+    ref_img = None
+    ran = {}
+    for mode in orc.GFX950_MODES:
+        co = orc.ref_kernel_gfx950(p, c["ss"], mode, build=False)
+        if co is None:
+            continue
+        if ref_img is None:
+            ref_img, _, _ = oracle.render(p, arrays)
+        gpu_img, ms = refgpu.render(co, p, arrays, block=block, repeats=3 if mode in ("default", "strict") else 0)
+        row = _compare(oracle, opt, ref_img, gpu_img)
+        row["work_group"] = list(block)
+        if ms is not None:
+            rays = c["counters"]["primary_rays"] + c["counters"]["ao_rays"]
+            row["kernel_ms"] = round(ms, 3)
+            row["mrays_per_s"] = round(rays / ms / 1e3, 1)
+        ran[mode] = row
+    if not ran:
+        pytest.skip("no gfx950 code object of the reference kernel for this case under oracle/_ref/")
+    REPORT[name] = ran
+    with open(_report_path(), "w") as f:
+        json.dump(REPORT, f, indent=1, sort_keys=True)
+    # -- what must hold exactly --
+    # geometric builtins pinned to the IEEE definitions: the only library code left in a primary-only frame
+    # is `/` and `sqrt` (correctly rounded in these builds), so the reference's own code reproduces the oracle
+    for mode in ("ieee_geom", "ieee_all"):
+        if mode in ran and not c["ao"]:
+            assert ran[mode]["float_words_differ"] == 0, (mode, ran[mode])
+    # with the ring angles' sin/cos/cospi/sinpi evaluated in double as well, AO frames too
+    if "ieee_all" in ran:
+        assert ran["ieee_all"]["float_words_differ"] == 0, ran["ieee_all"]
+    # -- what is only measured: the real library's rounding.  Sanity bound: it is a rounding-level
+    # difference, not a different image (silhouette pixels may flip between hit and miss).
+    for mode in ("default", "strict"):
+        if mode in ran:
+            assert ran[mode]["pixels_differ_by_more_than_1"] <= 0.002 * ran[mode]["pixels"] + 4, (mode, ran[mode])
