@@ -11,11 +11,17 @@ in HBM before the timed region starts.  Rays are counted as the reference would
 cast them: one primary ray per sub-pixel plus, with AO on, 28 (default ring
 set) any-hit rays per hit sub-pixel.
 
+`--gpus N` with N > 1 from a bare shell starts N ranks itself (a child
+`python -m torch.distributed.run`, before this process touches torch or the GPU);
+under an external torchrun (RANK / WORLD_SIZE in the environment) it is a rank.
+
 Rank 0 prints ONE JSON line (contract in the task description) carrying
-`roofline` (dominant kernel, algorithmic bytes of the REFERENCE traversal over
-the HIP-event kernel time, against the 8 TB/s HBM peak) and, at N = 1,
-`cpu_baseline` (the reference's own kernel compiled for x86-64 when
-oracle/_ref/ holds it, else this repo's C restatement, on the host cores).
+`roofline` -- the bound the dominant kernel is actually under (vector-instruction
+issue; the 12 MB scene is cache-resident), with the contractual HBM line of
+SURVEY.md 8d (algorithmic bytes of the REFERENCE traversal over the HIP-event
+kernel time, and the HBM bytes the PMC counters really saw) under `roofline.hbm`
+-- and, at N = 1, `cpu_baseline` (the reference's own kernel compiled for x86-64
+when oracle/_ref/ holds it, else this repo's C restatement, on the host cores).
 """
 from __future__ import annotations
 
@@ -30,6 +36,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# Vector-instruction issue (MI355X_MICROARCH.md, "Wave scheduling"): a SIMD-32 issues a wave64 VALU instruction over
+# 2 cycles, i.e. at most 0.5 per clock per SIMD (a lone wave sustains 0.25); 256 CUs x 4 SIMDs at 2.4 GHz.
+VALU_PEAK_PER_CLK_SIMD = 0.5
+SIMDS, CLOCK_HZ = 1024, 2.4e9
 
 # Workloads = the configs of BASELINE.json that fit one GPU; `golden` names the
 # tests/golden/golden.json entry that pins the output and supplies the
@@ -51,13 +61,13 @@ WORKLOADS = {
         mesh="bunny", bvh="longest", width=1920, height=1080, ss=16, ao=3, golden=None,
         label="bunny.off 1920x1080 -s 16 -a 3 (4x4 supersample grid: 7680x4320 sub-pixels)"),
     "bunny_1080p_s64": dict(
-        mesh="bunny", bvh="longest", width=1920, height=1080, ss=64, ao=3, golden=None,
+        mesh="bunny", bvh="longest", width=1920, height=1080, ss=64, ao=3, golden="bunny_1080p_s64_a3",
         label="bunny.off 1920x1080 -s 64 -a 3 (regular 8x8 supersample grid: 15360x8640 sub-pixels)"),
     "interior_4k_ao": dict(
-        mesh="interior", bvh="longest", width=3840, height=2160, ss=1, ao=3, golden=None,
+        mesh="interior", bvh="longest", width=3840, height=2160, ss=1, ao=3, golden="interior_4k_s1_a3",
         label="interior stand-in for the missing sibenik.off, 3840x2160 -s 1 -a 3"),
     "interior_1080p_ao": dict(
-        mesh="interior", bvh="longest", width=1920, height=1080, ss=1, ao=3, golden=None,
+        mesh="interior", bvh="longest", width=1920, height=1080, ss=1, ao=3, golden="interior_1080p_s1_a3",
         label="interior stand-in for the missing sibenik.off, 1920x1080 -s 1 -a 3"),
 }
 DEFAULT_WORKLOAD = "bunny_1080p_ao"
@@ -85,6 +95,31 @@ def algorithmic_bytes(counters: dict, subpixels: int) -> dict:
     primary = (36 * counters["primary_node_visits"] + 60 * counters["primary_tri_tests"]
                + 48 * counters["primary_hits"] + 4 * subpixels)
     return {"ao": ao, "primary": primary, "frame": ao + primary}
+
+
+def kernel_source_sha() -> str:
+    """Identifies the kernels the PMC counters under profiles/ were collected for: sha256 over the sources that
+    decide what a launch executes (kernels, record layouts, scene packing, the walk tree)."""
+    h = hashlib.sha256()
+    for name in ("kernels.hip", "device_types.h", "scene_pack.cc", "walk_tree.cc"):
+        with open(os.path.join(ROOT, "opencl_raytracer_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def pmc_for(workload: str):
+    """PMC counters of `workload`'s dominant kernel from profiles/pmc.json (collected by tools/pmc_collect.sh in
+    separate rocprofv3 --pmc passes, corrected as MI355X_MICROARCH.md prescribes) -- or None when they were
+    collected for other kernel sources than the ones in this tree."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc.json")) as f:
+            pmc = json.load(f)
+    except (OSError, ValueError):
+        return None
+    entry = pmc.get("workloads", {}).get(workload)
+    if entry is None or pmc.get("kernel_source_sha256") != kernel_source_sha():
+        return None
+    return dict(entry, source=pmc.get("source"))
 
 
 def host_cores() -> int:
@@ -163,13 +198,23 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ  # under torch.distributed.run
+    if not launched and args.gpus > 1:
+        # A bare `python bench.py --gpus N`: start the N ranks as FRESH processes.  This process has not imported
+        # torch or touched the GPU yet (and must not: a process that initialised HIP may not exec or fork ranks).
+        import socket
+        import subprocess
+
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd).returncode)  # rank 0's JSON line goes straight to our stdout
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
 
     import numpy as np
     import torch
@@ -186,7 +231,9 @@ def main():
     device_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(device_index)
     device = torch.device("cuda", device_index)
-    if world > 1:
+    if backend == "nccl" and world > torch.cuda.device_count():
+        sys.exit(f"bench.py: {world} ranks but {torch.cuda.device_count()} visible GPU(s): one rank per GPU")
+    if launched:  # also for a world of one: the RCCL communicator and the gather are then exercised on a one-GPU box
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
@@ -207,24 +254,23 @@ def main():
     host.set_stream(stream.cuda_stream)
 
     # band buffers: equal-sized on every rank so the gather is one collective
-    from opencl_raytracer_amd.multi_gpu import BandLayout, gather_bands
+    from opencl_raytracer_amd.multi_gpu import BandGatherer, BandLayout
 
     layout = BandLayout(opt, world)
     assert layout.local_rows(rank) == host.local_rows
     band = torch.zeros((layout.max_rows, opt.width), dtype=torch.uint8, device=device)
+    staged = launched and backend != "nccl"  # rehearsal path: the gather is staged through host memory
+    gather = BandGatherer(layout, rank, "cpu" if staged else device)
     result = {}
 
     def step():
         host.render_async()
         host.resize_into_device(band.data_ptr())
-        if world > 1 and backend != "nccl":
-            result["final"] = gather_bands(band.cpu(), layout, rank)  # rehearsal path: host-staged gather
-        else:
-            result["final"] = gather_bands(band, layout, rank)
+        result["final"] = gather(band.cpu() if staged else band)
 
     def fence():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if launched:
             dist.barrier()
         torch.cuda.synchronize(device)
 
@@ -244,8 +290,8 @@ def main():
     st = host.stats()
     my_rays = st["primary_rays"] + st["ao_rays"]
     kernel_ms = host.total_kernel_ms / max(1, host.kernel_launches)
-    ao_ms = host.total_ao_ms / max(1, host.kernel_launches)
-    if world > 1:
+    ao_ms = host.total_ao_ms / max(1, host.kernel_launches)  # HIP events right around the ao_kernel launch
+    if launched:
         t = torch.tensor([elapsed, kernel_ms, ao_ms], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms_max, ao_ms_max = float(t[0]), float(t[1]), float(t[2])
@@ -282,57 +328,57 @@ def main():
                      "synthetic interior scene, stand-in for the missing sibenik.off (tools/make_interior_mesh.py)")
                     + ", fixed camera, no randomness in this path",
             "config": {"workload": w["label"], "rays_per_frame": total_rays, "primary_hits": total_hits,
-                       "parallelism": f"image bands x{world}" + (f", {'RCCL' if backend == 'nccl' else backend} gather to rank 0" if world > 1 else ""),
+                       "parallelism": f"image bands x{world}" + (f", {'RCCL' if backend == 'nccl' else backend} gather to rank 0" if launched else ""),
                        "pgm_md5": pgm_md5, "pgm_matches_golden": golden_md5 is not None,
                        "scene_build_s": round(t_scene, 3), "device": torch.cuda.get_device_name(device)},
         }
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu, _ = cpu_baseline(opt, scene, final_u8, w)
-            if counters is None and cpu is not None:
-                pass
-        traffic, valu_insts = None, None
-        try:  # HBM bytes per AO launch from the PMC passes of profiles/ (collected separately)
-            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-                pmc = json.load(f)
-            traffic = pmc.get(args.workload) if world == 1 else None
-            valu_insts = pmc.get(args.workload + "_valu_insts") if world == 1 else None
-        except OSError:
-            pass
         has_ao = bool(opt.enable_ao)
         dominant = "ao_kernel" if has_ao else "primary_kernel"
         dominant_ms = ao_ms_max if has_ao else kernel_ms_max
+        seconds = dominant_ms * 1e-3
+        pmc = pmc_for(args.workload) if world == 1 else None  # counters are per launch of the WHOLE frame on one GPU
+        # The contractual HBM line: algorithmic bytes of the reference traversal over the measured
+        # launch time, beside the HBM bytes the counters really saw.  The scene is cache-resident, so this is NOT
+        # the bound the kernel is under; `x_peak` may exceed 1 and is therefore not called a fraction.
+        hbm = {"peak": HBM_PEAK_GBS, "unit": "GB/s"}
         if counters is not None:
             sub = opt.total_width * opt.total_height
             parts = algorithmic_bytes(counters, sub)
             bytes_per_launch = (parts["ao"] if has_ao else parts["frame"]) / world  # bands are interleaved over ranks
-            achieved = bytes_per_launch / (dominant_ms * 1e-3) / 1e9
-            out["roofline"] = {
-                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": dominant,
-                "kernel_ms": round(dominant_ms, 4), "algorithmic_bytes_per_launch": int(bytes_per_launch),
-                "frame_kernels_ms": round(kernel_ms_max, 4),
-                "frame_algorithmic_GBps": round(parts["frame"] / world / (kernel_ms_max * 1e-3) / 1e9, 1),
-                # what actually bounds the kernel: vector-instruction issue (instruction count from the PMC pass, launch
-                # time measured live; ceiling measured by tools/microbench/valu_rate.hip on the slab test's instruction mix)
-                "valu_issue": None if not (valu_insts and has_ao) else {
-                    "achieved": round(valu_insts / (dominant_ms * 1e-3 * 2.4e9 * 1024), 3), "ceiling": 0.42,
-                    "unit": "wave64 VALU instr/clk/SIMD (1024 SIMDs, 2.4 GHz)", "insts_per_launch": int(valu_insts)},
-                "note": "algorithmic bytes = REFERENCE traversal (36 B/node visit + 60 B/triangle test [+ 48 B/hit + "
-                        "4 B/sub-pixel for the primary pass]); the 12 MB scene is cache-resident, so the kernel is "
-                        "bound by vector-instruction issue and scalar-load latency, not by HBM: frac > 1 is possible "
-                        "(DESIGN.md)",
-            }
+            hbm.update(algorithmic_bytes_per_launch=int(bytes_per_launch),
+                       algorithmic_GBps=round(bytes_per_launch / seconds / 1e9, 1),
+                       algorithmic_x_peak=round(bytes_per_launch / seconds / 1e9 / HBM_PEAK_GBS, 3),
+                       frame_algorithmic_GBps=round(parts["frame"] / world / (kernel_ms_max * 1e-3) / 1e9, 1))
+        traffic = None
+        if pmc is not None:
+            traffic = int(pmc["hbm_bytes"])
+            hbm.update(measured_bytes_per_launch=traffic, measured_GBps=round(traffic / seconds / 1e9, 1),
+                       measured_frac=round(traffic / seconds / 1e9 / HBM_PEAK_GBS, 4))
+        hbm["note"] = ("algorithmic bytes = REFERENCE traversal (36 B/node visit + 60 B/triangle test [+ 48 B/hit + 4 B/"
+                       "sub-pixel for the primary pass]); they are served by the scalar cache and L2, not by HBM")
+        # The binding roofline: vector-instruction issue.  Instruction count per launch from the PMC pass of the same
+        # kernel sources (profiles/pmc.json, null if the sources changed since), launch time measured live.
+        roof = {"bound": "valu", "achieved": None, "peak": VALU_PEAK_PER_CLK_SIMD,
+                "unit": "wave64 VALU instr/clk/SIMD (1024 SIMDs, 2.4 GHz)", "frac": None, "traffic": traffic,
+                "kernel": dominant, "kernel_ms": round(dominant_ms, 4), "frame_kernels_ms": round(kernel_ms_max, 4)}
+        if pmc is not None:
+            rate = pmc["valu_insts"] / (seconds * CLOCK_HZ * SIMDS)
+            roof.update(achieved=round(rate, 4), frac=round(rate / VALU_PEAK_PER_CLK_SIMD, 4),
+                        insts_per_launch=int(pmc["valu_insts"]), ceiling_measured=pmc.get("valu_ceiling_measured"),
+                        levels=pmc.get("levels"), counters_from=pmc.get("source"))
         else:
-            out["roofline"] = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
-                               "traffic": traffic, "kernel": dominant, "kernel_ms": round(dominant_ms, 4),
-                               "frame_kernels_ms": round(kernel_ms_max, 4)}
+            roof["counters_from"] = None if world > 1 else "profiles/pmc.json is missing or was collected for other kernel sources"
+        roof["hbm"] = hbm
+        out["roofline"] = roof
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
 
     host.close()
-    if world > 1:
+    if launched:
         dist.destroy_process_group()
 
 

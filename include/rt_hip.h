@@ -143,7 +143,7 @@ int rt_use_private_stream(rt_host *h);
 /* Ray counts of the last frame and HIP-event timing of the ray-casting passes
  * on the launch stream (last frame, running total in ms and number of frames
  * since the reset): *_kernel_ms covers every pass of a frame, *_ao_ms the
- * ambient-occlusion passes (ordering + AO + resolve) alone. */
+ * launch of the ambient-occlusion kernel alone (0 for frames without AO). */
 int rt_get_stats(rt_host *h, rt_stats *out);
 float rt_last_kernel_ms(const rt_host *h);
 double rt_total_kernel_ms(const rt_host *h);

@@ -6,6 +6,9 @@
 #include <cstdlib>
 #include <iostream>
 
+namespace ocrt {
+namespace cli {
+
 #ifndef NO_COLORS
 const char *Color::RESET = "\033[0m";
 const char *Color::RED = "\033[0;91m";
@@ -88,3 +91,6 @@ std::string Info::str() const {
 		ss << c.str() << std::endl;
 	return ss.str();
 }
+
+}  // namespace cli
+}  // namespace ocrt

@@ -5,6 +5,11 @@
 // observable matters here: the phase names and line shapes of
 // reference src/info.cc:14-42 (they delimit what "Rendering image" times) and
 // the millisecond wall clock of reference src/timer.cc:11-18.
+//
+// Everything lives in namespace ocrt::cli: the reference defines global `Color`, `Info`
+// and `Timer` classes of its own (src/color.cc, info.cc, timer.cc, with a different
+// layout), and a maintainer who links those files next to libocrt_hip.so must not get
+// two definitions of one symbol.
 #pragma once
 #include <cstddef>
 #include <functional>
@@ -12,6 +17,9 @@
 #include <string>
 #include <utility>
 #include <vector>
+
+namespace ocrt {
+namespace cli {
 
 struct Color {
 	static const char *RESET, *RED, *GREEN, *YELLOW, *BLUE, *PURPLE, *CYAN, *WHITE;
@@ -55,3 +63,6 @@ class Info {
 		std::vector<std::pair<std::string, std::string>> attributes;
 		std::vector<Info> children;
 };
+
+}  // namespace cli
+}  // namespace ocrt

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <cstring>
 #include <sstream>
 
 namespace ocrt {
@@ -58,6 +59,7 @@ DeviceRenderer::DeviceRenderer(const RayTracer::Options &options, int device_, u
 	, d_tile_hits(nullptr)
 	, d_order(nullptr)
 	, d_counters(nullptr)
+	, image_bytes(0)
 	, tile_count(0)
 	, compute_units(0)
 	, scene_ready(false)
@@ -93,10 +95,10 @@ DeviceRenderer::DeviceRenderer(const RayTracer::Options &options, int device_, u
 	hipStream_t s;
 	OCRT_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
 	own_stream = stream = s;
-	// The float image is allocated at full size on every rank (bands are written
-	// in place, like the reference's single image buffer); the uint8 band buffer
-	// is compact.
-	d_image = device_alloc((size_t) rt.totalWidth * rt.totalHeight * sizeof(float));
+	// Float image and uint8 buffer both hold this rank's bands only, back to back
+	// (whole tile rows, so the last band may run past the image's height).
+	image_bytes = (size_t) kp.local_tile_rows * TILE_H * rt.totalWidth * sizeof(float);
+	d_image = device_alloc(image_bytes);
 	d_u8 = device_alloc((size_t) local_out_rows * opts.width);
 	// hit list: 64 slots per tile; ordered tile lists: one segment per XCD group
 	const size_t order_slots = (size_t) ((kp.tiles_x + 1) / 2) * 2 * kp.local_tile_rows;
@@ -110,7 +112,7 @@ DeviceRenderer::DeviceRenderer(const RayTracer::Options &options, int device_, u
 		OCRT_HIP(hipGetDeviceProperties(&prop, device));
 		compute_units = (uint32_t) prop.multiProcessorCount;
 	}
-	OCRT_HIP(hipMemsetAsync(d_image, 0, (size_t) rt.totalWidth * rt.totalHeight * sizeof(float), (hipStream_t) stream));
+	OCRT_HIP(hipMemsetAsync(d_image, 0, image_bytes, (hipStream_t) stream));
 	OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));
 }
 
@@ -124,6 +126,7 @@ DeviceRenderer::~DeviceRenderer() {
 	for (auto &ev : free_events) {
 		(void) hipEventDestroy((hipEvent_t) ev.start);
 		(void) hipEventDestroy((hipEvent_t) ev.ao_start);
+		(void) hipEventDestroy((hipEvent_t) ev.ao_stop);
 		(void) hipEventDestroy((hipEvent_t) ev.stop);
 	}
 	freeScene();
@@ -188,7 +191,7 @@ size_t DeviceRenderer::upload(const PackedScene &scene) {
 		OCRT_HIP(hipMemcpy(d_ao, table.data(), ao_bytes, hipMemcpyHostToDevice));
 	OCRT_HIP(hipDeviceSynchronize());
 	scene_ready = true;
-	return nodes_bytes + tris_bytes + shade_bytes + ao_bytes + (size_t) rt.totalWidth * rt.totalHeight * sizeof(float) +
+	return nodes_bytes + tris_bytes + shade_bytes + ao_bytes + image_bytes +
 	       (size_t) local_out_rows * opts.width + tile_count * (64 * (sizeof(HitRec) + sizeof(uint32_t)) + 2 * sizeof(uint32_t)) +
 	       sizeof(FrameCounters);
 }
@@ -202,11 +205,12 @@ void DeviceRenderer::enqueueRender() {
 		ev = free_events.back();
 		free_events.pop_back();
 	} else {
-		hipEvent_t a, b, c;
+		hipEvent_t a, b, c, d;
 		OCRT_HIP(hipEventCreate(&a));
 		OCRT_HIP(hipEventCreate(&b));
 		OCRT_HIP(hipEventCreate(&c));
-		ev = { a, b, c };
+		OCRT_HIP(hipEventCreate(&d));
+		ev = { a, b, c, d };
 	}
 	hipStream_t s = (hipStream_t) stream;
 	OCRT_HIP(hipEventRecord((hipEvent_t) ev.start, s));
@@ -216,9 +220,9 @@ void DeviceRenderer::enqueueRender() {
 #endif
 	launch_primary(d_nodes, d_tris, d_shade, (float *) d_image, d_hits, d_occluded, d_tile_hits, d_counters, kp, stream);
 	OCRT_HIP(hipGetLastError());
-	OCRT_HIP(hipEventRecord((hipEvent_t) ev.ao_start, s));
+	ev.ao_timed = kp.ao_mode != AO_NONE && kp.ao_dirs > 0 && tile_count > 0;
 	launch_ao(d_nodes, d_tris, d_ao, (float *) d_image, d_hits, d_occluded, d_tile_hits, d_order, d_counters, kp,
-	          compute_units, stream);
+	          compute_units, stream, ev.ao_start, ev.ao_stop);
 	OCRT_HIP(hipGetLastError());
 	OCRT_HIP(hipEventRecord((hipEvent_t) ev.stop, s));
 	pending_events.push_back(ev);
@@ -241,7 +245,8 @@ void DeviceRenderer::synchronize() {
 	for (auto &ev : pending_events) {
 		float ms = 0, ao_ms = 0;
 		OCRT_HIP(hipEventElapsedTime(&ms, (hipEvent_t) ev.start, (hipEvent_t) ev.stop));
-		OCRT_HIP(hipEventElapsedTime(&ao_ms, (hipEvent_t) ev.ao_start, (hipEvent_t) ev.stop));
+		if (ev.ao_timed)
+			OCRT_HIP(hipEventElapsedTime(&ao_ms, (hipEvent_t) ev.ao_start, (hipEvent_t) ev.ao_stop));
 		last_ms = ms;
 		last_ao_ms = ao_ms;
 		total_ms += ms;
@@ -254,8 +259,22 @@ void DeviceRenderer::synchronize() {
 
 void DeviceRenderer::downloadFloat(float *host_image) {
 	synchronize();
-	OCRT_HIP(hipMemcpy(host_image, d_image, (size_t) rt.totalWidth * rt.totalHeight * sizeof(float),
-	                   hipMemcpyDeviceToHost));
+	const size_t row_bytes = (size_t) rt.totalWidth * sizeof(float);
+	if (part.nranks == 1) {  // local rows are the image's rows (plus, possibly, padding below it)
+		OCRT_HIP(hipMemcpy(host_image, d_image, row_bytes * rt.totalHeight, hipMemcpyDeviceToHost));
+		return;
+	}
+	// a partitioned host: its bands go to their place in the caller's full-size image, the other ranks' rows are 0
+	std::memset(host_image, 0, row_bytes * rt.totalHeight);
+	const uint32_t band_rows = part.band_tile_rows * TILE_H;
+	for (uint32_t local = 0; local < kp.local_tile_rows * TILE_H; local += band_rows) {
+		const uint32_t global = ((local / band_rows) * part.nranks + part.rank) * band_rows;
+		if (global >= rt.totalHeight)
+			break;
+		const uint32_t rows = rt.totalHeight - global < band_rows ? rt.totalHeight - global : band_rows;
+		OCRT_HIP(hipMemcpy((char *) host_image + row_bytes * global, (const char *) d_image + row_bytes * local,
+		                   row_bytes * rows, hipMemcpyDeviceToHost));
+	}
 }
 
 void DeviceRenderer::downloadResizedLocal(unsigned char *host) {

@@ -43,7 +43,7 @@ class DeviceRenderer {
 		// the kernel-time statistics.
 		void synchronize();
 
-		void downloadFloat(float *host_image);          // full totalWidth x totalHeight
+		void downloadFloat(float *host_image);          // full totalWidth x totalHeight (rows of other ranks' bands: 0)
 		void downloadResizedLocal(unsigned char *host); // localRows() x width, compact
 		void downloadResizedFull(unsigned char *host);  // width x height (needs nranks == 1)
 
@@ -54,7 +54,7 @@ class DeviceRenderer {
 
 		RenderStats stats();   // ray counts of the last frame (device counters)
 		float lastKernelMs() const { return last_ms; }      // all passes of the last frame
-		float lastAoMs() const { return last_ao_ms; }       // ordering + AO + resolve passes of the last frame
+		float lastAoMs() const { return last_ao_ms; }       // the ao_kernel launch alone (0 when the frame has no AO pass)
 		double totalKernelMs() const { return total_ms; }
 		double totalAoMs() const { return total_ao_ms; }
 		uint64_t kernelLaunches() const { return launches; }
@@ -81,11 +81,13 @@ class DeviceRenderer {
 		uint32_t local_out_rows;
 		void *own_stream, *stream;
 		void *d_nodes, *d_tris, *d_shade, *d_ao, *d_image, *d_u8, *d_hits, *d_occluded, *d_tile_hits, *d_order, *d_counters;
+		size_t image_bytes;  // float image of this rank's bands
 		size_t tile_count;
 		uint32_t compute_units;
 		bool scene_ready, frame_ready;
 		struct FrameEvents {
-			void *start, *ao_start, *stop;
+			void *start, *ao_start, *ao_stop, *stop;  // frame begin, around the ao_kernel launch alone, frame end
+			bool ao_timed = false;                    // the frame had an AO pass (ao_start / ao_stop were recorded)
 		};
 		std::vector<FrameEvents> pending_events, free_events;
 		float last_ms, last_ao_ms;
@@ -98,7 +100,7 @@ void launch_primary(const void *nodes, const void *tris, const void *shade, floa
                     void *occluded_of, void *tile_hits, void *counters, const KernelParams &P, void *stream);
 void launch_ao(const void *nodes, const void *tris, const void *ao_table, float *image, void *hits,
                void *occluded_of, void *tile_hits, void *order, void *counters, const KernelParams &P,
-               uint32_t compute_units, void *stream);
+               uint32_t compute_units, void *stream, void *event_before_ao, void *event_after_ao);
 void launch_resize(const float *tmp, unsigned char *out, const KernelParams &P, uint32_t out_width, uint32_t n,
                    uint32_t local_out_rows, void *stream);
 

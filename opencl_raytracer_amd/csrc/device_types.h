@@ -96,7 +96,7 @@ struct KernelParams {
 	int32_t scene_regular; // every box finite, |coord| <= 1e37 and lo <= hi: min/max slab form allowed
 	int32_t ao_regular;    // AO_MAX_DISTANCE > 0 (needed by the folded form of the slab test)
 	int32_t scene_nested;  // every child box lies inside its parent's box: the shared walk's fast form is allowed
-	int32_t shared_walk;   // the node array is a binary tree (children partition the parent's index range)
+	int32_t shared_walk;   // sibling subtrees tile their parent's index range (any arity): one shared node index is safe
 	float primary_below;   // largest float below the primary rays' max_distance (100000.0f)
 	float ao_below;        // largest float below AO_MAX_DISTANCE
 	int32_t debug_no_sort; // debug knob OCRT_NO_SORT: claim tiles in arbitrary order instead of heaviest first
@@ -107,7 +107,7 @@ struct KernelParams {
 	uint32_t ao_claim_max;  // most (tile, direction) units one AO claim takes; 0 = a twelfth of a wave's share, 4 .. ao_dirs
 	uint32_t ao_claim_div;  // (set by launch_ao: 12 x the waves per XCD group)
 	uint32_t ao_guide;      // an AO claim takes 1/ao_guide of the (tile, direction) units left in its queue; the host
-	                        // sets the factor (2), launch_ao multiplies it by the waves per XCD group
+	                        // sets the factor (1, debug knob OCRT_AO_GUIDE), launch_ao multiplies it by the waves per XCD group
 	uint32_t tiles_x;      // tiles per image row
 	uint32_t local_tile_rows;  // tile rows this rank owns
 	Partition part;

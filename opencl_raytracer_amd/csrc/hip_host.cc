@@ -9,6 +9,9 @@
 #include "device_renderer.h"
 #include "scene_pack.h"
 
+using ocrt::cli::Color;
+using ocrt::cli::Info;
+
 namespace {
 
 // The reference's check(): report and leave (reference include/opencl_host.h:21-26).

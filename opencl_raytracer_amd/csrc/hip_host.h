@@ -4,9 +4,20 @@
 // argument meaning, same error behaviour, so reference src/render.cc:84-116
 // compiles against it through the alias at the bottom of this file.
 #pragma once
+// The reference's opencl_host.h pulls in <iostream> itself and, through CL/cl.hpp,
+// <utility> <limits> <iterator> <exception> <cstring> <cstdlib> ...; callers written against it
+// (reference src/render.cc:136 uses std::ostream_iterator without including <iterator>)
+// rely on that, so the drop-in provides the same set.
 #include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <exception>
+#include <iostream>
+#include <iterator>
+#include <limits>
 #include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "device_types.h"

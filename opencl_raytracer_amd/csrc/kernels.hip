@@ -324,7 +324,8 @@ __device__ __forceinline__ void advance_walkers(const SceneViews &scene, const R
 // Shared walk.  The 64 rays of a wave visit the union of their nodes together:
 // one wave-uniform node index `at`, so a node (and a leaf's triangle) arrives by
 // scalar loads and the box is tested out of SGPRs; no per-lane index, no gathers,
-// no scheduling.  Needs the node array to be a binary tree (KernelParams::shared_walk).
+// no scheduling.  Needs sibling subtrees to tile their parent's index range (KernelParams::shared_walk;
+// checked at upload for the uploaded binary tree and again for the rebuilt, possibly wider one).
 //
 // Fast form (`exact` false: regular scene with nested boxes, regular rays): every
 // live lane tests every visited box.  A lane that missed an ancestor also misses
@@ -334,7 +335,16 @@ __device__ __forceinline__ void advance_walkers(const SceneViews &scene, const R
 //
 // Exact form: each lane also keeps `mine`, the next node of its OWN walk, tests a
 // box only when at == mine, and uses the reference's select-based slab test: lane
-// by lane that is the reference walk itself, whatever the boxes and rays hold.
+// by lane that is the reference's walk (src/intersect_kernel.cl:184-213) of the node
+// array the kernel was given, whatever the boxes and rays hold.  For damaged scene
+// arrays that array is the uploaded one, so this IS the reference walk.  On a regular,
+// nested scene it may be the rebuilt tree (scene_pack.cc); the form is then only taken by
+// packets holding a ray that is not "selectable" -- a NaN direction or origin (zero-length
+// vertex normals), all three reciprocals infinite -- and such a ray fails the slab test
+// at the ROOT of any tree (`NaN < max_distance` is false, reference :60), so it tests no
+// triangle in either tree, while its selectable neighbours get, lane by lane, the
+// monotone slab test on nested boxes, for which the tree does not matter.
+// tests/test_hip_parity.py::test_zero_normals_on_a_rebuilt_tree covers it.
 // `at` never overtakes a live lane's `mine` because subtree ranges nest.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ bool shared_box(bool exact, const float4 lo, const float4 hi, const Ray &ray, float max_distance,
@@ -723,6 +733,8 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
 	const uint32_t x = tile_x * TILE_W + (lane & 7u);
 	const uint32_t y = tile_y * TILE_H + (lane >> 3);
 	const bool active = x < P.width && y < P.height;
+	// the float image holds this rank's bands only, one after the other: row `local_y` of it is image row `y`
+	const uint32_t local_y = local_row * TILE_H + (lane >> 3);
 	const uint32_t count = P.node_count;
 
 	// reference src/intersect_kernel.cl:279-295
@@ -901,7 +913,7 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
 	}
 	const bool want_ao = P.ao_mode != AO_NONE && P.ao_dirs > 0;
 	if (active && !(hit && want_ao))
-		image[(size_t) y * P.width + x] = value;  // final already
+		image[(size_t) local_y * P.width + x] = value;  // final already
 
 	// the tile's hits go into the tile's own 64 slots of the hit list, compacted
 	const unsigned long long hit_mask = wave_ballot(hit);
@@ -923,7 +935,7 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
 		rec.ox = best.px; rec.oy = best.py; rec.oz = best.pz;
 		rec.value = value;
 		rec.nx = nx; rec.ny = ny; rec.nz = nz;
-		rec.pixel = y * P.width + x;
+		rec.pixel = local_y * P.width + x;  // index into this rank's band image
 		const size_t slot = (size_t) tile * 64u + rank_in(hit_mask);
 		hits[slot] = rec;
 		occluded_of[slot] = 0u;
@@ -1206,7 +1218,10 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 						// rounds differently from the host's: this mode is outside the bit-exact contract.
 						const uint32_t j = dir0 + k;
 						along_normal = j == 0u;
-						Rng rng = rng_seed(536870923u * sh.pixel[h]);
+						// the generator is seeded with the sub-pixel's index in the WHOLE image (reference :169, :279-281)
+						const uint32_t local_y = sh.pixel[h] / P.width, x = sh.pixel[h] - local_y * P.width;
+						const uint32_t y = global_tile_row(P.part, local_y / TILE_H) * TILE_H + (local_y & (TILE_H - 1u));
+						Rng rng = rng_seed(536870923u * (y * P.width + x));
 						for (uint32_t skip = 1; skip < j; ++skip) {
 							rng_next(rng);
 							rng_next(rng);
@@ -1361,9 +1376,11 @@ __global__ __launch_bounds__(256) void resolve_kernel(const HitRec *__restrict__
 
 // Supersample box filter + 8-bit quantisation on the device: one thread per
 // output pixel, ssY-major / ssX-minor float summation and truncating store,
-// exactly reference src/ray_tracer.cc:3-16.  Works on this rank's bands only:
-// local output row j of the compact band buffer is global row
-// (band_local * nranks + rank) * rows_per_band + j % rows_per_band.
+// exactly reference src/ray_tracer.cc:3-16.  Works on this rank's bands only: both the
+// float image and the 8-bit buffer hold them back to back, so local output row j is
+// the box filter of local sub-pixel rows j*n .. j*n+n-1; it is global row
+// (band_local * nranks + rank) * rows_per_band + j % rows_per_band, and rows past the
+// image's height are written as 0.
 __global__ __launch_bounds__(256) void resize_kernel(const float *__restrict__ tmp, unsigned char *__restrict__ out,
                                                      uint32_t width, uint32_t height, uint32_t total_width, uint32_t n,
                                                      Partition part, uint32_t rows_per_band) {
@@ -1377,7 +1394,7 @@ __global__ __launch_bounds__(256) void resize_kernel(const float *__restrict__ t
 	if (y < height) {
 		float total = 0.0f;
 		for (uint32_t sy = 0; sy < n; ++sy) {
-			const float *row = tmp + (size_t) (y * n + sy) * total_width + (size_t) x * n;
+			const float *row = tmp + (size_t) (j * n + sy) * total_width + (size_t) x * n;
 			for (uint32_t sx = 0; sx < n; ++sx)
 				total += row[sx];
 		}
@@ -1401,7 +1418,7 @@ void launch_primary(const void *nodes, const void *tris, const void *shade, floa
 
 void launch_ao(const void *nodes, const void *tris, const void *ao_table, float *image, void *hits,
                void *occluded_of, void *tile_hits, void *order, void *counters, const KernelParams &params,
-               uint32_t compute_units, void *stream) {
+               uint32_t compute_units, void *stream, void *event_before_ao, void *event_after_ao) {
 	if (params.tiles_x * params.local_tile_rows == 0 || params.ao_mode == AO_NONE || params.ao_dirs == 0)
 		return;
 	hipStream_t s = (hipStream_t) stream;
@@ -1420,9 +1437,14 @@ void launch_ao(const void *nodes, const void *tris, const void *ao_table, float 
 	P.ao_guide = P.ao_guide * (waves_per_group ? waves_per_group : 1u);
 	P.ao_claim_div = 12u * (waves_per_group ? waves_per_group : 1u);
 	auto launch = [&](auto kernel) {
+		// (the events bracket the ao_kernel launch alone: its duration is the one the roofline is quoted for)
+		if (event_before_ao)
+			(void) hipEventRecord((hipEvent_t) event_before_ao, s);
 		hipLaunchKernelGGL(kernel, dim3(ao_blocks), dim3(64 * AO_WAVES), 0, s, (const float4 *) nodes, (const float4 *) tris,
 		                   (const float4 *) ao_table, (const HitRec *) hits, (uint32_t *) occluded_of,
 		                   (const uint32_t *) order, (FrameCounters *) counters, P);
+		if (event_after_ao)
+			(void) hipEventRecord((hipEvent_t) event_after_ao, s);
 	};
 	if (P.ao_mode == AO_UNIFORM) {
 		if (P.shared_walk)

@@ -32,8 +32,11 @@ class Tokens {
 		float next_float() {
 			const char *p;
 			size_t n;
-			return next(&p, &n) ? std::strtof(p, nullptr) : 0.0f;
+			if (!next(&p, &n))
+				throw std::runtime_error("Unexpected end of OFF file");
+			return std::strtof(p, nullptr);
 		}
+		size_t bytes_left() const { return buf.size() - pos; }
 		bool next_uint(unsigned long *out) {
 			const char *p;
 			size_t n;
@@ -76,6 +79,10 @@ void load_off_mesh(const std::string &filename, Mesh *mesh) {
 	in.next_uint(&num_vertices);
 	in.next_uint(&num_faces);
 	in.next_uint(&num_edges);
+	// A vertex takes at least 6 bytes of text ("0 0 0\n"), a face at least 8 ("3 0 0 0\n"): a header that
+	// promises more than the file can hold is a truncated or hostile file, not a reason to reserve memory.
+	if (num_vertices > (in.bytes_left() + 1) / 6 || num_faces > (in.bytes_left() + 1) / 8)
+		throw std::runtime_error("OFF header counts exceed the file size");
 	mesh->vertices.reserve(num_vertices);
 	mesh->faces.reserve(num_faces * 3 + 3);
 	for (unsigned long i = 0; i < num_vertices; ++i) {
@@ -86,13 +93,15 @@ void load_off_mesh(const std::string &filename, Mesh *mesh) {
 	}
 	for (unsigned long i = 0; i < num_faces; ++i) {
 		unsigned long corners = 0;
-		in.next_uint(&corners);
+		if (!in.next_uint(&corners))
+			throw std::runtime_error("Unexpected end of OFF file");
 		if (corners != 3)
 			throw std::runtime_error("Invalid face with != 3 vertices");
 		unsigned long vidx[3] = { 0, 0, 0 };
 		bool indices_good = true;
 		for (int j = 0; j < 3; ++j) {
-			in.next_uint(&vidx[j]);
+			if (!in.next_uint(&vidx[j]))
+				throw std::runtime_error("Unexpected end of OFF file");
 			if (vidx[j] >= num_vertices) {
 				std::cout << "OFF Loader: Warning: Face " << i << " has invalid vertex " << vidx[j]
 				          << ", skipping face." << std::endl;

@@ -15,6 +15,9 @@
 #include "mesh.h"
 #include "ray_tracer.h"
 
+using ocrt::cli::Color;
+using ocrt::cli::Info;
+
 namespace {
 
 struct OptionSpec {

@@ -81,8 +81,45 @@ PackedScene pack_scene(const std::vector<uint32_t> &faces, const std::vector<uin
 	// than what was uploaded.  (Damaged arrays keep their tree: the exact form of the walk follows it.)
 	if (out.regular && out.nested && !std::getenv("OCRT_KEEP_TREE")) {  // (debug knob)
 		std::vector<NodeRec> rebuilt = contract_walk_tree(rebuild_walk_tree(out.nodes), 0.5);
-		if (!rebuilt.empty() && tree_cost(rebuilt) < tree_cost(out.nodes))
-			out.nodes.swap(rebuilt);
+		if (!rebuilt.empty() && tree_cost(rebuilt) < tree_cost(out.nodes)) {
+			// The flags above were computed on the uploaded array; the kernels walk this one, so it has to
+			// earn them again: an inner node may have more than two children here (contraction), what the
+			// shared walk needs is that sibling subtrees tile their parent's index range, every leaf index
+			// appears once, and boxes are regular and nested.
+			bool regular = true, nested = true, ranges = rebuilt.size() >= 1 && rebuilt[0].skip == rebuilt.size();
+			std::vector<unsigned char> seen(tri_count, 0);
+			size_t leaves = 0;
+			for (size_t i = 0; ranges && i < rebuilt.size(); ++i) {
+				const NodeRec &p = rebuilt[i];
+				for (unsigned k = 0; k < 3; ++k)
+					if (!(std::fabs(p.lo[k]) <= 1.0e37f) || !(std::fabs(p.hi[k]) <= 1.0e37f) || !(p.lo[k] <= p.hi[k]))
+						regular = false;
+				if (p.skip == 0 || i + p.skip > rebuilt.size()) {
+					ranges = false;
+				} else if (p.skip == 1) {
+					if (p.leaf >= tri_count || seen[p.leaf]++)
+						ranges = false;
+					++leaves;
+				} else {
+					if (p.leaf != 0xFFFFFFFFu)
+						ranges = false;
+					size_t c = i + 1;
+					while (ranges && c < i + p.skip) {
+						const NodeRec &child = rebuilt[c];
+						if (child.skip == 0 || c + child.skip > i + p.skip)
+							ranges = false;
+						for (unsigned k = 0; k < 3; ++k)
+							if (!(p.lo[k] <= child.lo[k]) || !(child.hi[k] <= p.hi[k]))
+								nested = false;
+						c += child.skip;
+					}
+				}
+			}
+			if (ranges && leaves == tri_count && regular && nested) {
+				out.nodes.swap(rebuilt);
+				out.rebuilt = true;
+			}
+		}
 	}
 
 	out.tris.resize(tri_count);

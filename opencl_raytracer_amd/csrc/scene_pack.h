@@ -14,10 +14,15 @@ struct PackedScene {
 	std::vector<NodeRec> nodes;
 	std::vector<TriRec> tris;
 	std::vector<ShadeRec> shade;
+	// The flags describe `nodes` as the kernels will walk it -- the uploaded array, or (rebuilt = true) the
+	// cheaper tree over the same leaves that pack_scene put in its place and re-validated.
 	bool regular = false;  // all boxes finite, |coord| <= 1e37, lo <= hi (see kernels.hip slab_hit_regular)
-	bool binary_tree = false;  // every inner node's index range is exactly its two children's ranges
-	bool nested = false;       // ... and its box contains both children's boxes (true for any tree built by
+	bool binary_tree = false;  // sibling subtrees tile their parent's index range (the UPLOADED array must be a full
+	                           // binary tree, what the reference's triangle counter assumes; a rebuilt one may have
+	                           // inner nodes with more children: the skip list and the shared walk do not care)
+	bool nested = false;       // ... and every node's box contains its children's boxes (true for any tree built by
 	                           // uniting child boxes; arbitrary uploaded arrays need not be)
+	bool rebuilt = false;      // `nodes` is the rebuilt tree, not the uploaded one
 };
 
 // Validates the arrays against each other (every index and skip count is

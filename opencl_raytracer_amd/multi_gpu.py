@@ -54,22 +54,54 @@ class BandLayout:
         return self._device_indices[key]
 
 
+class BandGatherer:
+    """The one exchange step of a multi-GPU frame, with its buffers allocated once: every
+    rank's (max_rows, width) uint8 band buffer goes to rank 0 by ONE gather (RCCL over
+    xGMI under the "nccl" backend), straight into the slices of a stacked receive buffer;
+    rank 0 then moves the rows to their place in the final image with one indexed copy.
+
+    `collective=None` runs the gather whenever a process group is initialised -- also for
+    a world of one, which is how the RCCL path is exercised on a one-GPU box."""
+
+    def __init__(self, layout: BandLayout, rank: int, device, group=None, collective: Optional[bool] = None):
+        import torch
+        import torch.distributed as dist
+
+        self.layout, self.rank, self.group = layout, rank, group
+        self.collective = (dist.is_available() and dist.is_initialized()) if collective is None else collective
+        if layout.world > 1 and not self.collective:
+            raise RuntimeError("a frame split over several ranks needs an initialised process group")
+        self.src, self.dst = layout.indices_on(device)
+        width, height = layout.options.width, layout.options.height
+        self.stacked = self.parts = self.final = None
+        if rank == 0:
+            self.final = torch.empty((height, width), dtype=torch.uint8, device=device)
+            if self.collective:
+                self.stacked = torch.empty((layout.world, layout.max_rows, width), dtype=torch.uint8, device=device)
+                self.parts = list(self.stacked.unbind(0))  # views: the gather writes into `stacked` itself
+
+    def __call__(self, band):
+        """band: this rank's (max_rows, width) uint8 rows.  Returns the assembled image on rank 0, None elsewhere."""
+        import torch
+        import torch.distributed as dist
+
+        if self.collective:
+            dist.gather(band, self.parts, dst=0, group=self.group)
+            if self.rank != 0:
+                return None
+            rows = self.stacked.view(-1, self.stacked.shape[-1])
+        else:
+            rows = band
+        torch.index_select(rows, 0, self.src, out=self.final) if self._identity_dst() else \
+            self.final.index_copy_(0, self.dst, rows.index_select(0, self.src))
+        return self.final
+
+    def _identity_dst(self) -> bool:
+        # one rank: dst is 0..height-1 in order, so the selected rows ARE the image
+        return self.layout.world == 1
+
+
 def gather_bands(band, layout: BandLayout, rank: int, group=None):
     """Gathers every rank's (max_rows, width) uint8 band buffer to rank 0 and
     returns the assembled (height, width) image there (None elsewhere)."""
-    import torch
-    import torch.distributed as dist
-
-    src, dst = layout.indices_on(band.device)
-    if layout.world == 1:
-        return band.index_select(0, src)
-    gather_list: Optional[list] = None
-    if rank == 0:
-        gather_list = [torch.empty_like(band) for _ in range(layout.world)]
-    dist.gather(band, gather_list, dst=0, group=group)
-    if rank != 0:
-        return None
-    stacked = torch.cat(gather_list, dim=0)
-    final = torch.empty((layout.options.height, layout.options.width), dtype=band.dtype, device=band.device)
-    final.index_copy_(0, dst, stacked.index_select(0, src))
-    return final
+    return BandGatherer(layout, rank, band.device, group=group, collective=layout.world > 1)(band)

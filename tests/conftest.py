@@ -40,9 +40,13 @@ def rt():
 
 
 def mesh_file(name: str) -> str:
-    from tools.meshes import bunny_path
+    from tools.meshes import bunny_path, interior_path
 
-    return bunny_path() if name == "bunny" else os.path.join(GOLDEN_DIR, "meshes", name + ".off")
+    if name == "bunny":
+        return bunny_path()
+    if name == "interior":  # the generated, labelled stand-in for the missing sibenik.off
+        return interior_path()
+    return os.path.join(GOLDEN_DIR, "meshes", name + ".off")
 
 
 _SCENES = {}

@@ -17,7 +17,9 @@ ORACLE_CASES = [
     "blob_33x17_s1_a0", "ties_33_s1_a3", "ties_33_s1_a3_sah", "ties_64_s4_a3", "ties_5x3_s1_a1", "single_32_s1_a3",
 ]
 # full-size cases are checked against the committed digests only
-DIGEST_CASES = ["bunny_1080p_s1_a0", "bunny_1080p_s1_a3", "bunny_600_defaults"]
+# (BASELINE.json configs 2-5: bunny 1080p, interior stand-in 1080p and 4K, bunny with 64 samples per pixel)
+DIGEST_CASES = ["bunny_1080p_s1_a0", "bunny_1080p_s1_a3", "bunny_600_defaults", "interior_1080p_s1_a3",
+                "interior_4k_s1_a3", "bunny_1080p_s64_a3"]
 
 
 def render_hip(rt, scene, opt, rank=0, nranks=1):
@@ -65,6 +67,47 @@ def test_full_size_golden_digests(rt, golden, scene_for, name):
     st = host.stats()
     assert st["primary_hits"] == c["counters"]["primary_hits"]
     assert st["ao_occluded"] == c["counters"]["ao_occluded"]
+    host.close()
+
+
+def test_interior_standin_is_the_pinned_mesh(rt, golden, scene_for):
+    """The interior stand-in is generated (tools/make_interior_mesh.py), not stored: its arrays must be the ones
+    the reference's loader and builder produced when the goldens were made."""
+    import hashlib as h
+
+    scene, arrays = scene_for("interior", "longest")
+    g = golden["scenes"]["interior/longest"]
+    assert h.sha256(arrays.vertices.tobytes()).hexdigest() == g["vertices"]
+    assert h.sha256(arrays.nodes.tobytes()).hexdigest() == g["nodes"]
+    assert h.sha256(arrays.aabbs.tobytes()).hexdigest() == g["aabbs"]
+    assert h.sha256(arrays.faces.tobytes()).hexdigest() == g["sorted_faces"]
+
+
+def test_zero_normals_on_a_rebuilt_tree(rt, oracle, scene_for, monkeypatch):
+    """Zero-length vertex normals give NaN shading normals, hence NaN ambient-occlusion rays: their packets take
+    the exact form of the shared walk -- here on the REBUILT tree of a regular scene (no OCRT_KEEP_TREE), where
+    that form is not the reference's own walk of the uploaded array but must still give its result."""
+    import orc
+
+    monkeypatch.delenv("OCRT_KEEP_TREE", raising=False)
+    _, arrays = scene_for("blob", "longest")
+    normals = arrays.normals.copy()
+    normals[::7] = 0.0  # every 7th vertex normal: triangles with one, two or three zero normals
+    normals[arrays.faces.reshape(-1, 3)[::5].ravel()] = 0.0  # ... and every 5th triangle with all three zero: NaN normals
+    damaged = orc.SceneArrays(arrays.faces, arrays.nodes, arrays.aabbs, arrays.vertices, normals)
+    opt = rt.Options.defaults(width=160, height=120, n_super_samples=1, ao_num_samples=3, ao_max_distance=0.4)
+    host = rt.Host(opt, 0)
+    host.upload(damaged.faces, damaged.nodes, damaged.aabbs, damaged.vertices, damaged.normals)
+    host.render()
+    ref_img, counters, _ = oracle.render(orc.params_from_options(opt), damaged)
+    got = host.download()
+    # the case really occurs in this frame: a NaN normal shades to clamp(NaN) = 0 on a hit sub-pixel
+    clean_img, _, _ = oracle.render(orc.params_from_options(opt), arrays)
+    assert np.count_nonzero((ref_img == 0.0) & (clean_img > 0.0)) > 20
+    same = (bits(got) == bits(ref_img)) | (np.isnan(got) & np.isnan(ref_img))
+    assert same.all(), int((~same).sum())
+    st = host.stats()
+    assert st["primary_hits"] == counters["primary_hits"] and st["ao_occluded"] == counters["ao_occluded"]
     host.close()
 
 

@@ -18,7 +18,7 @@ def sha(a):
 
 
 @pytest.mark.parametrize("key", ["bunny/longest", "bunny/sah", "blob/longest", "blob/sah", "ties/longest", "ties/sah",
-                                 "single/longest"])
+                                 "single/longest", "interior/longest"])
 def test_scene_arrays_match_reference(rt, golden, scene_for, key):
     mesh, bvh = key.split("/")
     g = golden["scenes"][key]
@@ -58,6 +58,24 @@ def test_scene_from_arrays_equals_file(rt, scene_for):
     again = rt.Scene.from_arrays(sc.vertices, sc.faces).build_bvh(0)
     assert np.array_equal(bits(again.vnormals), bits(sc.vnormals))
     assert np.array_equal(again.nodes, sc.nodes) and np.array_equal(bits(again.aabbs), bits(sc.aabbs))
+
+
+def test_loader_rejects_truncated_and_oversized_headers(rt, tmp_path):
+    """A header that promises more than the file holds must fail, not reserve memory for it or pad with zeros."""
+    huge = tmp_path / "huge.off"
+    huge.write_text("OFF\n4000000000 4000000000 0\n0 0 0\n")
+    with pytest.raises(rt.RtError) as e:
+        rt.Scene.load_off(str(huge))
+    assert "exceed the file size" in e.value.message
+    cut = tmp_path / "cut.off"
+    cut.write_text("OFF\n3 1 0\n0.000000 0.000000 0.000000\n1.000000 0 0\n0 1")  # last coordinate and the face missing
+    with pytest.raises(rt.RtError) as e:
+        rt.Scene.load_off(str(cut))
+    assert "Unexpected end" in e.value.message
+    cut.write_text("OFF\n3 1 0\n0 0 0\n1 0 0\n0 1 0\n3 0 1               ")
+    with pytest.raises(rt.RtError) as e:
+        rt.Scene.load_off(str(cut))
+    assert "Unexpected end" in e.value.message
 
 
 def test_loader_errors(rt, tmp_path):

@@ -1,0 +1,68 @@
+"""The RCCL leg of the multi-GPU path on real hardware.
+
+The reference is single-device (src/opencl_host.cc:16-32); splitting a frame over ranks
+and gathering the bands is new code, rehearsed over gloo on the CPU
+(tests/test_distributed_cpu.py).  Here bench.py itself runs as rank(s) under
+torch.distributed.run with the "nccl" backend (= RCCL): communicator creation, the band
+gather into rank 0's stacked buffer, the barrier and the max/sum all-reduces of the timing
+contract all execute on the GPU box -- with one rank on a one-GPU box, with two where the
+box has two GPUs.  The assembled PGM must be the golden one."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_bench(nproc, extra_env=None, bare=False):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(extra_env or {})
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    args = ["--gpus", str(nproc), "--steps", "3", "--warmup", "1", "--workload", "bunny_600_defaults", "--no-cpu-baseline"]
+    if bare:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr",
+               "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py")] + args
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_rccl_world_of_one_runs_the_gather(golden):
+    out = _run_bench(1)
+    assert out["n_gpus"] == 1 and "RCCL gather" in out["config"]["parallelism"]
+    assert out["config"]["pgm_md5"] == golden["renders"]["bunny_600_defaults"]["pgm_md5"]
+    assert out["config"]["pgm_matches_golden"] is True and out["value"] > 0
+
+
+def test_rccl_two_ranks_assemble_the_golden_frame(golden):
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (one rank per GPU under RCCL)")
+    out = _run_bench(2)
+    assert out["n_gpus"] == 2 and out["config"]["pgm_md5"] == golden["renders"]["bunny_600_defaults"]["pgm_md5"]
+
+
+def test_bare_gpus_flag_starts_its_own_ranks(golden):
+    """`python bench.py --gpus N` from a bare shell (the driver's command shape) spawns the ranks itself."""
+    import torch
+
+    n = 2 if torch.cuda.device_count() >= 2 else 1
+    if n == 1:
+        # one GPU: rehearse the spawn path with two gloo ranks sharing the device (host-staged gather)
+        out = _run_bench(2, extra_env={"OCRT_BENCH_BACKEND": "gloo"}, bare=True)
+        assert out["n_gpus"] == 2
+    else:
+        out = _run_bench(2, bare=True)
+        assert out["n_gpus"] == 2 and "RCCL" in out["config"]["parallelism"]
+    assert out["config"]["pgm_md5"] == golden["renders"]["bunny_600_defaults"]["pgm_md5"]
