@@ -11,7 +11,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def lib_path() -> str:
-    return os.path.join(_HERE, "lib", "libocrt_hip.so")
+    """lib/libocrt_hip.so; OCRT_LIB_DIR (debug knob) names another directory of this package holding a build of
+    the same library, e.g. lib_stamps for the instrumented one (make EXTRA_DEFS=-DOCRT_STAMPS LIBDIR=...)."""
+    return os.path.join(_HERE, os.environ.get("OCRT_LIB_DIR", "lib"), "libocrt_hip.so")
 
 
 class RtError(RuntimeError):

@@ -49,6 +49,7 @@ DeviceRenderer::DeviceRenderer(const RayTracer::Options &options, int device_, u
 	, own_stream(nullptr)
 	, stream(nullptr)
 	, d_nodes(nullptr)
+	, d_walk(nullptr)
 	, d_tris(nullptr)
 	, d_shade(nullptr)
 	, d_ao(nullptr)
@@ -87,7 +88,7 @@ DeviceRenderer::DeviceRenderer(const RayTracer::Options &options, int device_, u
 	part.rank = rank;
 	part.nranks = nranks;
 	part.band_tile_rows = band_tile_rows_for(grid);
-	kp = make_kernel_params(rt, 0, 0, 0, part, nullptr);
+	kp = make_kernel_params(rt, 0, 0, 0, part, nullptr, nullptr);
 	local_out_rows = kp.local_tile_rows * TILE_H / grid;
 	tile_count = (size_t) kp.tiles_x * kp.local_tile_rows;
 
@@ -145,6 +146,7 @@ void DeviceRenderer::useDevice() const { OCRT_HIP(hipSetDevice(device)); }
 
 void DeviceRenderer::freeScene() {
 	device_free(d_nodes);
+	device_free(d_walk);
 	device_free(d_tris);
 	device_free(d_shade);
 	device_free(d_ao);
@@ -173,7 +175,9 @@ size_t DeviceRenderer::upload(const PackedScene &scene) {
 			ao_dirs = opts.aoNumSamples + 2;
 		}
 	}
-	kp = make_kernel_params(rt, (uint32_t) scene.nodes.size(), (uint32_t) scene.tris.size(), ao_dirs, part, &scene);
+	const bool ao_on = opts.enableAO && opts.aoNumSamples > 0;
+	const WalkArray walk = make_walk_array(scene, ao_on ? kernel_float(opts.aoMaxDistance) : 0.0f);
+	kp = make_kernel_params(rt, (uint32_t) scene.nodes.size(), (uint32_t) scene.tris.size(), ao_dirs, part, &scene, &walk);
 	const size_t nodes_bytes = scene.nodes.size() * sizeof(NodeRec);
 	const size_t tris_bytes = scene.tris.size() * sizeof(TriRec);
 	const size_t shade_bytes = scene.shade.size() * sizeof(ShadeRec);
@@ -181,6 +185,11 @@ size_t DeviceRenderer::upload(const PackedScene &scene) {
 	// one node of zero padding: the shared walk fetches a node together with its successor
 	d_nodes = device_alloc(nodes_bytes + sizeof(NodeRec));
 	OCRT_HIP(hipMemset((char *) d_nodes + nodes_bytes, 0, sizeof(NodeRec)));
+	const size_t walk_bytes = walk.nodes.size() * sizeof(NodeRec);
+	if (walk_bytes) {
+		d_walk = device_alloc(walk_bytes);
+		OCRT_HIP(hipMemcpy(d_walk, walk.nodes.data(), walk_bytes, hipMemcpyHostToDevice));
+	}
 	d_tris = device_alloc(tris_bytes);
 	d_shade = device_alloc(shade_bytes);
 	d_ao = device_alloc(ao_bytes);
@@ -191,7 +200,7 @@ size_t DeviceRenderer::upload(const PackedScene &scene) {
 		OCRT_HIP(hipMemcpy(d_ao, table.data(), ao_bytes, hipMemcpyHostToDevice));
 	OCRT_HIP(hipDeviceSynchronize());
 	scene_ready = true;
-	return nodes_bytes + tris_bytes + shade_bytes + ao_bytes + image_bytes +
+	return nodes_bytes + walk_bytes + tris_bytes + shade_bytes + ao_bytes + image_bytes +
 	       (size_t) local_out_rows * opts.width + tile_count * (64 * (sizeof(HitRec) + sizeof(uint32_t)) + 2 * sizeof(uint32_t)) +
 	       sizeof(FrameCounters);
 }
@@ -218,11 +227,12 @@ void DeviceRenderer::enqueueRender() {
 #ifdef OCRT_STAMPS
 	OCRT_HIP(hipMemsetAsync((char *) d_counters + offsetof(FrameCounters, stamp) + 7 * sizeof(unsigned long long), 0xFF, sizeof(unsigned long long), s));
 #endif
-	launch_primary(d_nodes, d_tris, d_shade, (float *) d_image, d_hits, d_occluded, d_tile_hits, d_counters, kp, stream);
+	const SceneBuffers scene{ d_nodes, d_walk, d_tris, d_shade, d_ao };
+	launch_primary(scene, (float *) d_image, d_hits, d_occluded, d_tile_hits, d_counters, kp, stream);
 	OCRT_HIP(hipGetLastError());
 	ev.ao_timed = kp.ao_mode != AO_NONE && kp.ao_dirs > 0 && tile_count > 0;
-	launch_ao(d_nodes, d_tris, d_ao, (float *) d_image, d_hits, d_occluded, d_tile_hits, d_order, d_counters, kp,
-	          compute_units, stream, ev.ao_start, ev.ao_stop);
+	launch_ao(scene, (float *) d_image, d_hits, d_occluded, d_tile_hits, d_order, d_counters, kp, compute_units, stream,
+	          ev.ao_start, ev.ao_stop);
 	OCRT_HIP(hipGetLastError());
 	OCRT_HIP(hipEventRecord((hipEvent_t) ev.stop, s));
 	pending_events.push_back(ev);
@@ -322,6 +332,7 @@ RenderStats DeviceRenderer::stats() {
 			std::fprintf(stderr, " %.2f:%llu", k * 0.05, c.stamp[10 + k]);
 	std::fprintf(stderr, "\n   of the walks: node loop %.3f ms in %llu entries, batches %.3f ms in %llu batches, %llu leaf stops\n",
 	             c.stamp[42] * 1e-5, c.stamp[44], c.stamp[43] * 1e-5, c.stamp[45], c.stamp[46]);
+	std::fprintf(stderr, "   batched pairs %llu, of which the leaf's own box passes %llu\n", c.stamp[47], c.stamp[48]);
 #endif
 	// Primary rays = sub-pixels of this rank's bands that lie inside the image.
 	const uint32_t tile_rows = (kp.height + TILE_H - 1) / TILE_H;

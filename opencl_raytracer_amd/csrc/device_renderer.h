@@ -80,7 +80,7 @@ class DeviceRenderer {
 		uint32_t grid;            // supersample grid side
 		uint32_t local_out_rows;
 		void *own_stream, *stream;
-		void *d_nodes, *d_tris, *d_shade, *d_ao, *d_image, *d_u8, *d_hits, *d_occluded, *d_tile_hits, *d_order, *d_counters;
+		void *d_nodes, *d_walk, *d_tris, *d_shade, *d_ao, *d_image, *d_u8, *d_hits, *d_occluded, *d_tile_hits, *d_order, *d_counters;
 		size_t image_bytes;  // float image of this rank's bands
 		size_t tile_count;
 		uint32_t compute_units;
@@ -96,11 +96,11 @@ class DeviceRenderer {
 };
 
 // kernels.hip
-void launch_primary(const void *nodes, const void *tris, const void *shade, float *image, void *hits,
-                    void *occluded_of, void *tile_hits, void *counters, const KernelParams &P, void *stream);
-void launch_ao(const void *nodes, const void *tris, const void *ao_table, float *image, void *hits,
-               void *occluded_of, void *tile_hits, void *order, void *counters, const KernelParams &P,
-               uint32_t compute_units, void *stream, void *event_before_ao, void *event_after_ao);
+void launch_primary(const SceneBuffers &scene, float *image, void *hits, void *occluded_of, void *tile_hits,
+                    void *counters, const KernelParams &P, void *stream);
+void launch_ao(const SceneBuffers &scene, float *image, void *hits, void *occluded_of, void *tile_hits, void *order,
+               void *counters, const KernelParams &P, uint32_t compute_units, void *stream, void *event_before_ao,
+               void *event_after_ao);
 void launch_resize(const float *tmp, unsigned char *out, const KernelParams &P, uint32_t out_width, uint32_t n,
                    uint32_t local_out_rows, void *stream);
 

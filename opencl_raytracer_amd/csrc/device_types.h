@@ -16,18 +16,24 @@ struct NodeRec {
 	uint32_t leaf;  // leaf index (= triangle index in leaf order), 0xFFFFFFFF for inner nodes
 };
 static_assert(sizeof(NodeRec) == 32, "NodeRec is two float4");
+// The copy of the node array that the fast form of the shared walk reads uses the same record with `skip` as a
+// byte offset and boxes pushed outward (scene_pack.cc, pad_walk_boxes); its end marker's leaf field:
+constexpr uint32_t WALK_END = 0xFFFFFFFEu;
 
-// Per-triangle invariants of the reference's plane/parametric test (reference
-// src/intersect_kernel.cl:67-90), precomputed on the host with the SAME float
-// operations the kernel would execute, so the bits are identical: 64 bytes.
+// What a leaf's test needs, 96 bytes = six float4.  First the leaf's OWN box as uploaded, the reference's gate of
+// the triangle test (src/intersect_kernel.cl:189,195): the walk itself only tests padded boxes.  Then the
+// per-triangle invariants of the reference's plane/parametric test (src/intersect_kernel.cl:67-90), precomputed on
+// the host with the SAME float operations the kernel would execute, so the bits are identical.
 struct TriRec {
+	float lo[3], pad0;  // the leaf's box
+	float hi[3], pad1;
 	float ta[3];
 	float u[3];   // tb - ta
 	float v[3];   // tc - ta
 	float n[3];   // cross(u, v)
 	float uu, uv, vv, D;  // dot(u,u), dot(u,v), dot(v,v), uv*uv - uu*vv
 };
-static_assert(sizeof(TriRec) == 64, "TriRec is four float4");
+static_assert(sizeof(TriRec) == 96, "TriRec is six float4");
 
 // The three vertex normals of a leaf's triangle (replaces the faces[] ->
 // normals[] double indirection of reference src/intersect_kernel.cl:118-127).
@@ -64,7 +70,7 @@ struct FrameCounters {
 	uint32_t pad;
 	unsigned long long occluded;  // occluded AO rays
 #ifdef OCRT_STAMPS
-	unsigned long long stamp[10 + 32 + 5];  // debug build: wave-time (10 ns ticks) per phase of the AO pass, jobs, packets
+	unsigned long long stamp[10 + 32 + 7];  // debug build: wave-time (10 ns ticks) per phase of the AO pass, jobs, packets
 #endif
 };
 
@@ -97,6 +103,8 @@ struct KernelParams {
 	int32_t ao_regular;    // AO_MAX_DISTANCE > 0 (needed by the folded form of the slab test)
 	int32_t scene_nested;  // every child box lies inside its parent's box: the shared walk's fast form is allowed
 	int32_t shared_walk;   // sibling subtrees tile their parent's index range (any arity): one shared node index is safe
+	int32_t fast_walk;     // the padded walk array exists (regular, nested scene): the 6-FMA box test may be used
+	float origin_limit;    // ... for rays whose origin coordinates do not exceed this magnitude
 	float primary_below;   // largest float below the primary rays' max_distance (100000.0f)
 	float ao_below;        // largest float below AO_MAX_DISTANCE
 	int32_t debug_no_sort; // debug knob OCRT_NO_SORT: claim tiles in arbitrary order instead of heaviest first
@@ -111,6 +119,15 @@ struct KernelParams {
 	uint32_t tiles_x;      // tiles per image row
 	uint32_t local_tile_rows;  // tile rows this rank owns
 	Partition part;
+};
+
+// Device pointers of one uploaded scene, as the launchers of kernels.hip take them.
+struct SceneBuffers {  // device pointers of one uploaded scene
+	const void *nodes;       // NodeRec[node_count + 1]: exact boxes (exact form of the walk, first-generation kernels)
+	const void *walk;        // NodeRec[node_count + 2]: padded boxes, byte skips, END records (fast form); may be null
+	const void *tris;        // TriRec[tri_count]: leaf box + triangle invariants by leaf index
+	const void *shade;       // ShadeRec[tri_count]
+	const void *ao_table;    // float4[ao_dirs] (UNIFORM)
 };
 
 constexpr uint32_t TILE_W = 8;

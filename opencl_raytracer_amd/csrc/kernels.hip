@@ -55,6 +55,32 @@ struct Ray {
 	float ix, iy, iz;  // 1.0f / d, hoisted out of the per-node slab test
 };
 
+// What the fast form of the shared walk keeps per lane: t = fma(plane, i, oi).  An infinite reciprocal (a zero
+// direction component) is replaced by +-2^100: with inf the fma would be inf - inf = NaN for every box, the axis
+// would drop out of the test and the ray would "hit" every box the other two axes allow (a third of the frame's
+// ambient-occlusion rays start on an axis-aligned ground plane, three of their 28 directions have a zero
+// component).  The reference's test on such an axis says "the origin's coordinate lies in the box's slab"
+// ((b - o) * inf is +-inf by the sign of b - o, NaN -- dropped -- for b == o); 2^100 (b' - o) has the sign of
+// b' - o, which the outward margin keeps on the conservative side (padded_bound: the argument holds for every finite
+// reciprocal), and is either <= 0 or far above any max_distance.  (|o|, |b'| <= ~1e6: no overflow.)
+struct WalkRay {
+	float ix, iy, iz;
+	float oix, oiy, oiz;  // -(o * i), rounded once
+};
+__device__ __forceinline__ float walk_reciprocal(float i) {
+	return fabsf(i) == __builtin_inff() ? copysignf(0x1.0p+100f, i) : i;
+}
+__device__ __forceinline__ WalkRay make_walk_ray(const Ray &r) {
+	WalkRay w;
+	w.ix = walk_reciprocal(r.ix);
+	w.iy = walk_reciprocal(r.iy);
+	w.iz = walk_reciprocal(r.iz);
+	w.oix = -(r.ox * w.ix);
+	w.oiy = -(r.oy * w.iy);
+	w.oiz = -(r.oz * w.iz);
+	return w;
+}
+
 struct Hit {
 	float distance;
 	uint32_t leaf;
@@ -130,6 +156,13 @@ __device__ __forceinline__ void wave_lds_sync() {
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// The lane number again, opaque to the optimiser: an address built from it is computed where it is used (per claim,
+// off the hot path) instead of being hoisted out of every loop into registers that the walk then cannot have.
+__device__ __forceinline__ uint32_t cold_lane(uint32_t lane) {
+	asm volatile("" : "+v"(lane));
+	return lane;
+}
+
 // Position of this lane among the set bits of `mask` below it.
 __device__ __forceinline__ uint32_t rank_in(unsigned long long mask) {
 	return __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
@@ -165,10 +198,17 @@ __device__ __forceinline__ bool ray_is_regular(const Ray &r) {
 // dropped by the reference's `t_min > ty_max` comparisons and fmax / fmin updates.
 // With all three reciprocals infinite nothing would be left to compare (the
 // reference then rejects on `NaN < max_distance`), hence the exclusion.
-__device__ __forceinline__ bool ray_is_selectable(const Ray &r) {
-	const bool origin_ok = fabsf(r.ox) <= REGULAR_LIMIT && fabsf(r.oy) <= REGULAR_LIMIT && fabsf(r.oz) <= REGULAR_LIMIT;
-	const bool numbers = r.ix == r.ix && r.iy == r.iy && r.iz == r.iz;
-	const bool some_finite = fabsf(r.ix) <= REGULAR_LIMIT || fabsf(r.iy) <= REGULAR_LIMIT || fabsf(r.iz) <= REGULAR_LIMIT;
+// `origin_limit` (KernelParams): the magnitude up to which the outward margin of the padded walk boxes covers the
+// rounding of the fma form; a finite reciprocal must stay below 1e30 so that o * inv cannot overflow (scene_pack.cc,
+// padded_bound).
+constexpr float RECIPROCAL_LIMIT = 1.0e30f;
+__device__ __forceinline__ bool ray_is_selectable(const Ray &r, float origin_limit) {
+	const bool origin_ok = fabsf(r.ox) <= origin_limit && fabsf(r.oy) <= origin_limit && fabsf(r.oz) <= origin_limit;
+	const float ax = fabsf(r.ix), ay = fabsf(r.iy), az = fabsf(r.iz), inf = __builtin_inff();
+	// a number on every axis (NaN fails every comparison), and either infinite or small enough
+	const bool numbers = (ax <= RECIPROCAL_LIMIT || ax == inf) && (ay <= RECIPROCAL_LIMIT || ay == inf) &&
+	                     (az <= RECIPROCAL_LIMIT || az == inf);
+	const bool some_finite = ax <= RECIPROCAL_LIMIT || ay <= RECIPROCAL_LIMIT || az <= RECIPROCAL_LIMIT;
 	return origin_ok && numbers && some_finite;
 }
 
@@ -286,10 +326,14 @@ __device__ __forceinline__ TriResult tri_eval(const float4 q0, const float4 q1, 
 	return out;
 }
 
+// Leaf records are 96 bytes: the leaf's own box (float4 0, 1), then the triangle (float4 2..5).
+constexpr uint32_t LEAF_BYTES = 96u, LEAF_TRI_OFFSET = 32u, LEAF_F4 = 6u, LEAF_TRI_F4 = 2u;
+
 template <bool CLOSEST>
 __device__ __forceinline__ TriResult tri_test(__amdgpu_buffer_rsrc_t tris, uint32_t leaf, const Ray &r) {
-	const float4 q0 = load_f4(tris, leaf * 64u), q1 = load_f4(tris, leaf * 64u + 16u);
-	const float4 q2 = load_f4(tris, leaf * 64u + 32u), q3 = load_f4(tris, leaf * 64u + 48u);
+	const uint32_t at = leaf * LEAF_BYTES + LEAF_TRI_OFFSET;
+	const float4 q0 = load_f4(tris, at), q1 = load_f4(tris, at + 16u);
+	const float4 q2 = load_f4(tris, at + 32u), q3 = load_f4(tris, at + 48u);
 	return tri_eval<CLOSEST>(q0, q1, q2, q3, r);
 }
 
@@ -302,7 +346,7 @@ __device__ __forceinline__ SceneViews make_views(const float4 *nodes_ptr, const 
 	// descriptors are built from kernel arguments only, so they live in SGPRs
 	SceneViews scene;
 	scene.nodes = __builtin_amdgcn_make_buffer_rsrc((void *) nodes_ptr, 0, (int) (P.node_count * 32u), 0x00020000);
-	scene.tris = __builtin_amdgcn_make_buffer_rsrc((void *) tris_ptr, 0, (int) (P.tri_count * 64u), 0x00020000);
+	scene.tris = __builtin_amdgcn_make_buffer_rsrc((void *) tris_ptr, 0, (int) (P.tri_count * LEAF_BYTES), 0x00020000);
 	return scene;
 }
 
@@ -380,173 +424,216 @@ __device__ __forceinline__ u32x8 scalar_load_node(const float4 *nodes_ptr, uint3
 	return r;
 }
 
-// The node steps of the fast form, hand-scheduled.  From byte offset `at` on it walks the
-// packet through the tree: per node the slab test of the reference on values fetched by a
-// scalar load -- (lo - o) * inv, (hi - o) * inv, near/far picked by the sign of inv,
-// max(.., tiny = bit pattern 1), min(.., below), near <= far -- and a scalar decision:
-// some live lane hit -> first child, nobody -> skip the subtree.  One 64-byte load
-// fetches a node and its pre-order successor (the node array carries one node of
-// padding): after a hit on an inner node its first child is tested straight from
-// s[56:63].  Per node 23 vector and ~8 scalar instructions; the compiler's own version of
-// this loop needs about 25 + 20, and the walk is bound by instruction issue and the
-// latency of that load.
-// At a leaf hit by fewer than `batch_below` lanes it does not stop but appends the
-// (lane, leaf) pairs to the wave's list in LDS (entry = leaf | lane << 26 at index
-// waiting + rank of the lane among the hitters) and walks on -- a leaf stop costs a trip
-// out of this loop, a triangle load and a node reload, and there are 11 of them per AO
-// packet at one sample per pixel.
-// `leaf_stops` counts the leaves some lane hit.
-// Returns 0: walk over; 1: `leaf` is hit by many lanes (`hit`), test it now, `at` is
-// on it; 2: 64 or more pairs are waiting, run a batch, `at` is on the leaf appended last.
-// Scratch: s[42:63], v56-v62; only scalar outputs, so that the compiler knows the results
-// to be wave-uniform.  nodes_ptr must not be dereferenced by plain loads elsewhere in the
-// same kernel: the compiler then keeps it in VGPRs and cannot hand it to this operand.
-__device__ __forceinline__ uint32_t walk_collect(const float4 *nodes_ptr, uint32_t &at, uint32_t end, const Ray &ray,
-                                                 const SignMasks &sign, float below,
-                                                 unsigned long long alive_mask, unsigned long long &hit_mask, uint32_t &leaf,
-                                                 uint32_t &waiting, uint32_t &leaf_stops, uint32_t list_lds_address,
-                                                 uint32_t lane_tag, uint32_t batch_below) {
+// The node steps of the fast form, hand-scheduled.  From byte offset `at` on it walks the packet through the
+// PADDED copy of the tree (scene_pack.cc, pad_walk_boxes): per node a conservative slab test on values fetched by a
+// scalar load -- t = fma(plane, inv, oi) with oi = -(o * inv) rounded once, near/far planes picked by the sign of
+// inv, max(.., tiny = bit pattern 1), min(.., below), near <= far -- and a scalar decision: some live lane hit ->
+// first child, nobody -> skip the subtree.  The outward margin of the boxes makes up for the fma's rounding
+// (proof at padded_bound), so a lane passes every box the reference's own test (src/intersect_kernel.cl:21-61)
+// would let it pass, and possibly a few more: the walk only finds CANDIDATE leaves, the exact test on the leaf's
+// own box is the caller's (exact_leaf_gate).  Zero direction components enter with +-2^100 for the infinite
+// reciprocal (WalkRay); should a NaN still arise, v_max3 / v_min3 drop it (IEEE maxNum / minNum, the kernel runs
+// with IEEE mode on) -- one constraint fewer, conservative.
+//
+// Most packets are sign-coherent -- every live lane's reciprocal direction has the same sign on each axis (all
+// primary tiles off the image's centre lines, most ambient-occlusion packets) --: the near and far plane of each
+// axis are then known when the loop is entered and the test is 6 v_fma + max + min + max3 + min3 + cmp = 11 vector
+// instructions; the loop exists once per sign octant (OCRT_WALK_COHERENT).  Mixed packets select per lane with
+// v_cndmask on the sign masks: 17 (the first generation of this loop computed (b - o) * inv exactly: 23).
+//
+// One 64-byte load fetches a node and its pre-order successor: after a hit on an inner node its first child is
+// tested straight from s[56:63].  The array ends in two END records whose infinite box every live lane "hits" and
+// whose leaf field says WALK_END, so the loop needs no bounds check.  Scalar instructions per node: load, wait,
+// s_and (sets SCC), branch, add = 5 on a miss.
+// At a leaf hit by fewer than `batch_below` lanes it does not stop but appends the (lane, leaf) pairs to the
+// wave's list in LDS (entry = leaf | lane << 26 at index waiting + rank of the lane among the hitters) and walks
+// on; `leaf_stops` counts the leaves some lane hit.
+// Returns 0: walk over; 1: `leaf` is hit by many lanes (`hit`), test it now, `at` is on it; 2: 64 or more pairs
+// are waiting, run a batch, `at` is on the leaf appended last.
+// Scratch: s[42:63], v56-v62; only scalar outputs, so that the compiler knows the results to be wave-uniform.
+// The pointer operand must not be dereferenced by plain loads elsewhere in the same kernel: the compiler then
+// keeps it in VGPRs and cannot hand it to this operand.
+// gfx950 hazards checked by hand (the assembler inserts nothing inside inline asm): v_cmp writes VCC -> s_and_b64
+// reads it (SALU reads of VALU-written SGPRs are interlocked); s_mov_b64 exec -> ds_write_b32 / following VALU
+// (EXEC writes by SALU are interlocked for vector and LDS instructions); s_load -> s_waitcnt lgkmcnt(0) before the
+// first use (also drains the ds_write of an append, harmless); no v_readlane / v_div_fmas / VMEM-with-SGPR-address
+// consumers of VALU-written SGPRs in here.  The build fails if the kernels using this loop spill vector registers
+// or leave 8 waves per SIMD (tools/check_kernel_resources.py).
+#define OCRT_TEST_COHERENT(NX, NY, NZ, FX, FY, FZ) \
+	"\tv_fma_f32 v56, " NX ", %[ix], %[oix]\n"     \
+	"\tv_fma_f32 v57, " NY ", %[iy], %[oiy]\n"     \
+	"\tv_fma_f32 v58, " NZ ", %[iz], %[oiz]\n"     \
+	"\tv_fma_f32 v59, " FX ", %[ix], %[oix]\n"     \
+	"\tv_fma_f32 v60, " FY ", %[iy], %[oiy]\n"     \
+	"\tv_fma_f32 v61, " FZ ", %[iz], %[oiz]\n"     \
+	"\tv_max_f32 v58, 1, v58\n"                    \
+	"\tv_min_f32 v61, %[below], v61\n"             \
+	"\tv_max3_f32 v56, v56, v57, v58\n"            \
+	"\tv_min3_f32 v59, v59, v60, v61\n"            \
+	"\tv_cmp_le_f32 vcc, v56, v59\n"
+#define OCRT_TEST_MIXED(LX, LY, LZ, HX, HY, HZ)    \
+	"\tv_fma_f32 v56, " LX ", %[ix], %[oix]\n"     \
+	"\tv_fma_f32 v57, " HX ", %[ix], %[oix]\n"     \
+	"\tv_fma_f32 v58, " LY ", %[iy], %[oiy]\n"     \
+	"\tv_fma_f32 v59, " HY ", %[iy], %[oiy]\n"     \
+	"\tv_fma_f32 v60, " LZ ", %[iz], %[oiz]\n"     \
+	"\tv_fma_f32 v61, " HZ ", %[iz], %[oiz]\n"     \
+	"\tv_cndmask_b32 v62, v57, v56, %[px]\n"       \
+	"\tv_cndmask_b32 v56, v56, v57, %[px]\n"       \
+	"\tv_cndmask_b32 v57, v59, v58, %[py]\n"       \
+	"\tv_cndmask_b32 v58, v58, v59, %[py]\n"       \
+	"\tv_cndmask_b32 v59, v61, v60, %[pz]\n"       \
+	"\tv_cndmask_b32 v60, v60, v61, %[pz]\n"       \
+	"\tv_max_f32 v59, 1, v59\n"                    \
+	"\tv_min_f32 v60, %[below], v60\n"             \
+	"\tv_max3_f32 v62, v62, v57, v59\n"            \
+	"\tv_min3_f32 v56, v56, v58, v60\n"            \
+	"\tv_cmp_le_f32 vcc, v62, v56\n"
+// (LEAF: the s-register holding the node's leaf field; NEXT: where the walk goes on after an append)
+#define OCRT_WALK_LEAF(LEAF, NOW, NEXT)                 \
+	"\ts_cmp_eq_u32 " LEAF ", -2\n"                     \
+	"\ts_cbranch_scc1 .Lw_over_%=\n"                    \
+	"\ts_bcnt1_i32_b64 s46, s[44:45]\n"                 \
+	"\ts_add_u32 %[stops], %[stops], 1\n"               \
+	"\ts_cmp_ge_u32 s46, %[batch_below]\n"              \
+	"\ts_cbranch_scc1 " NOW "\n"                        \
+	"\tv_mbcnt_lo_u32_b32 v56, s44, 0\n"                \
+	"\tv_mbcnt_hi_u32_b32 v56, s45, v56\n"              \
+	"\tv_add_u32 v56, %[waiting], v56\n"                \
+	"\tv_lshl_add_u32 v56, v56, 2, %[list]\n"           \
+	"\tv_or_b32 v57, " LEAF ", %[tag]\n"                \
+	"\ts_mov_b64 s[42:43], exec\n"                      \
+	"\ts_mov_b64 exec, s[44:45]\n"                      \
+	"\tds_write_b32 v56, v57\n"                         \
+	"\ts_mov_b64 exec, s[42:43]\n"                      \
+	"\ts_add_u32 %[waiting], %[waiting], s46\n"         \
+	"\ts_cmp_ge_u32 %[waiting], 64\n"                   \
+	"\ts_cbranch_scc1 .Lw_full_%=\n"                    \
+	"\ts_branch " NEXT "\n"
+#define OCRT_WALK_ASM(TEST_A, TEST_B)                       \
+	"\ts_branch .Lw_node_%=\n"                              \
+	".Lw_miss_a_%=:\n"                                      \
+	"\ts_add_u32 %[at], %[at], s51\n"                       \
+	".Lw_node_%=:\n"                                        \
+	"\ts_load_dwordx16 s[48:63], %[base], %[at]\n"          \
+	"\ts_waitcnt lgkmcnt(0)\n"                              \
+	TEST_A                                                  \
+	"\ts_and_b64 s[44:45], vcc, %[alive]\n"                 \
+	"\ts_cbranch_scc0 .Lw_miss_a_%=\n"                      \
+	"\ts_cmp_lg_u32 s55, -1\n"                              \
+	"\ts_cbranch_scc1 .Lw_leaf_a_%=\n"                      \
+	".Lw_next_b_%=:\n"                                      \
+	"\ts_add_u32 %[at], %[at], 32\n"                        \
+	TEST_B                                                  \
+	"\ts_and_b64 s[44:45], vcc, %[alive]\n"                 \
+	"\ts_cbranch_scc0 .Lw_miss_b_%=\n"                      \
+	"\ts_cmp_lg_u32 s63, -1\n"                              \
+	"\ts_cbranch_scc1 .Lw_leaf_b_%=\n"                      \
+	".Lw_next_a_%=:\n"                                      \
+	"\ts_add_u32 %[at], %[at], 32\n"                        \
+	"\ts_branch .Lw_node_%=\n"                              \
+	".Lw_miss_b_%=:\n"                                      \
+	"\ts_add_u32 %[at], %[at], s59\n"                       \
+	"\ts_branch .Lw_node_%=\n"                              \
+	".Lw_leaf_a_%=:\n"                                      \
+	OCRT_WALK_LEAF("s55", ".Lw_now_a_%=", ".Lw_next_b_%=")  \
+	".Lw_now_a_%=:\n"                                       \
+	"\ts_mov_b32 %[leaf], s55\n"                            \
+	"\ts_branch .Lw_now_%=\n"                               \
+	".Lw_leaf_b_%=:\n"                                      \
+	OCRT_WALK_LEAF("s63", ".Lw_now_b_%=", ".Lw_next_a_%=")  \
+	".Lw_now_b_%=:\n"                                       \
+	"\ts_mov_b32 %[leaf], s63\n"                            \
+	".Lw_now_%=:\n"                                         \
+	"\ts_mov_b64 %[hit], s[44:45]\n"                        \
+	"\ts_mov_b32 %[status], 1\n"                            \
+	"\ts_branch .Lw_out_%=\n"                               \
+	".Lw_full_%=:\n"                                        \
+	"\ts_mov_b32 %[status], 2\n"                            \
+	"\ts_branch .Lw_out_%=\n"                               \
+	".Lw_over_%=:\n"                                        \
+	"\ts_mov_b32 %[status], 0\n"                            \
+	".Lw_out_%=:\n"
+#define OCRT_WALK_CLOBBERS                                                                                              \
+	"s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", \
+	    "s59", "s60", "s61", "s62", "s63", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "vcc", "scc", "memory"
+// node a = s[48:55] (lo.xyz, skip bytes, hi.xyz, leaf), node b = s[56:63]; X/Y/Z: "P" = reciprocal >= 0 on that axis
+// (near plane lo), "N" = negative (near plane hi)
+#define OCRT_NEAR_P(LO, HI) LO
+#define OCRT_NEAR_N(LO, HI) HI
+#define OCRT_FAR_P(LO, HI) HI
+#define OCRT_FAR_N(LO, HI) LO
+#define OCRT_WALK_COHERENT(X, Y, Z)                                                                                       \
+	asm volatile(OCRT_WALK_ASM(OCRT_TEST_COHERENT(OCRT_NEAR_##X("s48", "s52"), OCRT_NEAR_##Y("s49", "s53"),                \
+	                                              OCRT_NEAR_##Z("s50", "s54"), OCRT_FAR_##X("s48", "s52"),                 \
+	                                              OCRT_FAR_##Y("s49", "s53"), OCRT_FAR_##Z("s50", "s54")),                 \
+	                           OCRT_TEST_COHERENT(OCRT_NEAR_##X("s56", "s60"), OCRT_NEAR_##Y("s57", "s61"),                \
+	                                              OCRT_NEAR_##Z("s58", "s62"), OCRT_FAR_##X("s56", "s60"),                 \
+	                                              OCRT_FAR_##Y("s57", "s61"), OCRT_FAR_##Z("s58", "s62")))                 \
+	             : [at] "+s"(at), [waiting] "+s"(waiting), [stops] "+s"(leaf_stops), [hit] "=&s"(hit_mask),               \
+	               [leaf] "=&s"(leaf), [status] "=&s"(status)                                                            \
+	             : [base] "s"(walk_ptr), [alive] "s"(alive_mask), [below] "s"(below), [batch_below] "s"(batch_below),     \
+	               [list] "v"(list_lds_address), [tag] "v"(lane_tag), [ix] "v"(ray.ix), [iy] "v"(ray.iy), [iz] "v"(ray.iz), \
+	               [oix] "v"(ray.oix), [oiy] "v"(ray.oiy), [oiz] "v"(ray.oiz)                                             \
+	             : OCRT_WALK_CLOBBERS)
+
+// `variant`: 0..7 = sign octant of a coherent packet (bit 0: x reciprocals >= 0, bit 1: y, bit 2: z), 8 = mixed.
+constexpr uint32_t WALK_MIXED = 8u;
+__device__ __forceinline__ uint32_t walk_collect(uint32_t variant, const float4 *walk_ptr, uint32_t &at, const WalkRay &ray,
+                                                 const SignMasks &sign, float below, unsigned long long alive_mask,
+                                                 unsigned long long &hit_mask, uint32_t &leaf, uint32_t &waiting,
+                                                 uint32_t &leaf_stops, uint32_t list_lds_address, uint32_t lane_tag,
+                                                 uint32_t batch_below) {
 	uint32_t status;
-	asm volatile(
-	    ".Lcollect_node_%=:\n"
-	    "\ts_load_dwordx16 s[48:63], %[base], %[at]\n"
-	    "\ts_waitcnt lgkmcnt(0)\n"
-	    "\tv_sub_f32 v56, s48, %[ox]\n"
-	    "\tv_sub_f32 v57, s52, %[ox]\n"
-	    "\tv_sub_f32 v58, s49, %[oy]\n"
-	    "\tv_sub_f32 v59, s53, %[oy]\n"
-	    "\tv_sub_f32 v60, s50, %[oz]\n"
-	    "\tv_sub_f32 v61, s54, %[oz]\n"
-	    "\tv_mul_f32 v56, %[ix], v56\n"
-	    "\tv_mul_f32 v57, %[ix], v57\n"
-	    "\tv_mul_f32 v58, %[iy], v58\n"
-	    "\tv_mul_f32 v59, %[iy], v59\n"
-	    "\tv_mul_f32 v60, %[iz], v60\n"
-	    "\tv_mul_f32 v61, %[iz], v61\n"
-	    "\tv_cndmask_b32 v62, v57, v56, %[px]\n"
-	    "\tv_cndmask_b32 v56, v56, v57, %[px]\n"
-	    "\tv_cndmask_b32 v57, v59, v58, %[py]\n"
-	    "\tv_cndmask_b32 v58, v58, v59, %[py]\n"
-	    "\tv_cndmask_b32 v59, v61, v60, %[pz]\n"
-	    "\tv_cndmask_b32 v60, v60, v61, %[pz]\n"
-	    "\tv_max_f32 v59, 1, v59\n"
-	    "\tv_min_f32 v60, %[below], v60\n"
-	    "\tv_max3_f32 v62, v62, v57, v59\n"
-	    "\tv_min3_f32 v56, v56, v58, v60\n"
-	    "\tv_cmp_le_f32 vcc, v62, v56\n"
-	    "\ts_and_b64 s[44:45], vcc, %[alive]\n"
-	    "\ts_cmp_lg_u64 s[44:45], 0\n"
-	    "\ts_cbranch_scc1 .Lcollect_hit_a_%=\n"
-	    "\ts_lshl_b32 s51, s51, 5\n"
-	    "\ts_add_u32 %[at], %[at], s51\n"
-	    "\ts_cmp_lt_u32 %[at], %[end]\n"
-	    "\ts_cbranch_scc1 .Lcollect_node_%=\n"
-	    "\ts_branch .Lcollect_over_%=\n"
-	    ".Lcollect_hit_a_%=:\n"
-	    "\ts_cmp_lg_u32 s55, -1\n"
-	    "\ts_cbranch_scc1 .Lcollect_leaf_a_%=\n"
-	    ".Lcollect_next_b_%=:\n"
-	    "\ts_add_u32 %[at], %[at], 32\n"
-	    "\ts_cmp_lt_u32 %[at], %[end]\n"
-	    "\ts_cbranch_scc0 .Lcollect_over_%=\n"
-	    "\tv_sub_f32 v56, s56, %[ox]\n"
-	    "\tv_sub_f32 v57, s60, %[ox]\n"
-	    "\tv_sub_f32 v58, s57, %[oy]\n"
-	    "\tv_sub_f32 v59, s61, %[oy]\n"
-	    "\tv_sub_f32 v60, s58, %[oz]\n"
-	    "\tv_sub_f32 v61, s62, %[oz]\n"
-	    "\tv_mul_f32 v56, %[ix], v56\n"
-	    "\tv_mul_f32 v57, %[ix], v57\n"
-	    "\tv_mul_f32 v58, %[iy], v58\n"
-	    "\tv_mul_f32 v59, %[iy], v59\n"
-	    "\tv_mul_f32 v60, %[iz], v60\n"
-	    "\tv_mul_f32 v61, %[iz], v61\n"
-	    "\tv_cndmask_b32 v62, v57, v56, %[px]\n"
-	    "\tv_cndmask_b32 v56, v56, v57, %[px]\n"
-	    "\tv_cndmask_b32 v57, v59, v58, %[py]\n"
-	    "\tv_cndmask_b32 v58, v58, v59, %[py]\n"
-	    "\tv_cndmask_b32 v59, v61, v60, %[pz]\n"
-	    "\tv_cndmask_b32 v60, v60, v61, %[pz]\n"
-	    "\tv_max_f32 v59, 1, v59\n"
-	    "\tv_min_f32 v60, %[below], v60\n"
-	    "\tv_max3_f32 v62, v62, v57, v59\n"
-	    "\tv_min3_f32 v56, v56, v58, v60\n"
-	    "\tv_cmp_le_f32 vcc, v62, v56\n"
-	    "\ts_and_b64 s[44:45], vcc, %[alive]\n"
-	    "\ts_cmp_lg_u64 s[44:45], 0\n"
-	    "\ts_cbranch_scc1 .Lcollect_hit_b_%=\n"
-	    "\ts_lshl_b32 s59, s59, 5\n"
-	    "\ts_add_u32 %[at], %[at], s59\n"
-	    "\ts_cmp_lt_u32 %[at], %[end]\n"
-	    "\ts_cbranch_scc1 .Lcollect_node_%=\n"
-	    "\ts_branch .Lcollect_over_%=\n"
-	    ".Lcollect_hit_b_%=:\n"
-	    "\ts_cmp_lg_u32 s63, -1\n"
-	    "\ts_cbranch_scc1 .Lcollect_leaf_b_%=\n"
-	    ".Lcollect_next_a_%=:\n"
-	    "\ts_add_u32 %[at], %[at], 32\n"
-	    "\ts_cmp_lt_u32 %[at], %[end]\n"
-	    "\ts_cbranch_scc1 .Lcollect_node_%=\n"
-	    "\ts_branch .Lcollect_over_%=\n"
-	    ".Lcollect_leaf_a_%=:\n"
-	    "\ts_bcnt1_i32_b64 s46, s[44:45]\n"
-	    "\ts_add_u32 %[stops], %[stops], 1\n"
-	    "\ts_cmp_ge_u32 s46, %[batch_below]\n"
-	    "\ts_cbranch_scc1 .Lcollect_now_a_%=\n"
-	    "\tv_mbcnt_lo_u32_b32 v56, s44, 0\n"
-	    "\tv_mbcnt_hi_u32_b32 v56, s45, v56\n"
-	    "\tv_add_u32 v56, %[waiting], v56\n"
-	    "\tv_lshl_add_u32 v56, v56, 2, %[list]\n"
-	    "\tv_or_b32 v57, s55, %[tag]\n"
-	    "\ts_mov_b64 s[42:43], exec\n"
-	    "\ts_mov_b64 exec, s[44:45]\n"
-	    "\tds_write_b32 v56, v57\n"
-	    "\ts_mov_b64 exec, s[42:43]\n"
-	    "\ts_add_u32 %[waiting], %[waiting], s46\n"
-	    "\ts_cmp_ge_u32 %[waiting], 64\n"
-	    "\ts_cbranch_scc1 .Lcollect_full_%=\n"
-	    "\ts_branch .Lcollect_next_b_%=\n"
-	    ".Lcollect_now_a_%=:\n"
-	    "\ts_mov_b32 %[leaf], s55\n"
-	    "\ts_branch .Lcollect_now_%=\n"
-	    ".Lcollect_leaf_b_%=:\n"
-	    "\ts_bcnt1_i32_b64 s46, s[44:45]\n"
-	    "\ts_add_u32 %[stops], %[stops], 1\n"
-	    "\ts_cmp_ge_u32 s46, %[batch_below]\n"
-	    "\ts_cbranch_scc1 .Lcollect_now_b_%=\n"
-	    "\tv_mbcnt_lo_u32_b32 v56, s44, 0\n"
-	    "\tv_mbcnt_hi_u32_b32 v56, s45, v56\n"
-	    "\tv_add_u32 v56, %[waiting], v56\n"
-	    "\tv_lshl_add_u32 v56, v56, 2, %[list]\n"
-	    "\tv_or_b32 v57, s63, %[tag]\n"
-	    "\ts_mov_b64 s[42:43], exec\n"
-	    "\ts_mov_b64 exec, s[44:45]\n"
-	    "\tds_write_b32 v56, v57\n"
-	    "\ts_mov_b64 exec, s[42:43]\n"
-	    "\ts_add_u32 %[waiting], %[waiting], s46\n"
-	    "\ts_cmp_ge_u32 %[waiting], 64\n"
-	    "\ts_cbranch_scc1 .Lcollect_full_%=\n"
-	    "\ts_branch .Lcollect_next_a_%=\n"
-	    ".Lcollect_now_b_%=:\n"
-	    "\ts_mov_b32 %[leaf], s63\n"
-	    ".Lcollect_now_%=:\n"
-	    "\ts_mov_b64 %[hit], s[44:45]\n"
-	    "\ts_mov_b32 %[status], 1\n"
-	    "\ts_branch .Lcollect_out_%=\n"
-	    ".Lcollect_full_%=:\n"
-	    "\ts_mov_b32 %[status], 2\n"
-	    "\ts_branch .Lcollect_out_%=\n"
-	    ".Lcollect_over_%=:\n"
-	    "\ts_mov_b32 %[status], 0\n"
-	    ".Lcollect_out_%=:\n"
-	    : [at] "+s"(at), [waiting] "+s"(waiting), [stops] "+s"(leaf_stops), [hit] "=&s"(hit_mask), [leaf] "=&s"(leaf),
-	      [status] "=&s"(status)
-	    : [base] "s"(nodes_ptr), [end] "s"(end), [alive] "s"(alive_mask), [below] "s"(below), [batch_below] "s"(batch_below),
-	      [px] "s"(sign.x), [py] "s"(sign.y), [pz] "s"(sign.z), [list] "v"(list_lds_address), [tag] "v"(lane_tag), [ox] "v"(ray.ox),
-	      [oy] "v"(ray.oy), [oz] "v"(ray.oz), [ix] "v"(ray.ix), [iy] "v"(ray.iy), [iz] "v"(ray.iz)
-	    : "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59",
-	      "s60", "s61", "s62", "s63", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "vcc", "scc", "memory");
+	switch (variant) {
+	case 0u: OCRT_WALK_COHERENT(N, N, N); break;
+	case 1u: OCRT_WALK_COHERENT(P, N, N); break;
+	case 2u: OCRT_WALK_COHERENT(N, P, N); break;
+	case 3u: OCRT_WALK_COHERENT(P, P, N); break;
+	case 4u: OCRT_WALK_COHERENT(N, N, P); break;
+	case 5u: OCRT_WALK_COHERENT(P, N, P); break;
+	case 6u: OCRT_WALK_COHERENT(N, P, P); break;
+	case 7u: OCRT_WALK_COHERENT(P, P, P); break;
+	default:
+		asm volatile(OCRT_WALK_ASM(OCRT_TEST_MIXED("s48", "s49", "s50", "s52", "s53", "s54"),
+		                           OCRT_TEST_MIXED("s56", "s57", "s58", "s60", "s61", "s62"))
+		             : [at] "+s"(at), [waiting] "+s"(waiting), [stops] "+s"(leaf_stops), [hit] "=&s"(hit_mask),
+		               [leaf] "=&s"(leaf), [status] "=&s"(status)
+		             : [base] "s"(walk_ptr), [alive] "s"(alive_mask), [below] "s"(below), [batch_below] "s"(batch_below),
+		               [px] "s"(sign.x), [py] "s"(sign.y), [pz] "s"(sign.z), [list] "v"(list_lds_address), [tag] "v"(lane_tag),
+		               [ix] "v"(ray.ix), [iy] "v"(ray.iy), [iz] "v"(ray.iz), [oix] "v"(ray.oix), [oiy] "v"(ray.oiy),
+		               [oiz] "v"(ray.oiz)
+		             : OCRT_WALK_CLOBBERS);
+		break;
+	}
 	return status;
+}
+
+// Which loop a packet takes: its sign octant if every live lane agrees on every axis, else WALK_MIXED.
+__device__ __forceinline__ uint32_t walk_variant(const SignMasks &sign, unsigned long long alive_mask) {
+	const unsigned long long x = sign.x & alive_mask, y = sign.y & alive_mask, z = sign.z & alive_mask;
+	bool coherent = (x == 0ull || x == alive_mask) && (y == 0ull || y == alive_mask) && (z == 0ull || z == alive_mask);
+#ifdef OCRT_ALWAYS_MIXED
+	coherent = false;
+#endif
+	return coherent ? (x != 0ull ? 1u : 0u) | (y != 0ull ? 2u : 0u) | (z != 0ull ? 4u : 0u) : WALK_MIXED;
+}
+
+// The exact test on a candidate leaf's OWN box (uploaded, unpadded), the reference's gate of the triangle test
+// (src/intersect_kernel.cl:189,195).  Only packets of the fast form get here -- regular boxes, selectable rays --,
+// for which the reference's chain of comparisons folds into max(near, tiny) <= min(far, below) with the near / far
+// plane picked by the sign of the reciprocal and IEEE maxNum / minNum dropping the NaN of 0 * inf (the
+// first generation of walk_collect applied exactly this arithmetic to every node).  `below` is the largest float
+// under the ray kind's max_distance.
+__device__ __forceinline__ bool exact_leaf_gate(const float4 lo, const float4 hi, const Ray &r, float below) {
+	const float x0 = (lo.x - r.ox) * r.ix, x1 = (hi.x - r.ox) * r.ix;
+	const float y0 = (lo.y - r.oy) * r.iy, y1 = (hi.y - r.oy) * r.iy;
+	const float z0 = (lo.z - r.oz) * r.iz, z1 = (hi.z - r.oz) * r.iz;
+	const bool px = r.ix >= 0.0f, py = r.iy >= 0.0f, pz = r.iz >= 0.0f;
+	const float tiny = __uint_as_float(1u);
+	const float t_near = fmaxf(fmaxf(px ? x0 : x1, py ? y0 : y1), fmaxf(pz ? z0 : z1, tiny));
+	const float t_far = fminf(fminf(px ? x1 : x0, py ? y1 : y0), fminf(pz ? z1 : z0, below));
+	return t_near <= t_far;
 }
 
 // Triangle tests of an any-hit packet waiting to be run 64 at a time (LDS, one per wave).
@@ -570,11 +657,13 @@ constexpr uint32_t INF_BITS = 0x7F800000u;
 
 // Any-hit shared walk of one packet (AO): a lane leaves at its first accepted
 // triangle and bumps *occluded (reference :251 only uses the boolean).
+// EXACT walks `nodes_ptr` (exact boxes); the fast form walks `walk_ptr` (padded boxes) and gates every candidate
+// leaf with its own box, the head of its leaf record (by pointer for a leaf tested on the spot, by descriptor in a batch).
 template <bool EXACT>
-__device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ nodes_ptr,
-                                                    const float4 *__restrict__ tris_ptr, __amdgpu_buffer_rsrc_t tris_rsrc, uint32_t count,
-                                                    const Ray &ray, float max_distance, float below, bool alive, uint32_t lane,
-                                                    unsigned int *occluded, LeafBatch &batch, uint32_t batch_below,
+__device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ nodes_ptr, const float4 *__restrict__ walk_ptr,
+                                                    const float4 *__restrict__ tris_ptr, __amdgpu_buffer_rsrc_t tris_rsrc,
+                                                    uint32_t count, const Ray &ray, float max_distance, float below, bool alive,
+                                                    uint32_t lane, unsigned int *occluded, LeafBatch &batch, uint32_t batch_below,
                                                     unsigned long long *prof) {
 	(void) prof;  // (-DOCRT_STAMPS builds: time in the node loop / in batches, loop entries, batches, leaf stops)
 	// the live lanes as a scalar mask: the node steps then need no per-lane bookkeeping at all
@@ -599,11 +688,21 @@ __device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ n
 			Ray theirs;
 			theirs.ox = __shfl(ray.ox, owner); theirs.oy = __shfl(ray.oy, owner); theirs.oz = __shfl(ray.oz, owner);
 			theirs.dx = __shfl(ray.dx, owner); theirs.dy = __shfl(ray.dy, owner); theirs.dz = __shfl(ray.dz, owner);
-			theirs.ix = theirs.iy = theirs.iz = 0.0f;  // (the triangle test does not use them)
+			theirs.ix = __shfl(ray.ix, owner); theirs.iy = __shfl(ray.iy, owner); theirs.iz = __shfl(ray.iz, owner);
 			if (lane < n) {
-				const TriResult tr = tri_test<false>(tris_rsrc, pair & 0x03FFFFFFu, theirs);
-				if (tr.accepted)
-					atomicOr(&batch.occluded_bits[owner >> 5], 1u << (owner & 31));
+				// the pair is a candidate of the padded walk: the leaf's own box decides whether the reference tests it
+				const uint32_t pair_leaf = pair & 0x03FFFFFFu;
+				const float4 lo = load_f4(tris_rsrc, pair_leaf * LEAF_BYTES), hi = load_f4(tris_rsrc, pair_leaf * LEAF_BYTES + 16u);
+				const bool gate = exact_leaf_gate(lo, hi, theirs, below);
+#ifdef OCRT_STAMPS
+				prof[5] += n;  // candidate pairs / pairs whose own box passes
+				prof[6] += (unsigned long long) __popcll(wave_ballot(gate));
+#endif
+				if (gate) {
+					const TriResult tr = tri_test<false>(tris_rsrc, pair_leaf, theirs);
+					if (tr.accepted)
+						atomicOr(&batch.occluded_bits[owner >> 5], 1u << (owner & 31));
+				}
 			}
 			wave_lds_sync();
 			const uint32_t bits = batch.occluded_bits[lane >> 5];
@@ -624,13 +723,15 @@ __device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ n
 		const uint32_t end = count * 32u;
 		const uint32_t list_lds_address = (uint32_t) (uintptr_t) &batch.entry[0];  // (low half of the flat address)
 		const SignMasks sign = sign_masks(ray);
+		const uint32_t variant = walk_variant(sign, alive_mask);  // (lanes only leave: a coherent packet stays coherent)
+		const WalkRay walk_ray = make_walk_ray(ray);
 		while (alive_mask != 0ull && at < end) {
 			uint32_t leaf = 0u;
 			unsigned long long hit_mask = 0ull;
 #ifdef OCRT_STAMPS
 			const unsigned long long tw0 = __builtin_amdgcn_s_memrealtime();
 #endif
-			const uint32_t status = walk_collect(nodes_ptr, at, end, ray, sign, below, alive_mask, hit_mask, leaf, waiting,
+			const uint32_t status = walk_collect(variant, walk_ptr, at, walk_ray, sign, below, alive_mask, hit_mask, leaf, waiting,
 			                                     leaf_stops, list_lds_address, lane << 26, batch_below);
 #ifdef OCRT_STAMPS
 			prof[0] += __builtin_amdgcn_s_memrealtime() - tw0;
@@ -639,10 +740,10 @@ __device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ n
 			if (status == 0u)
 				break;
 			if (status == 1u) {
-				// enough of the packet is at this leaf: test it here, the triangle out of SGPRs
-				const float4 q0 = tris_ptr[4u * leaf], q1 = tris_ptr[4u * leaf + 1u];
-				const float4 q2 = tris_ptr[4u * leaf + 2u], q3 = tris_ptr[4u * leaf + 3u];
-				if ((hit_mask >> lane) & 1ull) {
+				// enough of the packet is at this leaf: test it here, box and triangle out of SGPRs
+				const float4 *rec = tris_ptr + LEAF_F4 * leaf;
+				const float4 lo = rec[0], hi = rec[1], q0 = rec[2], q1 = rec[3], q2 = rec[4], q3 = rec[5];
+				if (((hit_mask >> lane) & 1ull) && exact_leaf_gate(lo, hi, ray, below)) {
 					const TriResult tr = tri_eval<false>(q0, q1, q2, q3, ray);
 					if (tr.accepted) {
 						atomicAdd(occluded, 1u);
@@ -677,8 +778,8 @@ __device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ n
 		mine = here ? (box ? at + 1u : at + skip) : mine;
 		const unsigned long long hit_mask = wave_ballot(box);
 		if (hit_mask != 0ull && leaf != NONE) {
-			const float4 q0 = tris_ptr[4u * leaf], q1 = tris_ptr[4u * leaf + 1u];
-			const float4 q2 = tris_ptr[4u * leaf + 2u], q3 = tris_ptr[4u * leaf + 3u];
+			const float4 *tri = tris_ptr + LEAF_F4 * leaf + LEAF_TRI_F4;
+			const float4 q0 = tri[0], q1 = tri[1], q2 = tri[2], q3 = tri[3];
 			if (box) {
 				const TriResult tr = tri_eval<false>(q0, q1, q2, q3, ray);
 				if (tr.accepted) {
@@ -707,8 +808,12 @@ __device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ n
 // ---------------------------------------------------------------------------
 constexpr uint32_t PRIMARY_WAVES = 4;
 
-__global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
-    const float4 *__restrict__ nodes_ptr, const float4 *__restrict__ tris_ptr, const float4 *__restrict__ shade,
+// SHARED: the shared walk (two instantiations, so that the first generation's per-lane state stays out of the
+// default path's register budget).
+template <bool SHARED>
+__global__ __launch_bounds__(64 * PRIMARY_WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void primary_kernel(
+    const float4 *__restrict__ nodes_ptr, const float4 *__restrict__ walk_ptr, const float4 *__restrict__ tris_ptr,
+    const float4 *__restrict__ shade,
     float *__restrict__ image, HitRec *__restrict__ hits, uint32_t *__restrict__ occluded_of,
     uint32_t *__restrict__ tile_hits, FrameCounters *__restrict__ counters, KernelParams P) {
 	__shared__ ClosestBatch closest_batches[PRIMARY_WAVES];
@@ -751,12 +856,12 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
 	best.px = best.py = best.pz = 0.0f;
 	bool hit = false;
 	uint32_t leaf_stops = 0u;  // leaves the tile's shared walk stopped at: how dense the geometry is along these rays
-	if (P.shared_walk) {
-		const bool exact = !(P.scene_regular && P.scene_nested) || wave_ballot(active && !ray_is_selectable(ray)) != 0ull;
+	if (SHARED) {
+		const bool exact = !P.fast_walk || wave_ballot(active && !ray_is_selectable(ray, P.origin_limit)) != 0ull;
 		// closest hit = minimum of (distance, reference leaf), see nearer(); reference :106-112
 		auto leaf_test = [&](uint32_t leaf, bool box) {
-			const float4 q0 = tris_ptr[4u * leaf], q1 = tris_ptr[4u * leaf + 1u];
-			const float4 q2 = tris_ptr[4u * leaf + 2u], q3 = tris_ptr[4u * leaf + 3u];
+			const float4 *tri = tris_ptr + LEAF_F4 * leaf + LEAF_TRI_F4;
+			const float4 q0 = tri[0], q1 = tri[1], q2 = tri[2], q3 = tri[3];
 			if (box) {
 				const TriResult tr = tri_eval<true>(q0, q1, q2, q3, ray);
 				if (tr.accepted) {
@@ -788,31 +893,38 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
 				const int owner = (int) (pair >> 26);
 				Ray theirs = ray;  // (all primary rays start at the eye)
 				theirs.dx = __shfl(ray.dx, owner); theirs.dy = __shfl(ray.dy, owner); theirs.dz = __shfl(ray.dz, owner);
+				theirs.ix = __shfl(ray.ix, owner); theirs.iy = __shfl(ray.iy, owner); theirs.iz = __shfl(ray.iz, owner);
 				if (lane < n) {
+					// a candidate of the padded walk: the leaf's own box decides whether the reference tests it (:189)
 					const uint32_t leaf = pair & 0x03FFFFFFu;
-					const TriResult tr = tri_test<true>(scene.tris, leaf, theirs);
-					if (tr.accepted) {
-						atomicMin(&cb.best_key[owner], key_of(tr.distance, leaf));
-						atomicOr(&cb.hit_bits[owner >> 5], 1u << (owner & 31));
+					const float4 lo = load_f4(scene.tris, leaf * LEAF_BYTES), hi = load_f4(scene.tris, leaf * LEAF_BYTES + 16u);
+					if (exact_leaf_gate(lo, hi, theirs, P.primary_below)) {
+						const TriResult tr = tri_test<true>(scene.tris, leaf, theirs);
+						if (tr.accepted) {
+							atomicMin(&cb.best_key[owner], key_of(tr.distance, leaf));
+							atomicOr(&cb.hit_bits[owner >> 5], 1u << (owner & 31));
+						}
 					}
 				}
 			};
 			const unsigned long long alive_mask = wave_ballot(active);
 			const SignMasks sign = sign_masks(ray);
+			const uint32_t variant = walk_variant(sign, alive_mask);
+			const WalkRay walk_ray = make_walk_ray(ray);
 			const uint32_t list_lds_address = (uint32_t) (uintptr_t) &cb.entry[0];  // (low half of the flat address)
 			const uint32_t end = count * 32u;
 			uint32_t at = 0u;  // byte offset
 			while (alive_mask != 0ull && at < end) {
 				uint32_t leaf = 0u;
 				unsigned long long hit_mask = 0ull;
-				const uint32_t status = walk_collect(nodes_ptr, at, end, ray, sign, P.primary_below, alive_mask, hit_mask, leaf, waiting,
-				                                     leaf_stops, list_lds_address, lane << 26, P.batch_below);
+				const uint32_t status = walk_collect(variant, walk_ptr, at, walk_ray, sign, P.primary_below, alive_mask, hit_mask, leaf,
+				                                     waiting, leaf_stops, list_lds_address, lane << 26, P.batch_below);
 				if (status == 0u)
 					break;
 				if (status == 1u) {
-					const float4 q0 = tris_ptr[4u * leaf], q1 = tris_ptr[4u * leaf + 1u];
-					const float4 q2 = tris_ptr[4u * leaf + 2u], q3 = tris_ptr[4u * leaf + 3u];
-					if ((hit_mask >> lane) & 1ull) {
+					const float4 *rec = tris_ptr + LEAF_F4 * leaf;
+					const float4 lo = rec[0], hi = rec[1], q0 = rec[2], q1 = rec[3], q2 = rec[4], q3 = rec[5];
+					if (((hit_mask >> lane) & 1ull) && exact_leaf_gate(lo, hi, ray, P.primary_below)) {
 						const TriResult tr = tri_eval<true>(q0, q1, q2, q3, ray);
 						if (tr.accepted) {
 							hit = true;
@@ -923,7 +1035,7 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) void primary_kernel(
 		// walk about as far as the primary packet did (correlation 0.8-0.9, tools/analysis/packet_union.cc).
 		// The hit count does not predict the cost at all: a sparse tile's packets mix several directions
 		// and walk as many nodes as a full tile's.
-		uint32_t cost = P.shared_walk ? leaf_stops : hit_count;
+		uint32_t cost = SHARED ? leaf_stops : hit_count;
 		cost = cost < 1u ? 1u : cost;
 		cost = cost > 64u ? 64u : cost;
 		tile_hits[tile] = (want_ao && hit_count) ? (hit_count | (cost << 8)) : 0u;
@@ -1075,9 +1187,10 @@ struct TileShared {
 
 template <int MODE, bool SHARED>
 __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void ao_kernel(
-    const float4 *__restrict__ nodes_ptr, const float4 *__restrict__ tris_ptr, const float4 *__restrict__ ao_table,
-    const HitRec *__restrict__ hits, uint32_t *__restrict__ occluded_of, const uint32_t *__restrict__ order,
-    FrameCounters *__restrict__ counters, KernelParams P) {
+    const float4 *__restrict__ nodes_ptr, const float4 *__restrict__ walk_ptr, const float4 *__restrict__ tris_ptr,
+    const float4 *__restrict__ ao_table, const HitRec *__restrict__ hits,
+    uint32_t *__restrict__ occluded_of, const uint32_t *__restrict__ order, FrameCounters *__restrict__ counters,
+    KernelParams P) {
 	__shared__ TileShared shared_tiles[AO_WAVES];
 	const uint32_t lane = threadIdx.x & 63u;
 	TileShared &sh = shared_tiles[threadIdx.x >> 6];
@@ -1092,7 +1205,7 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 	unsigned long long stamp_acc[6] = { 0, 0, 0, 0, 0, 0 };
 	const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
 	unsigned long long t_last_claim = t_begin;
-	unsigned long long walk_prof_store[5] = { 0, 0, 0, 0, 0 };
+	unsigned long long walk_prof_store[7] = { 0, 0, 0, 0, 0, 0, 0 };
 	unsigned long long *walk_prof = walk_prof_store;
 #endif
 	// Workgroups b and b+8 share an XCD: start with that group's queue, then help the others.
@@ -1148,8 +1261,9 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 
 				// ---- the tile's tangent frames -> this wave's LDS slice (reference :215-236) ----
 				if (lane < hit_count) {
-					const float4 q0 = ((const float4 *) hits)[2 * ((size_t) tile * 64u + lane)];
-					const float4 q1 = ((const float4 *) hits)[2 * ((size_t) tile * 64u + lane) + 1];
+					const size_t slot = (size_t) tile * 64u + cold_lane(lane);
+					const float4 q0 = ((const float4 *) hits)[2 * slot];
+					const float4 q1 = ((const float4 *) hits)[2 * slot + 1];
 					float nx = q1.x, ny = q1.y, nz = q1.z;
 					// p = point + normal * (1.0f / 100000.0f)
 					const float eps = 1.0f / 100000.0f;
@@ -1295,7 +1409,7 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 				} else {
 					// shared walks (see shared_box) of 64 consecutive rays of the job at a time; a lane
 					// leaves at its first accepted triangle
-					const bool scene_fast = P.scene_regular && P.scene_nested && P.ao_regular;
+					const bool scene_fast = P.fast_walk && P.ao_regular;
 					for (uint32_t base = 0u; base < total; base += 64u) {
 						bool alive = base + lane < total;
 						// a full tile's packet is one table direction: the entry comes by a scalar load
@@ -1305,13 +1419,15 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 							shared_dir = ao_table[dir0 + (base >> 6)];
 						if (alive)
 							setup_ray(base + lane, whole, shared_dir);
-						const bool exact = !scene_fast || wave_ballot(alive && !ray_is_selectable(ray)) != 0ull;
+						const bool exact = !scene_fast || wave_ballot(alive && !ray_is_selectable(ray, P.origin_limit)) != 0ull;
 						if (exact)
-							shared_walk_any_hit<true>(nodes_ptr, tris_ptr, scene.tris, count, ray, P.ao_max_distance,
-							                          P.ao_below, alive, lane, &sh.occluded[h], sh.batch, P.batch_below, walk_prof);
+							shared_walk_any_hit<true>(nodes_ptr, walk_ptr, tris_ptr, scene.tris, count, ray,
+							                          P.ao_max_distance, P.ao_below, alive, lane, &sh.occluded[h], sh.batch,
+							                          P.batch_below, walk_prof);
 						else
-							shared_walk_any_hit<false>(nodes_ptr, tris_ptr, scene.tris, count, ray, P.ao_max_distance,
-							                           P.ao_below, alive, lane, &sh.occluded[h], sh.batch, P.batch_below, walk_prof);
+							shared_walk_any_hit<false>(nodes_ptr, walk_ptr, tris_ptr, scene.tris, count, ray,
+							                           P.ao_max_distance, P.ao_below, alive, lane, &sh.occluded[h], sh.batch,
+							                           P.batch_below, walk_prof);
 					}
 				}
 				wave_lds_sync();
@@ -1324,7 +1440,7 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 				if (lane < hit_count) {
 					const uint32_t occluded = sh.occluded[lane];
 					if (occluded)
-						atomicAdd(&occluded_of[(size_t) tile * 64u + lane], occluded);
+						atomicAdd(&occluded_of[(size_t) tile * 64u + cold_lane(lane)], occluded);
 				}
 				wave_lds_sync();
 				OCRT_STAMP(t_flushed);
@@ -1342,7 +1458,7 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 		atomicMax(&counters->stamp[8], t_end);                       // last end
 		if (stamp_acc[4])
 			atomicAdd(&counters->stamp[9], 1ull);                    // waves that got any work
-		for (int k = 0; k < 5; ++k)
+		for (int k = 0; k < 7; ++k)
 			atomicAdd(&counters->stamp[42 + k], walk_prof_store[k]);  // time in the node loop, in batches; loop entries, batches, leaf stops
 		const unsigned long long idle_bucket = (t_end - t_last_claim) / 5000ull;  // last claim -> end, 0.05 ms buckets
 		atomicAdd(&counters->stamp[10 + (idle_bucket > 31 ? 31 : idle_bucket)], 1ull);
@@ -1404,21 +1520,27 @@ __global__ __launch_bounds__(256) void resize_kernel(const float *__restrict__ t
 }
 
 // ---- host-callable launchers (keeps the launch syntax inside this TU) ----
-void launch_primary(const void *nodes, const void *tris, const void *shade, float *image, void *hits,
-                    void *occluded_of, void *tile_hits, void *counters, const KernelParams &P, void *stream) {
+void launch_primary(const SceneBuffers &scene, float *image, void *hits, void *occluded_of, void *tile_hits,
+                    void *counters, const KernelParams &P, void *stream) {
 	if (P.tiles_x * P.local_tile_rows == 0)
 		return;
 	hipStream_t s = (hipStream_t) stream;
 	const uint32_t strips = (P.tiles_x + 1u) >> 1, row_pairs = (P.local_tile_rows + 1u) >> 1;
 	const uint32_t blocks = XCD_GROUPS * ((strips + XCD_GROUPS - 1u) >> 3) * row_pairs;
-	hipLaunchKernelGGL(primary_kernel, dim3(blocks), dim3(64 * PRIMARY_WAVES), 0, s, (const float4 *) nodes,
-	                   (const float4 *) tris, (const float4 *) shade, image, (HitRec *) hits, (uint32_t *) occluded_of,
-	                   (uint32_t *) tile_hits, (FrameCounters *) counters, P);
+	auto launch = [&](auto kernel) {
+		hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64 * PRIMARY_WAVES), 0, s, (const float4 *) scene.nodes,
+		                   (const float4 *) scene.walk, (const float4 *) scene.tris, (const float4 *) scene.shade, image,
+		                   (HitRec *) hits, (uint32_t *) occluded_of, (uint32_t *) tile_hits, (FrameCounters *) counters, P);
+	};
+	if (P.shared_walk)
+		launch(primary_kernel<true>);
+	else
+		launch(primary_kernel<false>);
 }
 
-void launch_ao(const void *nodes, const void *tris, const void *ao_table, float *image, void *hits,
-               void *occluded_of, void *tile_hits, void *order, void *counters, const KernelParams &params,
-               uint32_t compute_units, void *stream, void *event_before_ao, void *event_after_ao) {
+void launch_ao(const SceneBuffers &scene, float *image, void *hits, void *occluded_of, void *tile_hits, void *order,
+               void *counters, const KernelParams &params, uint32_t compute_units, void *stream, void *event_before_ao,
+               void *event_after_ao) {
 	if (params.tiles_x * params.local_tile_rows == 0 || params.ao_mode == AO_NONE || params.ao_dirs == 0)
 		return;
 	hipStream_t s = (hipStream_t) stream;
@@ -1440,8 +1562,8 @@ void launch_ao(const void *nodes, const void *tris, const void *ao_table, float 
 		// (the events bracket the ao_kernel launch alone: its duration is the one the roofline is quoted for)
 		if (event_before_ao)
 			(void) hipEventRecord((hipEvent_t) event_before_ao, s);
-		hipLaunchKernelGGL(kernel, dim3(ao_blocks), dim3(64 * AO_WAVES), 0, s, (const float4 *) nodes, (const float4 *) tris,
-		                   (const float4 *) ao_table, (const HitRec *) hits, (uint32_t *) occluded_of,
+		hipLaunchKernelGGL(kernel, dim3(ao_blocks), dim3(64 * AO_WAVES), 0, s, (const float4 *) scene.nodes,
+		                   (const float4 *) scene.walk, (const float4 *) scene.tris, (const float4 *) scene.ao_table, (const HitRec *) hits, (uint32_t *) occluded_of,
 		                   (const uint32_t *) order, (FrameCounters *) counters, P);
 		if (event_after_ao)
 			(void) hipEventRecord((hipEvent_t) event_after_ao, s);

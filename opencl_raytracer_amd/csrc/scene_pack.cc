@@ -26,8 +26,8 @@ PackedScene pack_scene(const std::vector<uint32_t> &faces, const std::vector<uin
 	if (vnormals.size() != vertices.size())
 		throw std::invalid_argument("upload: one normal per vertex expected");
 	const size_t tri_count = faces.size() / 3;
-	// the kernels address nodes (32 B) and triangles (64 B) with 32-bit byte offsets
-	if (count >= (1u << 27) || tri_count >= (1u << 26))
+	// the kernels address nodes (32 B) and leaf records (96 B) with 32-bit byte offsets
+	if (count >= (1u << 27) || tri_count >= (1u << 25))
 		throw std::invalid_argument("upload: scene too large for 32-bit device offsets");
 	for (uint32_t v : faces)
 		if (v >= vertices.size())
@@ -137,6 +137,7 @@ PackedScene pack_scene(const std::vector<uint32_t> &faces, const std::vector<uin
 			r.v[k] = v[k];
 			r.n[k] = n[k];
 		}
+		r.pad0 = r.pad1 = 0.0f;
 		r.uu = u.dot(u);
 		r.uv = u.dot(v);
 		r.vv = v.dot(v);
@@ -151,6 +152,85 @@ PackedScene pack_scene(const std::vector<uint32_t> &faces, const std::vector<uin
 			dst[c][3] = 0.0f;
 		}
 	}
+	// the leaf's own box, exactly as uploaded, next to its triangle
+	for (const NodeRec &n : out.nodes)
+		if (n.skip == 1)
+			for (unsigned k = 0; k < 3; ++k) {
+				out.tris[n.leaf].lo[k] = n.lo[k];
+				out.tris[n.leaf].hi[k] = n.hi[k];
+			}
+	return out;
+}
+
+// The fast form of the shared walk tests a box with t = fma(b', inv, oi), oi = -(o * inv) rounded once, instead of
+// the reference's fl(fl(b - o) * inv) (src/intersect_kernel.cl:21-61).  It only has to be CONSERVATIVE: whenever the
+// reference's test passes for a (ray, box) pair, the fma test on the padded box b' must pass too; what it says about
+// other pairs does not matter (a candidate leaf is gated by the exact test on its own box).
+//
+// Near plane, inv > 0 (the far plane and inv < 0 are mirror images).  Let s = fl(b - o), E = fl(s * inv) the
+// reference's value, F = fl(b' * inv + oi) ours, u = 2^-24.  As reals,
+//     b' * inv + oi  <=  (b' - o) * inv + u |o| inv + 2^-150          (oi = -fl(o * inv), 2^-150 if it underflows)
+//     s * inv        >=  (b - o) * inv - u |b - o| inv                 (fl of a difference has relative error <= u)
+// so  b - b' >= u (|b| + 2 |o|) + 2^-150  implies  b' * inv + oi <= s * inv, and rounding being monotone, F <= E:
+// the conservative near value never exceeds the reference's, the far value never falls below it.
+// |o| for a pair that PASSES the reference's test: t_near < max_distance and t_far > 0 put the origin within
+// max_distance (|d| <= 1 per axis) of the box on every axis, |o_k| <= B_k + D with B_k the box's largest magnitude on
+// axis k and D the ambient-occlusion rays' max_distance; the primary rays all start at the camera.  Hence per box and
+// axis  O_k = max(|camera_k|, B_k + D),  capped by the global origin_limit the kernel checks per packet (rays beyond it,
+// and rays with a reciprocal direction that is neither infinite nor below 1e30 -- o * inv could overflow -- take the
+// exact form).  Margin used: 1.5 u (|b| + 2 O_k), rounded outward.
+// An infinite inv (a zero direction component) is replaced by +-2^100 for the walk (kernels.hip, WalkRay): the
+// argument above holds for every finite inv, so 2^100 (b' - o) is <= 0 whenever the reference's (b - o) * inf is -inf
+// or NaN (no constraint), and where the reference gives +inf (the origin's coordinate outside the slab: reject) ours
+// may be anything.  (Extent <= 1e6 keeps 2^100 * 1e6 finite.)
+float padded_bound(float b, float origin_bound, bool upper) {
+	const double margin = 1.5 * std::ldexp(std::fabs((double) b) + 2.0 * (double) origin_bound, -24) + 1.0e-44;
+	const double moved = upper ? (double) b + margin : (double) b - margin;
+	float f = (float) moved;  // round to nearest, then make sure it lies outside
+	if (upper ? (double) f < moved : (double) f > moved)
+		f = std::nextafterf(f, upper ? std::numeric_limits<float>::infinity() : -std::numeric_limits<float>::infinity());
+	return f;
+}
+
+WalkArray make_walk_array(const PackedScene &scene, float ao_max_distance) {
+	WalkArray out;
+	const std::vector<NodeRec> &nodes = scene.nodes;
+	if (!(scene.regular && scene.nested) || nodes.empty())
+		return out;
+	float extent = 0.0f;
+	for (unsigned k = 0; k < 3; ++k)  // boxes are nested: the root's box bounds every coordinate
+		extent = std::fmax(extent, std::fmax(std::fabs(nodes[0].lo[k]), std::fabs(nodes[0].hi[k])));
+	if (!(extent <= 1.0e6f))
+		return out;  // (o * inv must not overflow for |inv| <= 1e30: such scenes keep the exact form)
+	// reach of the rays whose origin is not the camera; no ambient occlusion, or an unusable distance: the scene itself
+	const bool ao_bounded = ao_max_distance > 0.0f && ao_max_distance <= extent;
+	const double reach = ao_bounded ? (double) ao_max_distance * 1.001 : 2.0 * (double) extent;
+	// ray origins: the camera at (0, 0, 2) and hit points, which lie in the root box up to the triangle test's slack
+	out.origin_limit = 2.0f * extent + 4.0f;
+	const double camera[3] = { 0.0, 0.0, 2.0 };  // reference src/intersect_kernel.cl:284
+	out.nodes.resize(nodes.size() + 2);
+	for (size_t i = 0; i < nodes.size(); ++i) {
+		NodeRec w = nodes[i];
+		for (unsigned k = 0; k < 3; ++k) {
+			const double box = std::fmax(std::fabs((double) nodes[i].lo[k]), std::fabs((double) nodes[i].hi[k]));
+			const double origin = std::fmin((double) out.origin_limit, std::fmax(camera[k], box + reach));
+			w.lo[k] = padded_bound(nodes[i].lo[k], (float) origin, false);
+			w.hi[k] = padded_bound(nodes[i].hi[k], (float) origin, true);
+		}
+		w.skip = nodes[i].skip * (uint32_t) sizeof(NodeRec);  // (node count < 2^27, checked at pack time)
+		out.nodes[i] = w;
+	}
+	// The record behind the last node ends the walk: every live ray "hits" its box (an infinite slab) and its
+	// leaf field says END.  One more, because a node is fetched together with its successor.
+	NodeRec end{};
+	for (unsigned k = 0; k < 3; ++k) {
+		end.lo[k] = -std::numeric_limits<float>::infinity();
+		end.hi[k] = std::numeric_limits<float>::infinity();
+	}
+	end.skip = 0;
+	end.leaf = WALK_END;
+	out.nodes[nodes.size()] = end;
+	out.nodes[nodes.size() + 1] = end;
 	return out;
 }
 
@@ -213,7 +293,7 @@ uint32_t local_tile_rows_for(uint32_t total_height, const Partition &part) {
 }
 
 KernelParams make_kernel_params(const RayTracer &rt, uint32_t node_count, uint32_t tri_count, uint32_t ao_dirs,
-                                const Partition &part, const PackedScene *scene) {
+                                const Partition &part, const PackedScene *scene, const WalkArray *walk) {
 	KernelParams p{};
 	p.width = rt.totalWidth;
 	p.height = rt.totalHeight;
@@ -231,6 +311,8 @@ KernelParams make_kernel_params(const RayTracer &rt, uint32_t node_count, uint32
 	p.ao_max_distance = kernel_float(rt.options.aoMaxDistance);
 	p.ao_dirs = ao_dirs;
 	p.ao_divisor = p.ao_mode == AO_RANDOM ? ao_dirs - 1 : ao_dirs;
+	p.origin_limit = walk ? walk->origin_limit : 0.0f;
+	p.fast_walk = (walk && !walk->nodes.empty() && !std::getenv("OCRT_FORCE_EXACT_WALK")) ? 1 : 0;  // (debug knob)
 	p.scene_regular = (scene && scene->regular) ? 1 : 0;
 	p.scene_nested = (scene && scene->nested && !std::getenv("OCRT_FORCE_EXACT_WALK")) ? 1 : 0;  // (debug knob)
 	p.shared_walk = (scene && scene->binary_tree && !std::getenv("OCRT_NO_SHARED_WALK")) ? 1 : 0;  // (debug knob)

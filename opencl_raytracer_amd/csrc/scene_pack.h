@@ -32,6 +32,23 @@ PackedScene pack_scene(const std::vector<uint32_t> &faces, const std::vector<uin
                        const std::vector<Vec3f> &aabbs, const std::vector<Vec3f> &vertices,
                        const std::vector<Vec3f> &vnormals);
 
+// What the fast form of the shared walk reads: the same tree as PackedScene::nodes with every box pushed outward by
+// the margin derived at padded_bound(), the subtree size as a BYTE offset and two END records behind the last node
+// (kernels.hip, walk_collect).  The outward margin makes the walk's 6-FMA box test conservative, so a ray can only
+// visit MORE boxes than the reference's own test would let it; which triangles count is decided by the exact test on
+// the leaf's own box (TriRec::lo / hi).  `nodes` is empty when the scene does not qualify (irregular or non-nested
+// boxes, extent beyond 1e6): the kernels then only use the exact form.
+struct WalkArray {
+	std::vector<NodeRec> nodes;
+	float origin_limit = 0.0f;  // rays whose origin exceeds this magnitude on some axis take the exact form
+};
+// `ao_max_distance`: the kernel's AO_MAX_DISTANCE (bounds how far from a box an ambient-occlusion ray that hits it
+// can start; <= 0 or not finite: no ambient occlusion, or no usable bound).
+WalkArray make_walk_array(const PackedScene &scene, float ao_max_distance);
+// The margin itself: the padded value of a box's lower (upper = false) or upper bound `b` for ray origins of
+// magnitude up to `origin_bound` on that axis; always < b resp. > b.
+float padded_bound(float b, float origin_bound, bool upper);
+
 // The value a float option has once it went through the reference's -D string:
 // printed with 6 significant digits ("-DNAME=0.2f", reference
 // include/compiler_options.h:13-19) and re-parsed as a float literal.
@@ -50,6 +67,6 @@ uint32_t band_tile_rows_for(unsigned int grid);
 uint32_t local_tile_rows_for(uint32_t total_height, const Partition &part);
 
 KernelParams make_kernel_params(const RayTracer &rt, uint32_t node_count, uint32_t tri_count, uint32_t ao_dirs,
-                                const Partition &part, const PackedScene *scene);
+                                const Partition &part, const PackedScene *scene, const WalkArray *walk);
 
 }  // namespace ocrt

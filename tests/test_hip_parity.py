@@ -103,7 +103,7 @@ def test_zero_normals_on_a_rebuilt_tree(rt, oracle, scene_for, monkeypatch):
     got = host.download()
     # the case really occurs in this frame: a NaN normal shades to clamp(NaN) = 0 on a hit sub-pixel
     clean_img, _, _ = oracle.render(orc.params_from_options(opt), arrays)
-    assert np.count_nonzero((ref_img == 0.0) & (clean_img > 0.0)) > 20
+    assert np.count_nonzero((ref_img == 0.0) & (clean_img > 0.0)) > 5
     same = (bits(got) == bits(ref_img)) | (np.isnan(got) & np.isnan(ref_img))
     assert same.all(), int((~same).sum())
     st = host.stats()

@@ -7,12 +7,13 @@ the build when a hot kernel would spill vector registers to scratch or run at fe
 kernels pinned to a 64-VGPR budget (`amdgpu_waves_per_eu(8, 8)`), so growth in live VGPRs
 would otherwise turn into silent scratch traffic in the hottest loop.
 
-    check_kernel_resources.py <remarks.txt> [--table out.txt]
+    check_kernel_resources.py <remarks.txt> [--table out.txt] [--report-only]
 
-Hot kernels (must have VGPR spill 0, scratch 0, occupancy 8): primary_kernel and the
-UNIFORM instantiations of ao_kernel (template argument 1).  The RANDOM instantiations
-(template argument 2, outside the bit-exact contract and off the default path) must keep
-the occupancy; their spills are reported, not fatal.  SGPR spills go to VGPR lanes
+Hot kernels (must have VGPR spill 0, scratch 0, occupancy 8): the default path, i.e. the
+shared-walk instantiations primary_kernel<true> and ao_kernel<1, true> (1 = UNIFORM).  The
+first-generation instantiations (<.., false>, debug knob OCRT_NO_SHARED_WALK) and the RANDOM
+mode (ao_kernel<2, ..>, outside the bit-exact contract) must keep the occupancy; their
+spills are reported, not fatal.  SGPR spills go to VGPR lanes
 (v_writelane / v_readlane outside the loops), not to memory; they are reported too.
 """
 import re
@@ -59,8 +60,9 @@ def main():
                f"{k.get('ScratchSize [bytes/lane]', '?'):>8s} {k.get('Occupancy [waves/SIMD]', '?'):>10s} "
                f"{k.get('SGPRs Spill', '?'):>10s} {k.get('VGPRs Spill', '?'):>10s} {k.get('LDS Size [bytes/block]', '?'):>7s}")
         lines.append(row)
-        hot = name.startswith("primary_kernel") or name.startswith("ao_kernel<1,")
-        walker = hot or name.startswith("ao_kernel<")
+        # hot: the default path = shared-walk instantiations of the primary pass and of the UNIFORM ambient-occlusion pass
+        hot = name.startswith("primary_kernel<true>") or name.startswith("ao_kernel<1, true>")
+        walker = hot or name.startswith("ao_kernel<") or name.startswith("primary_kernel<")
         if walker and k.get("Occupancy [waves/SIMD]") != "8":
             errors.append(f"{name}: occupancy {k.get('Occupancy [waves/SIMD]')} waves/SIMD, the walk is scheduled for 8")
         if hot and (k.get("VGPRs Spill") != "0" or k.get("ScratchSize [bytes/lane]") != "0"):
@@ -71,7 +73,9 @@ def main():
         with open(sys.argv[sys.argv.index("--table") + 1], "w") as f:
             f.write(table)
     print(table, end="")
-    if errors:
+    if errors and "--report-only" in sys.argv:  # instrumented builds (-DOCRT_STAMPS) carry extra live values
+        print("check_kernel_resources (report only): " + "; ".join(errors))
+    elif errors:
         sys.exit("check_kernel_resources: " + "; ".join(errors))
 
 
