@@ -302,6 +302,12 @@ void DeviceRenderer::downloadResizedFull(unsigned char *host) {
 	OCRT_HIP(hipMemcpy(host, d_u8, (size_t) opts.height * opts.width, hipMemcpyDeviceToHost));
 }
 
+uint32_t DeviceRenderer::globalRowOf(uint32_t local_row) const {
+	const uint32_t rows_per_band = part.band_tile_rows * TILE_H / grid;
+	const uint32_t band_local = local_row / rows_per_band;
+	return (band_local * part.nranks + part.rank) * rows_per_band + local_row % rows_per_band;
+}
+
 void DeviceRenderer::setStream(void *hip_stream) {
 	synchronize();
 	stream = hip_stream;

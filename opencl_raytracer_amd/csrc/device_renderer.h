@@ -43,6 +43,12 @@ class DeviceRenderer {
 		// the kernel-time statistics.
 		void synchronize();
 
+		// The compact uint8 band buffer on this renderer's device (localRows() x width bytes), valid after
+		// enqueueResize() has completed; and the stream everything is enqueued on.
+		const void *deviceBands() const { return d_u8; }
+		void *streamHandle() const { return stream; }
+		uint32_t globalRowOf(uint32_t local_row) const;  // output row of a local band row (may be >= height: padding)
+
 		void downloadFloat(float *host_image);          // full totalWidth x totalHeight (rows of other ranks' bands: 0)
 		void downloadResizedLocal(unsigned char *host); // localRows() x width, compact
 		void downloadResizedFull(unsigned char *host);  // width x height (needs nranks == 1)

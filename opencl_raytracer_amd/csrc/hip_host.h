@@ -79,5 +79,35 @@ class HipHost {
 		std::unique_ptr<ocrt::DeviceRenderer> impl;
 };
 
+// One frame on several GPUs of a node, in ONE process (`render --gpus N`): the scene is replicated, the image is cut
+// into bands of whole supersample blocks dealt round-robin to the devices (ocrt::Partition), every device renders and
+// box-filters its own bands, and the 8-bit bands are copied device-to-device over xGMI (hipMemcpyPeerAsync) into a
+// staging buffer on the first device, from where the assembled image is read.  Same member names as HipHost, so the
+// CLI drives either.  New: the reference is single-device (src/opencl_host.cc:16-32).
+class HipHostGroup {
+	public:
+		// `devices` GPUs starting at device `first` (< 0: $OCRT_DEVICE or 0).  More ranks than visible GPUs is an error
+		// unless $OCRT_SHARE_DEVICES is set (rehearsal on a smaller box: ranks are mapped round-robin).
+		HipHostGroup(const RayTracer &rt, unsigned int devices, int first = -1);
+		~HipHostGroup();
+		HipHostGroup(const HipHostGroup &) = delete;
+		HipHostGroup &operator=(const HipHostGroup &) = delete;
+
+		void upload(const std::vector<uint32_t> &faces, const std::vector<uint32_t> &nodes,
+		            const std::vector<Vec3f> &aabbs, const std::vector<Vec3f> &vertices,
+		            const std::vector<Vec3f> &vnormals);
+		bool operator()();                            // all devices render their bands; blocks until every one is done
+		void downloadResized(unsigned char *image);   // resize on every device, gather, assemble width x height bytes
+		float lastKernelMs() const;                   // slowest device's kernel time of the last frame
+		ocrt::RenderStats lastStats();                // summed over the devices
+		unsigned int size() const { return (unsigned int) hosts.size(); }
+
+	private:
+		const RayTracer &rt;
+		std::vector<std::unique_ptr<ocrt::DeviceRenderer>> hosts;
+		void *staging;        // on hosts[0]'s device: the devices' band buffers back to back
+		size_t staging_bytes;
+};
+
 // Source compatibility with callers written against the reference.
 using OpenCLHost = HipHost;

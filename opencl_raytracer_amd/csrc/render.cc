@@ -1,7 +1,10 @@
 // render.cc -- `render [OPTIONS] INPUT_MESH OUTPUT_IMAGE`: the reference's CLI
 // (reference src/render.cc:16-139, flag table :23-30) on the HIP render host.
 // Same flags, defaults, phase lines and PGM format; `-h` is HEIGHT, help is
-// `--help` only.  New: `--device N`, and a Mrays/s summary line.
+// `--help` only.  New: `--device N`, `--gpus N` (one frame on N GPUs of the node, bands gathered over xGMI),
+// `--host-resize` (the reference's own download + RayTracer::resize instead of the fused device resize), and a
+// Mrays/s summary line.
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -40,6 +43,8 @@ const OptionSpec OPTIONS[] = {
 	{ 's', "supersamples", "Specifies the number of supersamples to use." },
 	{ 'r', "bvh-strategy", "Specifies the strategy of BVH construction (longest|sah)." },
 	{ 0, "device", "Specifies the HIP device index to render on (default: $OCRT_DEVICE or 0)." },
+	{ 0, "gpus", "Renders the frame on this many GPUs of the node (image bands dealt round-robin, gathered over xGMI)." },
+	{ 0, "host-resize", "Downloads the float image and resizes it on the host, as the reference does [0|1]." },
 };
 
 void usage(const char *argv0) {
@@ -70,6 +75,8 @@ void usage(const char *argv0) {
 struct CliOptions : RayTracer::Options {
 	std::string in, out;
 	int device = -1;
+	unsigned int gpus = 1;
+	bool host_resize = false;
 
 	CliOptions(int argc, const char **argv) : RayTracer::Options(RayTracer::defaults()) {
 		std::vector<std::string> positional;
@@ -140,6 +147,10 @@ struct CliOptions : RayTracer::Options {
 			nSuperSamples = (unsigned int) std::atoi(value);
 		else if (name == "device")
 			device = std::atoi(value);
+		else if (name == "gpus")
+			gpus = (unsigned int) std::atoi(value);
+		else if (name == "host-resize")
+			host_resize = std::atoi(value) != 0;
 		else if (name == "ambient-occlusion-method") {
 			if (std::strcmp(value, "uniform") == 0)
 				aoMethod = RayTracer::AmbientOcclusionMethod::UNIFORM;
@@ -158,6 +169,62 @@ struct CliOptions : RayTracer::Options {
 	}
 };
 
+void download_floats(HipHost &host, float *image);
+void download_floats(HipHostGroup &host, float *image);
+
+// The frame itself, for one device (HipHost) or several (HipHostGroup): the phases of reference src/render.cc:84-128
+// under their own names -- scripts that read the reference's output keep working: "Loading OpenCL kernel" is the
+// face sort + scene upload there as well (:86-105), whatever its name says.
+template <class Host>
+void render_frame(Host &host, const CliOptions &options, const RayTracer &rt, Mesh &mesh, BVH &bvh,
+                  std::vector<unsigned char> &image) {
+	std::size_t total_time = 0;
+	total_time += Info::measure("Loading OpenCL kernel", [&] {
+		std::vector<uint32_t> sorted_faces = sort_faces_by_leaf_order(mesh, bvh);
+		mesh.faces.clear();
+		bvh.triangles.clear();
+		host.upload(sorted_faces, bvh.nodes, bvh.aabbs, mesh.vertices, mesh.vnormals);
+		return true;
+	}, true);
+	std::cout << std::endl
+	          << Color::BLUE << "<- " << Info::Palette::SECTION << "Rendering section" << Color::BLUE << " ->" << std::endl;
+	total_time += Info::measure("Rendering image", [&] { return host(); });
+	std::cout << std::endl;
+	if (options.host_resize) {
+		// the reference's flow: float image to the host (:114-117), box filter there (:120-123)
+		std::vector<float> tmp((size_t) rt.totalWidth * rt.totalHeight);
+		Info::measure("Loading memory", [&] {
+			download_floats(host, tmp.data());
+			return true;
+		});
+		total_time += Info::measure("Resizing image on host", [&] {
+			rt.resize(tmp.data(), image.data());
+			return true;
+		});
+	} else {
+		total_time += Info::measure("Resizing image on device", [&] {
+			host.downloadResized(image.data());  // (includes "Loading memory": width x height bytes)
+			return true;
+		});
+	}
+	const ocrt::RenderStats stats = host.lastStats();
+	const double rays = (double) stats.primary_rays + (double) stats.ao_rays;
+	std::cout << Info::Palette::NORMAL << "Rays: " << Info::Palette::HIGHLIGHT << stats.primary_rays
+	          << Info::Palette::NORMAL << " primary + " << Info::Palette::HIGHLIGHT << stats.ao_rays
+	          << Info::Palette::NORMAL << " ambient occlusion; kernel " << Info::Palette::HIGHLIGHT
+	          << host.lastKernelMs() << " ms" << Info::Palette::NORMAL << " = " << Info::Palette::HIGHLIGHT
+	          << (host.lastKernelMs() > 0 ? rays / (host.lastKernelMs() * 1e3) : 0.0) << " Mrays/s" << Color::RESET
+	          << std::endl;
+	std::cout << Info::Palette::NORMAL << "Total time (without loading memory and building the BVH): "
+	          << Info::formatTime(total_time) << std::endl;
+}
+
+void download_floats(HipHost &host, float *image) { host.download(image); }
+void download_floats(HipHostGroup &, float *) {
+	std::cerr << Info::Palette::WARNING << "--host-resize needs a single device" << Color::RESET << std::endl;
+	std::exit(EXIT_FAILURE);
+}
+
 }  // namespace
 
 int main(int argc, const char **argv) {
@@ -172,6 +239,23 @@ int main(int argc, const char **argv) {
 	          << Color::BLUE << "- " << Info::Palette::NORMAL << "Triangles: " << Info::Palette::HIGHLIGHT
 	          << (mesh.faces.size() / 3) << Color::RESET << std::endl;
 	RayTracer rt(options);
+	if (options.enableAO && options.aoMethod == RayTracer::AmbientOcclusionMethod::UNIFORM) {
+		// the reference's notice and its own ray estimate (:63-74; it prints 25 for the default three rings, the
+		// kernel casts 28: the inner loop there runs to ray_count inclusive, src/intersect_kernel.cl:242)
+		unsigned int rays = 0;
+		const float degrees = (float) (M_PI / 180);
+		for (unsigned int ring = 0; ring < options.aoNumSamples; ++ring) {
+			const float step = (options.aoAlphaMax * degrees) / options.aoNumSamples;
+			const float elevation = (step * ring) + (options.aoAlphaMin * degrees);
+			rays += (unsigned int) (2.0f * M_PI * std::cos(elevation) / step);
+		}
+		std::cout << Info::Palette::WARNING
+		          << "IMPORTANT INFO: You've enabled 'Uniform AO hemispheres'. You have entered a circle count of "
+		          << options.aoNumSamples << ". This will result in " << rays
+		          << " rays. Note that the Uniform AO Hemisphere will generate much better pictures without noise with less "
+		             "rays and time than you would need using randomized hemispheres."
+		          << Color::RESET << std::endl;
+	}
 	BVH bvh(options.bvhMethod);
 	Info::measure("Building BVH", [&] {
 		bvh.buildBVH(mesh);
@@ -180,34 +264,14 @@ int main(int argc, const char **argv) {
 	std::cout << std::endl
 	          << Color::BLUE << "<- " << Info::Palette::SECTION << "Device section" << Color::BLUE << " ->" << std::endl;
 	HipHost::printInfo();
-	std::size_t total_time = 0;
-	HipHost host(rt, options.device);
-	total_time += Info::measure("Loading HIP scene", [&] {
-		std::vector<uint32_t> sorted_faces = sort_faces_by_leaf_order(mesh, bvh);
-		mesh.faces.clear();
-		bvh.triangles.clear();
-		host.upload(sorted_faces, bvh.nodes, bvh.aabbs, mesh.vertices, mesh.vnormals);
-		return true;
-	}, true);
-	std::cout << std::endl
-	          << Color::BLUE << "<- " << Info::Palette::SECTION << "Rendering section" << Color::BLUE << " ->" << std::endl;
-	total_time += Info::measure("Rendering image", [&] { return host(); });
 	std::vector<unsigned char> image((size_t) options.width * options.height);
-	std::cout << std::endl;
-	total_time += Info::measure("Resizing image on device and loading memory", [&] {
-		host.downloadResized(image.data());
-		return true;
-	});
-	const ocrt::RenderStats stats = host.lastStats();
-	const double rays = (double) stats.primary_rays + (double) stats.ao_rays;
-	std::cout << Info::Palette::NORMAL << "Rays: " << Info::Palette::HIGHLIGHT << stats.primary_rays
-	          << Info::Palette::NORMAL << " primary + " << Info::Palette::HIGHLIGHT << stats.ao_rays
-	          << Info::Palette::NORMAL << " ambient occlusion; kernel " << Info::Palette::HIGHLIGHT
-	          << host.lastKernelMs() << " ms" << Info::Palette::NORMAL << " = " << Info::Palette::HIGHLIGHT
-	          << (host.lastKernelMs() > 0 ? rays / (host.lastKernelMs() * 1e3) : 0.0) << " Mrays/s" << Color::RESET
-	          << std::endl;
-	std::cout << Info::Palette::NORMAL << "Total time (without building the BVH): " << Info::formatTime(total_time)
-	          << std::endl;
+	if (options.gpus > 1) {
+		HipHostGroup host(rt, options.gpus, options.device);
+		render_frame(host, options, rt, mesh, bvh, image);
+	} else {
+		HipHost host(rt, options.device);
+		render_frame(host, options, rt, mesh, bvh, image);
+	}
 	std::FILE *out = std::fopen(options.out.c_str(), "wb");
 	if (!out) {
 		std::cerr << Info::Palette::WARNING << "Error opening output file!" << Color::RESET << std::endl;

@@ -80,7 +80,10 @@ PackedScene pack_scene(const std::vector<uint32_t> &faces, const std::vector<uin
 	// The walk may use any tree over the same leaves (walk_tree.h): take a binned-SAH one when it is cheaper
 	// than what was uploaded.  (Damaged arrays keep their tree: the exact form of the walk follows it.)
 	if (out.regular && out.nested && !std::getenv("OCRT_KEEP_TREE")) {  // (debug knob)
-		std::vector<NodeRec> rebuilt = contract_walk_tree(rebuild_walk_tree(out.nodes), 0.5);
+		double threshold = 0.5;
+		if (const char *env = std::getenv("OCRT_CONTRACT"))  // debug knob: area ratio above which an inner node is dropped
+			threshold = std::atof(env);
+		std::vector<NodeRec> rebuilt = contract_walk_tree(rebuild_walk_tree(out.nodes), threshold);
 		if (!rebuilt.empty() && tree_cost(rebuilt) < tree_cost(out.nodes)) {
 			// The flags above were computed on the uploaded array; the kernels walk this one, so it has to
 			// earn them again: an inner node may have more than two children here (contraction), what the

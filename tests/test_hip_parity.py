@@ -216,24 +216,43 @@ def test_interior_standin_matches_oracle(rt, oracle):
 
 
 def test_render_cli_writes_the_golden_pgm(rt, golden, tmp_path):
-    """End to end through the `render` binary: same flags as the reference CLI,
-    PGM file byte-identical to the golden one."""
+    """End to end through the `render` binary: same flags as the reference CLI (src/render.cc:19-43), the
+    reference's phase lines and ray notice (:63-128), PGM file byte-identical to the golden one -- on one device,
+    with the reference's own host-side resize, and with the frame split over several ranks (`--gpus`, here mapped
+    onto the one GPU of the box) and gathered."""
     import os
     import subprocess
 
     from conftest import ROOT, mesh_file
 
     exe = os.path.join(ROOT, "opencl_raytracer_amd", "bin", "render")
-    for name, extra in (("bunny_256_s1_a3", []), ("blob_128x96_s4_a3_sah", ["-r", "sah"])):
+    env = dict(os.environ, OCRT_SHARE_DEVICES="1")
+    runs = (("bunny_256_s1_a3", []), ("blob_128x96_s4_a3_sah", ["-r", "sah"]), ("bunny_256_s1_a3", ["--host-resize", "1"]),
+            ("bunny_101x77_s9_a2", ["--gpus", "3"]), ("bunny_600_defaults", ["--gpus=8"]), ("blob_128x96_s4_a3", ["--gpus", "2"]))
+    for name, extra in runs:
         c = golden["renders"][name]
         out = tmp_path / (name + ".pgm")
         cmd = [exe, "-w", str(c["width"]), "-h", str(c["height"]), "-s", str(c["ss"]),
                "--ambient-occlusion-samples=" + str(c["ao"]), "-d", str(c["aod"]), "-f", str(c["focal"])] + extra + \
               [mesh_file(c["mesh"]), str(out)]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        assert r.returncode == 0, r.stderr
-        assert "Rendering image" in r.stdout and "Building BVH" in r.stdout
-        assert hashlib.md5(out.read_bytes()).hexdigest() == c["pgm_md5"]
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        for phase in ("Building BVH", "Loading OpenCL kernel", "Rendering image", "Total time (without loading memory"):
+            assert phase in r.stdout, (phase, extra)
+        if "--host-resize" in extra:
+            assert "Loading memory" in r.stdout and "Resizing image on host" in r.stdout
+        if c["ao"]:
+            assert "IMPORTANT INFO: You've enabled 'Uniform AO hemispheres'" in r.stdout
+            if c["ao"] == 3:
+                assert "This will result in 25 rays." in r.stdout  # the reference's own estimate (the kernel casts 28)
+        if "--gpus" in " ".join(extra):
+            assert "Rank 1 of" in r.stdout
+        assert hashlib.md5(out.read_bytes()).hexdigest() == c["pgm_md5"], (name, extra)
+    # more ranks than GPUs without the rehearsal knob: refused, like any other bad device request
+    env.pop("OCRT_SHARE_DEVICES")
+    if rt.device_count() < 4:
+        r = subprocess.run([exe, "--gpus", "4", mesh_file("blob"), str(tmp_path / "x.pgm")], capture_output=True, text=True, env=env)
+        assert r.returncode != 0 and "more ranks than visible HIP devices" in (r.stdout + r.stderr)
 
 
 @pytest.mark.parametrize("mesh,samples", [("blob", 6), ("bunny", 16)])

@@ -60,6 +60,22 @@ def test_scene_from_arrays_equals_file(rt, scene_for):
     assert np.array_equal(again.nodes, sc.nodes) and np.array_equal(bits(again.aabbs), bits(sc.aabbs))
 
 
+def test_padded_walk_boxes_never_lose_a_pair_the_reference_accepts(rt, tmp_path):
+    """tests/walk_margin_check.cc: 4 M random and adversarial (ray, box) pairs -- origins on and one ulp off box planes,
+    zero and denormal-small direction components, flat boxes, extents from 1/16 to 2048 -- through the reference's slab
+    test and through the fast walk's fma test on the padded box (scene_pack.cc, padded_bound): the latter must accept
+    whatever the former accepts.  Self-check: without the margin the same run does report misses."""
+    exe = tmp_path / "walk_margin_check"
+    lib_dir = os.path.join(ROOT, "opencl_raytracer_amd", "lib")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-o", str(exe), os.path.join(ROOT, "tests", "walk_margin_check.cc"),
+                    "-L" + lib_dir, "-locrt_hip", "-Wl,-rpath," + lib_dir], check=True)
+    r = subprocess.run([str(exe), "4000000"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert " 0 of them missed" in r.stdout
+    r = subprocess.run([str(exe), "4000000", "1"], capture_output=True, text=True)
+    assert r.returncode == 0, "the unpadded self-check found no miss: the test has no teeth\n" + r.stdout[-500:]
+
+
 def test_loader_rejects_truncated_and_oversized_headers(rt, tmp_path):
     """A header that promises more than the file holds must fail, not reserve memory for it or pad with zeros."""
     huge = tmp_path / "huge.off"
