@@ -112,8 +112,8 @@ struct KernelParams {
 	uint32_t leaf_min;      // ... test triangles once this many leaves are pending (OCRT_LEAF_MIN)
 	uint32_t batch_below;   // AO: a leaf hit by fewer lanes than this has its triangle tests deferred and batched
 	uint32_t cost_shift;    // ordering key of a block of 64 tiles = 1 + (sum of its tiles' cost classes >> cost_shift)
-	uint32_t ao_claim_max;  // most (tile, direction) units one AO claim takes; 0 = a twelfth of a wave's share, 4 .. ao_dirs
-	uint32_t ao_claim_div;  // (set by launch_ao: 12 x the waves per XCD group)
+	uint32_t ao_claim_max;  // most (tile, direction) units one AO claim takes; 0 = a sixth of a wave's share, 4 .. ao_dirs
+	uint32_t ao_claim_div;  // (set by launch_ao: 6 x the waves per XCD group)
 	uint32_t ao_guide;      // an AO claim takes 1/ao_guide of the (tile, direction) units left in its queue; the host
 	                        // sets the factor (1, debug knob OCRT_AO_GUIDE), launch_ao multiplies it by the waves per XCD group
 	uint32_t tiles_x;      // tiles per image row

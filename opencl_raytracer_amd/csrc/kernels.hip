@@ -1555,9 +1555,14 @@ void launch_ao(const SceneBuffers &scene, float *image, void *hits, void *occlud
 	if ((units + AO_WAVES - 1) / AO_WAVES < ao_blocks)
 		ao_blocks = (uint32_t) ((units + AO_WAVES - 1) / AO_WAVES);
 	KernelParams P = params;
+	// Largest claim = 1/CLAIM_SHARE of a wave's share of its group's (tile, direction) units, 4 .. ao_dirs: small enough
+	// for the waves to finish together, large enough to amortise the ~12 us a claim costs (atomic, order entry, hit
+	// records, tangent frames).  Swept on the padded-box kernel (profiles/r02_notes.md): 12 -> 6 is worth 5-9 % at one
+	// sample per pixel (claims of 7-10 directions instead of 5) and nothing at 16+, where the cap of ao_dirs applies.
+	constexpr uint32_t CLAIM_SHARE = 6u;
 	const uint32_t waves_per_group = (ao_blocks * AO_WAVES + XCD_GROUPS - 1u) / XCD_GROUPS;
 	P.ao_guide = P.ao_guide * (waves_per_group ? waves_per_group : 1u);
-	P.ao_claim_div = 12u * (waves_per_group ? waves_per_group : 1u);
+	P.ao_claim_div = CLAIM_SHARE * (waves_per_group ? waves_per_group : 1u);
 	auto launch = [&](auto kernel) {
 		// (the events bracket the ao_kernel launch alone: its duration is the one the roofline is quoted for)
 		if (event_before_ao)
