@@ -1,1 +1,2 @@
-for i in 1 2; do tools/ab_run.sh 12; done
+python3 tools/pcie_inclusive.py 2>&1 | tail -3
+python3 tools/partition_probe.py 2>&1 | tail -6
