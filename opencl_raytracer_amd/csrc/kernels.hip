@@ -163,6 +163,14 @@ __device__ __forceinline__ uint32_t cold_lane(uint32_t lane) {
 	return lane;
 }
 
+// The lane number recomputed (two instructions) where it is needed, opaque to the optimiser (which would otherwise
+// compute it once and hold it in a register across the walks).
+__device__ __forceinline__ uint32_t fresh_lane() {
+	uint32_t lane;
+	asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+	return lane;
+}
+
 // Position of this lane among the set bits of `mask` below it.
 __device__ __forceinline__ uint32_t rank_in(unsigned long long mask) {
 	return __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
@@ -662,12 +670,20 @@ constexpr uint32_t INF_BITS = 0x7F800000u;
 template <bool EXACT>
 __device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ nodes_ptr, const float4 *__restrict__ walk_ptr,
                                                     const float4 *__restrict__ tris_ptr, __amdgpu_buffer_rsrc_t tris_rsrc,
-                                                    uint32_t count, const Ray &ray, float max_distance, float below, bool alive,
-                                                    uint32_t lane, unsigned int *occluded, LeafBatch &batch, uint32_t batch_below,
-                                                    unsigned long long *prof) {
+                                                    uint32_t count, const Ray &ray_in, const float (&frame)[12][64], uint32_t h,
+                                                    float max_distance, float below, bool alive, unsigned int *occluded,
+                                                    LeafBatch &batch, uint32_t batch_below, unsigned long long *prof) {
 	(void) prof;  // (-DOCRT_STAMPS builds: time in the node loop / in batches, loop entries, batches, leaf stops)
 	// the live lanes as a scalar mask: the node steps then need no per-lane bookkeeping at all
 	unsigned long long alive_mask = wave_ballot(alive);
+	// Registers held across the walk are scarce (64 per lane at 8 waves per SIMD, 7 of them the loop's own): the
+	// ray's origin stays in the tile's LDS table (frame[0..2][h], where setup_ray took it from) and is read again
+	// where a triangle or a leaf's own box is tested, and the lane number is recomputed where it is needed.
+	auto with_origin = [&]() {
+		Ray r = ray_in;
+		r.ox = frame[0][h]; r.oy = frame[1][h]; r.oz = frame[2][h];
+		return r;
+	};
 	if (!EXACT) {
 		// The triangle tests are not run where the walk meets them -- a leaf is hit by 15 of the 64
 		// rays on average -- but collected as (ray, leaf) pairs and run 64 at a time, each lane taking
@@ -683,8 +699,10 @@ __device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ n
 			const unsigned long long tb0 = __builtin_amdgcn_s_memrealtime();
 #endif
 			wave_lds_sync();
+			const uint32_t lane = fresh_lane();
 			const uint32_t pair = batch.entry[lane < n ? lane : 0u];
 			const int owner = (int) (pair >> 26);
+			const Ray ray = with_origin();
 			Ray theirs;
 			theirs.ox = __shfl(ray.ox, owner); theirs.oy = __shfl(ray.oy, owner); theirs.oz = __shfl(ray.oz, owner);
 			theirs.dx = __shfl(ray.dx, owner); theirs.dy = __shfl(ray.dy, owner); theirs.dz = __shfl(ray.dz, owner);
@@ -722,9 +740,10 @@ __device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ n
 		uint32_t at = 0u;  // byte offset of the node (count < 2^27, checked at upload)
 		const uint32_t end = count * 32u;
 		const uint32_t list_lds_address = (uint32_t) (uintptr_t) &batch.entry[0];  // (low half of the flat address)
-		const SignMasks sign = sign_masks(ray);
+		const SignMasks sign = sign_masks(ray_in);
 		const uint32_t variant = walk_variant(sign, alive_mask);  // (lanes only leave: a coherent packet stays coherent)
-		const WalkRay walk_ray = make_walk_ray(ray);
+		const WalkRay walk_ray = make_walk_ray(with_origin());
+		const uint32_t lane_tag = fresh_lane() << 26;
 		while (alive_mask != 0ull && at < end) {
 			uint32_t leaf = 0u;
 			unsigned long long hit_mask = 0ull;
@@ -732,7 +751,7 @@ __device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ n
 			const unsigned long long tw0 = __builtin_amdgcn_s_memrealtime();
 #endif
 			const uint32_t status = walk_collect(variant, walk_ptr, at, walk_ray, sign, below, alive_mask, hit_mask, leaf, waiting,
-			                                     leaf_stops, list_lds_address, lane << 26, batch_below);
+			                                     leaf_stops, list_lds_address, lane_tag, batch_below);
 #ifdef OCRT_STAMPS
 			prof[0] += __builtin_amdgcn_s_memrealtime() - tw0;
 			prof[2] += 1;
@@ -743,7 +762,8 @@ __device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ n
 				// enough of the packet is at this leaf: test it here, box and triangle out of SGPRs
 				const float4 *rec = tris_ptr + LEAF_F4 * leaf;
 				const float4 lo = rec[0], hi = rec[1], q0 = rec[2], q1 = rec[3], q2 = rec[4], q3 = rec[5];
-				if (((hit_mask >> lane) & 1ull) && exact_leaf_gate(lo, hi, ray, below)) {
+				const Ray ray = with_origin();
+				if (((hit_mask >> fresh_lane()) & 1ull) && exact_leaf_gate(lo, hi, ray, below)) {
 					const TriResult tr = tri_eval<false>(q0, q1, q2, q3, ray);
 					if (tr.accepted) {
 						atomicAdd(occluded, 1u);
@@ -754,8 +774,9 @@ __device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ n
 			} else {
 				run_batch(64u);
 				waiting -= 64u;
-				if (lane < waiting)  // the pairs beyond the batch move to the front
-					batch.entry[lane] = batch.entry[64u + lane];
+				const uint32_t me = fresh_lane();
+				if (me < waiting)  // the pairs beyond the batch move to the front
+					batch.entry[me] = batch.entry[64u + me];
 			}
 			at += 32u;
 		}
@@ -766,6 +787,7 @@ __device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ n
 #endif
 		return;
 	}
+	const Ray ray = ray_in;
 	uint32_t mine = 0u;
 	uint32_t at = 0u;
 	while (at < count) {
@@ -1192,8 +1214,9 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
     uint32_t *__restrict__ occluded_of, const uint32_t *__restrict__ order, FrameCounters *__restrict__ counters,
     KernelParams P) {
 	__shared__ TileShared shared_tiles[AO_WAVES];
-	const uint32_t lane = threadIdx.x & 63u;
-	TileShared &sh = shared_tiles[threadIdx.x >> 6];
+	__shared__ unsigned int wg_claim[2];  // the workgroup's current claim: first unit, units per wave
+	const uint32_t wave = (uint32_t) __builtin_amdgcn_readfirstlane((int) threadIdx.x) >> 6;  // (scalar)
+	TileShared &sh = shared_tiles[wave];
 	const SceneViews scene = make_views(nodes_ptr, tris_ptr, P);
 	const uint32_t count = P.node_count;
 	const uint32_t strips = (P.tiles_x + 1u) >> 1;
@@ -1224,23 +1247,34 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 			claim_max = claim_max < 4u ? 4u : claim_max > P.ao_dirs ? P.ao_dirs : claim_max;
 		}
 		for (;;) {
-			// look before claiming: most visits to a foreign group find its queue drained,
-			// and a plain load does not queue up behind the other waves' atomics
-			OCRT_STAMP(t_claim);
-			const uint32_t seen = __hip_atomic_load(&counters->queue[group].head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			if (seen >= units)
-				break;
-			// Guided self-scheduling: a claim is 1/ao_guide of what is left (ao_guide = the waves
-			// of a group) -- whole tiles while there is plenty, so the per-tile set-up is
-			// paid once, single directions at the end, so the frame does not wait for a long last job.
-			uint32_t want = (units - seen) / P.ao_guide;
-			want = want < 1u ? 1u : want > claim_max ? claim_max : want;
-			uint32_t claimed = 0u;
-			if (lane == 0u)
-				claimed = atomicAdd(&counters->queue[group].head, want);
-			claimed = (uint32_t) __builtin_amdgcn_readfirstlane((int) claimed);  // (lane 0 is always active here)
+			// The WORKGROUP claims (thread 0: a plain load first -- most visits to a foreign group find its queue
+			// drained, and a load does not queue up behind the other workgroups' atomics --, then one returning
+			// atomic), and its four waves take consecutive quarters of the claim: they then work on the same tile,
+			// or on neighbouring ones, at the same time, and share its nodes in the CU's scalar cache (63 % of the
+			// scalar loads of the per-wave claims missed it, profiles/r02_notes.md) and its hit records in L2.
+			// Guided self-scheduling: a wave's share is 1/ao_guide of what is left (ao_guide = the waves of a
+			// group), at most claim_max -- several directions of a tile while there is plenty, so the per-tile
+			// set-up is amortised; single directions at the end, so the frame does not wait for a long last job.
+			if (wave == 0u && fresh_lane() == 0u) {
+				const uint32_t seen = __hip_atomic_load(&counters->queue[group].head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				uint32_t per_wave = 0u, first = units;
+				if (seen < units) {
+					per_wave = (units - seen) / P.ao_guide;
+					per_wave = per_wave < 1u ? 1u : per_wave > claim_max ? claim_max : per_wave;
+					first = atomicAdd(&counters->queue[group].head, per_wave * AO_WAVES);
+				}
+				wg_claim[0] = first;
+				wg_claim[1] = per_wave;
+			}
+			__syncthreads();
+			const uint32_t wg_claimed = (uint32_t) __builtin_amdgcn_readfirstlane((int) wg_claim[0]);
+			const uint32_t want = (uint32_t) __builtin_amdgcn_readfirstlane((int) wg_claim[1]);
+			__syncthreads();  // (everybody has read the claim before thread 0 writes the next one)
+			if (wg_claimed >= units)
+				break;  // (the same for all four waves)
+			const uint32_t claimed = wg_claimed + wave * want;
 			if (claimed >= units)
-				break;
+				continue;  // nothing left for this wave; it meets the others again at the next claim
 			const uint32_t claim_end = claimed + want < units ? claimed + want : units;
 			OCRT_STAMP(t_claimed);
 			OCRT_STAMP_ADD(0, t_claimed - t_claim);
@@ -1260,8 +1294,10 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 				const uint32_t hit_count = (entry >> 26) + 1u;
 
 				// ---- the tile's tangent frames -> this wave's LDS slice (reference :215-236) ----
+				{
+				const uint32_t lane = fresh_lane();  // (recomputed where it is needed: no register held across the walks)
 				if (lane < hit_count) {
-					const size_t slot = (size_t) tile * 64u + cold_lane(lane);
+					const size_t slot = (size_t) tile * 64u + lane;
 					const float4 q0 = ((const float4 *) hits)[2 * slot];
 					const float4 q1 = ((const float4 *) hits)[2 * slot + 1];
 					float nx = q1.x, ny = q1.y, nz = q1.z;
@@ -1294,6 +1330,7 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 				sh.occluded[lane] = 0u;
 				if (lane < 2u)
 					sh.batch.occluded_bits[lane] = 0u;
+				}
 				wave_lds_sync();
 				OCRT_STAMP(t_frames);
 				OCRT_STAMP_ADD(1, t_frames - t_job);
@@ -1411,6 +1448,7 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 					// leaves at its first accepted triangle
 					const bool scene_fast = P.fast_walk && P.ao_regular;
 					for (uint32_t base = 0u; base < total; base += 64u) {
+						const uint32_t lane = fresh_lane();
 						bool alive = base + lane < total;
 						// a full tile's packet is one table direction: the entry comes by a scalar load
 						const bool whole = hit_count == 64u;
@@ -1421,12 +1459,12 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 							setup_ray(base + lane, whole, shared_dir);
 						const bool exact = !scene_fast || wave_ballot(alive && !ray_is_selectable(ray, P.origin_limit)) != 0ull;
 						if (exact)
-							shared_walk_any_hit<true>(nodes_ptr, walk_ptr, tris_ptr, scene.tris, count, ray,
-							                          P.ao_max_distance, P.ao_below, alive, lane, &sh.occluded[h], sh.batch,
+							shared_walk_any_hit<true>(nodes_ptr, walk_ptr, tris_ptr, scene.tris, count, ray, sh.frame, h,
+							                          P.ao_max_distance, P.ao_below, alive, &sh.occluded[h], sh.batch,
 							                          P.batch_below, walk_prof);
 						else
-							shared_walk_any_hit<false>(nodes_ptr, walk_ptr, tris_ptr, scene.tris, count, ray,
-							                           P.ao_max_distance, P.ao_below, alive, lane, &sh.occluded[h], sh.batch,
+							shared_walk_any_hit<false>(nodes_ptr, walk_ptr, tris_ptr, scene.tris, count, ray, sh.frame, h,
+							                           P.ao_max_distance, P.ao_below, alive, &sh.occluded[h], sh.batch,
 							                           P.batch_below, walk_prof);
 					}
 				}
@@ -1437,10 +1475,13 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 				OCRT_STAMP_ADD(5, (total + 63u) / 64u);
 
 				// ---- this job's share of the occlusion counts ----
-				if (lane < hit_count) {
-					const uint32_t occluded = sh.occluded[lane];
-					if (occluded)
-						atomicAdd(&occluded_of[(size_t) tile * 64u + cold_lane(lane)], occluded);
+				{
+					const uint32_t lane = fresh_lane();
+					if (lane < hit_count) {
+						const uint32_t occluded = sh.occluded[lane];
+						if (occluded)
+							atomicAdd(&occluded_of[(size_t) tile * 64u + lane], occluded);
+					}
 				}
 				wave_lds_sync();
 				OCRT_STAMP(t_flushed);

@@ -245,6 +245,9 @@ def test_render_cli_writes_the_golden_pgm(rt, golden, tmp_path):
             assert "IMPORTANT INFO: You've enabled 'Uniform AO hemispheres'" in r.stdout
             if c["ao"] == 3:
                 assert "This will result in 25 rays." in r.stdout  # the reference's own estimate (the kernel casts 28)
+        # the device table of OpenCLHost::printInfo (reference src/opencl_host.cc:76-119), HIP edition
+        for line in ("Hardware information", "Max compute units", "Wavefront size", "Using Device" if "--gpus" not in " ".join(extra) else "Rank 0 of"):
+            assert line in r.stdout, line
         if "--gpus" in " ".join(extra):
             assert "Rank 1 of" in r.stdout
         assert hashlib.md5(out.read_bytes()).hexdigest() == c["pgm_md5"], (name, extra)
