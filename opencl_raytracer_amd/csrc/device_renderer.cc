@@ -2,6 +2,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <sstream>
@@ -340,6 +341,19 @@ RenderStats DeviceRenderer::stats() {
 	             c.stamp[42] * 1e-5, c.stamp[44], c.stamp[43] * 1e-5, c.stamp[45], c.stamp[46]);
 	std::fprintf(stderr, "   batched pairs %llu, of which the leaf's own box passes %llu\n", c.stamp[47], c.stamp[48]);
 #endif
+	if (std::getenv("OCRT_PRINT_COST")) {  // debug knob: the tiles' AO cost classes (leaves the primary packet stopped at)
+		std::vector<uint32_t> th(tile_count);
+		OCRT_HIP(hipMemcpy(th.data(), d_tile_hits, tile_count * sizeof(uint32_t), hipMemcpyDeviceToHost));
+		unsigned long long tiles = 0, cost = 0, hits = 0;
+		for (uint32_t v : th)
+			if (v) {
+				++tiles;
+				cost += v >> 8;
+				hits += v & 0xFFu;
+			}
+		std::fprintf(stderr, "hit tiles %llu, mean cost class %.2f, mean hits per tile %.1f\n", tiles, tiles ? (double) cost / tiles : 0.0,
+		             tiles ? (double) hits / tiles : 0.0);
+	}
 	// Primary rays = sub-pixels of this rank's bands that lie inside the image.
 	const uint32_t tile_rows = (kp.height + TILE_H - 1) / TILE_H;
 	unsigned long long rows = 0;

@@ -62,7 +62,8 @@ static_assert(sizeof(HitRec) == 32, "HitRec is two float4");
 struct alignas(128) GroupQueue {
 	uint32_t head;        // next unclaimed entry of the group's ordered tile list
 	uint32_t work_tiles;  // non-empty tiles of the group (written by the ordering step)
-	uint32_t pad[30];
+	uint32_t cost_sum;    // sum of their AO cost classes (ditto)
+	uint32_t pad[29];
 };
 struct FrameCounters {
 	GroupQueue queue[XCD_GROUPS];
@@ -112,8 +113,8 @@ struct KernelParams {
 	uint32_t leaf_min;      // ... test triangles once this many leaves are pending (OCRT_LEAF_MIN)
 	uint32_t batch_below;   // AO: a leaf hit by fewer lanes than this has its triangle tests deferred and batched
 	uint32_t cost_shift;    // ordering key of a block of 64 tiles = 1 + (sum of its tiles' cost classes >> cost_shift)
-	uint32_t ao_claim_max;  // most (tile, direction) units one AO claim takes; 0 = a sixth of a wave's share, 4 .. ao_dirs
-	uint32_t ao_claim_div;  // (set by launch_ao: 6 x the waves per XCD group)
+	uint32_t ao_claim_max;  // most (tile, direction) units one wave's share of a claim holds; 0 = ao_kernel's rule (a quarter of a tile, or a whole tile)
+	uint32_t ao_claim_div;  // (set by launch_ao: the waves per XCD group)
 	uint32_t ao_guide;      // an AO claim takes 1/ao_guide of the (tile, direction) units left in its queue; the host
 	                        // sets the factor (1, debug knob OCRT_AO_GUIDE), launch_ao multiplies it by the waves per XCD group
 	uint32_t tiles_x;      // tiles per image row

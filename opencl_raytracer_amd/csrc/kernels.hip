@@ -1086,6 +1086,7 @@ __global__ __launch_bounds__(1024) void order_kernel(const uint32_t *__restrict_
                                                      uint32_t *__restrict__ order, FrameCounters *__restrict__ counters,
                                                      KernelParams P) {
 	__shared__ unsigned int bucket[65];  // non-empty tiles per key, then the keys' write cursors
+	__shared__ unsigned int cost_total;  // sum of the group's tiles' cost classes
 	const uint32_t group = blockIdx.x;
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	const uint32_t strips = (P.tiles_x + 1u) >> 1;
@@ -1097,6 +1098,8 @@ __global__ __launch_bounds__(1024) void order_kernel(const uint32_t *__restrict_
 		segment += ((strips + XCD_GROUPS - 1u - g) >> 3) * 2u * P.local_tile_rows;
 	if (threadIdx.x < 65u)
 		bucket[threadIdx.x] = 0u;
+	if (threadIdx.x == 0u)
+		cost_total = 0u;
 	__syncthreads();
 	// tile e of the group: strip (e / (2 * rows)), then row-major 2-wide; returns its cost class (0: no work)
 	auto class_of = [&](uint32_t e, uint32_t &tile) -> uint32_t {
@@ -1113,21 +1116,23 @@ __global__ __launch_bounds__(1024) void order_kernel(const uint32_t *__restrict_
 	};
 	// One wave per block of 64 spatially consecutive tiles (2 wide, 32 high).  key: the block's cost, 1..64.
 	const uint32_t n_blocks = (tiles_here + 63u) >> 6;
-	auto block_key = [&](uint32_t block, uint32_t &tile, uint32_t &cls, unsigned long long &work_mask) -> uint32_t {
+	auto block_key = [&](uint32_t block, uint32_t &tile, uint32_t &cls, unsigned long long &work_mask, uint32_t &cost) -> uint32_t {
 		cls = class_of(block * 64u + lane, tile);
 		work_mask = wave_ballot(cls != 0u);
-		uint32_t cost = cls;
+		cost = cls;
 		for (int offset = 32; offset >= 1; offset >>= 1)
 			cost += (uint32_t) __shfl_xor((int) cost, offset);
 		const uint32_t key = P.debug_no_sort ? 1u : 1u + (cost >> P.cost_shift);
 		return key > 64u ? 64u : key;
 	};
 	for (uint32_t block = wave; block < n_blocks; block += 16u) {
-		uint32_t tile = 0u, cls;
+		uint32_t tile = 0u, cls, cost;
 		unsigned long long work_mask;
-		const uint32_t key = block_key(block, tile, cls, work_mask);
-		if (lane == 0u && work_mask != 0ull)
+		const uint32_t key = block_key(block, tile, cls, work_mask, cost);
+		if (lane == 0u && work_mask != 0ull) {
 			atomicAdd(&bucket[key], (uint32_t) __popcll(work_mask));
+			atomicAdd(&cost_total, cost);
+		}
 	}
 	__syncthreads();
 	if (threadIdx.x == 0) {
@@ -1139,13 +1144,14 @@ __global__ __launch_bounds__(1024) void order_kernel(const uint32_t *__restrict_
 			running += n;
 		}
 		counters->queue[group].work_tiles = running;
+		counters->queue[group].cost_sum = cost_total;
 		counters->queue[group].head = 0u;
 	}
 	__syncthreads();
 	for (uint32_t block = wave; block < n_blocks; block += 16u) {
-		uint32_t tile = 0u, cls;
+		uint32_t tile = 0u, cls, cost;
 		unsigned long long work_mask;
-		const uint32_t key = block_key(block, tile, cls, work_mask);
+		const uint32_t key = block_key(block, tile, cls, work_mask, cost);
 		if (work_mask == 0ull)
 			continue;
 		uint32_t base = 0u;
@@ -1240,13 +1246,20 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 			segment += ((strips + XCD_GROUPS - 1u - g) >> 3) * 2u * P.local_tile_rows;
 		// the group's work in units of (tile, table direction), tile-major
 		const uint32_t units = counters->queue[group].work_tiles * P.ao_dirs;
-		// largest claim: small enough for about a dozen claims per wave, so that the waves finish together
+		// A wave's largest claim.  A quarter of a tile's directions, so that the workgroup's four waves take ONE tile
+		// together (the best locality, and the finest balance); whole tiles per wave where packets are cheap and
+		// plentiful -- a tile's mean cost class (the leaves its primary packet stopped at) below 8 and 512 or more
+		// units per wave: 16+ samples per pixel -- because there the ~12 us of set-up per claim (hit records,
+		// tangent frames) weigh more than the locality.  Swept per workload: profiles/r02_notes.md.
 		uint32_t claim_max = P.ao_claim_max;
 		if (claim_max == 0u) {
-			claim_max = units / P.ao_claim_div;
-			claim_max = claim_max < 4u ? 4u : claim_max > P.ao_dirs ? P.ao_dirs : claim_max;
+			const uint32_t tiles = counters->queue[group].work_tiles, cost = counters->queue[group].cost_sum;
+			const bool cheap_and_plenty = cost < 8u * tiles && units >= 512u * P.ao_claim_div;
+			claim_max = cheap_and_plenty ? P.ao_dirs : (P.ao_dirs + AO_WAVES - 1u) / AO_WAVES;
+			claim_max = claim_max < 1u ? 1u : claim_max;
 		}
 		for (;;) {
+			OCRT_STAMP(t_claim);
 			// The WORKGROUP claims (thread 0: a plain load first -- most visits to a foreign group find its queue
 			// drained, and a load does not queue up behind the other workgroups' atomics --, then one returning
 			// atomic), and its four waves take consecutive quarters of the claim: they then work on the same tile,
@@ -1596,14 +1609,9 @@ void launch_ao(const SceneBuffers &scene, float *image, void *hits, void *occlud
 	if ((units + AO_WAVES - 1) / AO_WAVES < ao_blocks)
 		ao_blocks = (uint32_t) ((units + AO_WAVES - 1) / AO_WAVES);
 	KernelParams P = params;
-	// Largest claim = 1/CLAIM_SHARE of a wave's share of its group's (tile, direction) units, 4 .. ao_dirs: small enough
-	// for the waves to finish together, large enough to amortise the ~12 us a claim costs (atomic, order entry, hit
-	// records, tangent frames).  Swept on the padded-box kernel (profiles/r02_notes.md): 12 -> 6 is worth 5-9 % at one
-	// sample per pixel (claims of 7-10 directions instead of 5) and nothing at 16+, where the cap of ao_dirs applies.
-	constexpr uint32_t CLAIM_SHARE = 6u;
 	const uint32_t waves_per_group = (ao_blocks * AO_WAVES + XCD_GROUPS - 1u) / XCD_GROUPS;
 	P.ao_guide = P.ao_guide * (waves_per_group ? waves_per_group : 1u);
-	P.ao_claim_div = CLAIM_SHARE * (waves_per_group ? waves_per_group : 1u);
+	P.ao_claim_div = waves_per_group ? waves_per_group : 1u;  // (the waves of a group, for ao_kernel's claim rule)
 	auto launch = [&](auto kernel) {
 		// (the events bracket the ao_kernel launch alone: its duration is the one the roofline is quoted for)
 		if (event_before_ao)
