@@ -131,6 +131,10 @@ struct SceneBuffers {  // device pointers of one uploaded scene
 	const void *ao_table;    // float4[ao_dirs] (UNIFORM)
 };
 
+// Waves per workgroup of the ambient-occlusion pass: they take consecutive parts of a claim (kernels.hip), which is
+// why the host deals the UNIFORM direction table to that many groups (device_renderer.cc).
+constexpr uint32_t AO_WORKGROUP_WAVES = 4;
+
 constexpr uint32_t TILE_W = 8;
 constexpr uint32_t TILE_H = 8;
 

@@ -1190,7 +1190,7 @@ __device__ __forceinline__ float rng_float(Rng &v) { return 2.32830643653869629E
 // ---------------------------------------------------------------------------
 // Pass 2: ambient occlusion.  Persistent, independent waves; one tile at a time.
 // ---------------------------------------------------------------------------
-constexpr uint32_t AO_WAVES = 4;
+constexpr uint32_t AO_WAVES = AO_WORKGROUP_WAVES;
 constexpr uint32_t AO_BLOCKS_PER_CU = 8;
 
 // LDS slice of one wave: the tile's hit table, structure of arrays and lane-major
@@ -1503,7 +1503,7 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 		}
 	}
 #ifdef OCRT_STAMPS
-	if (lane == 0u) {
+	if (fresh_lane() == 0u) {
 		const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
 		for (int k = 0; k < 6; ++k)
 			atomicAdd(&counters->stamp[k], stamp_acc[k]);           // claim, frames, walks, flush (10 ns ticks); jobs, packets

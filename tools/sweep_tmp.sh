@@ -1,3 +1,3 @@
-for W in bunny_1080p_ao bunny_600_defaults interior_1080p_ao interior_4k_ao bunny_1080p_s4 bunny_1080p_s16 bunny_1080p_s64; do
-  echo -n "$W: "; OCRT_PRINT_COST=1 python3 tools/prof_run.py --workload $W --frames 1 2>&1 | grep "mean cost"
+for W in bunny_1080p_ao bunny_600_defaults bunny_1080p_s16 interior_1080p_ao interior_4k_ao; do
+  for L in lib lib_w2 lib_w8; do echo -n "$L: "; OCRT_LIB_DIR=$L timeout -k 5 100 python3 tools/prof_run.py --workload $W --frames 12 | tail -1; done
 done
