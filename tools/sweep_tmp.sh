@@ -1,3 +1,6 @@
-for W in bunny_1080p_ao bunny_600_defaults bunny_1080p_s16 interior_1080p_ao interior_4k_ao; do
-  for L in lib lib_w2 lib_w8; do echo -n "$L: "; OCRT_LIB_DIR=$L timeout -k 5 100 python3 tools/prof_run.py --workload $W --frames 12 | tail -1; done
-done
+W="bunny_1080p_s16 bunny_1080p_s64 interior_4k_ao bunny_1080p_s4"
+run() { for w in $W; do echo -n "$1: "; env $2 python3 tools/prof_run.py --workload $w --frames 8 | tail -1; done; }
+run rule "X=1"
+run claim7 "OCRT_AO_CLAIM_MAX=7"
+run claim14 "OCRT_AO_CLAIM_MAX=14"
+run claim28 "OCRT_AO_CLAIM_MAX=28"
