@@ -17,8 +17,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import opencl_raytracer_amd as rt  # noqa: E402
 import orc  # noqa: E402
 
-KNOBS = [{}, {"OCRT_BATCH_BELOW": "0"}, {"OCRT_BATCH_BELOW": "65"}, {"OCRT_AO_CLAIM_MAX": "1"}, {"OCRT_KEEP_TREE": "1"},
-         {"OCRT_FORCE_EXACT_WALK": "1"}, {"OCRT_AO_BLOCKS": "2"}, {"OCRT_NO_SHARED_WALK": "1"}]
+KNOBS = [{}, {}, {}, {"OCRT_BATCH_BELOW": "0"}, {"OCRT_BATCH_BELOW": "65"}, {"OCRT_AO_CLAIM_MAX": "1"}, {"OCRT_AO_CLAIM_MAX": "28"},
+         {"OCRT_KEEP_TREE": "1"}, {"OCRT_FORCE_EXACT_WALK": "1"}, {"OCRT_AO_BLOCKS": "2"}, {"OCRT_NO_SHARED_WALK": "1"},
+         {"OCRT_CONTRACT": "0.3"}, {"OCRT_CONTRACT": "2.0"}, {"OCRT_AO_GUIDE": "3"}]
 
 
 def main():
@@ -30,6 +31,11 @@ def main():
         for bvh in (0, 1):
             scene = rt.Scene.load_off(os.path.join(ROOT, "tests", "golden", "meshes", name + ".off")).build_bvh(bvh)
             meshes[name, bvh] = (scene, orc.SceneArrays.from_scene(scene))
+    from tools.meshes import bunny_path, interior_path  # (the big scenes: longest-axis trees only)
+
+    for name, path in (("bunny", bunny_path()), ("interior", interior_path())):
+        scene = rt.Scene.load_off(path).build_bvh(0)
+        meshes[name, 0] = (scene, orc.SceneArrays.from_scene(scene))
     bad = 0
     for case in range(n_cases):
         name, bvh = rng.choice(list(meshes))
