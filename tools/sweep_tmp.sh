@@ -1,6 +1,8 @@
-W="bunny_1080p_s16 bunny_1080p_s64 interior_4k_ao bunny_1080p_s4"
-run() { for w in $W; do echo -n "$1: "; env $2 python3 tools/prof_run.py --workload $w --frames 8 | tail -1; done; }
-run rule "X=1"
-run claim7 "OCRT_AO_CLAIM_MAX=7"
-run claim14 "OCRT_AO_CLAIM_MAX=14"
-run claim28 "OCRT_AO_CLAIM_MAX=28"
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+rm -rf $R/gpurun_out/pmc3
+for C in "SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_DCACHE_REQ SQC_DCACHE_MISSES_DUPLICATE"; do
+  i=$((i+1))
+  timeout -k 10 180 rocprofv3 --pmc $C --output-format csv -d $R/gpurun_out/pmc3/p$i -- python3 $R/tools/prof_run.py --frames 2 --workload bunny_1080p_ao > $R/gpurun_out/pmc3.p$i.log 2>&1 || echo "pass $i failed"
+done
+python3 $R/tools/pmc_summary.py $R/gpurun_out/pmc3 kernel
