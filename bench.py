@@ -370,6 +370,14 @@ def main():
             roof.update(achieved=round(rate, 4), frac=round(rate / VALU_PEAK_PER_CLK_SIMD, 4),
                         insts_per_launch=int(pmc["valu_insts"]), ceiling_measured=pmc.get("valu_ceiling_measured"),
                         levels=pmc.get("levels"), counters_from=pmc.get("source"))
+            if pmc.get("valu_ceiling_measured"):
+                roof["frac_of_measured_ceiling"] = round(rate / pmc["valu_ceiling_measured"], 4)
+            # the hardware's own view, from the counter pass: cycles the SIMDs spent issuing vector instructions
+            # (SQ_ACTIVE_INST_VALU, quad-cycles summed over the SIMDs) over the cycles the launch took
+            # (GRBM_GUI_ACTIVE, summed over the 8 XCDs)
+            if pmc.get("active_inst_valu_quad_cycles") and pmc.get("gui_active_cycles"):
+                roof["valu_busy_counters"] = round(pmc["active_inst_valu_quad_cycles"] * 4.0 / SIMDS /
+                                                   (pmc["gui_active_cycles"] / 8.0), 4)
         else:
             roof["counters_from"] = None if world > 1 else "profiles/pmc.json is missing or was collected for other kernel sources"
         roof["hbm"] = hbm

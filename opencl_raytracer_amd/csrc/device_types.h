@@ -106,6 +106,8 @@ struct KernelParams {
 	int32_t shared_walk;   // sibling subtrees tile their parent's index range (any arity): one shared node index is safe
 	int32_t fast_walk;     // the padded walk array exists (regular, nested scene): the 6-FMA box test may be used
 	float origin_limit;    // ... for rays whose origin coordinates do not exceed this magnitude
+	float walk_scale;      // ~ 1 / ao_max_distance: the ambient-occlusion rays' node test measures t in these units
+	                       // (kernels.hip, OCRT_TEST_COHERENT_SCALED); 0 = unusable, those rays take the exact form
 	float primary_below;   // largest float below the primary rays' max_distance (100000.0f)
 	float ao_below;        // largest float below AO_MAX_DISTANCE
 	int32_t debug_no_sort; // debug knob OCRT_NO_SORT: claim tiles in arbitrary order instead of heaviest first

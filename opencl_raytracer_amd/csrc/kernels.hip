@@ -70,11 +70,13 @@ struct WalkRay {
 __device__ __forceinline__ float walk_reciprocal(float i) {
 	return fabsf(i) == __builtin_inff() ? copysignf(0x1.0p+100f, i) : i;
 }
-__device__ __forceinline__ WalkRay make_walk_ray(const Ray &r) {
+// `scale`: 1 for the plain form (t in ray units); the SCALED form of the node test (walk_collect<true>) measures t in
+// units of the ray's max_distance, scale = KernelParams::walk_scale ~ 1 / max_distance.
+__device__ __forceinline__ WalkRay make_walk_ray(const Ray &r, float scale) {
 	WalkRay w;
-	w.ix = walk_reciprocal(r.ix);
-	w.iy = walk_reciprocal(r.iy);
-	w.iz = walk_reciprocal(r.iz);
+	w.ix = walk_reciprocal(r.ix) * scale;
+	w.iy = walk_reciprocal(r.iy) * scale;
+	w.iz = walk_reciprocal(r.iz) * scale;
 	w.oix = -(r.ox * w.ix);
 	w.oiy = -(r.oy * w.iy);
 	w.oiz = -(r.oz * w.iz);
@@ -213,9 +215,10 @@ constexpr float RECIPROCAL_LIMIT = 1.0e30f;
 __device__ __forceinline__ bool ray_is_selectable(const Ray &r, float origin_limit) {
 	const bool origin_ok = fabsf(r.ox) <= origin_limit && fabsf(r.oy) <= origin_limit && fabsf(r.oz) <= origin_limit;
 	const float ax = fabsf(r.ix), ay = fabsf(r.iy), az = fabsf(r.iz), inf = __builtin_inff();
-	// a number on every axis (NaN fails every comparison), and either infinite or small enough
+	// a number on every axis (NaN fails every comparison), either infinite or small enough, and the reciprocal of a
+	// unit vector's component (the margins convert an underflow in t to plane units with |inv| >= 1/2)
 	const bool numbers = (ax <= RECIPROCAL_LIMIT || ax == inf) && (ay <= RECIPROCAL_LIMIT || ay == inf) &&
-	                     (az <= RECIPROCAL_LIMIT || az == inf);
+	                     (az <= RECIPROCAL_LIMIT || az == inf) && fminf(fminf(ax, ay), az) >= 0.5f;
 	const bool some_finite = ax <= RECIPROCAL_LIMIT || ay <= RECIPROCAL_LIMIT || az <= RECIPROCAL_LIMIT;
 	return origin_ok && numbers && some_finite;
 }
@@ -447,7 +450,12 @@ __device__ __forceinline__ u32x8 scalar_load_node(const float4 *nodes_ptr, uint3
 // primary tiles off the image's centre lines, most ambient-occlusion packets) --: the near and far plane of each
 // axis are then known when the loop is entered and the test is 6 v_fma + max + min + max3 + min3 + cmp = 11 vector
 // instructions; the loop exists once per sign octant (OCRT_WALK_COHERENT).  Mixed packets select per lane with
-// v_cndmask on the sign masks: 17 (the first generation of this loop computed (b - o) * inv exactly: 23).
+// v_cndmask on the sign masks: 17 (the first generation of this loop computed (b - o) * inv exactly: 23).  The
+// any-hit rays of the ambient-occlusion pass, whose max_distance is one number per frame, take the SCALED form of
+// the test: 9 and 15 (OCRT_TEST_COHERENT_SCALED below).  What an instruction costs here (tools/microbench/
+// valu_rate_probe.hip, 8 waves per SIMD): ~2.3 cycles per SIMD for v_fma / v_mul / v_add / v_mov on registers, ~4.2
+// for everything else (min / max / max3 / cmp / cndmask, v_pk_fma_f32, and alone also an fma with a scalar operand):
+// the 11-instruction test runs at 35.7 cycles, the 9-instruction one at 28.3, a v_pk_fma_f32 version with 8 at 35.9.
 //
 // One 64-byte load fetches a node and its pre-order successor: after a hit on an inner node its first child is
 // tested straight from s[56:63].  The array ends in two END records whose infinite box every live lane "hits" and
@@ -497,6 +505,38 @@ __device__ __forceinline__ u32x8 scalar_load_node(const float4 *nodes_ptr, uint3
 	"\tv_max3_f32 v62, v62, v57, v59\n"            \
 	"\tv_min3_f32 v56, v56, v58, v60\n"            \
 	"\tv_cmp_le_f32 vcc, v62, v56\n"
+// The SCALED form (any-hit rays, whose max_distance is one number per frame): the reciprocals carry a factor
+// ~ 1 / max_distance, so "t < max_distance" reads "t' <= 1" and both limits fit the CLAMP modifier of the z-axis fmas
+// (clamp to [0, 1]): near = max3(x, y, clamp(z)), far = min3(x, y, clamp(z)), hit iff near < far -- 9 vector
+// instructions, 15 for mixed packets (clamping both z values before the select equals clamping the selected one).
+// The comparison is strict so that a box behind the origin on z (far clamped to 0, near >= 0) fails; why no pair the
+// reference accepts is lost to that: scene_pack.cc, padded_bound ("The scaled form").
+#define OCRT_TEST_COHERENT_SCALED(NX, NY, NZ, FX, FY, FZ) \
+	"\tv_fma_f32 v56, " NX ", %[ix], %[oix]\n"            \
+	"\tv_fma_f32 v57, " NY ", %[iy], %[oiy]\n"            \
+	"\tv_fma_f32 v58, " NZ ", %[iz], %[oiz] clamp\n"      \
+	"\tv_fma_f32 v59, " FX ", %[ix], %[oix]\n"            \
+	"\tv_fma_f32 v60, " FY ", %[iy], %[oiy]\n"            \
+	"\tv_fma_f32 v61, " FZ ", %[iz], %[oiz] clamp\n"      \
+	"\tv_max3_f32 v56, v56, v57, v58\n"                   \
+	"\tv_min3_f32 v59, v59, v60, v61\n"                   \
+	"\tv_cmp_lt_f32 vcc, v56, v59\n"
+#define OCRT_TEST_MIXED_SCALED(LX, LY, LZ, HX, HY, HZ) \
+	"\tv_fma_f32 v56, " LX ", %[ix], %[oix]\n"         \
+	"\tv_fma_f32 v57, " HX ", %[ix], %[oix]\n"         \
+	"\tv_fma_f32 v58, " LY ", %[iy], %[oiy]\n"         \
+	"\tv_fma_f32 v59, " HY ", %[iy], %[oiy]\n"         \
+	"\tv_fma_f32 v60, " LZ ", %[iz], %[oiz] clamp\n"   \
+	"\tv_fma_f32 v61, " HZ ", %[iz], %[oiz] clamp\n"   \
+	"\tv_cndmask_b32 v62, v57, v56, %[px]\n"           \
+	"\tv_cndmask_b32 v56, v56, v57, %[px]\n"           \
+	"\tv_cndmask_b32 v57, v59, v58, %[py]\n"           \
+	"\tv_cndmask_b32 v58, v58, v59, %[py]\n"           \
+	"\tv_cndmask_b32 v59, v61, v60, %[pz]\n"           \
+	"\tv_cndmask_b32 v60, v60, v61, %[pz]\n"           \
+	"\tv_max3_f32 v62, v62, v57, v59\n"                \
+	"\tv_min3_f32 v56, v56, v58, v60\n"                \
+	"\tv_cmp_lt_f32 vcc, v62, v56\n"
 // (LEAF: the s-register holding the node's leaf field; NEXT: where the walk goes on after an append)
 #define OCRT_WALK_LEAF(LEAF, NOW, NEXT)                 \
 	"\ts_cmp_eq_u32 " LEAF ", -2\n"                     \
@@ -571,13 +611,13 @@ __device__ __forceinline__ u32x8 scalar_load_node(const float4 *nodes_ptr, uint3
 #define OCRT_NEAR_N(LO, HI) HI
 #define OCRT_FAR_P(LO, HI) HI
 #define OCRT_FAR_N(LO, HI) LO
-#define OCRT_WALK_COHERENT(X, Y, Z)                                                                                       \
-	asm volatile(OCRT_WALK_ASM(OCRT_TEST_COHERENT(OCRT_NEAR_##X("s48", "s52"), OCRT_NEAR_##Y("s49", "s53"),                \
-	                                              OCRT_NEAR_##Z("s50", "s54"), OCRT_FAR_##X("s48", "s52"),                 \
-	                                              OCRT_FAR_##Y("s49", "s53"), OCRT_FAR_##Z("s50", "s54")),                 \
-	                           OCRT_TEST_COHERENT(OCRT_NEAR_##X("s56", "s60"), OCRT_NEAR_##Y("s57", "s61"),                \
-	                                              OCRT_NEAR_##Z("s58", "s62"), OCRT_FAR_##X("s56", "s60"),                 \
-	                                              OCRT_FAR_##Y("s57", "s61"), OCRT_FAR_##Z("s58", "s62")))                 \
+#define OCRT_WALK_COHERENT(TEST, X, Y, Z)                                                                                 \
+	asm volatile(OCRT_WALK_ASM(TEST(OCRT_NEAR_##X("s48", "s52"), OCRT_NEAR_##Y("s49", "s53"),                              \
+	                                OCRT_NEAR_##Z("s50", "s54"), OCRT_FAR_##X("s48", "s52"),                               \
+	                                OCRT_FAR_##Y("s49", "s53"), OCRT_FAR_##Z("s50", "s54")),                               \
+	                           TEST(OCRT_NEAR_##X("s56", "s60"), OCRT_NEAR_##Y("s57", "s61"),                              \
+	                                OCRT_NEAR_##Z("s58", "s62"), OCRT_FAR_##X("s56", "s60"),                               \
+	                                OCRT_FAR_##Y("s57", "s61"), OCRT_FAR_##Z("s58", "s62")))                               \
 	             : [at] "+s"(at), [waiting] "+s"(waiting), [stops] "+s"(leaf_stops), [hit] "=&s"(hit_mask),               \
 	               [leaf] "=&s"(leaf), [status] "=&s"(status)                                                            \
 	             : [base] "s"(walk_ptr), [alive] "s"(alive_mask), [below] "s"(below), [batch_below] "s"(batch_below),     \
@@ -585,34 +625,42 @@ __device__ __forceinline__ u32x8 scalar_load_node(const float4 *nodes_ptr, uint3
 	               [oix] "v"(ray.oix), [oiy] "v"(ray.oiy), [oiz] "v"(ray.oiz)                                             \
 	             : OCRT_WALK_CLOBBERS)
 
+#define OCRT_WALK_MIXED(TEST)                                                                                             \
+	asm volatile(OCRT_WALK_ASM(TEST("s48", "s49", "s50", "s52", "s53", "s54"), TEST("s56", "s57", "s58", "s60", "s61", "s62")) \
+	             : [at] "+s"(at), [waiting] "+s"(waiting), [stops] "+s"(leaf_stops), [hit] "=&s"(hit_mask),               \
+	               [leaf] "=&s"(leaf), [status] "=&s"(status)                                                            \
+	             : [base] "s"(walk_ptr), [alive] "s"(alive_mask), [below] "s"(below), [batch_below] "s"(batch_below),     \
+	               [px] "s"(sign.x), [py] "s"(sign.y), [pz] "s"(sign.z), [list] "v"(list_lds_address), [tag] "v"(lane_tag), \
+	               [ix] "v"(ray.ix), [iy] "v"(ray.iy), [iz] "v"(ray.iz), [oix] "v"(ray.oix), [oiy] "v"(ray.oiy),          \
+	               [oiz] "v"(ray.oiz)                                                                                    \
+	             : OCRT_WALK_CLOBBERS)
+#define OCRT_WALK_SWITCH(COHERENT_TEST, MIXED_TEST)                     \
+	switch (variant) {                                                  \
+	case 0u: OCRT_WALK_COHERENT(COHERENT_TEST, N, N, N); break;         \
+	case 1u: OCRT_WALK_COHERENT(COHERENT_TEST, P, N, N); break;         \
+	case 2u: OCRT_WALK_COHERENT(COHERENT_TEST, N, P, N); break;         \
+	case 3u: OCRT_WALK_COHERENT(COHERENT_TEST, P, P, N); break;         \
+	case 4u: OCRT_WALK_COHERENT(COHERENT_TEST, N, N, P); break;         \
+	case 5u: OCRT_WALK_COHERENT(COHERENT_TEST, P, N, P); break;         \
+	case 6u: OCRT_WALK_COHERENT(COHERENT_TEST, N, P, P); break;         \
+	case 7u: OCRT_WALK_COHERENT(COHERENT_TEST, P, P, P); break;         \
+	default: OCRT_WALK_MIXED(MIXED_TEST); break;                        \
+	}
+
 // `variant`: 0..7 = sign octant of a coherent packet (bit 0: x reciprocals >= 0, bit 1: y, bit 2: z), 8 = mixed.
+// SCALED: `ray` was made with the frame's walk_scale and `below` is not looked at (the limit is 1.0).
 constexpr uint32_t WALK_MIXED = 8u;
+template <bool SCALED>
 __device__ __forceinline__ uint32_t walk_collect(uint32_t variant, const float4 *walk_ptr, uint32_t &at, const WalkRay &ray,
                                                  const SignMasks &sign, float below, unsigned long long alive_mask,
                                                  unsigned long long &hit_mask, uint32_t &leaf, uint32_t &waiting,
                                                  uint32_t &leaf_stops, uint32_t list_lds_address, uint32_t lane_tag,
                                                  uint32_t batch_below) {
 	uint32_t status;
-	switch (variant) {
-	case 0u: OCRT_WALK_COHERENT(N, N, N); break;
-	case 1u: OCRT_WALK_COHERENT(P, N, N); break;
-	case 2u: OCRT_WALK_COHERENT(N, P, N); break;
-	case 3u: OCRT_WALK_COHERENT(P, P, N); break;
-	case 4u: OCRT_WALK_COHERENT(N, N, P); break;
-	case 5u: OCRT_WALK_COHERENT(P, N, P); break;
-	case 6u: OCRT_WALK_COHERENT(N, P, P); break;
-	case 7u: OCRT_WALK_COHERENT(P, P, P); break;
-	default:
-		asm volatile(OCRT_WALK_ASM(OCRT_TEST_MIXED("s48", "s49", "s50", "s52", "s53", "s54"),
-		                           OCRT_TEST_MIXED("s56", "s57", "s58", "s60", "s61", "s62"))
-		             : [at] "+s"(at), [waiting] "+s"(waiting), [stops] "+s"(leaf_stops), [hit] "=&s"(hit_mask),
-		               [leaf] "=&s"(leaf), [status] "=&s"(status)
-		             : [base] "s"(walk_ptr), [alive] "s"(alive_mask), [below] "s"(below), [batch_below] "s"(batch_below),
-		               [px] "s"(sign.x), [py] "s"(sign.y), [pz] "s"(sign.z), [list] "v"(list_lds_address), [tag] "v"(lane_tag),
-		               [ix] "v"(ray.ix), [iy] "v"(ray.iy), [iz] "v"(ray.iz), [oix] "v"(ray.oix), [oiy] "v"(ray.oiy),
-		               [oiz] "v"(ray.oiz)
-		             : OCRT_WALK_CLOBBERS);
-		break;
+	if (SCALED) {
+		OCRT_WALK_SWITCH(OCRT_TEST_COHERENT_SCALED, OCRT_TEST_MIXED_SCALED)
+	} else {
+		OCRT_WALK_SWITCH(OCRT_TEST_COHERENT, OCRT_TEST_MIXED)
 	}
 	return status;
 }
@@ -671,8 +719,9 @@ template <bool EXACT>
 __device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ nodes_ptr, const float4 *__restrict__ walk_ptr,
                                                     const float4 *__restrict__ tris_ptr, __amdgpu_buffer_rsrc_t tris_rsrc,
                                                     uint32_t count, const Ray &ray_in, const float (&frame)[12][64], uint32_t h,
-                                                    float max_distance, float below, bool alive, unsigned int *occluded,
-                                                    LeafBatch &batch, uint32_t batch_below, unsigned long long *prof) {
+                                                    float max_distance, float below, float walk_scale, bool alive,
+                                                    unsigned int *occluded, LeafBatch &batch, uint32_t batch_below,
+                                                    unsigned long long *prof) {
 	(void) prof;  // (-DOCRT_STAMPS builds: time in the node loop / in batches, loop entries, batches, leaf stops)
 	// the live lanes as a scalar mask: the node steps then need no per-lane bookkeeping at all
 	unsigned long long alive_mask = wave_ballot(alive);
@@ -742,7 +791,7 @@ __device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ n
 		const uint32_t list_lds_address = (uint32_t) (uintptr_t) &batch.entry[0];  // (low half of the flat address)
 		const SignMasks sign = sign_masks(ray_in);
 		const uint32_t variant = walk_variant(sign, alive_mask);  // (lanes only leave: a coherent packet stays coherent)
-		const WalkRay walk_ray = make_walk_ray(with_origin());
+		const WalkRay walk_ray = make_walk_ray(with_origin(), walk_scale);
 		const uint32_t lane_tag = fresh_lane() << 26;
 		while (alive_mask != 0ull && at < end) {
 			uint32_t leaf = 0u;
@@ -750,8 +799,8 @@ __device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ n
 #ifdef OCRT_STAMPS
 			const unsigned long long tw0 = __builtin_amdgcn_s_memrealtime();
 #endif
-			const uint32_t status = walk_collect(variant, walk_ptr, at, walk_ray, sign, below, alive_mask, hit_mask, leaf, waiting,
-			                                     leaf_stops, list_lds_address, lane_tag, batch_below);
+			const uint32_t status = walk_collect<true>(variant, walk_ptr, at, walk_ray, sign, below, alive_mask, hit_mask, leaf,
+			                                           waiting, leaf_stops, list_lds_address, lane_tag, batch_below);
 #ifdef OCRT_STAMPS
 			prof[0] += __builtin_amdgcn_s_memrealtime() - tw0;
 			prof[2] += 1;
@@ -932,15 +981,15 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) __attribute__((amdgpu_waves_per
 			const unsigned long long alive_mask = wave_ballot(active);
 			const SignMasks sign = sign_masks(ray);
 			const uint32_t variant = walk_variant(sign, alive_mask);
-			const WalkRay walk_ray = make_walk_ray(ray);
+			const WalkRay walk_ray = make_walk_ray(ray, 1.0f);
 			const uint32_t list_lds_address = (uint32_t) (uintptr_t) &cb.entry[0];  // (low half of the flat address)
 			const uint32_t end = count * 32u;
 			uint32_t at = 0u;  // byte offset
 			while (alive_mask != 0ull && at < end) {
 				uint32_t leaf = 0u;
 				unsigned long long hit_mask = 0ull;
-				const uint32_t status = walk_collect(variant, walk_ptr, at, walk_ray, sign, P.primary_below, alive_mask, hit_mask, leaf,
-				                                     waiting, leaf_stops, list_lds_address, lane << 26, P.batch_below);
+				const uint32_t status = walk_collect<false>(variant, walk_ptr, at, walk_ray, sign, P.primary_below, alive_mask, hit_mask,
+				                                            leaf, waiting, leaf_stops, list_lds_address, lane << 26, P.batch_below);
 				if (status == 0u)
 					break;
 				if (status == 1u) {
@@ -1255,7 +1304,12 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 		if (claim_max == 0u) {
 			const uint32_t tiles = counters->queue[group].work_tiles, cost = counters->queue[group].cost_sum;
 			const bool cheap_and_plenty = cost < 8u * tiles && units >= 512u * P.ao_claim_div;
-			claim_max = cheap_and_plenty ? P.ao_dirs : (P.ao_dirs + AO_WAVES - 1u) / AO_WAVES;
+			const uint32_t quarter = (P.ao_dirs + AO_WAVES - 1u) / AO_WAVES;
+			// ... and less than a quarter where work is scarce (one GPU's share of a frame split eight ways holds 8
+			// units per wave): half a quarter below 24 units per wave, a third below 12 -- the frame then ends when its
+			// heaviest tile does, and more waves should share that one (tools/partition_probe.py: -13 % at 1/8).
+			const uint32_t per_wave = units / P.ao_claim_div;
+			claim_max = cheap_and_plenty ? P.ao_dirs : per_wave < 12u ? quarter / 3u : per_wave < 24u ? (quarter + 1u) / 2u : quarter;
 			claim_max = claim_max < 1u ? 1u : claim_max;
 		}
 		for (;;) {
@@ -1459,7 +1513,7 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 				} else {
 					// shared walks (see shared_box) of 64 consecutive rays of the job at a time; a lane
 					// leaves at its first accepted triangle
-					const bool scene_fast = P.fast_walk && P.ao_regular;
+					const bool scene_fast = P.fast_walk && P.ao_regular && P.walk_scale > 0.0f;
 					for (uint32_t base = 0u; base < total; base += 64u) {
 						const uint32_t lane = fresh_lane();
 						bool alive = base + lane < total;
@@ -1473,11 +1527,11 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 						const bool exact = !scene_fast || wave_ballot(alive && !ray_is_selectable(ray, P.origin_limit)) != 0ull;
 						if (exact)
 							shared_walk_any_hit<true>(nodes_ptr, walk_ptr, tris_ptr, scene.tris, count, ray, sh.frame, h,
-							                          P.ao_max_distance, P.ao_below, alive, &sh.occluded[h], sh.batch,
+							                          P.ao_max_distance, P.ao_below, P.walk_scale, alive, &sh.occluded[h], sh.batch,
 							                          P.batch_below, walk_prof);
 						else
 							shared_walk_any_hit<false>(nodes_ptr, walk_ptr, tris_ptr, scene.tris, count, ray, sh.frame, h,
-							                           P.ao_max_distance, P.ao_below, alive, &sh.occluded[h], sh.batch,
+							                           P.ao_max_distance, P.ao_below, P.walk_scale, alive, &sh.occluded[h], sh.batch,
 							                           P.batch_below, walk_prof);
 					}
 				}

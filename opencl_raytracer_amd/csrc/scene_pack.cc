@@ -186,13 +186,46 @@ PackedScene pack_scene(const std::vector<uint32_t> &faces, const std::vector<uin
 // argument above holds for every finite inv, so 2^100 (b' - o) is <= 0 whenever the reference's (b - o) * inf is -inf
 // or NaN (no constraint), and where the reference gives +inf (the origin's coordinate outside the slab: reject) ours
 // may be anything.  (Extent <= 1e6 keeps 2^100 * 1e6 finite.)
-float padded_bound(float b, float origin_bound, bool upper) {
-	const double margin = 1.5 * std::ldexp(std::fabs((double) b) + 2.0 * (double) origin_bound, -24) + 1.0e-44;
+//
+// The scaled form (kernels.hip, OCRT_TEST_COHERENT_SCALED; any-hit rays of one max_distance D per frame) replaces inv
+// by inv' = fl(inv * r), r = walk_scale_for(D) ~ 1 / D, and the two limits "t_near < D", "t_far > 0" by the fma's
+// clamp to [0, 1] on the z axis, compared STRICTLY:  max3(near'_x, near'_y, clamp near'_z) < min3(far'_x, far'_y,
+// clamp far'_z).  (Strictly, because a box behind the origin on z has its negative far'_z clamped to 0, and 0 <= 0
+// would let every such box through whose x and y slabs contain the origin -- a line through the whole scene.)
+// Write Y = b' * inv' + oi' as a real, oi' = -fl(o * inv'), F' = fl(Y), X = s * inv as a real (E = fl(X)).  The
+// argument above never used what inv is; with a further margin d on every plane it reads
+//     near:  Y <= s * inv' - d |inv'|,      far:  Y >= s * inv' + d |inv'|,
+// the underflow term being 2^-150 / |inv'| <= 2^-128 in plane units (|inv| >= 1/2: directions are unit vectors up to
+// rounding, ray_is_selectable checks it; r >= 2^-21).  d = 14u D is enough (u D r >= u (1 - 2^-21), |inv'| >= r / 2):
+//  * far, reference E > 0: s * inv' > 0, so Y >= d |inv'| >= 6.9u and F' >= 6.9u > 0.
+//  * near, reference E < D: s * inv < D, s * inv' < D r (1 + u) <= 1 by the choice of r, Y <= 1 - 6.9u, F' < 1.
+//  * near_i against far_j (any two planes), reference E_i <= E_j (and E_j > 0): if E_i <= 0, F'_i <= 0 < F'_j.  If
+//    E_j >= 1.01 D, F'_j >= fl(1.01 D r (1 - 3u)) > 1 > F'_i (a clamped far'_z is 1, still above).  Otherwise
+//    0 < E_i <= E_j < 1.01 D; as reals X_i <= X_j (1 + 2.1u), and inv'_i / inv_i, inv'_j / inv_j differ by at most
+//    (1 +- u)^2 -- the one thing the scaling adds:
+//        Y_j - Y_i >= r [(1 - u) (X_j + d |inv_j|) - (1 + u) ((1 + 2.1u) X_j - d |inv_i|)]
+//                  >= r (1 - u) d |inv_j| - 4.2u r X_j  >  (1 - u) 7u (1 - 2^-21) - 4.3u  >  2.2u,
+//    (r X_j < 1.02), and both values being below 1.05 their roundings move them by less than 1.05u each: F'_i < F'_j.
+//  * a clamp never breaks this: clamping is monotone, F'_near < 1 and F'_far > 0 keep a clamped partner apart.
+// Margin used for it: 16u * 1.001 D.  Infinite reciprocals: as above, 2^100 r stays finite and keeps the sign of b' - o.
+float padded_bound(float b, float origin_bound, bool upper, float scaled_reach) {
+	const double margin = 1.5 * std::ldexp(std::fabs((double) b) + 2.0 * (double) origin_bound, -24) +
+	                      16.0 * std::ldexp((double) scaled_reach, -24) + 1.0e-38;
 	const double moved = upper ? (double) b + margin : (double) b - margin;
 	float f = (float) moved;  // round to nearest, then make sure it lies outside
 	if (upper ? (double) f < moved : (double) f > moved)
 		f = std::nextafterf(f, upper ? std::numeric_limits<float>::infinity() : -std::numeric_limits<float>::infinity());
 	return f;
+}
+
+float walk_scale_for(float max_distance) {
+	if (!(max_distance >= 0x1.0p-20f && max_distance <= 0x1.0p+20f))
+		return 0.0f;
+	const double want = (1.0 - std::ldexp(1.0, -22)) / (double) max_distance;
+	float r = (float) want;
+	while ((double) r * (double) max_distance * (1.0 + std::ldexp(1.0, -23)) > 1.0)
+		r = std::nextafterf(r, 0.0f);
+	return r;
 }
 
 WalkArray make_walk_array(const PackedScene &scene, float ao_max_distance) {
@@ -210,6 +243,8 @@ WalkArray make_walk_array(const PackedScene &scene, float ao_max_distance) {
 	const double reach = ao_bounded ? (double) ao_max_distance * 1.001 : 2.0 * (double) extent;
 	// ray origins: the camera at (0, 0, 2) and hit points, which lie in the root box up to the triangle test's slack
 	out.origin_limit = 2.0f * extent + 4.0f;
+	out.ao_scale = walk_scale_for(ao_max_distance);
+	const float scaled_reach = out.ao_scale > 0.0f ? ao_max_distance * 1.001f : 0.0f;
 	const double camera[3] = { 0.0, 0.0, 2.0 };  // reference src/intersect_kernel.cl:284
 	out.nodes.resize(nodes.size() + 2);
 	for (size_t i = 0; i < nodes.size(); ++i) {
@@ -217,8 +252,8 @@ WalkArray make_walk_array(const PackedScene &scene, float ao_max_distance) {
 		for (unsigned k = 0; k < 3; ++k) {
 			const double box = std::fmax(std::fabs((double) nodes[i].lo[k]), std::fabs((double) nodes[i].hi[k]));
 			const double origin = std::fmin((double) out.origin_limit, std::fmax(camera[k], box + reach));
-			w.lo[k] = padded_bound(nodes[i].lo[k], (float) origin, false);
-			w.hi[k] = padded_bound(nodes[i].hi[k], (float) origin, true);
+			w.lo[k] = padded_bound(nodes[i].lo[k], (float) origin, false, scaled_reach);
+			w.hi[k] = padded_bound(nodes[i].hi[k], (float) origin, true, scaled_reach);
 		}
 		w.skip = nodes[i].skip * (uint32_t) sizeof(NodeRec);  // (node count < 2^27, checked at pack time)
 		out.nodes[i] = w;
@@ -315,6 +350,9 @@ KernelParams make_kernel_params(const RayTracer &rt, uint32_t node_count, uint32
 	p.ao_dirs = ao_dirs;
 	p.ao_divisor = p.ao_mode == AO_RANDOM ? ao_dirs - 1 : ao_dirs;
 	p.origin_limit = walk ? walk->origin_limit : 0.0f;
+	// (the array's margins hold for the max_distance it was made for: the renderer re-makes it when that changes)
+	p.walk_scale = (walk && walk->ao_scale > 0.0f && walk->ao_scale == walk_scale_for(p.ao_max_distance) &&
+	                !std::getenv("OCRT_NO_SCALED_WALK")) ? walk->ao_scale : 0.0f;  // (debug knob)
 	p.fast_walk = (walk && !walk->nodes.empty() && !std::getenv("OCRT_FORCE_EXACT_WALK")) ? 1 : 0;  // (debug knob)
 	p.scene_regular = (scene && scene->regular) ? 1 : 0;
 	p.scene_nested = (scene && scene->nested && !std::getenv("OCRT_FORCE_EXACT_WALK")) ? 1 : 0;  // (debug knob)

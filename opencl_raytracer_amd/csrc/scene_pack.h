@@ -41,13 +41,19 @@ PackedScene pack_scene(const std::vector<uint32_t> &faces, const std::vector<uin
 struct WalkArray {
 	std::vector<NodeRec> nodes;
 	float origin_limit = 0.0f;  // rays whose origin exceeds this magnitude on some axis take the exact form
+	float ao_scale = 0.0f;      // walk_scale_for(ao_max_distance) the margins were sized for (0: none)
 };
 // `ao_max_distance`: the kernel's AO_MAX_DISTANCE (bounds how far from a box an ambient-occlusion ray that hits it
 // can start; <= 0 or not finite: no ambient occlusion, or no usable bound).
 WalkArray make_walk_array(const PackedScene &scene, float ao_max_distance);
 // The margin itself: the padded value of a box's lower (upper = false) or upper bound `b` for ray origins of
 // magnitude up to `origin_bound` on that axis; always < b resp. > b.
-float padded_bound(float b, float origin_bound, bool upper);
+// `scaled_reach`: the max_distance (x 1.001) of the rays that use the SCALED node test on this array, 0 if none do.
+float padded_bound(float b, float origin_bound, bool upper, float scaled_reach = 0.0f);
+// The factor the scaled node test multiplies the reciprocal directions with: the largest float r with
+// r * max_distance * (1 + 2^-23) <= 1, or 0 where the scaled form must not be used (max_distance not a positive
+// number within 2^-20 .. 2^20).
+float walk_scale_for(float max_distance);
 
 // The value a float option has once it went through the reference's -D string:
 // printed with 6 significant digits ("-DNAME=0.2f", reference

@@ -6,6 +6,9 @@
 // box, the fma test on the padded box passes too.  This program throws random and adversarial (ray, box) pairs at
 // both tests with the kernel's exact arithmetic (std::fmaf = one rounding; maxNum / minNum like v_max3 / v_min3)
 // and reports every pair that the reference accepts and the conservative test rejects.  Exit code 0 = none.
+// Ambient-occlusion pairs also go through the SCALED form of the test (reciprocals times walk_scale_for(max_distance),
+// z-axis values clamped to [0, 1]; kernels.hip, OCRT_TEST_COHERENT_SCALED).  (Its extra margin term is there by
+// proof: the base margin's slack hides its absence from random pairs, grazing ones included.)
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -14,7 +17,8 @@
 #include <random>
 
 namespace ocrt {
-float padded_bound(float b, float origin_bound, bool upper);  // libocrt_hip.so
+float padded_bound(float b, float origin_bound, bool upper, float scaled_reach);  // libocrt_hip.so
+float walk_scale_for(float max_distance);
 }
 
 namespace {
@@ -61,6 +65,25 @@ bool conservative_slab(const float plo[3], const float phi[3], const float o[3],
 	return n <= f;
 }
 
+// kernels.hip, OCRT_TEST_MIXED_SCALED / OCRT_TEST_COHERENT_SCALED: reciprocals times `scale`, the z-axis fmas clamped
+// to [0, 1] (v_fma_f32 ... clamp: NaN -> 0 with DX10_CLAMP, which is what amdhsa kernels run with)
+float clamp01(float v) { return v != v ? 0.0f : std::fmin(std::fmax(v, 0.0f), 1.0f); }
+bool scaled_slab(const float plo[3], const float phi[3], const float o[3], const float d[3], float scale) {
+	float near[3], far[3];
+	for (int k = 0; k < 3; ++k) {
+		const float inv = 1.0f / d[k];
+		const float wi = walk_reciprocal(inv) * scale;
+		const float oi = -(o[k] * wi);
+		float a = std::fmaf(plo[k], wi, oi), b = std::fmaf(phi[k], wi, oi);
+		if (k == 2) { a = clamp01(a); b = clamp01(b); }
+		near[k] = inv >= 0 ? a : b;
+		far[k] = inv >= 0 ? b : a;
+	}
+	const float n = std::fmax(std::fmax(near[0], near[1]), near[2]);
+	const float f = std::fmin(std::fmin(far[0], far[1]), far[2]);
+	return n < f;  // strictly: a box behind the origin on z (far clamped to 0) must fail
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
@@ -69,7 +92,7 @@ int main(int argc, char **argv) {
 	std::mt19937_64 rng(20261004);
 	std::uniform_real_distribution<float> unit(-1.0f, 1.0f);
 	std::uniform_int_distribution<int> pick(0, 15);
-	long accepted = 0, failures = 0;
+	long accepted = 0, failures = 0, scaled_cases = 0, scaled_failures = 0;
 	for (long c = 0; c < cases; ++c) {
 		const float extent = std::ldexp(1.0f, pick(rng) - 4);         // scene extents 1/16 .. 2048
 		const float max_distance = (c & 1) ? 100000.0f : extent * std::ldexp(1.0f, -(pick(rng) % 6));  // primary / AO rays
@@ -95,6 +118,28 @@ int main(int argc, char **argv) {
 			}
 		}
 		if ((c & 1) == 1) { o[0] = 0.0f; o[1] = 0.0f; o[2] = 2.0f; }  // primary rays start at the camera
+		if ((c & 6) == 2) {
+			// grazing: the ray leaves through the far plane of one axis where it enters through the near plane of
+			// another (a box edge), at a distance below max_distance -- near and far t agree to a few ulps
+			const int i = pick(rng) % 3, j = (i + 1 + pick(rng) % 2) % 3;
+			float t = std::fabs(unit(rng)) * max_distance;
+			if ((c & 8) == 8) {
+				// ... far out along the ray, which runs mostly along j and starts near the coordinate origin: the
+				// planes' own magnitude buys the least slack against the scaled form's per-axis rounding there
+				t = (0.5f + 0.5f * std::fabs(unit(rng))) * max_distance;
+				for (int k = 0; k < 3; ++k)
+					o[k] = unit(rng) * max_distance * std::ldexp(1.0f, -8);
+				d[j] = std::copysign(0.9f + 0.1f * std::fabs(unit(rng)), d[j]);
+				d[i] = std::copysign(0.05f + 0.3f * std::fabs(unit(rng)), d[i] == 0.0f ? 1.0f : d[i]);
+			}
+			if (d[i] != 0.0f && d[j] != 0.0f) {
+				const float pi = o[i] + d[i] * t, pj = o[j] + d[j] * t;
+				float span = std::fabs(unit(rng)) * extent * std::ldexp(1.0f, -(pick(rng) % 12));
+				if (d[i] > 0) { lo[i] = pi; hi[i] = pi + span; } else { hi[i] = pi; lo[i] = pi - span; }   // near plane of i at t
+				span = std::fabs(unit(rng)) * extent * std::ldexp(1.0f, -(pick(rng) % 12));
+				if (d[j] > 0) { hi[j] = pj; lo[j] = pj - span; } else { lo[j] = pj; hi[j] = pj + span; }   // far plane of j at t
+			}
+		}
 		// reciprocals must be infinite or below 1e30, origins within the scene (ray_is_selectable)
 		bool selectable = false;
 		for (int k = 0; k < 3; ++k) {
@@ -113,12 +158,26 @@ int main(int argc, char **argv) {
 		const float scene = 2.0f * extent;  // |coordinates| <= 2 extent here
 		const bool ao_bounded = (c & 1) == 0 && max_distance <= scene;
 		const double reach = ao_bounded ? (double) max_distance * 1.001 : 2.0 * (double) scene;
+		// the scaled form serves the ambient-occlusion rays where walk_scale_for() allows it
+		const float scale = (c & 1) == 0 ? ocrt::walk_scale_for(max_distance) : 0.0f;
+		const float scaled_reach = scale > 0.0f ? max_distance * 1.001f : 0.0f;
 		float plo[3], phi[3];
 		for (int k = 0; k < 3; ++k) {
 			const double box = std::fmax(std::fabs((double) lo[k]), std::fabs((double) hi[k]));
 			const double origin = std::fmin(2.0 * scene + 4.0, std::fmax(camera[k], box + reach));
-			plo[k] = unpadded ? lo[k] : ocrt::padded_bound(lo[k], (float) origin, false);
-			phi[k] = unpadded ? hi[k] : ocrt::padded_bound(hi[k], (float) origin, true);
+			plo[k] = unpadded ? lo[k] : ocrt::padded_bound(lo[k], (float) origin, false, scaled_reach);
+			phi[k] = unpadded ? hi[k] : ocrt::padded_bound(hi[k], (float) origin, true, scaled_reach);
+		}
+		if (scale > 0.0f) {
+			bool unit_like = true;  // (ray_is_selectable: finite reciprocals are those of a unit vector's components)
+			for (int k = 0; k < 3; ++k)
+				unit_like = unit_like && std::fabs(1.0f / d[k]) >= 0.5f;
+			if (unit_like) {
+				++scaled_cases;
+				if (!scaled_slab(plo, phi, o, d, scale) && ++scaled_failures <= 10 && !unpadded)
+					std::printf("MISSED (scaled): o %a %a %a d %a %a %a lo %a %a %a hi %a %a %a md %a\n", o[0], o[1], o[2], d[0], d[1],
+					            d[2], lo[0], lo[1], lo[2], hi[0], hi[1], hi[2], max_distance);
+			}
 		}
 		const float below = std::nextafter(max_distance, -INF);
 		if (!conservative_slab(plo, phi, o, d, below)) {
@@ -128,7 +187,8 @@ int main(int argc, char **argv) {
 		}
 	}
 	std::printf("%ld pairs accepted by the reference's box test, %ld of them missed by the conservative test\n", accepted, failures);
+	std::printf("%ld of those through the scaled test as well, %ld of them missed\n", scaled_cases, scaled_failures);
 	if (unpadded)
-		return failures > 0 ? 0 : 1;
-	return failures == 0 && accepted > cases / 100 ? 0 : 1;
+		return failures > 0 && scaled_failures > 0 ? 0 : 1;
+	return failures == 0 && scaled_failures == 0 && accepted > cases / 100 && scaled_cases > cases / 400 ? 0 : 1;
 }

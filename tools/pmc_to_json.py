@@ -62,8 +62,11 @@ def main():
                 "l2_requests": c.get("TCC_REQ_sum"), "l2_hits": c.get("TCC_HIT_sum"), "l2_misses": c.get("TCC_MISS_sum"),
                 "hbm_bytes": (2.0 * fetch_kb + write_kb) * 1024.0,
             },
-            # measured by tools/microbench/valu_rate.hip on the slab test's instruction mix, 8 waves per SIMD (round 1)
-            "valu_ceiling_measured": 0.42,
+            # What one SIMD sustains on the node test's own instruction mix with 8 waves resident
+            # (tools/microbench/valu_rate_probe.hip, profiles/r02_valu_rate_probe.txt): 3.15 cycles per instruction for the
+            # 9-instruction test of the ambient-occlusion pass, 3.24 for the 11-instruction one of the primary pass; only
+            # v_fma / v_mul / v_add / v_mov on registers reach the guide's 2 cycles (2.3 measured).
+            "valu_ceiling_measured": round(1.0 / 3.15, 3) if WORKLOADS[w]["ao"] else round(1.0 / 3.24, 3),
         }
         result["workloads"][w] = entry
     json.dump(result, sys.stdout, indent=1)
