@@ -374,9 +374,10 @@ def main():
                 roof["frac_of_measured_ceiling"] = round(rate / pmc["valu_ceiling_measured"], 4)
             # the hardware's own view, from the counter pass: cycles the SIMDs spent issuing vector instructions
             # (SQ_ACTIVE_INST_VALU, quad-cycles summed over the SIMDs) over the cycles the launch took
-            # (GRBM_GUI_ACTIVE, summed over the 8 XCDs)
+            # (GRBM_GUI_ACTIVE, summed over the 8 XCDs).  The counter books 4 cycles per instruction; v_fma / v_mul /
+            # v_add on registers issue in 2.3 (tools/microbench/valu_rate_probe.hip), so a saturated SIMD can read > 1.
             if pmc.get("active_inst_valu_quad_cycles") and pmc.get("gui_active_cycles"):
-                roof["valu_busy_counters"] = round(pmc["active_inst_valu_quad_cycles"] * 4.0 / SIMDS /
+                roof["valu_nominal_issue_share"] = round(pmc["active_inst_valu_quad_cycles"] * 4.0 / SIMDS /
                                                    (pmc["gui_active_cycles"] / 8.0), 4)
         else:
             roof["counters_from"] = None if world > 1 else "profiles/pmc.json is missing or was collected for other kernel sources"

@@ -19,7 +19,7 @@ import orc  # noqa: E402
 
 KNOBS = [{}, {}, {}, {"OCRT_BATCH_BELOW": "0"}, {"OCRT_BATCH_BELOW": "65"}, {"OCRT_AO_CLAIM_MAX": "1"}, {"OCRT_AO_CLAIM_MAX": "28"},
          {"OCRT_KEEP_TREE": "1"}, {"OCRT_FORCE_EXACT_WALK": "1"}, {"OCRT_AO_BLOCKS": "2"}, {"OCRT_NO_SHARED_WALK": "1"},
-         {"OCRT_CONTRACT": "0.3"}, {"OCRT_CONTRACT": "2.0"}, {"OCRT_AO_GUIDE": "3"}]
+         {"OCRT_CONTRACT": "0.3"}, {"OCRT_CONTRACT": "2.0"}, {"OCRT_AO_GUIDE": "3"}, {"OCRT_NO_SCALED_WALK": "1"}]
 
 
 def main():
@@ -46,7 +46,7 @@ def main():
         os.environ.update(knobs)
         opt = rt.Options.defaults(width=rng.randint(1, 150), height=rng.randint(1, 110),
                                   n_super_samples=rng.choice([1, 1, 2, 4, 5, 9, 16]), ao_num_samples=rng.choice([0, 1, 2, 3, 3, 4, 6]),
-                                  ao_max_distance=rng.choice([0.05, 0.2, 0.2, 0.5, 3.0]), focal_length=rng.choice([0.7, 1.0, 1.0, 1.6]),
+                                  ao_max_distance=rng.choice([0.05, 0.2, 0.2, 0.5, 3.0, 0.25, 1.0, 0.0371, 7.3e-7, 2.5e6, 17.0]), focal_length=rng.choice([0.7, 1.0, 1.0, 1.6]),
                                   enable_shading=rng.choice([1, 1, 0]))
         opt.ao_alpha_min = rng.choice([4, 4, 10, 0])
         opt.ao_alpha_max = rng.choice([90, 90, 60])
