@@ -258,17 +258,30 @@ def main():
 
     layout = BandLayout(opt, world)
     assert layout.local_rows(rank) == host.local_rows
-    band = torch.zeros((layout.max_rows, opt.width), dtype=torch.uint8, device=device)
+    # Two band buffers and two gatherers: frame i's bands are on the wire (RCCL's own stream) while frame i + 1 is
+    # rendered; a frame is finished -- gather waited for, rows moved into place on rank 0 -- right after the next one
+    # has been enqueued, and the last one before the closing fence, so K timed steps are K complete frames.
+    bands = [torch.zeros((layout.max_rows, opt.width), dtype=torch.uint8, device=device) for _ in range(2)]
     staged = launched and backend != "nccl"  # rehearsal path: the gather is staged through host memory
-    gather = BandGatherer(layout, rank, "cpu" if staged else device)
-    result = {}
+    gatherers = [BandGatherer(layout, rank, "cpu" if staged else device) for _ in range(2)]
+    result = {"frames": 0, "open": None}
+
+    def finish_open():
+        if result["open"] is not None:
+            result["final"] = gatherers[result["open"]].finish()
+            result["open"] = None
 
     def step():
+        k = result["frames"] & 1
         host.render_async()
-        host.resize_into_device(band.data_ptr())
-        result["final"] = gather(band.cpu() if staged else band)
+        host.resize_into_device(bands[k].data_ptr())
+        gatherers[k].start(bands[k].cpu() if staged else bands[k])
+        finish_open()  # the frame before this one
+        result["open"] = k
+        result["frames"] += 1
 
     def fence():
+        finish_open()
         torch.cuda.synchronize(device)
         if launched:
             dist.barrier()

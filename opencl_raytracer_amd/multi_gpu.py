@@ -74,6 +74,7 @@ class BandGatherer:
         self.src, self.dst = layout.indices_on(device)
         width, height = layout.options.width, layout.options.height
         self.stacked = self.parts = self.final = None
+        self._pending = self._band = None
         if rank == 0:
             self.final = torch.empty((height, width), dtype=torch.uint8, device=device)
             if self.collective:
@@ -82,11 +83,31 @@ class BandGatherer:
 
     def __call__(self, band):
         """band: this rank's (max_rows, width) uint8 rows.  Returns the assembled image on rank 0, None elsewhere."""
-        import torch
+        self.start(band)
+        return self.finish()
+
+    def start(self, band) -> None:
+        """Issues the gather of `band` without waiting for it (the collective runs on the backend's own stream once
+        the work queued on the current stream has produced the band); `finish` completes the frame.  A caller with two
+        gatherers and two band buffers can render the next frame while this one is on the wire."""
         import torch.distributed as dist
 
+        if self._pending is not None:
+            raise RuntimeError("BandGatherer.start called again before finish")
+        self._band = band
+        self._pending = dist.gather(band, self.parts, dst=0, group=self.group, async_op=True) if self.collective else True
+
+    def finish(self):
+        """Waits for the gather issued by `start` (a stream-level wait under RCCL) and, on rank 0, moves the rows to
+        their place.  Returns the assembled image on rank 0, None elsewhere."""
+        import torch
+
+        if self._pending is None:
+            raise RuntimeError("BandGatherer.finish without start")
         if self.collective:
-            dist.gather(band, self.parts, dst=0, group=self.group)
+            self._pending.wait()
+        band, self._pending, self._band = self._band, None, None
+        if self.collective:
             if self.rank != 0:
                 return None
             rows = self.stacked.view(-1, self.stacked.shape[-1])
