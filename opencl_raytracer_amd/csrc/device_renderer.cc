@@ -336,18 +336,30 @@ RenderStats DeviceRenderer::stats() {
 	OCRT_HIP(hipMemcpy(&c, d_counters, sizeof c, hipMemcpyDeviceToHost));
 	out.primary_hits = c.primary_hits;
 	out.ao_occluded = c.occluded;
+#ifdef OCRT_TAIL
+	std::fprintf(stderr, "AO pass: last wave ended %.3f ms after the ordering step; waves by the time they ended at (0.05 ms buckets):", (c.stamp[8] - c.stamp[7]) * 1e-5);
+	for (int k = 0; k < 32; ++k)
+		if (c.stamp[10 + k])
+			std::fprintf(stderr, " %.2f:%llu", k * 0.05, c.stamp[10 + k]);
+	std::fprintf(stderr, "\n");
+#endif
 #ifdef OCRT_STAMPS
 	std::fprintf(stderr, "AO wave-time: claim %.3f ms, frames %.3f ms, walks %.3f ms, flush %.3f ms over %llu jobs / %llu packets\n",
 	             c.stamp[0] * 1e-5, c.stamp[1] * 1e-5, c.stamp[2] * 1e-5, c.stamp[3] * 1e-5, c.stamp[4], c.stamp[5]);
 	std::fprintf(stderr, "   wave lifetimes sum %.3f ms, kernel span %.3f ms, %llu waves worked\n", c.stamp[6] * 1e-5,
 	             (c.stamp[8] - c.stamp[7]) * 1e-5, c.stamp[9]);
-	std::fprintf(stderr, "   waves by time from their last claim to their end (0.05 ms buckets):");
+	std::fprintf(stderr, "   waves by the time they ended at, from the first wave's start (0.1 ms buckets):");
 	for (int k = 0; k < 32; ++k)
 		if (c.stamp[10 + k])
-			std::fprintf(stderr, " %.2f:%llu", k * 0.05, c.stamp[10 + k]);
+			std::fprintf(stderr, " %.1f:%llu", k * 0.1, c.stamp[10 + k]);
 	std::fprintf(stderr, "\n   of the walks: node loop %.3f ms in %llu entries, batches %.3f ms in %llu batches, %llu leaf stops\n",
 	             c.stamp[42] * 1e-5, c.stamp[44], c.stamp[43] * 1e-5, c.stamp[45], c.stamp[46]);
 	std::fprintf(stderr, "   batched pairs %llu, of which the leaf's own box passes %llu\n", c.stamp[47], c.stamp[48]);
+	std::fprintf(stderr, "   jobs by duration (from 2^k us on):");
+	for (int k = 0; k < 14; ++k)
+		if (c.stamp[49 + k])
+			std::fprintf(stderr, " %d:%llu", 1 << k, c.stamp[49 + k]);
+	std::fprintf(stderr, "\n   packets in the exact form %llu, wave-time of the jobs holding them %.3f ms\n", c.stamp[63], c.stamp[64] * 1e-5);
 #endif
 	if (std::getenv("OCRT_PRINT_COST")) {  // debug knob: the tiles' AO cost classes (leaves the primary packet stopped at)
 		std::vector<uint32_t> th(tile_count);

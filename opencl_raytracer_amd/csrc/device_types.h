@@ -70,8 +70,8 @@ struct FrameCounters {
 	uint32_t primary_hits;        // hit sub-pixels
 	uint32_t pad;
 	unsigned long long occluded;  // occluded AO rays
-#ifdef OCRT_STAMPS
-	unsigned long long stamp[10 + 32 + 7];  // debug build: wave-time (10 ns ticks) per phase of the AO pass, jobs, packets
+#if defined(OCRT_STAMPS) || defined(OCRT_TAIL)
+	unsigned long long stamp[10 + 32 + 7 + 16];  // debug build: wave-time (10 ns ticks) per phase of the AO pass, jobs, packets
 #endif
 };
 
@@ -117,8 +117,8 @@ struct KernelParams {
 	uint32_t cost_shift;    // ordering key of a block of 64 tiles = 1 + (sum of its tiles' cost classes >> cost_shift)
 	uint32_t ao_claim_max;  // most (tile, direction) units one wave's share of a claim holds; 0 = ao_kernel's rule (a quarter of a tile, or a whole tile)
 	uint32_t ao_claim_div;  // (set by launch_ao: the waves per XCD group)
-	uint32_t ao_guide;      // an AO claim takes 1/ao_guide of the (tile, direction) units left in its queue; the host
-	                        // sets the factor (1, debug knob OCRT_AO_GUIDE), launch_ao multiplies it by the waves per XCD group
+	uint32_t ao_guide;      // 0 (default): AO claims never shrink; n > 0 (debug knob OCRT_AO_GUIDE): a claim takes
+	                        // 1/ao_guide of the (tile, direction) units left in its queue, launch_ao multiplies n by the waves per XCD group
 	uint32_t tiles_x;      // tiles per image row
 	uint32_t local_tile_rows;  // tile rows this rank owns
 	Partition part;

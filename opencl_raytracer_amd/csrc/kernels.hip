@@ -1195,6 +1195,9 @@ __global__ __launch_bounds__(1024) void order_kernel(const uint32_t *__restrict_
 		counters->queue[group].work_tiles = running;
 		counters->queue[group].cost_sum = cost_total;
 		counters->queue[group].head = 0u;
+#ifdef OCRT_TAIL  // (the AO pass starts right after this kernel: its waves' end times are counted from here)
+		atomicMax(&counters->stamp[7], __builtin_amdgcn_s_memrealtime());
+#endif
 	}
 	__syncthreads();
 	for (uint32_t block = wave; block < n_blocks; block += 16u) {
@@ -1319,14 +1322,15 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 			// atomic), and its four waves take consecutive quarters of the claim: they then work on the same tile,
 			// or on neighbouring ones, at the same time, and share its nodes in the CU's scalar cache (63 % of the
 			// scalar loads of the per-wave claims missed it, profiles/r02_notes.md) and its hit records in L2.
-			// Guided self-scheduling: a wave's share is 1/ao_guide of what is left (ao_guide = the waves of a
-			// group), at most claim_max -- several directions of a tile while there is plenty, so the per-tile
-			// set-up is amortised; single directions at the end, so the frame does not wait for a long last job.
+			// A wave's share is claim_max units to the end of the queue.  (Guided self-scheduling -- the share
+			// shrinking to 1/ao_guide of what is left per wave of the group -- is kept behind OCRT_AO_GUIDE: the
+			// single directions it hands out at the end cost a claim each, two barriers and a tile set-up, and
+			// lengthened the pass by 3-5 %; the costly tiles are claimed first anyway, order_kernel.)
 			if (wave == 0u && fresh_lane() == 0u) {
 				const uint32_t seen = __hip_atomic_load(&counters->queue[group].head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				uint32_t per_wave = 0u, first = units;
 				if (seen < units) {
-					per_wave = (units - seen) / P.ao_guide;
+					per_wave = P.ao_guide ? (units - seen) / P.ao_guide : claim_max;
 					per_wave = per_wave < 1u ? 1u : per_wave > claim_max ? claim_max : per_wave;
 					first = atomicAdd(&counters->queue[group].head, per_wave * AO_WAVES);
 				}
@@ -1514,6 +1518,9 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 					// shared walks (see shared_box) of 64 consecutive rays of the job at a time; a lane
 					// leaves at its first accepted triangle
 					const bool scene_fast = P.fast_walk && P.ao_regular && P.walk_scale > 0.0f;
+#ifdef OCRT_STAMPS
+					uint32_t job_exact = 0u;
+#endif
 					for (uint32_t base = 0u; base < total; base += 64u) {
 						const uint32_t lane = fresh_lane();
 						bool alive = base + lane < total;
@@ -1525,6 +1532,9 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 						if (alive)
 							setup_ray(base + lane, whole, shared_dir);
 						const bool exact = !scene_fast || wave_ballot(alive && !ray_is_selectable(ray, P.origin_limit)) != 0ull;
+#ifdef OCRT_STAMPS
+						job_exact += exact ? 1u : 0u;
+#endif
 						if (exact)
 							shared_walk_any_hit<true>(nodes_ptr, walk_ptr, tris_ptr, scene.tris, count, ray, sh.frame, h,
 							                          P.ao_max_distance, P.ao_below, P.walk_scale, alive, &sh.occluded[h], sh.batch,
@@ -1534,6 +1544,12 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 							                           P.ao_max_distance, P.ao_below, P.walk_scale, alive, &sh.occluded[h], sh.batch,
 							                           P.batch_below, walk_prof);
 					}
+#ifdef OCRT_STAMPS
+					if (fresh_lane() == 0u && job_exact) {
+						atomicAdd(&counters->stamp[63], (unsigned long long) job_exact);  // packets that took the exact form
+						atomicAdd(&counters->stamp[64], (__builtin_amdgcn_s_memrealtime() - t_frames));  // ... and the time of the jobs holding them
+					}
+#endif
 				}
 				wave_lds_sync();
 				OCRT_STAMP(t_walked);
@@ -1553,9 +1569,25 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 				wave_lds_sync();
 				OCRT_STAMP(t_flushed);
 				OCRT_STAMP_ADD(3, t_flushed - t_walked);
+#ifdef OCRT_STAMPS
+				if (fresh_lane() == 0u) {  // jobs by duration: bucket k holds those of 2^k .. 2^(k+1) microseconds
+					const unsigned long long us = (t_flushed - t_job) / 100ull;
+					const int bucket = us == 0ull ? 0 : 63 - __builtin_clzll(us);
+					atomicAdd(&counters->stamp[49 + (bucket > 15 ? 15 : bucket)], 1ull);
+				}
+#endif
 			}
 		}
 	}
+#ifdef OCRT_TAIL  // minimal: nothing is kept across the pass, one load and two atomics when the wave ends
+	if (fresh_lane() == 0u) {
+		const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
+		const unsigned long long origin = __hip_atomic_load(&counters->stamp[7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const unsigned long long end_bucket = (t_end - origin) / 5000ull;  // 0.05 ms
+		atomicAdd(&counters->stamp[10 + (end_bucket > 31 ? 31 : end_bucket)], 1ull);
+		atomicMax(&counters->stamp[8], t_end);
+	}
+#endif
 #ifdef OCRT_STAMPS
 	if (fresh_lane() == 0u) {
 		const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
@@ -1568,8 +1600,12 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 			atomicAdd(&counters->stamp[9], 1ull);                    // waves that got any work
 		for (int k = 0; k < 7; ++k)
 			atomicAdd(&counters->stamp[42 + k], walk_prof_store[k]);  // time in the node loop, in batches; loop entries, batches, leaf stops
-		const unsigned long long idle_bucket = (t_end - t_last_claim) / 5000ull;  // last claim -> end, 0.05 ms buckets
-		atomicAdd(&counters->stamp[10 + (idle_bucket > 31 ? 31 : idle_bucket)], 1ull);
+		// when this wave ended, counted from the first wave's start (settled long before any wave ends), 0.1 ms buckets:
+		// how the occupancy decays towards the end of the launch
+		(void) t_last_claim;
+		const unsigned long long first = __hip_atomic_load(&counters->stamp[7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const unsigned long long end_bucket = (t_end - (first < t_begin ? first : t_begin)) / 10000ull;
+		atomicAdd(&counters->stamp[10 + (end_bucket > 31 ? 31 : end_bucket)], 1ull);
 	}
 #endif
 }

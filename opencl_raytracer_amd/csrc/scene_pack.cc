@@ -362,7 +362,7 @@ KernelParams make_kernel_params(const RayTracer &rt, uint32_t node_count, uint32
 	p.refill_min = refill_min ? (uint32_t) std::atoi(refill_min) : 16u;
 	p.leaf_min = leaf_min ? (uint32_t) std::atoi(leaf_min) : 16u;
 	const char *guide = std::getenv("OCRT_AO_GUIDE");  // debug knob
-	p.ao_guide = guide && std::atoi(guide) > 0 ? (uint32_t) std::atoi(guide) : 1u;
+	p.ao_guide = guide && std::atoi(guide) > 0 ? (uint32_t) std::atoi(guide) : 0u;  // (0: claims never shrink, the default)
 	const char *claim_max = std::getenv("OCRT_AO_CLAIM_MAX");  // debug knob
 	p.ao_claim_max = claim_max && std::atoi(claim_max) > 0 ? (uint32_t) std::atoi(claim_max) : 0u;
 	p.ao_claim_div = 1u;

@@ -158,6 +158,26 @@ int main(int argc, char **argv) {
 			}
 		}
 		packets += ND; root_visits += rv;
+		if (getenv("DUMP_TILES")) {
+			// cost class as primary_kernel computes it: leaves the tile's shared primary walk stopped at
+			R pr[64];
+			for (int l = 0; l < 64; ++l) {
+				const int x = tx * 8 + (l & 7), y = ty * 8 + (l >> 3);
+				R &r = pr[l]; r.o[0] = 0; r.o[1] = 0; r.o[2] = 2; r.live = true;
+				float d[3] = { (x + 0.5f) / a - W / (2.0f * a), -((y + 0.5f) / a - H / (2.0f * a)), -1.0f };
+				float len = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+				for (int k = 0; k < 3; ++k) { r.d[k] = d[k] / len; r.inv[k] = 1.0f / r.d[k]; }
+			}
+			int leaf_stops = 0, node_tests = 0, leaf_pairs = 0;
+			for (size_t i = 0; i < N;) {
+				int hits = 0;
+				++node_tests;
+				for (int l = 0; l < 64; ++l) hits += slab(P.nodes[i], pr[l], 100000.0f);
+				if (hits) { if (P.nodes[i].skip == 1) { ++leaf_stops; leaf_pairs += hits; } ++i; } else i += P.nodes[i].skip;
+			}
+#pragma omp critical
+			printf("TILE %d %d hits %d class %d ao_node_tests %llu prim_nodes %d prim_pairs %d\n", tx, ty, nh, leaf_stops, rv, node_tests, leaf_pairs);
+		}
 #pragma omp critical
 		for (int b = 0; b < 5; ++b) { entry_visits[b] += ev[b]; entry_tests[b] += tests[b]; entry_count[b] += lists[b].size(); }
 	}
