@@ -196,6 +196,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--in-flight", type=int, default=3, choices=[1, 2, 3, 4],
+                    help="renderers per GPU taking the frames alternately (1: one frame at a time)")
     args = ap.parse_args()
 
     launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ  # under torch.distributed.run
@@ -245,43 +247,69 @@ def main():
     scene = rt.Scene.load_off(mesh_path(w["mesh"])).build_bvh(opt.bvh_method)
     t_scene = time.perf_counter() - t0
 
-    host = rt.Host(opt, device_index, rank, world)
-    host.upload_scene(scene)
-    # One explicit torch stream carries the kernels, the resize and (through
-    # torch.distributed's stream sync) the gather, so they are ordered.
+    # Several renderers of the same scene on this GPU, each on its own stream, take the frames in turn: while frame i's
+    # ambient-occlusion pass runs out (its last quarter runs at falling occupancy: the queues are drained, the
+    # workgroups end one by one) the next frames' passes fill the wave slots it frees, and the latency-bound primary
+    # pass runs beside a vector-issue-bound one.  Headline workload: 1.56 ms per frame with one renderer, 1.35 with
+    # two, 1.27 with three (default), 1.27 with four.  One frame at a time: --in-flight 1.
+    hosts = [rt.Host(opt, device_index, rank, world) for _ in range(max(1, args.in_flight))]
+    for h in hosts:
+        h.upload_scene(scene)
+    # (each host's own stream, created by the library: streams handed out by torch's pool ended up on ONE hardware
+    # queue here -- rocprofv3's kernel trace showed every kernel of both renderers in the same queue, one after the other)
+    render_streams = [torch.cuda.ExternalStream(h.stream_handle, device=device) for h in hosts]
+    host = hosts[0]
+    # The gather and the assembly of the final image run on a third stream (torch.distributed syncs with the current one).
     stream = torch.cuda.Stream(device)
     torch.cuda.set_stream(stream)
-    host.set_stream(stream.cuda_stream)
 
     # band buffers: equal-sized on every rank so the gather is one collective
     from opencl_raytracer_amd.multi_gpu import BandGatherer, BandLayout
 
     layout = BandLayout(opt, world)
     assert layout.local_rows(rank) == host.local_rows
-    # Two band buffers and two gatherers: frame i's bands are on the wire (RCCL's own stream) while frame i + 1 is
-    # rendered; a frame is finished -- gather waited for, rows moved into place on rank 0 -- right after the next one
-    # has been enqueued, and the last one before the closing fence, so K timed steps are K complete frames.
-    bands = [torch.zeros((layout.max_rows, opt.width), dtype=torch.uint8, device=device) for _ in range(2)]
+    # One band buffer and one gatherer per renderer: frame i's bands are gathered (RCCL's own stream) and its rows moved
+    # into place on rank 0 while frame i + 1 is rendered -- a frame is finished right after the next one has been
+    # enqueued, and the last one before the closing fence, so K timed steps are K complete frames.
+    slots = len(hosts) if len(hosts) > 1 else 2
+    bands = [torch.zeros((layout.max_rows, opt.width), dtype=torch.uint8, device=device) for _ in range(slots)]
     staged = launched and backend != "nccl"  # rehearsal path: the gather is staged through host memory
-    gatherers = [BandGatherer(layout, rank, "cpu" if staged else device) for _ in range(2)]
-    result = {"frames": 0, "open": None}
+    gatherers = [BandGatherer(layout, rank, "cpu" if staged else device) for _ in range(slots)]
+    released = [None] * slots  # event: the slot's band and gatherer were last read (its frame was assembled)
+    result = {"frames": 0}
+    open_frames = []  # slots of the frames enqueued and not yet finished, oldest first
 
-    def finish_open():
-        if result["open"] is not None:
-            result["final"] = gatherers[result["open"]].finish()
-            result["open"] = None
+    def finish_oldest():
+        k = open_frames.pop(0)
+        h, rs = hosts[k % len(hosts)], render_streams[k % len(hosts)]
+        if len(hosts) > 1:
+            # The CPU waits for the frame (the next ones are already queued on the other renderers' streams), and only
+            # then issues its gather: a stream-level wait for a frame that has just begun would sit in a hardware
+            # queue as a barrier packet, and HIP streams share hardware queues -- with the collective's stream in
+            # play such a barrier ended up ahead of another renderer's kernels and the frames ran one after the other.
+            h.sync()
+        else:
+            stream.wait_stream(rs)
+        gatherers[k].start(bands[k].cpu() if staged else bands[k])
+        result["final"] = gatherers[k].finish()
+        released[k] = torch.cuda.Event()
+        released[k].record(stream)
 
     def step():
-        k = result["frames"] & 1
-        host.render_async()
-        host.resize_into_device(bands[k].data_ptr())
-        gatherers[k].start(bands[k].cpu() if staged else bands[k])
-        finish_open()  # the frame before this one
-        result["open"] = k
+        k = result["frames"] % slots
+        h, rs = hosts[k % len(hosts)], render_streams[k % len(hosts)]
+        if released[k] is not None:  # the frame that used this band buffer before has been assembled
+            released[k].synchronize() if len(hosts) > 1 else rs.wait_event(released[k])
+        h.render_async()
+        h.resize_into_device(bands[k].data_ptr())
+        open_frames.append(k)
         result["frames"] += 1
+        while len(open_frames) > max(1, len(hosts) - 1):  # the oldest frame -- the newer ones are queued behind it
+            finish_oldest()
 
     def fence():
-        finish_open()
+        while open_frames:
+            finish_oldest()
         torch.cuda.synchronize(device)
         if launched:
             dist.barrier()
@@ -290,20 +318,23 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    host.sync()
-    host.reset_timers()
+    for h in hosts:
+        h.sync()
+        h.reset_timers()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    host.sync()  # folds the HIP event pairs into the kernel-time statistics
+    for h in hosts:
+        h.sync()  # folds the HIP event pairs into the kernel-time statistics
 
     # whole-job numbers: max time over ranks, sum of rays over ranks
     st = host.stats()
     my_rays = st["primary_rays"] + st["ao_rays"]
-    kernel_ms = host.total_kernel_ms / max(1, host.kernel_launches)
-    ao_ms = host.total_ao_ms / max(1, host.kernel_launches)  # HIP events right around the ao_kernel launch
+    launches = max(1, sum(h.kernel_launches for h in hosts))
+    kernel_ms = sum(h.total_kernel_ms for h in hosts) / launches
+    ao_ms = sum(h.total_ao_ms for h in hosts) / launches  # HIP events right around the ao_kernel launch
     if launched:
         t = torch.tensor([elapsed, kernel_ms, ao_ms], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -343,7 +374,7 @@ def main():
                     + ", fixed camera, no randomness in this path",
             "config": {"workload": w["label"], "rays_per_frame": total_rays, "primary_hits": total_hits,
                        "parallelism": f"image bands x{world}" + (f", {'RCCL' if backend == 'nccl' else backend} gather to rank 0" if launched else ""),
-                       "pgm_md5": pgm_md5, "pgm_matches_golden": golden_md5 is not None,
+                       "frames_in_flight": len(hosts), "pgm_md5": pgm_md5, "pgm_matches_golden": golden_md5 is not None,
                        "scene_build_s": round(t_scene, 3), "device": torch.cuda.get_device_name(device)},
         }
         cpu = None
@@ -394,13 +425,23 @@ def main():
                                                    (pmc["gui_active_cycles"] / 8.0), 4)
         else:
             roof["counters_from"] = None if world > 1 else "profiles/pmc.json is missing or was collected for other kernel sources"
+        # With several frames in flight a launch shares the device with its neighbours' and takes longer than alone;
+        # what the device does per unit of time is the frame's vector instructions over the time per frame.
+        if pmc is not None and pmc.get("frame_valu_insts"):
+            frame_rate = pmc["frame_valu_insts"] / (ms_per_step * 1e-3 * CLOCK_HZ * SIMDS)
+            roof["frame"] = {"valu_insts_per_frame": int(pmc["frame_valu_insts"]), "ms_per_frame": round(ms_per_step, 4),
+                             "achieved": round(frame_rate, 4), "frac": round(frame_rate / VALU_PEAK_PER_CLK_SIMD, 4),
+                             "frac_of_measured_ceiling": round(frame_rate / pmc["valu_ceiling_measured"], 4)
+                             if pmc.get("valu_ceiling_measured") else None,
+                             "frames_in_flight": len(hosts)}
         roof["hbm"] = hbm
         out["roofline"] = roof
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
 
-    host.close()
+    for h in hosts:
+        h.close()
     if launched:
         dist.destroy_process_group()
 

@@ -139,6 +139,11 @@ int rt_resize_into_device(rt_host *h, void *device_u8);
  * stream) / return to the host's private non-blocking stream. */
 int rt_set_stream(rt_host *h, void *hip_stream);
 int rt_use_private_stream(rt_host *h);
+/* The hipStream_t this host's work is enqueued on right now (its private stream unless rt_set_stream replaced it),
+ * for callers that order their own streams against it with events -- e.g. two hosts of the same scene on one GPU
+ * taking frames alternately, so that one frame's last workgroups and the next frame's first share the device
+ * (bench.py).  No counterpart in the reference: its queue is private to OpenCLHost (include/opencl_host.h:129). */
+int rt_get_stream(rt_host *h, void **hip_stream);
 
 /* Ray counts of the last frame and HIP-event timing of the ray-casting passes
  * on the launch stream (last frame, running total in ms and number of frames

@@ -118,6 +118,7 @@ _SIGNATURES = {
     "rt_resize_into_device": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rt_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rt_use_private_stream": (C.c_int, [C.c_void_p]),
+    "rt_get_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "rt_get_stats": (C.c_int, [C.c_void_p, C.POINTER(_Stats)]),
     "rt_last_kernel_ms": (C.c_float, [C.c_void_p]),
     "rt_total_kernel_ms": (C.c_double, [C.c_void_p]),
@@ -336,6 +337,13 @@ class Host:
 
     def use_private_stream(self) -> None:
         _check(load_library().rt_use_private_stream(self._h))
+
+    @property
+    def stream_handle(self) -> int:
+        """The hipStream_t (as an integer) this host enqueues on."""
+        p = C.c_void_p()
+        _check(load_library().rt_get_stream(self._h, C.byref(p)))
+        return int(p.value or 0)
 
     def stats(self) -> dict:
         s = _Stats()

@@ -297,6 +297,13 @@ int rt_set_stream(rt_host *h, void *hip_stream) {
 	return guarded([&] { h->dev->setStream(hip_stream); });
 }
 
+int rt_get_stream(rt_host *h, void **hip_stream) {
+	if (!h || !hip_stream)
+		return fail(RT_E_INVALID, "null argument");
+	*hip_stream = h->dev->streamHandle();
+	return RT_OK;
+}
+
 int rt_use_private_stream(rt_host *h) {
 	if (!h)
 		return fail(RT_E_INVALID, "null host");

@@ -1,5 +1,7 @@
 #include "device_renderer.h"
 
+#include <atomic>
+
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -94,8 +96,18 @@ DeviceRenderer::DeviceRenderer(const RayTracer::Options &options, int device_, u
 	tile_count = (size_t) kp.tiles_x * kp.local_tile_rows;
 
 	useDevice();
+	// The renderers of a process take the lowest and the highest stream priority in turn.  HIP maps streams onto a
+	// few hardware queues per priority class, and a hardware queue runs its packets in order: two renderers of one
+	// scene that take frames alternately (bench.py, so that the last workgroups of one frame's ambient-occlusion pass
+	// and the first of the next frame's primary pass share the device) must not land in the same queue -- which is
+	// what happened with equal priorities once torch.distributed had created its streams (rocprofv3 --kernel-trace:
+	// every kernel of both renderers in one queue, one after the other).  Different classes never share a queue.
+	static std::atomic<unsigned> renderers_created{ 0 };
+	int least = 0, greatest = 0;
+	OCRT_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+	const bool odd = (renderers_created.fetch_add(1) & 1u) != 0u;
 	hipStream_t s;
-	OCRT_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+	OCRT_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, odd ? greatest : least));
 	own_stream = stream = s;
 	// Float image and uint8 buffer both hold this rank's bands only, back to back
 	// (whole tile rows, so the last band may run past the image's height).

@@ -381,3 +381,25 @@ def test_scheduling_knobs_do_not_change_the_image(rt, golden, scene_for, knobs, 
         assert host.stats()["ao_occluded"] == case["counters"]["ao_occluded"]
         host.close()
 
+
+
+def test_three_renderers_in_flight_give_the_golden_frames(rt, golden, scene_for):
+    """bench.py keeps three renderers of one scene busy on one GPU, frames enqueued in turn on their own streams
+    (different stream priorities: different hardware queues) and collected later: every frame must still be the golden one,
+    and the streams the hosts report must be three different ones."""
+    c = golden["renders"]["bunny_1080p_s1_a3"]
+    opt = options_for(rt, c)
+    scene, _ = scene_for(c["mesh"], c["bvh"])
+    hosts = [rt.Host(opt, 0) for _ in range(3)]
+    for h in hosts:
+        h.upload_scene(scene)
+    assert len({h.stream_handle for h in hosts}) == 3 and all(h.stream_handle for h in hosts)
+    for frame in range(9):  # nine frames in turn, nobody waits in between
+        hosts[frame % 3].render_async()
+    for h in hosts:
+        h.sync()
+        assert hashlib.md5(rt.pgm_bytes(h.download_u8())).hexdigest() == c["pgm_md5"]
+        assert hashlib.sha256(h.download().tobytes()).hexdigest() == c["float_sha256"]
+        st = h.stats()
+        assert st["primary_hits"] == c["counters"]["primary_hits"] and st["ao_occluded"] == c["counters"]["ao_occluded"]
+        h.close()

@@ -47,6 +47,8 @@ def main():
         entry = {
             "kernel": names[0],
             "valu_insts": c.get("SQ_INSTS_VALU"), "salu_insts": c.get("SQ_INSTS_SALU"), "smem_insts": c.get("SQ_INSTS_SMEM"),
+            # every kernel of a frame together (primary, order, ao, resolve; the resize is not part of prof_run's frames)
+            "frame_valu_insts": sum(k.get("SQ_INSTS_VALU", 0.0) for name, k in kernels.items() if "ocrt::" in name),
             "vmem_rd_insts": c.get("SQ_INSTS_VMEM_RD"), "lds_insts": c.get("SQ_INSTS_LDS"), "branch_insts": c.get("SQ_INSTS_BRANCH"),
             "waves": c.get("SQ_WAVES"), "wave_quad_cycles": c.get("SQ_WAVE_CYCLES"), "busy_cycles": c.get("SQ_BUSY_CYCLES"),
             "wait_any_quad_cycles": c.get("SQ_WAIT_ANY"), "wait_inst_any_quad_cycles": c.get("SQ_WAIT_INST_ANY"),
