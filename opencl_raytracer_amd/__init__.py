@@ -8,6 +8,7 @@ if the shared library is missing, importing :mod:`opencl_raytracer_amd.api`
 raises.
 """
 from .api import (  # noqa: F401
+    FrameRing,
     Host,
     Options,
     RtError,

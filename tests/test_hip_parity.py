@@ -385,21 +385,28 @@ def test_scheduling_knobs_do_not_change_the_image(rt, golden, scene_for, knobs, 
 
 def test_three_renderers_in_flight_give_the_golden_frames(rt, golden, scene_for):
     """bench.py keeps three renderers of one scene busy on one GPU, frames enqueued in turn on their own streams
-    (different stream priorities: different hardware queues) and collected later: every frame must still be the golden one,
-    and the streams the hosts report must be three different ones."""
+    (different stream priorities: different hardware queues) and collected later -- rt.FrameRing is that as a class:
+    every frame must still be the golden one, and the streams the hosts report must be three different ones."""
     c = golden["renders"]["bunny_1080p_s1_a3"]
     opt = options_for(rt, c)
     scene, _ = scene_for(c["mesh"], c["bvh"])
-    hosts = [rt.Host(opt, 0) for _ in range(3)]
-    for h in hosts:
-        h.upload_scene(scene)
-    assert len({h.stream_handle for h in hosts}) == 3 and all(h.stream_handle for h in hosts)
-    for frame in range(9):  # nine frames in turn, nobody waits in between
-        hosts[frame % 3].render_async()
-    for h in hosts:
-        h.sync()
-        assert hashlib.md5(rt.pgm_bytes(h.download_u8())).hexdigest() == c["pgm_md5"]
+    ring = rt.FrameRing(opt, scene, hosts=3)
+    assert len({h.stream_handle for h in ring.hosts}) == 3 and all(h.stream_handle for h in ring.hosts)
+    frames = []
+    for frame in range(9):  # three in flight at any time from the third on
+        if frame >= 3:
+            frames.append(ring.collect())
+        ring.submit()
+    with pytest.raises(RuntimeError):
+        ring.submit()
+    while len(frames) < 9:
+        frames.append(ring.collect())
+    with pytest.raises(RuntimeError):
+        ring.collect()
+    for u8 in frames:
+        assert hashlib.md5(rt.pgm_bytes(u8)).hexdigest() == c["pgm_md5"]
+    for h in ring.hosts:
         assert hashlib.sha256(h.download().tobytes()).hexdigest() == c["float_sha256"]
         st = h.stats()
         assert st["primary_hits"] == c["counters"]["primary_hits"] and st["ao_occluded"] == c["counters"]["ao_occluded"]
-        h.close()
+    ring.close()

@@ -14,4 +14,6 @@ cd $R
 for W in $WORKLOADS; do
   python3 bench.py --steps 20 --warmup 5 --workload $W $( [ $W = bunny_1080p_ao ] || echo --no-cpu-baseline ) 2>/dev/null | tail -1 > $OUT/bench_$W.json
   echo "$W: $(cut -c1-160 $OUT/bench_$W.json)"
+  # ... and one frame at a time (one renderer per GPU), for the kernels' own durations
+  python3 bench.py --steps 20 --warmup 5 --workload $W --no-cpu-baseline --in-flight 1 2>/dev/null | tail -1 > $OUT/bench_${W}__one_at_a_time.json
 done

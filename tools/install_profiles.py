@@ -31,7 +31,7 @@ def main():
         r = b["roofline"]
         print(f"{w:22s} {b['value']:9.1f} Mrays/s  {b['ms_per_step']:8.4f} ms/step  kernel {r['kernel_ms']:8.4f} ms  VALU {r['achieved']} "
               f"(frac {r['frac']}, of measured ceiling {r.get('frac_of_measured_ceiling')}, nominal issue share {r.get('valu_nominal_issue_share')})  "
-              f"HBM {r['hbm'].get('measured_frac')}")
+              f"HBM {r['hbm'].get('measured_frac')}  frame {r.get('frame')}")
 
 
 if __name__ == "__main__":
