@@ -196,8 +196,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=3, choices=[1, 2, 3, 4],
-                    help="renderers per GPU taking the frames alternately (1: one frame at a time)")
+    ap.add_argument("--in-flight", type=int, default=0, choices=[0, 1, 2, 3, 4, 5, 6],
+                    help="renderers per GPU taking the frames in turn (1: one frame at a time; 0 = by the number of "
+                         "ranks: 3 up to two GPUs, 4 at four, 6 at eight)")
     args = ap.parse_args()
 
     launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ  # under torch.distributed.run
@@ -252,7 +253,11 @@ def main():
     # workgroups end one by one) the next frames' passes fill the wave slots it frees, and the latency-bound primary
     # pass runs beside a vector-issue-bound one.  Headline workload: 1.56 ms per frame with one renderer, 1.35 with
     # two, 1.27 with three (default), 1.27 with four.  One frame at a time: --in-flight 1.
-    hosts = [rt.Host(opt, device_index, rank, world) for _ in range(max(1, args.in_flight))]
+    # The smaller a rank's share of the frame, the more of it is start and end of passes: one GPU's eighth of the
+    # headline frame takes 0.48 ms with one renderer, 0.31 with three, 0.29 with four, 0.25 with six; the whole frame
+    # 1.53 / 1.23 / 1.20 / 1.25 (tools/ring_sweep.py).  A step costs the CPU ~0.1 ms (tools/step_overhead_probe.py).
+    in_flight = args.in_flight if args.in_flight > 0 else 3 if world <= 2 else 4 if world <= 4 else 6
+    hosts = [rt.Host(opt, device_index, rank, world) for _ in range(in_flight)]
     for h in hosts:
         h.upload_scene(scene)
     # (each host's own stream, created by the library: streams handed out by torch's pool ended up on ONE hardware
