@@ -260,6 +260,7 @@ def main():
     hosts = [rt.Host(opt, device_index, rank, world) for _ in range(in_flight)]
     for h in hosts:
         h.upload_scene(scene)
+        h.set_device_share(len(hosts))
     # (each host's own stream, created by the library: streams handed out by torch's pool ended up on ONE hardware
     # queue here -- rocprofv3's kernel trace showed every kernel of both renderers in the same queue, one after the other)
     render_streams = [torch.cuda.ExternalStream(h.stream_handle, device=device) for h in hosts]

@@ -144,6 +144,9 @@ int rt_use_private_stream(rt_host *h);
  * taking frames alternately, so that one frame's last workgroups and the next frame's first share the device
  * (bench.py).  No counterpart in the reference: its queue is private to OpenCLHost (include/opencl_host.h:129). */
 int rt_get_stream(rt_host *h, void **hip_stream);
+/* Tell a host that `hosts` of them (it included) take frames in turn on its GPU: its persistent ambient-occlusion pass
+ * then leaves part of the chip to the other frames' passes instead of filling it (1, the default: alone). */
+int rt_set_device_share(rt_host *h, unsigned int hosts);
 
 /* Ray counts of the last frame and HIP-event timing of the ray-casting passes
  * on the launch stream (last frame, running total in ms and number of frames

@@ -119,6 +119,7 @@ _SIGNATURES = {
     "rt_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rt_use_private_stream": (C.c_int, [C.c_void_p]),
     "rt_get_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "rt_set_device_share": (C.c_int, [C.c_void_p, C.c_uint]),
     "rt_get_stats": (C.c_int, [C.c_void_p, C.POINTER(_Stats)]),
     "rt_last_kernel_ms": (C.c_float, [C.c_void_p]),
     "rt_total_kernel_ms": (C.c_double, [C.c_void_p]),
@@ -338,6 +339,10 @@ class Host:
     def use_private_stream(self) -> None:
         _check(load_library().rt_use_private_stream(self._h))
 
+    def set_device_share(self, hosts: int) -> None:
+        """`hosts` of them (this one included) take frames in turn on this GPU."""
+        _check(load_library().rt_set_device_share(self._h, int(hosts)))
+
     @property
     def stream_handle(self) -> int:
         """The hipStream_t (as an integer) this host enqueues on."""
@@ -388,6 +393,7 @@ class FrameRing:
         self.hosts = [Host(options, device, rank, nranks) for _ in range(hosts)]
         for h in self.hosts:
             h.upload_scene(scene)
+            h.set_device_share(hosts)
         self._next = 0
         self._open = []  # hosts with a frame in flight, oldest first
 

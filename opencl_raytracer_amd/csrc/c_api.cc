@@ -304,6 +304,13 @@ int rt_get_stream(rt_host *h, void **hip_stream) {
 	return RT_OK;
 }
 
+int rt_set_device_share(rt_host *h, unsigned int hosts) {
+	if (!h)
+		return fail(RT_E_INVALID, "null host");
+	h->dev->setDeviceShare(hosts);
+	return RT_OK;
+}
+
 int rt_use_private_stream(rt_host *h) {
 	if (!h)
 		return fail(RT_E_INVALID, "null host");

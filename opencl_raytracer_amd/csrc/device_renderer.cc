@@ -66,6 +66,7 @@ DeviceRenderer::DeviceRenderer(const RayTracer::Options &options, int device_, u
 	, image_bytes(0)
 	, tile_count(0)
 	, compute_units(0)
+	, device_share(1)
 	, scene_ready(false)
 	, frame_ready(false)
 	, last_ms(0)
@@ -252,7 +253,7 @@ void DeviceRenderer::enqueueRender() {
 	launch_primary(scene, (float *) d_image, d_hits, d_occluded, d_tile_hits, d_counters, kp, stream);
 	OCRT_HIP(hipGetLastError());
 	ev.ao_timed = kp.ao_mode != AO_NONE && kp.ao_dirs > 0 && tile_count > 0;
-	launch_ao(scene, (float *) d_image, d_hits, d_occluded, d_tile_hits, d_order, d_counters, kp, compute_units, stream,
+	launch_ao(scene, (float *) d_image, d_hits, d_occluded, d_tile_hits, d_order, d_counters, kp, aoWorkgroups(), stream,
 	          ev.ao_start, ev.ao_stop);
 	OCRT_HIP(hipGetLastError());
 	OCRT_HIP(hipEventRecord((hipEvent_t) ev.stop, s));

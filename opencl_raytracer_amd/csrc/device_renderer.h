@@ -47,6 +47,11 @@ class DeviceRenderer {
 		// enqueueResize() has completed; and the stream everything is enqueued on.
 		const void *deviceBands() const { return d_u8; }
 		void *streamHandle() const { return stream; }
+		// How many hosts take frames in turn on this GPU.  Alone, the persistent ambient-occlusion pass fills the chip
+		// (8 workgroups per CU); in company it leaves room -- 5.5 per CU -- so that the other frames' passes run beside
+		// it all the time and not only while it runs out (measured per workload: profiles/r02_notes.md).
+		void setDeviceShare(unsigned hosts) { device_share = hosts < 1u ? 1u : hosts; }
+		uint32_t aoWorkgroups() const { return device_share > 1u ? compute_units * 11u / 2u : compute_units * 8u; }
 		uint32_t globalRowOf(uint32_t local_row) const;  // output row of a local band row (may be >= height: padding)
 
 		void downloadFloat(float *host_image);          // full totalWidth x totalHeight (rows of other ranks' bands: 0)
@@ -90,6 +95,7 @@ class DeviceRenderer {
 		size_t image_bytes;  // float image of this rank's bands
 		size_t tile_count;
 		uint32_t compute_units;
+		uint32_t device_share;  // hosts that take frames in turn on this GPU (setDeviceShare), 1 = this one alone
 		bool scene_ready, frame_ready;
 		struct FrameEvents {
 			void *start, *ao_start, *ao_stop, *stop;  // frame begin, around the ao_kernel launch alone, frame end
@@ -105,7 +111,7 @@ class DeviceRenderer {
 void launch_primary(const SceneBuffers &scene, float *image, void *hits, void *occluded_of, void *tile_hits,
                     void *counters, const KernelParams &P, void *stream);
 void launch_ao(const SceneBuffers &scene, float *image, void *hits, void *occluded_of, void *tile_hits, void *order,
-               void *counters, const KernelParams &P, uint32_t compute_units, void *stream, void *event_before_ao,
+               void *counters, const KernelParams &P, uint32_t workgroups, void *stream, void *event_before_ao,
                void *event_after_ao);
 void launch_resize(const float *tmp, unsigned char *out, const KernelParams &P, uint32_t out_width, uint32_t n,
                    uint32_t local_out_rows, void *stream);

@@ -1242,8 +1242,7 @@ __device__ __forceinline__ float rng_float(Rng &v) { return 2.32830643653869629E
 // ---------------------------------------------------------------------------
 // Pass 2: ambient occlusion.  Persistent, independent waves; one tile at a time.
 // ---------------------------------------------------------------------------
-constexpr uint32_t AO_WAVES = AO_WORKGROUP_WAVES;
-constexpr uint32_t AO_BLOCKS_PER_CU = 8;
+constexpr uint32_t AO_WAVES = AO_WORKGROUP_WAVES;  // (workgroups per CU: DeviceRenderer::aoWorkgroups, 8 for a host alone)
 
 // LDS slice of one wave: the tile's hit table, structure of arrays and lane-major
 // so that consecutive hits sit in consecutive banks.
@@ -1683,7 +1682,7 @@ void launch_primary(const SceneBuffers &scene, float *image, void *hits, void *o
 }
 
 void launch_ao(const SceneBuffers &scene, float *image, void *hits, void *occluded_of, void *tile_hits, void *order,
-               void *counters, const KernelParams &params, uint32_t compute_units, void *stream, void *event_before_ao,
+               void *counters, const KernelParams &params, uint32_t workgroups, void *stream, void *event_before_ao,
                void *event_after_ao) {
 	if (params.tiles_x * params.local_tile_rows == 0 || params.ao_mode == AO_NONE || params.ao_dirs == 0)
 		return;
@@ -1693,7 +1692,7 @@ void launch_ao(const SceneBuffers &scene, float *image, void *hits, void *occlud
 	// persistent grid: what the chip holds, or one wave per (tile, direction) when the image is small
 	const uint32_t tiles = params.tiles_x * params.local_tile_rows;
 	const uint64_t units = (uint64_t) tiles * params.ao_dirs;
-	uint32_t ao_blocks = compute_units * AO_BLOCKS_PER_CU;
+	uint32_t ao_blocks = workgroups;  // (DeviceRenderer::aoWorkgroups: 8 per CU for a host alone on its GPU)
 	if (const char *env = getenv("OCRT_AO_BLOCKS"))  // debug knob
 		ao_blocks = (uint32_t) atoi(env);
 	if ((units + AO_WAVES - 1) / AO_WAVES < ao_blocks)
