@@ -431,15 +431,28 @@ def main():
                                                    (pmc["gui_active_cycles"] / 8.0), 4)
         else:
             roof["counters_from"] = None if world > 1 else "profiles/pmc.json is missing or was collected for other kernel sources"
-        # With several frames in flight a launch shares the device with its neighbours' and takes longer than alone;
-        # what the device does per unit of time is the frame's vector instructions over the time per frame.
+        # With several frames in flight a launch shares the device with its neighbours' and takes longer than alone
+        # (its event pair spans the time it waits for wave slots): the dominant kernel's instructions over ITS launch
+        # duration then say little about the kernel.  What the device does per unit of time is the vector
+        # instructions of a whole frame -- every kernel, counted by the same PMC pass -- over the measured time per
+        # frame; that is what `achieved` / `frac` hold in this case (`scope` says which), the per-launch figures of
+        # the timed region stay beside them under `launch`, and `--in-flight 1` gives the kernel alone.
+        roof["scope"] = "dominant kernel: its instructions per launch over its launch duration"
         if pmc is not None and pmc.get("frame_valu_insts"):
             frame_rate = pmc["frame_valu_insts"] / (ms_per_step * 1e-3 * CLOCK_HZ * SIMDS)
-            roof["frame"] = {"valu_insts_per_frame": int(pmc["frame_valu_insts"]), "ms_per_frame": round(ms_per_step, 4),
-                             "achieved": round(frame_rate, 4), "frac": round(frame_rate / VALU_PEAK_PER_CLK_SIMD, 4),
-                             "frac_of_measured_ceiling": round(frame_rate / pmc["valu_ceiling_measured"], 4)
-                             if pmc.get("valu_ceiling_measured") else None,
-                             "frames_in_flight": len(hosts)}
+            frame = {"valu_insts_per_frame": int(pmc["frame_valu_insts"]), "ms_per_frame": round(ms_per_step, 4),
+                     "achieved": round(frame_rate, 4), "frac": round(frame_rate / VALU_PEAK_PER_CLK_SIMD, 4),
+                     "frac_of_measured_ceiling": round(frame_rate / pmc["valu_ceiling_measured"], 4)
+                     if pmc.get("valu_ceiling_measured") else None,
+                     "frames_in_flight": len(hosts)}
+            roof["frame"] = frame
+            if len(hosts) > 1:
+                roof["launch"] = {"kernel": dominant, "kernel_ms_sharing_the_device": roof["kernel_ms"],
+                                  "achieved": roof["achieved"], "frac": roof["frac"],
+                                  "frac_of_measured_ceiling": roof.get("frac_of_measured_ceiling")}
+                roof.update(achieved=frame["achieved"], frac=frame["frac"],
+                            frac_of_measured_ceiling=frame["frac_of_measured_ceiling"],
+                            scope=f"frame: the vector instructions of all its kernels over the time per frame, {len(hosts)} frames in flight")
         roof["hbm"] = hbm
         out["roofline"] = roof
         if cpu is not None:

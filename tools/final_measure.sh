@@ -10,6 +10,7 @@ $R/tools/pmc_collect.sh $OUT/pmc $WORKLOADS > $R/$OUT/pmc.log 2>&1
 cp $R/$OUT/pmc/pmc.json $R/profiles/pmc.json
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/stats -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $R/$OUT/stats_bench.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/stats_one -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --in-flight 1 > $R/$OUT/stats_one_bench.log 2>&1
 cd $R
 for W in $WORKLOADS; do
   python3 bench.py --steps 20 --warmup 5 --workload $W $( [ $W = bunny_1080p_ao ] || echo --no-cpu-baseline ) 2>/dev/null | tail -1 > $OUT/bench_$W.json

@@ -22,6 +22,9 @@ def main():
     stats = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
     if stats:
         shutil.copy(stats[0], os.path.join(ROOT, "profiles", f"{prefix}_kernel_stats_bench_bunny_1080p_ao.csv"))
+    stats = glob.glob(os.path.join(src, "stats_one", "*", "*_kernel_stats.csv"))
+    if stats:
+        shutil.copy(stats[0], os.path.join(ROOT, "profiles", f"{prefix}_kernel_stats_bench_bunny_1080p_ao_one_at_a_time.csv"))
     lines = {}
     for path in sorted(glob.glob(os.path.join(src, "bench_*.json"))):
         lines[os.path.basename(path)[len("bench_"):-len(".json")]] = json.loads(open(path).read())
