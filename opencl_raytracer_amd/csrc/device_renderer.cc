@@ -200,6 +200,7 @@ size_t DeviceRenderer::upload(const PackedScene &scene) {
 	const bool ao_on = opts.enableAO && opts.aoNumSamples > 0;
 	const WalkArray walk = make_walk_array(scene, ao_on ? kernel_float(opts.aoMaxDistance) : 0.0f);
 	kp = make_kernel_params(rt, (uint32_t) scene.nodes.size(), (uint32_t) scene.tris.size(), ao_dirs, part, &scene, &walk);
+	kp.shared_device = device_share > 1u ? 1 : 0;
 	const size_t nodes_bytes = scene.nodes.size() * sizeof(NodeRec);
 	const size_t tris_bytes = scene.tris.size() * sizeof(TriRec);
 	const size_t shade_bytes = scene.shade.size() * sizeof(ShadeRec);

@@ -50,7 +50,10 @@ class DeviceRenderer {
 		// How many hosts take frames in turn on this GPU.  Alone, the persistent ambient-occlusion pass fills the chip
 		// (8 workgroups per CU); in company it leaves room -- 5.5 per CU -- so that the other frames' passes run beside
 		// it all the time and not only while it runs out (measured per workload: profiles/r02_notes.md).
-		void setDeviceShare(unsigned hosts) { device_share = hosts < 1u ? 1u : hosts; }
+		void setDeviceShare(unsigned hosts) {
+			device_share = hosts < 1u ? 1u : hosts;
+			kp.shared_device = device_share > 1u ? 1 : 0;
+		}
 		uint32_t aoWorkgroups() const { return device_share > 1u ? compute_units * 11u / 2u : compute_units * 8u; }
 		uint32_t globalRowOf(uint32_t local_row) const;  // output row of a local band row (may be >= height: padding)
 

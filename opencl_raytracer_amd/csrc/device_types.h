@@ -106,6 +106,7 @@ struct KernelParams {
 	int32_t shared_walk;   // sibling subtrees tile their parent's index range (any arity): one shared node index is safe
 	int32_t fast_walk;     // the padded walk array exists (regular, nested scene): the 6-FMA box test may be used
 	float origin_limit;    // ... for rays whose origin coordinates do not exceed this magnitude
+	int32_t shared_device;  // other hosts' frames run beside this one's (DeviceRenderer::setDeviceShare)
 	float walk_scale;      // ~ 1 / ao_max_distance: the ambient-occlusion rays' node test measures t in these units
 	                       // (kernels.hip, OCRT_TEST_COHERENT_SCALED); 0 = unusable, those rays take the exact form
 	float primary_below;   // largest float below the primary rays' max_distance (100000.0f)

@@ -1,0 +1,23 @@
+import os, sys, time
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import opencl_raytracer_amd as rt
+from bench import WORKLOADS, mesh_path, workload_options
+w = WORKLOADS[sys.argv[1]]
+n, hosts = int(sys.argv[2]), int(sys.argv[3])
+opt = workload_options(rt, w)
+scene = rt.Scene.load_off(mesh_path(w["mesh"])).build_bvh(opt.bvh_method)
+worst = 0.0
+for rank in range(min(n, 4)):
+    ring = rt.FrameRing(opt, scene, 0, rank, n, hosts=hosts)
+    for frames in (3 * hosts, 120):
+        t0 = time.perf_counter()
+        for f in range(frames):
+            if f >= hosts:
+                ring._open.pop(0).sync()
+            ring.submit()
+        while ring._open:
+            ring._open.pop(0).sync()
+        dt = (time.perf_counter() - t0) / frames * 1e3
+    worst = max(worst, dt)
+    ring.close()
+print(f"{sys.argv[1]} 1/{n} share, {hosts} hosts, {os.environ.get('OCRT_AO_CLAIM_MAX', 'rule')}: {worst:.3f} ms per frame", flush=True)
