@@ -90,7 +90,7 @@ int main(int argc, char **argv) {
 	const int ND = (int) table.size() / 4;
 	const float a = 1.0f * (W > H ? W : H);
 	const size_t budgets[5] = { 1, 2, 4, 8, 16 };
-	unsigned long long open_visits = 0;  // one entry, the walk runs on to the end of the array (no range check in the loop)
+	unsigned long long open_visits = 0, coherent_packets = 0;  // one entry, the walk runs on to the end of the array (no range check in the loop)
 	unsigned long long packets = 0, root_visits = 0, entry_visits[5] = { 0 }, entry_tests[5] = { 0 }, entry_count[5] = { 0 }, tiles = 0;
 #pragma omp parallel for schedule(dynamic, 1) reduction(+ : packets, root_visits, tiles, open_visits)
 	for (int ty = 0; ty < H / 8; ty += stride) for (int tx = 0; tx < W / 8; tx += stride) {
@@ -137,6 +137,12 @@ int main(int argc, char **argv) {
 				float l3 = sqrtf((bz[0] * bz[0] + bz[1] * bz[1]) + bz[2] * bz[2]); for (int k = 0; k < 3; ++k) bz[k] /= l3;
 				for (int k = 0; k < 3; ++k) { ar[l].o[k] = hp[l][k] + n[k] * 1e-5f; ar[l].d[k] = (bx[k] * table[4 * q] + n[k] * table[4 * q + 1]) + bz[k] * table[4 * q + 2]; ar[l].inv[k] = 1.0f / ar[l].d[k]; }
 			}
+			{  // sign coherence of the packet (kernels.hip, walk_variant): every ray agrees on every axis?
+				bool coherent = true;
+				for (int k = 0; k < 3; ++k) { int pos = 0; for (int l = 0; l < nh; ++l) pos += ar[l].inv[k] >= 0; coherent = coherent && (pos == 0 || pos == nh); }
+#pragma omp atomic
+				coherent_packets += coherent ? 1 : 0;
+			}
 			auto walk = [&](size_t from, size_t to, R *rays, int *live) {
 				unsigned long long v = 0;
 				for (size_t i = from; i < to && *live;) {
@@ -182,6 +188,7 @@ int main(int argc, char **argv) {
 		for (int b = 0; b < 5; ++b) { entry_visits[b] += ev[b]; entry_tests[b] += tests[b]; entry_count[b] += lists[b].size(); }
 	}
 	printf("%llu tiles with hits, %llu AO packets: %.1f node tests per packet from the root\n", tiles, packets, (double) root_visits / packets);
+	printf("  sign-coherent packets: %.1f %%\n", 100.0 * coherent_packets / packets);
 	printf("  one entry, walking on to the end of the array: %.1f node tests per packet (%.1f%%)\n", (double) open_visits / packets, 100.0 * open_visits / root_visits);
 	for (int b = 0; b < 5; ++b)
 		printf("  up to %2zu entries per tile (%.1f on average, found with %.1f box tests per tile): %.1f node tests per packet (%.1f%%)\n", budgets[b],
