@@ -52,6 +52,8 @@ def main():
         opt.ao_alpha_max = rng.choice([90, 90, 60])
         host = rt.Host(opt, 0)
         host.upload_scene(scene)
+        share = rng.choice([1, 1, 3, 6])  # (a host that is told it shares its GPU launches a smaller AO grid and keeps its claim size)
+        host.set_device_share(share)
         host.render()
         got = host.download()
         st = host.stats()
@@ -62,7 +64,7 @@ def main():
         if not (same and stats_ok):
             bad += 1
             print(f"MISMATCH case {case}: {name} bvh={bvh} {opt.width}x{opt.height} s{opt.n_super_samples} a{opt.ao_num_samples} "
-                  f"d{opt.ao_max_distance} f{opt.focal_length} knobs={knobs}: image {same}, stats {stats_ok}", flush=True)
+                  f"d{opt.ao_max_distance} f{opt.focal_length} knobs={knobs} share={share}: image {same}, stats {stats_ok}", flush=True)
         elif case % 20 == 0:
             print(f"case {case} ok", flush=True)
     print(f"{n_cases} cases, {bad} mismatches")
