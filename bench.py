@@ -192,8 +192,8 @@ def cpu_baseline(opt, scene, gpu_u8, w):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)  # (a quarter of a second of frames: the pipeline's fill and drain weigh 1-2 % at 50)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--in-flight", type=int, default=0, choices=[0, 1, 2, 3, 4, 5, 6],
