@@ -1,3 +1,8 @@
+"""Probe (GPU box): ms per frame of a 1/8, 1/4 and whole share of a frame with 1, 2, 3, 4 and 6 renderers taking frames in
+turn on the one GPU (rt.FrameRing) -- how many frames to keep in flight per GPU for a given number of ranks.
+
+    python3 tools/ring_sweep.py WORKLOAD
+"""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import opencl_raytracer_amd as rt

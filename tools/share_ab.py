@@ -1,3 +1,8 @@
+"""Probe (GPU box): ms per frame of one rank's share of a frame (rank 0..3 of `ranks`) with `hosts` renderers taking
+frames in turn on the one GPU (rt.FrameRing); reads OCRT_* knobs from the environment, for A/B runs.
+
+    python3 tools/share_ab.py WORKLOAD RANKS HOSTS
+"""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import opencl_raytracer_amd as rt
