@@ -54,6 +54,7 @@ typedef struct rt_stats {
 } rt_stats;
 
 typedef struct rt_host rt_host;   /* one render host = one OpenCLHost */
+typedef struct rt_ring rt_ring;   /* several render hosts of one scene on one GPU taking frames in turn */
 typedef struct rt_scene rt_scene; /* CPU-side mesh + BVH (the input producer) */
 
 const char *rt_last_error(void);
@@ -159,6 +160,78 @@ float rt_last_ao_ms(const rt_host *h);
 double rt_total_ao_ms(const rt_host *h);
 uint64_t rt_kernel_launches(const rt_host *h);
 void rt_reset_timers(rt_host *h);
+
+/* ---- frame ring: a steady stream of frames behind the same seam ------------------------------------------------
+ * The reference renders one blocking frame per OpenCLHost::operator()() (src/opencl_host.cc:137-149, called once by
+ * src/render.cc:109-111).  A ring is `hosts` render hosts of ONE scene on ONE GPU -- each with its own stream
+ * (consecutive hosts in different priority classes, hence different hardware queues) and its own captured hipGraph,
+ * so that a frame costs the CPU one graph launch -- that take frames in turn: the next frames' passes fill the wave
+ * slots a finishing ambient-occlusion pass frees.  A ring of ONE host is the reference's blocking frame.  With a
+ * communicator attached (rt_ring_attach_rccl) the ring also runs the one exchange step of a multi-GPU frame, the
+ * gather of the ranks' 8-bit bands on rank 0 and the assembly of the image there, behind the next frames.
+ * Every frame is complete: all ray passes + the device resize (RayTracer::resize, src/ray_tracer.cc:3-16). */
+rt_ring *rt_ring_create(const rt_options *o, int device, uint32_t rank, uint32_t nranks, uint32_t hosts);
+void rt_ring_destroy(rt_ring *r);
+/* OpenCLHost::upload (src/opencl_host.cc:120-136) for every host of the ring; same arguments as rt_upload. */
+int rt_ring_upload(rt_ring *r, const uint32_t *faces, uint32_t num_faces, const uint32_t *nodes, uint32_t num_nodes,
+                   const float *aabbs, const float *vertices, uint32_t num_vertices, const float *vnormals);
+int rt_ring_upload_scene(rt_ring *r, const rt_scene *s);
+uint32_t rt_ring_size(const rt_ring *r);        /* hosts */
+/* Band buffers: frame f is rendered by host f % size into buffer f % slots, slots = 2 * size, so that a frame's bands
+ * (and, with a communicator, its assembled image) stay untouched while the next `size` frames are submitted. */
+uint32_t rt_ring_slots(const rt_ring *r);
+uint32_t rt_ring_local_rows(const rt_ring *r);  /* output rows this rank owns (rt_local_rows) */
+uint32_t rt_ring_in_flight(const rt_ring *r);   /* frames submitted and not yet collected */
+/* Host `slot` of the ring as a BORROWED rt_host (statistics, timers, rt_download of its last frame): owned by the
+ * ring, rt_destroy on it is a no-op. */
+rt_host *rt_ring_host(rt_ring *r, uint32_t slot);
+/* 1 (default): a frame is one replay of the host's captured hipGraph; 0: the same launches one by one. */
+int rt_ring_set_graph_mode(rt_ring *r, int on);
+/* Band buffer `slot` (< rt_ring_slots) is caller-owned DEVICE memory from now on (rt_ring_local_rows * width bytes;
+ * NULL: the ring's own again), e.g. the send buffer of a caller-side collective. */
+int rt_ring_bind_output(rt_ring *r, uint32_t slot, void *device_u8);
+/* The non-blocking half of OpenCLHost::operator()(): enqueue the next frame on the next host; *frame (may be NULL)
+ * receives its number.  RT_E_STATE when every host already has a frame in flight. */
+int rt_ring_submit(rt_ring *r, uint64_t *frame);
+/* The blocking half: wait for the OLDEST frame in flight.  Out (each may be NULL): its number, its band buffer's slot,
+ * the device address of its bands (valid until frame + slots is submitted).  With a communicator attached its gather
+ * is enqueued. */
+int rt_ring_collect(rt_ring *r, uint64_t *frame, uint32_t *slot, const void **device_bands);
+/* rt_ring_collect + a device-to-device copy of the bands into caller memory (complete on return). */
+int rt_ring_collect_into_device(rt_ring *r, void *device_u8);
+/* One frame of a steady stream: submit, then collect until at most hosts - 1 frames are in flight (one host: none).
+ * rt_ring_run does `frames` such steps in one call; rt_ring_drain collects what is left and waits for the gathers. */
+int rt_ring_step(rt_ring *r);
+int rt_ring_run(rt_ring *r, uint32_t frames);
+int rt_ring_drain(rt_ring *r);
+/* The last collected frame on the device: its bands (= the image for nranks 1) without a communicator; with one, the
+ * assembled width x height image on rank 0 (waits for its gather) and NULL on the other ranks.  rt_ring_download_last
+ * copies width*height bytes to the host (OpenCLHost::download + RayTracer::resize, src/render.cc:114-123). */
+int rt_ring_last_image_device(rt_ring *r, const void **device_u8);
+int rt_ring_download_last(rt_ring *r, uint8_t *image);
+/* Time stamps of collected frames: ms from the last rt_ring_reset_clock to the frame's begin, the start and the end of
+ * its ambient-occlusion kernel, its end.  Begin and end are HIP events on the host's stream; the kernel's times are HIP
+ * events too for plain launches, and for graph replays -- whose event nodes cannot be timed -- the device's 100 MHz
+ * clock as the kernels stamped it into the frame's counters, read only after rt_ring_keep_frame_times(r, 1) (a small
+ * blocking copy per frame; 0 without it).  Kept for the last 256 frames (RT_E_STATE for older ones). */
+int rt_ring_reset_clock(rt_ring *r);
+int rt_ring_keep_frame_times(rt_ring *r, int on);
+int rt_ring_frame_times(const rt_ring *r, uint64_t frame, float ms[4]);
+/* Sums over the ring's hosts since rt_ring_reset_timers: kernel time of whole frames / of the ao_kernel launches alone
+ * (HIP events) and how many frames each sum covers.  Any out pointer may be NULL. */
+int rt_ring_timers(rt_ring *r, double *kernel_ms, uint64_t *frames, double *ao_ms, uint64_t *ao_frames);
+void rt_ring_reset_timers(rt_ring *r);
+/* What the frames collected since the last rt_ring_reset_clock cost the CPU: seconds inside submit (the launches),
+ * inside collect waiting for the device, inside collect otherwise; and their number.  Out pointers may be NULL. */
+int rt_ring_cpu_times(const rt_ring *r, double *submit_s, double *wait_s, double *collect_s, uint64_t *frames);
+/* The exchange step over RCCL, one process per GPU.  New: the reference is single-device (src/opencl_host.cc:16-32).
+ * rt_rccl_unique_id (rank 0) fills 128 bytes that the caller hands to every rank (e.g. torch.distributed broadcast);
+ * rt_ring_attach_rccl is collective (ncclCommInitRank with the ring's rank / nranks).  rt_rccl_available: 1 when
+ * librccl.so.1 can be opened (it is opened at run time; the library loads without it). */
+int rt_rccl_available(void);
+int rt_rccl_unique_id(void *out128);
+int rt_ring_attach_rccl(rt_ring *r, const void *unique_id128);
+int rt_ring_rccl_self_test(rt_ring *r);  /* grouped self send/recv on the ring's communicator, checked */
 
 /* OpenCLHost::printInfo, reference src/opencl_host.cc:76-119. */
 void rt_print_info(void);

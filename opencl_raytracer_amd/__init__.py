@@ -18,5 +18,7 @@ from .api import (  # noqa: F401
     load_library,
     partition_rows,
     pgm_bytes,
+    rccl_available,
+    rccl_unique_id,
     resize_cpu,
 )

@@ -127,6 +127,38 @@ _SIGNATURES = {
     "rt_total_ao_ms": (C.c_double, [C.c_void_p]),
     "rt_kernel_launches": (C.c_uint64, [C.c_void_p]),
     "rt_reset_timers": (None, [C.c_void_p]),
+    "rt_ring_create": (C.c_void_p, [C.POINTER(Options), C.c_int, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "rt_ring_destroy": (None, [C.c_void_p]),
+    "rt_ring_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                                 C.c_uint32, C.c_void_p]),
+    "rt_ring_upload_scene": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rt_ring_size": (C.c_uint32, [C.c_void_p]),
+    "rt_ring_slots": (C.c_uint32, [C.c_void_p]),
+    "rt_ring_local_rows": (C.c_uint32, [C.c_void_p]),
+    "rt_ring_in_flight": (C.c_uint32, [C.c_void_p]),
+    "rt_ring_host": (C.c_void_p, [C.c_void_p, C.c_uint32]),
+    "rt_ring_set_graph_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "rt_ring_bind_output": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
+    "rt_ring_submit": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "rt_ring_collect": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_void_p)]),
+    "rt_ring_collect_into_device": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rt_ring_step": (C.c_int, [C.c_void_p]),
+    "rt_ring_run": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "rt_ring_drain": (C.c_int, [C.c_void_p]),
+    "rt_ring_last_image_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "rt_ring_download_last": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rt_ring_reset_clock": (C.c_int, [C.c_void_p]),
+    "rt_ring_keep_frame_times": (C.c_int, [C.c_void_p, C.c_int]),
+    "rt_ring_frame_times": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_float)]),
+    "rt_ring_timers": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double),
+                                 C.POINTER(C.c_uint64)]),
+    "rt_ring_reset_timers": (None, [C.c_void_p]),
+    "rt_ring_cpu_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                    C.POINTER(C.c_uint64)]),
+    "rt_rccl_available": (C.c_int, []),
+    "rt_rccl_unique_id": (C.c_int, [C.c_void_p]),
+    "rt_ring_attach_rccl": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rt_ring_rccl_self_test": (C.c_int, [C.c_void_p]),
     "rt_print_info": (None, []),
     "rt_device_count": (C.c_int, []),
 }
@@ -269,9 +301,16 @@ class Host:
         if not self._h:
             _raise_last()
 
+    @classmethod
+    def _borrowed(cls, options: Options, handle: int) -> "Host":
+        h = cls.__new__(cls)
+        h.options, h._h, h._owned = options, handle, False
+        return h
+
     def close(self) -> None:
         if getattr(self, "_h", None):
-            load_library().rt_destroy(self._h)
+            if getattr(self, "_owned", True):
+                load_library().rt_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -380,42 +419,147 @@ class Host:
 
 
 class FrameRing:
-    """Several hosts of one scene on one GPU that take frames in turn, each on its own stream (the library gives
-    consecutive hosts streams of different priority, i.e. different hardware queues): the last workgroups of one
-    frame's ambient-occlusion pass and the first passes of the next frames share the device, which a single host --
-    one stream, one kernel after the other -- cannot offer.  `submit()` enqueues a frame and returns at once;
-    `collect()` waits for the oldest one and returns its 8-bit image.  bench.py does the same by hand around its
-    band gather; 1.56 -> 1.27 ms per frame with three hosts on the headline workload."""
+    """rt_ring: several render hosts of one scene on one GPU that take frames in turn (include/rt_hip.h, "frame
+    ring").  The library owns the hosts, their streams and captured graphs, the frame bookkeeping and -- with a
+    communicator attached -- the band gather; this class only forwards.  `submit()` enqueues a frame and returns at
+    once, `collect()` waits for the oldest one, `run(k)` is k steps of a steady stream in ONE call into the library."""
 
-    def __init__(self, options: Options, scene: "Scene", device: int = 0, rank: int = 0, nranks: int = 1, hosts: int = 3):
-        if hosts < 1:
-            raise ValueError("a ring needs at least one host")
-        self.hosts = [Host(options, device, rank, nranks) for _ in range(hosts)]
-        for h in self.hosts:
-            h.upload_scene(scene)
-            h.set_device_share(hosts)
-        self._next = 0
-        self._open = []  # hosts with a frame in flight, oldest first
-
-    def submit(self) -> None:
-        if len(self._open) == len(self.hosts):
-            raise RuntimeError("every host of the ring has a frame in flight: collect() one first")
-        h = self.hosts[self._next]
-        self._next = (self._next + 1) % len(self.hosts)
-        h.render_async()
-        self._open.append(h)
-
-    def collect(self) -> np.ndarray:
-        if not self._open:
-            raise RuntimeError("no frame in flight")
-        h = self._open.pop(0)
-        h.sync()
-        return h.download_u8()
+    def __init__(self, options: Options, scene: Optional["Scene"] = None, device: int = 0, rank: int = 0, nranks: int = 1,
+                 hosts: int = 3):
+        self.options = options
+        self._r = load_library().rt_ring_create(C.byref(options), device, rank, nranks, hosts)
+        if not self._r:
+            _raise_last()
+        if scene is not None:
+            self.upload_scene(scene)
 
     def close(self) -> None:
-        for h in self.hosts:
-            h.close()
-        self.hosts, self._open = [], []
+        if getattr(self, "_r", None):
+            load_library().rt_ring_destroy(self._r)
+            self._r = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload_scene(self, scene: "Scene") -> None:
+        _check(load_library().rt_ring_upload_scene(self._r, scene._h))
+
+    @property
+    def size(self) -> int:
+        return load_library().rt_ring_size(self._r)
+
+    @property
+    def slots(self) -> int:
+        """Band buffers (2 x size): frame f is rendered into buffer f % slots."""
+        return load_library().rt_ring_slots(self._r)
+
+    @property
+    def local_rows(self) -> int:
+        return load_library().rt_ring_local_rows(self._r)
+
+    @property
+    def in_flight(self) -> int:
+        return load_library().rt_ring_in_flight(self._r)
+
+    def host(self, slot: int) -> "Host":
+        """Host `slot` as a borrowed Host (statistics, timers, downloads of its last frame)."""
+        h = load_library().rt_ring_host(self._r, slot)
+        if not h:
+            raise IndexError(slot)
+        return Host._borrowed(self.options, h)
+
+    @property
+    def hosts(self):
+        return [self.host(k) for k in range(self.size)]
+
+    def set_graph_mode(self, on: bool) -> None:
+        _check(load_library().rt_ring_set_graph_mode(self._r, int(on)))
+
+    def bind_output(self, slot: int, device_ptr: int) -> None:
+        _check(load_library().rt_ring_bind_output(self._r, slot, device_ptr))
+
+    def submit(self) -> int:
+        f = C.c_uint64()
+        _check(load_library().rt_ring_submit(self._r, C.byref(f)))
+        return int(f.value)
+
+    def collect_info(self):
+        """Waits for the oldest frame; returns (frame number, slot, device address of its bands)."""
+        f, s, p = C.c_uint64(), C.c_uint32(), C.c_void_p()
+        _check(load_library().rt_ring_collect(self._r, C.byref(f), C.byref(s), C.byref(p)))
+        return int(f.value), int(s.value), int(p.value or 0)
+
+    def collect(self) -> np.ndarray:
+        """Waits for the oldest frame and returns its 8-bit image (an unpartitioned ring, or rank 0 of a gathering one)."""
+        self.collect_info()
+        return self.download_last()
+
+    def step(self) -> None:
+        _check(load_library().rt_ring_step(self._r))
+
+    def run(self, frames: int) -> None:
+        _check(load_library().rt_ring_run(self._r, int(frames)))
+
+    def drain(self) -> None:
+        _check(load_library().rt_ring_drain(self._r))
+
+    def last_image_device(self) -> int:
+        p = C.c_void_p()
+        _check(load_library().rt_ring_last_image_device(self._r, C.byref(p)))
+        return int(p.value or 0)
+
+    def download_last(self) -> np.ndarray:
+        img = np.empty((self.options.height, self.options.width), dtype=np.uint8)
+        _check(load_library().rt_ring_download_last(self._r, img.ctypes.data))
+        return img
+
+    def reset_clock(self) -> None:
+        _check(load_library().rt_ring_reset_clock(self._r))
+
+    def keep_frame_times(self, on: bool = True) -> None:
+        _check(load_library().rt_ring_keep_frame_times(self._r, int(on)))
+
+    def frame_times(self, frame: int):
+        """(begin, ao begin, ao end, end) of a collected frame in ms since reset_clock()."""
+        t = (C.c_float * 4)()
+        _check(load_library().rt_ring_frame_times(self._r, frame, t))
+        return tuple(float(x) for x in t)
+
+    def timers(self) -> dict:
+        k, a, nk, na = C.c_double(), C.c_double(), C.c_uint64(), C.c_uint64()
+        _check(load_library().rt_ring_timers(self._r, C.byref(k), C.byref(nk), C.byref(a), C.byref(na)))
+        return {"kernel_ms": k.value, "frames": int(nk.value), "ao_ms": a.value, "ao_frames": int(na.value)}
+
+    def reset_timers(self) -> None:
+        load_library().rt_ring_reset_timers(self._r)
+
+    def cpu_times(self) -> dict:
+        a, b, c, n = C.c_double(), C.c_double(), C.c_double(), C.c_uint64()
+        _check(load_library().rt_ring_cpu_times(self._r, C.byref(a), C.byref(b), C.byref(c), C.byref(n)))
+        return {"submit_s": a.value, "wait_s": b.value, "collect_s": c.value, "frames": int(n.value)}
+
+    def attach_rccl(self, unique_id: bytes) -> None:
+        """Collective over the job (ncclCommInitRank): every rank passes the 128 bytes rank 0 got from rccl_unique_id()."""
+        if len(unique_id) != 128:
+            raise ValueError("an RCCL unique id is 128 bytes")
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        _check(load_library().rt_ring_attach_rccl(self._r, buf))
+
+    def rccl_self_test(self) -> None:
+        _check(load_library().rt_ring_rccl_self_test(self._r))
+
+
+def rccl_available() -> bool:
+    return bool(load_library().rt_rccl_available())
+
+
+def rccl_unique_id() -> bytes:
+    buf = C.create_string_buffer(128)
+    _check(load_library().rt_rccl_unique_id(buf))
+    return buf.raw
 
 
 def resize_cpu(options: Options, tmp: np.ndarray) -> np.ndarray:

@@ -1,13 +1,17 @@
 // c_api.cc -- the extern "C" boundary declared in include/rt_hip.h.
 #include "../../include/rt_hip.h"
 
+#include <hip/hip_runtime.h>
+
 #include <cstring>
 #include <memory>
 #include <new>
 #include <string>
 
 #include "bvh.h"
+#include "band_gather.h"
 #include "device_renderer.h"
+#include "frame_ring.h"
 #include "hip_host.h"
 #include "mesh.h"
 #include "ray_tracer.h"
@@ -21,7 +25,13 @@ struct rt_scene {
 };
 
 struct rt_host {
-	std::unique_ptr<ocrt::DeviceRenderer> dev;
+	std::unique_ptr<ocrt::DeviceRenderer> owned;  // empty for a view of a ring's renderer (rt_ring_host)
+	ocrt::DeviceRenderer *dev = nullptr;
+};
+
+struct rt_ring {
+	std::unique_ptr<ocrt::FrameRing> ring;
+	std::vector<rt_host> views;  // rt_ring_host: the ring's renderers as borrowed rt_host handles
 };
 
 namespace {
@@ -183,13 +193,19 @@ rt_host *rt_create_on(const rt_options *o, int device, uint32_t rank, uint32_t n
 	std::unique_ptr<rt_host> h(new (std::nothrow) rt_host);
 	if (!h)
 		return nullptr;
-	const int rc = guarded([&] { h->dev.reset(new ocrt::DeviceRenderer(to_options(*o), device, rank, nranks)); });
+	const int rc = guarded([&] {
+		h->owned.reset(new ocrt::DeviceRenderer(to_options(*o), device, rank, nranks));
+		h->dev = h->owned.get();
+	});
 	return rc == RT_OK ? h.release() : nullptr;
 }
 
 rt_host *rt_create(const rt_options *o) { return rt_create_on(o, -1, 0, 1); }
 
-void rt_destroy(rt_host *h) { delete h; }
+void rt_destroy(rt_host *h) {
+	if (h && h->owned)  // (a view handed out by rt_ring_host belongs to its ring)
+		delete h;
+}
 
 int rt_upload(rt_host *h, const uint32_t *faces, uint32_t num_faces, const uint32_t *nodes, uint32_t num_nodes,
               const float *aabbs, const float *vertices, uint32_t num_vertices, const float *vnormals) {
@@ -337,6 +353,234 @@ uint64_t rt_kernel_launches(const rt_host *h) { return h ? h->dev->kernelLaunche
 void rt_reset_timers(rt_host *h) {
 	if (h)
 		h->dev->resetTimers();
+}
+
+/* ---- frame ring ------------------------------------------------------------------------------------------------ */
+rt_ring *rt_ring_create(const rt_options *o, int device, uint32_t rank, uint32_t nranks, uint32_t hosts) {
+	if (!o) {
+		fail(RT_E_INVALID, "null options");
+		return nullptr;
+	}
+	std::unique_ptr<rt_ring> r(new (std::nothrow) rt_ring);
+	if (!r)
+		return nullptr;
+	const int rc = guarded([&] {
+		r->ring.reset(new ocrt::FrameRing(to_options(*o), device, rank, nranks, hosts));
+		r->views.resize(r->ring->size());
+		for (uint32_t k = 0; k < r->ring->size(); ++k)
+			r->views[k].dev = &r->ring->host(k);
+	});
+	return rc == RT_OK ? r.release() : nullptr;
+}
+
+void rt_ring_destroy(rt_ring *r) { delete r; }
+
+int rt_ring_upload(rt_ring *r, const uint32_t *faces, uint32_t num_faces, const uint32_t *nodes, uint32_t num_nodes,
+                   const float *aabbs, const float *vertices, uint32_t num_vertices, const float *vnormals) {
+	if (!r || !faces || !nodes || !aabbs || !vertices || !vnormals)
+		return fail(RT_E_INVALID, "null argument");
+	return guarded([&] {
+		auto as_vec3 = [](const float *p, size_t n) {
+			std::vector<Vec3f> v(n);
+			for (size_t i = 0; i < n; ++i)
+				v[i] = Vec3f(p[4 * i], p[4 * i + 1], p[4 * i + 2]);
+			return v;
+		};
+		const std::vector<uint32_t> f(faces, faces + 3 * (size_t) num_faces);
+		const std::vector<uint32_t> n(nodes, nodes + num_nodes);
+		r->ring->upload(ocrt::pack_scene(f, n, as_vec3(aabbs, 2 * (size_t) num_nodes), as_vec3(vertices, num_vertices),
+		                                 as_vec3(vnormals, num_vertices)));
+	});
+}
+
+int rt_ring_upload_scene(rt_ring *r, const rt_scene *s) {
+	if (!r || !s)
+		return fail(RT_E_INVALID, "null argument");
+	if (!s->built)
+		return fail(RT_E_STATE, "scene has no BVH yet (call rt_scene_build_bvh)");
+	return guarded([&] {
+		r->ring->upload(ocrt::pack_scene(s->sorted_faces, s->bvh.nodes, s->bvh.aabbs, s->mesh.vertices, s->mesh.vnormals));
+	});
+}
+
+uint32_t rt_ring_size(const rt_ring *r) { return r ? r->ring->size() : 0; }
+uint32_t rt_ring_slots(const rt_ring *r) { return r ? r->ring->slots() : 0; }
+uint32_t rt_ring_local_rows(const rt_ring *r) { return r ? r->ring->localRows() : 0; }
+uint32_t rt_ring_in_flight(const rt_ring *r) { return r ? r->ring->inFlight() : 0; }
+rt_host *rt_ring_host(rt_ring *r, uint32_t slot) { return (r && slot < r->views.size()) ? &r->views[slot] : nullptr; }
+
+int rt_ring_set_graph_mode(rt_ring *r, int on) {
+	if (!r)
+		return fail(RT_E_INVALID, "null ring");
+	return guarded([&] { r->ring->setGraphMode(on != 0); });
+}
+
+int rt_ring_bind_output(rt_ring *r, uint32_t slot, void *device_u8) {
+	if (!r)
+		return fail(RT_E_INVALID, "null ring");
+	return guarded([&] { r->ring->bindOutput(slot, device_u8); });
+}
+
+int rt_ring_submit(rt_ring *r, uint64_t *frame) {
+	if (!r)
+		return fail(RT_E_INVALID, "null ring");
+	return guarded([&] {
+		const uint64_t f = r->ring->submit();
+		if (frame)
+			*frame = f;
+	});
+}
+
+int rt_ring_collect(rt_ring *r, uint64_t *frame, uint32_t *slot, const void **device_bands) {
+	if (!r)
+		return fail(RT_E_INVALID, "null ring");
+	return guarded([&] {
+		const ocrt::FrameRing::Collected c = r->ring->collect();
+		if (frame)
+			*frame = c.frame;
+		if (slot)
+			*slot = c.slot;
+		if (device_bands)
+			*device_bands = c.device_bands;
+	});
+}
+
+int rt_ring_collect_into_device(rt_ring *r, void *device_u8) {
+	if (!r || !device_u8)
+		return fail(RT_E_INVALID, "null argument");
+	return guarded([&] {
+		const ocrt::FrameRing::Collected c = r->ring->collect();
+		ocrt::DeviceRenderer &h = r->ring->host((uint32_t) (c.frame % r->ring->size()));
+		if (hipSetDevice(h.deviceIndex()) != hipSuccess ||
+		    hipMemcpyAsync(device_u8, c.device_bands, (size_t) h.localRows() * h.width(), hipMemcpyDeviceToDevice,
+		                   (hipStream_t) h.streamHandle()) != hipSuccess ||
+		    hipStreamSynchronize((hipStream_t) h.streamHandle()) != hipSuccess)
+			throw ocrt::DeviceError("copying a collected frame's bands failed");
+	});
+}
+
+int rt_ring_step(rt_ring *r) {
+	if (!r)
+		return fail(RT_E_INVALID, "null ring");
+	return guarded([&] { r->ring->step(); });
+}
+
+int rt_ring_run(rt_ring *r, uint32_t frames) {
+	if (!r)
+		return fail(RT_E_INVALID, "null ring");
+	return guarded([&] {
+		for (uint32_t k = 0; k < frames; ++k)
+			r->ring->step();
+	});
+}
+
+int rt_ring_drain(rt_ring *r) {
+	if (!r)
+		return fail(RT_E_INVALID, "null ring");
+	return guarded([&] { r->ring->drain(); });
+}
+
+int rt_ring_last_image_device(rt_ring *r, const void **device_u8) {
+	if (!r || !device_u8)
+		return fail(RT_E_INVALID, "null argument");
+	return guarded([&] { *device_u8 = r->ring->lastImageDevice(); });
+}
+
+int rt_ring_download_last(rt_ring *r, uint8_t *image) {
+	if (!r || !image)
+		return fail(RT_E_INVALID, "null argument");
+	return guarded([&] { r->ring->downloadLast(image); });
+}
+
+int rt_ring_reset_clock(rt_ring *r) {
+	if (!r)
+		return fail(RT_E_INVALID, "null ring");
+	return guarded([&] { r->ring->resetClock(); });
+}
+
+int rt_ring_keep_frame_times(rt_ring *r, int on) {
+	if (!r)
+		return fail(RT_E_INVALID, "null ring");
+	return guarded([&] { r->ring->keepFrameTimes(on != 0); });
+}
+
+int rt_ring_frame_times(const rt_ring *r, uint64_t frame, float ms[4]) {
+	if (!r || !ms)
+		return fail(RT_E_INVALID, "null argument");
+	return r->ring->frameTimes(frame, ms) ? RT_OK : fail(RT_E_STATE, "no time stamps kept for that frame");
+}
+
+int rt_ring_timers(rt_ring *r, double *kernel_ms, uint64_t *frames, double *ao_ms, uint64_t *ao_frames) {
+	if (!r)
+		return fail(RT_E_INVALID, "null ring");
+	double k = 0, a = 0;
+	uint64_t nk = 0, na = 0;
+	for (uint32_t s = 0; s < r->ring->size(); ++s) {
+		const ocrt::DeviceRenderer &h = r->ring->host(s);
+		k += h.totalKernelMs();
+		a += h.totalAoMs();
+		nk += h.kernelLaunches();
+		na += h.aoLaunches();
+	}
+	if (kernel_ms)
+		*kernel_ms = k;
+	if (frames)
+		*frames = nk;
+	if (ao_ms)
+		*ao_ms = a;
+	if (ao_frames)
+		*ao_frames = na;
+	return RT_OK;
+}
+
+int rt_ring_cpu_times(const rt_ring *r, double *submit_s, double *wait_s, double *collect_s, uint64_t *frames) {
+	if (!r)
+		return fail(RT_E_INVALID, "null ring");
+	const ocrt::FrameRing::CpuTimes &t = r->ring->cpuTimes();
+	if (submit_s)
+		*submit_s = t.submit_s;
+	if (wait_s)
+		*wait_s = t.wait_s;
+	if (collect_s)
+		*collect_s = t.collect_s;
+	if (frames)
+		*frames = t.frames;
+	return RT_OK;
+}
+
+void rt_ring_reset_timers(rt_ring *r) {
+	if (r)
+		for (uint32_t s = 0; s < r->ring->size(); ++s)
+			r->ring->host(s).resetTimers();
+}
+
+int rt_rccl_available(void) { return ocrt::rccl_available() ? 1 : 0; }
+
+int rt_rccl_unique_id(void *out128) {
+	if (!out128)
+		return fail(RT_E_INVALID, "null argument");
+	return guarded([&] { ocrt::rccl_unique_id(out128); });
+}
+
+int rt_ring_attach_rccl(rt_ring *r, const void *unique_id128) {
+	if (!r || !unique_id128)
+		return fail(RT_E_INVALID, "null argument");
+	return guarded([&] {
+		ocrt::DeviceRenderer &h = r->ring->host(0);
+		const ocrt::Partition &part = h.params().part;
+		r->ring->attachGather(std::unique_ptr<ocrt::BandGather>(new ocrt::BandGather(
+		    h.rayTracer().options, part.rank, part.nranks, h.deviceIndex(), unique_id128, r->ring->slots())));
+	});
+}
+
+int rt_ring_rccl_self_test(rt_ring *r) {
+	if (!r)
+		return fail(RT_E_INVALID, "null ring");
+	return guarded([&] {
+		if (!r->ring->hasGather())
+			throw std::logic_error("no communicator attached (rt_ring_attach_rccl)");
+		r->ring->gatherSelfTest();
+	});
 }
 
 void rt_print_info(void) { HipHost::printInfo(); }

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -43,7 +44,8 @@ int visible_device_count() {
 	return count;
 }
 
-DeviceRenderer::DeviceRenderer(const RayTracer::Options &options, int device_, unsigned int rank, unsigned int nranks)
+DeviceRenderer::DeviceRenderer(const RayTracer::Options &options, int device_, unsigned int rank, unsigned int nranks,
+                               int ring_slot)
 	: opts(options)
 	, rt(options)
 	, device(device_)
@@ -69,11 +71,18 @@ DeviceRenderer::DeviceRenderer(const RayTracer::Options &options, int device_, u
 	, device_share(1)
 	, scene_ready(false)
 	, frame_ready(false)
+	, graph_mode(true)
+	, scene_version(0)
+	, ao_blocks_override(0)
+	, epoch_event(nullptr)
+	, keep_stamps(false)
+	, last_times{ 0, 0, 0, 0 }
 	, last_ms(0)
 	, last_ao_ms(0)
 	, total_ms(0)
 	, total_ao_ms(0)
-	, launches(0) {
+	, launches(0)
+	, ao_launches(0) {
 	if (nranks == 0 || rank >= nranks)
 		throw std::invalid_argument("rank must be < nranks");
 	if (opts.width == 0 || opts.height == 0 || grid == 0)
@@ -97,18 +106,22 @@ DeviceRenderer::DeviceRenderer(const RayTracer::Options &options, int device_, u
 	tile_count = (size_t) kp.tiles_x * kp.local_tile_rows;
 
 	useDevice();
-	// The renderers of a process take the lowest and the highest stream priority in turn.  HIP maps streams onto a
-	// few hardware queues per priority class, and a hardware queue runs its packets in order: two renderers of one
-	// scene that take frames alternately (bench.py, so that the last workgroups of one frame's ambient-occlusion pass
-	// and the first of the next frame's primary pass share the device) must not land in the same queue -- which is
-	// what happened with equal priorities once torch.distributed had created its streams (rocprofv3 --kernel-trace:
-	// every kernel of both renderers in one queue, one after the other).  Different classes never share a queue.
-	static std::atomic<unsigned> renderers_created{ 0 };
+	// Renderers that take frames in turn on one GPU (FrameRing) get streams of DIFFERENT priority.  HIP maps streams
+	// onto a few hardware queues per priority class, and a hardware queue runs its packets in order: two renderers of
+	// one scene whose frames are meant to share the device -- the last workgroups of one frame's ambient-occlusion
+	// pass, the next frame's primary pass -- must not land in the same queue, which is what happened with equal
+	// priorities once torch.distributed had created its streams (rocprofv3 --kernel-trace: every kernel of both
+	// renderers in one queue, one after the other).  Different classes never share a queue.  The device offers
+	// `least - greatest + 1` classes (three on this GPU); slot k of a ring takes class k modulo that, so CONSECUTIVE
+	// renderers always differ -- which is what matters, a frame overlaps with its neighbours in the ring --, while
+	// slots a whole cycle apart share a class and may share a queue.  A renderer on its own (slot -1) takes the lowest
+	// class: whatever else the process runs on the device (a collective's kernels) is not held up by it.
 	int least = 0, greatest = 0;
 	OCRT_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-	const bool odd = (renderers_created.fetch_add(1) & 1u) != 0u;
+	const int classes = least - greatest + 1;
+	const int priority = ring_slot < 0 || classes < 2 ? least : least - ring_slot % classes;
 	hipStream_t s;
-	OCRT_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, odd ? greatest : least));
+	OCRT_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority));
 	own_stream = stream = s;
 	// Float image and uint8 buffer both hold this rank's bands only, back to back
 	// (whole tile rows, so the last band may run past the image's height).
@@ -136,6 +149,7 @@ DeviceRenderer::~DeviceRenderer() {
 		return;
 	if (stream)
 		(void) hipStreamSynchronize((hipStream_t) stream);
+	dropFrameGraphs();
 	for (auto &ev : pending_events)
 		free_events.push_back(ev);
 	for (auto &ev : free_events) {
@@ -223,15 +237,13 @@ size_t DeviceRenderer::upload(const PackedScene &scene) {
 		OCRT_HIP(hipMemcpy(d_ao, table.data(), ao_bytes, hipMemcpyHostToDevice));
 	OCRT_HIP(hipDeviceSynchronize());
 	scene_ready = true;
+	++scene_version;  // (a captured frame bakes the scene's pointers and launch constants in)
 	return nodes_bytes + walk_bytes + tris_bytes + shade_bytes + ao_bytes + image_bytes +
 	       (size_t) local_out_rows * opts.width + tile_count * (64 * (sizeof(HitRec) + sizeof(uint32_t)) + 2 * sizeof(uint32_t)) +
 	       sizeof(FrameCounters);
 }
 
-void DeviceRenderer::enqueueRender() {
-	if (!scene_ready)
-		throw std::logic_error("render called before upload");
-	useDevice();
+DeviceRenderer::FrameEvents DeviceRenderer::takeEvents() {
 	FrameEvents ev;
 	if (!free_events.empty()) {
 		ev = free_events.back();
@@ -244,8 +256,14 @@ void DeviceRenderer::enqueueRender() {
 		OCRT_HIP(hipEventCreate(&d));
 		ev = { a, b, c, d };
 	}
+	ev.ao_timed = false;
+	return ev;
+}
+
+// The launches of one frame on the stream: counters, primary pass, ordering step + ambient-occlusion pass + resolve
+// (launch_ao), and -- with a destination -- the device resize.  `ao_start` / `ao_stop` bracket the ao_kernel launch.
+void DeviceRenderer::launchFrame(void *device_u8, void *ao_start, void *ao_stop) {
 	hipStream_t s = (hipStream_t) stream;
-	OCRT_HIP(hipEventRecord((hipEvent_t) ev.start, s));
 	OCRT_HIP(hipMemsetAsync(d_counters, 0, sizeof(FrameCounters), s));
 #ifdef OCRT_STAMPS
 	OCRT_HIP(hipMemsetAsync((char *) d_counters + offsetof(FrameCounters, stamp) + 7 * sizeof(unsigned long long), 0xFF, sizeof(unsigned long long), s));
@@ -253,11 +271,113 @@ void DeviceRenderer::enqueueRender() {
 	const SceneBuffers scene{ d_nodes, d_walk, d_tris, d_shade, d_ao };
 	launch_primary(scene, (float *) d_image, d_hits, d_occluded, d_tile_hits, d_counters, kp, stream);
 	OCRT_HIP(hipGetLastError());
-	ev.ao_timed = kp.ao_mode != AO_NONE && kp.ao_dirs > 0 && tile_count > 0;
-	launch_ao(scene, (float *) d_image, d_hits, d_occluded, d_tile_hits, d_order, d_counters, kp, aoWorkgroups(), stream,
-	          ev.ao_start, ev.ao_stop);
+	launch_ao(scene, (float *) d_image, d_hits, d_occluded, d_tile_hits, d_order, d_counters, kp,
+	          ao_blocks_override ? ao_blocks_override : aoWorkgroups(), stream, ao_start, ao_stop);
 	OCRT_HIP(hipGetLastError());
+	if (device_u8) {
+		launch_resize((const float *) d_image, (unsigned char *) device_u8, kp, opts.width, grid, local_out_rows, stream);
+		OCRT_HIP(hipGetLastError());
+	}
+}
+
+void DeviceRenderer::enqueueRender() {
+	if (!scene_ready)
+		throw std::logic_error("render called before upload");
+	useDevice();
+	FrameEvents ev = takeEvents();
+	hipStream_t s = (hipStream_t) stream;
+	OCRT_HIP(hipEventRecord((hipEvent_t) ev.start, s));
+	ev.ao_timed = kp.ao_mode != AO_NONE && kp.ao_dirs > 0 && tile_count > 0;
+	launchFrame(nullptr, ev.ao_start, ev.ao_stop);
 	OCRT_HIP(hipEventRecord((hipEvent_t) ev.stop, s));
+	pending_events.push_back(ev);
+	frame_ready = true;
+}
+
+void DeviceRenderer::dropFrameGraphs() {
+	for (FrameGraph &g : frame_graphs) {
+		if (g.exec)
+			(void) hipGraphExecDestroy((hipGraphExec_t) g.exec);
+		if (g.graph)
+			(void) hipGraphDestroy((hipGraph_t) g.graph);
+	}
+	frame_graphs.clear();
+}
+
+void DeviceRenderer::enqueueFrame(void *device_u8) {
+	if (!scene_ready)
+		throw std::logic_error("render called before upload");
+	useDevice();
+	void *dst = device_u8 ? device_u8 : d_u8;
+	const bool has_ao = kp.ao_mode != AO_NONE && kp.ao_dirs > 0 && tile_count > 0;
+	hipStream_t s = (hipStream_t) stream;
+	if (!graph_mode) {
+		FrameEvents ev = takeEvents();
+		OCRT_HIP(hipEventRecord((hipEvent_t) ev.start, s));
+		ev.ao_timed = has_ao;
+		launchFrame(dst, ev.ao_start, ev.ao_stop);
+		OCRT_HIP(hipEventRecord((hipEvent_t) ev.stop, s));
+		pending_events.push_back(ev);
+		frame_ready = true;
+		return;
+	}
+	// The captured frame for this destination; everything else a graph bakes in (scene, stream, share of the device)
+	// invalidates all of them.
+	if (!frame_graphs.empty()) {
+		const FrameGraph &any = frame_graphs.front();
+		if (any.stream != stream || any.scene_version != scene_version || any.device_share != device_share) {
+			OCRT_HIP(hipStreamSynchronize(s));
+			dropFrameGraphs();
+		}
+	}
+	FrameGraph *g = nullptr;
+	for (FrameGraph &have : frame_graphs)
+		if (have.dst == dst)
+			g = &have;
+	if (!g) {
+		// Capture.  The graph holds the frame's launches with their arguments by value: the scene's pointers and
+		// launch constants, the destination of the resize, the size of the persistent grid.  No events inside: an
+		// event-record node cannot be timed (hipEventElapsedTime: invalid handle); the kernels stamp the device clock
+		// into the frame's counters instead (FrameCounters::tick_*).
+		if (frame_graphs.size() >= 4) {  // (a caller that keeps changing the destination: start over)
+			OCRT_HIP(hipStreamSynchronize(s));
+			dropFrameGraphs();
+		}
+		FrameGraph fresh;
+		OCRT_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+		hipGraph_t graph = nullptr;
+		try {
+			launchFrame(dst, nullptr, nullptr);
+		} catch (...) {
+			(void) hipStreamEndCapture(s, &graph);
+			if (graph)
+				(void) hipGraphDestroy(graph);
+			throw;
+		}
+		OCRT_HIP(hipStreamEndCapture(s, &graph));
+		fresh.graph = graph;
+		hipGraphExec_t exec = nullptr;
+		const hipError_t made = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+		if (made != hipSuccess) {
+			(void) hipGraphDestroy(graph);
+			OCRT_HIP(made);
+		}
+		fresh.exec = exec;
+		fresh.dst = dst;
+		fresh.stream = stream;
+		fresh.scene_version = scene_version;
+		fresh.device_share = device_share;
+		fresh.ao_events = has_ao;
+		fresh.valid = true;
+		frame_graphs.push_back(fresh);
+		g = &frame_graphs.back();
+	}
+	FrameEvents ev = takeEvents();
+	OCRT_HIP(hipEventRecord((hipEvent_t) ev.start, s));
+	OCRT_HIP(hipGraphLaunch((hipGraphExec_t) g->exec, s));
+	OCRT_HIP(hipEventRecord((hipEvent_t) ev.stop, s));
+	ev.ao_timed = false;
+	ev.graph_ao = g->ao_events;
 	pending_events.push_back(ev);
 	frame_ready = true;
 }
@@ -272,19 +392,51 @@ void DeviceRenderer::enqueueResizeInto(void *device_u8) {
 
 void DeviceRenderer::enqueueResize() { enqueueResizeInto(d_u8); }
 
+void DeviceRenderer::waitForStream() {
+	useDevice();
+	OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));
+}
+
 void DeviceRenderer::synchronize() {
 	useDevice();
 	OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));
-	for (auto &ev : pending_events) {
+	for (size_t k = 0; k < pending_events.size(); ++k) {
+		FrameEvents &ev = pending_events[k];
+		const bool newest = k + 1 == pending_events.size();
 		float ms = 0, ao_ms = 0;
 		OCRT_HIP(hipEventElapsedTime(&ms, (hipEvent_t) ev.start, (hipEvent_t) ev.stop));
-		if (ev.ao_timed)
+		// When the ao_kernel launch ran: by the frame's own HIP events (plain launches), or -- a replayed graph, whose
+		// event-record nodes hipEventElapsedTime refuses -- by the device clock the kernels stamped into the frame's
+		// counters (newest frame only, and only when asked for: it costs a small blocking copy).
+		float ao_begin_after_start = 0.0f;
+		bool ao_timed = ev.ao_timed;
+		if (ao_timed) {
 			OCRT_HIP(hipEventElapsedTime(&ao_ms, (hipEvent_t) ev.ao_start, (hipEvent_t) ev.ao_stop));
+			OCRT_HIP(hipEventElapsedTime(&ao_begin_after_start, (hipEvent_t) ev.start, (hipEvent_t) ev.ao_start));
+		} else if (ev.graph_ao && newest && keep_stamps) {
+			unsigned long long tick[3] = { 0, 0, 0 };
+			OCRT_HIP(hipMemcpy(tick, (const char *) d_counters + offsetof(FrameCounters, tick_begin), sizeof tick, hipMemcpyDeviceToHost));
+			if (tick[2] >= tick[1] && tick[1] >= tick[0] && tick[0] != 0) {
+				ao_ms = (float) ((double) (tick[2] - tick[1]) * 1e-5);  // 100 MHz clock -> ms
+				ao_begin_after_start = (float) ((double) (tick[1] - tick[0]) * 1e-5);
+				ao_timed = true;
+			}
+		}
+		if (ao_timed) {
+			total_ao_ms += ao_ms;
+			++ao_launches;
+		}
 		last_ms = ms;
 		last_ao_ms = ao_ms;
 		total_ms += ms;
-		total_ao_ms += ao_ms;
 		++launches;
+		if (epoch_event && newest) {
+			hipEvent_t epoch = (hipEvent_t) epoch_event;
+			OCRT_HIP(hipEventElapsedTime(&last_times[0], epoch, (hipEvent_t) ev.start));
+			OCRT_HIP(hipEventElapsedTime(&last_times[3], epoch, (hipEvent_t) ev.stop));
+			last_times[1] = ao_timed ? last_times[0] + ao_begin_after_start : 0.0f;
+			last_times[2] = ao_timed ? last_times[1] + ao_ms : 0.0f;
+		}
 		free_events.push_back(ev);
 	}
 	pending_events.clear();

@@ -24,7 +24,9 @@ int visible_device_count();
 
 class DeviceRenderer {
 	public:
-		DeviceRenderer(const RayTracer::Options &options, int device, unsigned int rank, unsigned int nranks);
+		// `ring_slot`: this renderer's index among the renderers that take frames in turn on its GPU (FrameRing), -1 for
+		// a renderer on its own.  It picks the priority class of the renderer's stream, see the constructor.
+		DeviceRenderer(const RayTracer::Options &options, int device, unsigned int rank, unsigned int nranks, int ring_slot = -1);
 		~DeviceRenderer();
 		DeviceRenderer(const DeviceRenderer &) = delete;
 		DeviceRenderer &operator=(const DeviceRenderer &) = delete;
@@ -39,9 +41,27 @@ class DeviceRenderer {
 		void enqueueResize();
 		// Same, but writes into caller-provided DEVICE memory (e.g. a torch tensor).
 		void enqueueResizeInto(void *device_u8);
+		// One whole frame -- counters, primary pass, ordering step, ambient-occlusion pass, resolve, device resize into
+		// `device_u8` (nullptr: this renderer's own band buffer) -- enqueued as ONE replay of a captured hipGraph
+		// (setGraphMode(false): as the same sequence of launches).  The graph is captured at the first call and again
+		// whenever what it bakes in has changed (scene, destination, stream, share of the device).
+		void enqueueFrame(void *device_u8 = nullptr);
+		void setGraphMode(bool on) { graph_mode = on; }
+		bool graphMode() const { return graph_mode; }
 		// Waits for everything enqueued so far and folds pending event pairs into
 		// the kernel-time statistics.
 		void synchronize();
+		void waitForStream();  // the wait alone (synchronize() then finds the stream idle)
+		// Frame time stamps: with an epoch event set (recorded by the caller on any stream of this device), synchronize()
+		// also keeps, for the last frame it folds, the milliseconds from the epoch to the frame's begin, to the start and
+		// the end of its ambient-occlusion kernel (0 for a frame without one) and to its end -- what a test needs to see
+		// that frames of different renderers really overlap on the device.
+		void setEpochEvent(void *event) { epoch_event = event; }
+		// A frame replayed from the captured graph holds no HIP events that could be timed; with this on, synchronize()
+		// reads the device-clock stamps the kernels left in the frame's counters (a 24-byte blocking copy per frame)
+		// for the ao_kernel times.  Plain launches always carry their own events.
+		void setKeepStamps(bool on) { keep_stamps = on; }
+		const float *lastFrameTimes() const { return last_times; }
 
 		// The compact uint8 band buffer on this renderer's device (localRows() x width bytes), valid after
 		// enqueueResize() has completed; and the stream everything is enqueued on.
@@ -72,7 +92,8 @@ class DeviceRenderer {
 		double totalKernelMs() const { return total_ms; }
 		double totalAoMs() const { return total_ao_ms; }
 		uint64_t kernelLaunches() const { return launches; }
-		void resetTimers() { total_ms = total_ao_ms = 0; launches = 0; last_ms = last_ao_ms = 0; }
+		uint64_t aoLaunches() const { return ao_launches; }  // frames whose ao_kernel launch was timed (totalAoMs)
+		void resetTimers() { total_ms = total_ao_ms = 0; launches = ao_launches = 0; last_ms = last_ao_ms = 0; }
 
 		uint32_t localRows() const { return local_out_rows; }  // output rows this rank owns
 		uint32_t width() const { return opts.width; }
@@ -103,11 +124,30 @@ class DeviceRenderer {
 		struct FrameEvents {
 			void *start, *ao_start, *ao_stop, *stop;  // frame begin, around the ao_kernel launch alone, frame end
 			bool ao_timed = false;                    // the frame had an AO pass (ao_start / ao_stop were recorded)
+			bool graph_ao = false;                    // ... as a replayed graph: the graph's own events hold the AO times
 		};
 		std::vector<FrameEvents> pending_events, free_events;
+		FrameEvents takeEvents();
+		void launchFrame(void *device_u8, void *ao_start, void *ao_stop);  // the launches of one frame, resize included
+		// the captured frame (enqueueFrame) and what it was captured for
+		struct FrameGraph {
+			void *graph = nullptr, *exec = nullptr;
+			void *dst = nullptr, *stream = nullptr;
+			uint64_t scene_version = 0;
+			uint32_t device_share = 0;
+			bool valid = false, ao_events = false;
+		};
+		std::vector<FrameGraph> frame_graphs;  // one per destination seen lately (a ring alternates between two per renderer)
+		void dropFrameGraphs();
+		bool graph_mode;
+		uint64_t scene_version;
+		uint32_t ao_blocks_override;  // (debug-knob builds: OCRT_AO_BLOCKS)
+		void *epoch_event;
+		bool keep_stamps;
+		float last_times[4];
 		float last_ms, last_ao_ms;
 		double total_ms, total_ao_ms;
-		uint64_t launches;
+		uint64_t launches, ao_launches;
 };
 
 // kernels.hip

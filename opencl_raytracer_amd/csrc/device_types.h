@@ -70,6 +70,11 @@ struct FrameCounters {
 	uint32_t primary_hits;        // hit sub-pixels
 	uint32_t pad;
 	unsigned long long occluded;  // occluded AO rays
+	// The device's own 100 MHz clock (s_memrealtime) read by the kernels: when the primary pass began (its first
+	// workgroup), when the ordering step ended = the ambient-occlusion pass may begin, when the last workgroup of
+	// the ambient-occlusion pass ended.  A frame replayed from a captured hipGraph has no HIP events inside it that
+	// could be timed (hipEventElapsedTime refuses event-record nodes); these say when its passes ran.
+	unsigned long long tick_begin, tick_ao_begin, tick_ao_end;
 #if defined(OCRT_STAMPS) || defined(OCRT_TAIL)
 	unsigned long long stamp[10 + 32 + 7 + 16];  // debug build: wave-time (10 ns ticks) per phase of the AO pass, jobs, packets
 #endif

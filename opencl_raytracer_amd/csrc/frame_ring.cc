@@ -1,0 +1,203 @@
+#include "frame_ring.h"
+
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <sstream>
+
+namespace ocrt {
+
+namespace {
+
+void hip_check(hipError_t err, const char *what) {
+	if (err != hipSuccess) {
+		std::ostringstream ss;
+		ss << "HIP error: " << hipGetErrorName(err) << " (" << hipGetErrorString(err) << ") in " << what;
+		throw DeviceError(ss.str());
+	}
+}
+#define OCRT_HIP(call) hip_check((call), #call)
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+}  // namespace
+
+FrameRing::FrameRing(const RayTracer::Options &options, int device, unsigned int rank, unsigned int nranks, unsigned int count)
+	: next_frame(0), last{ 0, 0, nullptr }, have_last(false), epoch(nullptr) {
+	if (count == 0 || count > 16)
+		throw std::invalid_argument("a frame ring holds 1 to 16 renderers");
+	for (unsigned int k = 0; k < count; ++k) {
+		hosts.emplace_back(new DeviceRenderer(options, device, rank, nranks, count > 1 ? (int) k : -1));
+		hosts.back()->setDeviceShare(count);
+	}
+	bound.assign(2 * count, nullptr);
+	gather_pending.assign(2 * count, false);
+	OCRT_HIP(hipSetDevice(hosts.front()->deviceIndex()));
+	extra.assign(count, nullptr);
+	for (unsigned int k = 0; k < count; ++k) {
+		const size_t bytes = (size_t) hosts[k]->localRows() * hosts[k]->width();
+		OCRT_HIP(hipMalloc(&extra[k], bytes ? bytes : 1));
+	}
+	hipEvent_t e;
+	OCRT_HIP(hipEventCreate(&e));
+	epoch = e;
+	resetClock();
+}
+
+FrameRing::~FrameRing() {
+	// renderers first (their destructors wait for their streams), then the gather, then the epoch event
+	try {
+		drain();
+	} catch (...) {
+	}
+	hosts.clear();
+	gather.reset();
+	for (void *p : extra)
+		if (p)
+			(void) hipFree(p);
+	if (epoch)
+		(void) hipEventDestroy((hipEvent_t) epoch);
+}
+
+size_t FrameRing::upload(const PackedScene &scene) {
+	drain();
+	size_t bytes = 0;
+	for (auto &h : hosts)
+		bytes += h->upload(scene);
+	return bytes;
+}
+
+void FrameRing::setGraphMode(bool on) {
+	for (auto &h : hosts)
+		h->setGraphMode(on);
+}
+
+void FrameRing::bindOutput(unsigned int slot, void *device_u8) {
+	if (slot >= bound.size())
+		throw std::invalid_argument("frame ring: no such slot");
+	for (const Collected &c : open)
+		if (c.slot == slot)
+			throw std::logic_error("frame ring: the slot has a frame in flight");
+	bound[slot] = device_u8;
+}
+
+void FrameRing::attachGather(std::unique_ptr<BandGather> g) {
+	drain();
+	if (g && g->slots() < bound.size())
+		throw std::invalid_argument("frame ring: the gather needs one slot per band buffer");
+	gather = std::move(g);
+}
+
+void FrameRing::waitSlotFree(unsigned int slot) {
+	if (gather && gather_pending[slot]) {
+		gather->wait(slot);  // (the slot's band buffer and final image are about to be written again)
+		gather_pending[slot] = false;
+	}
+}
+
+uint64_t FrameRing::submit() {
+	if (open.size() >= hosts.size())
+		throw std::logic_error("frame ring: every renderer has a frame in flight, collect one first");
+	const unsigned int slot = (unsigned int) (next_frame % bound.size());
+	const double t0 = now_s();
+	waitSlotFree(slot);  // (its gather was enqueued size() frames ago: long done)
+	hosts[next_frame % hosts.size()]->enqueueFrame(bufferOf(slot));
+	open.push_back(Collected{ next_frame, slot, nullptr });
+	cpu.submit_s += now_s() - t0;
+	return next_frame++;
+}
+
+FrameRing::Collected FrameRing::collect() {
+	if (open.empty())
+		throw std::logic_error("frame ring: no frame in flight");
+	Collected c = open.front();
+	open.pop_front();
+	DeviceRenderer &h = *hosts[c.frame % hosts.size()];
+	const double t0 = now_s();
+	h.waitForStream();
+	const double t1 = now_s();
+	h.synchronize();
+	c.device_bands = bufferOf(c.slot);
+	const float *t = h.lastFrameTimes();
+	times.push_back(Times{ c.frame, { t[0], t[1], t[2], t[3] } });
+	if (times.size() > kept_times)
+		times.pop_front();
+	if (gather) {
+		gather->enqueue(c.slot, c.device_bands);
+		gather_pending[c.slot] = true;
+	}
+	last = c;
+	have_last = true;
+	cpu.wait_s += t1 - t0;
+	cpu.collect_s += now_s() - t1;
+	++cpu.frames;
+	return c;
+}
+
+void FrameRing::step() {
+	submit();
+	const size_t keep = hosts.size() > 1 ? hosts.size() - 1 : 0;
+	while (open.size() > keep)
+		collect();
+}
+
+void FrameRing::drain() {
+	while (!open.empty())
+		collect();
+	for (unsigned int slot = 0; slot < bound.size(); ++slot)
+		waitSlotFree(slot);
+}
+
+void *FrameRing::bufferOf(unsigned int slot) const {
+	if (bound[slot])
+		return bound[slot];
+	const unsigned int n = (unsigned int) hosts.size();
+	return slot < n ? const_cast<void *>(hosts[slot]->deviceBands()) : extra[slot - n];
+}
+
+const void *FrameRing::lastImageDevice() {
+	if (!have_last)
+		throw std::logic_error("frame ring: no frame collected yet");
+	if (!gather)
+		return last.device_bands;
+	waitSlotFree(last.slot);
+	return gather->image(last.slot);
+}
+
+void FrameRing::downloadLast(unsigned char *host_image) {
+	const void *src = lastImageDevice();
+	if (!src)
+		throw std::logic_error("frame ring: the assembled image lives on rank 0");
+	if (!gather && hosts.front()->params().part.nranks != 1)
+		throw std::logic_error("frame ring: a partitioned ring without a gather holds bands, not the image");
+	OCRT_HIP(hipSetDevice(hosts.front()->deviceIndex()));
+	OCRT_HIP(hipMemcpy(host_image, src, (size_t) width() * height(), hipMemcpyDeviceToHost));
+}
+
+void FrameRing::resetClock() {
+	drain();
+	OCRT_HIP(hipSetDevice(hosts.front()->deviceIndex()));
+	OCRT_HIP(hipEventRecord((hipEvent_t) epoch, (hipStream_t) hosts.front()->streamHandle()));
+	OCRT_HIP(hipEventSynchronize((hipEvent_t) epoch));
+	for (auto &h : hosts)
+		h->setEpochEvent(epoch);
+	times.clear();
+	cpu = CpuTimes{};
+}
+
+void FrameRing::keepFrameTimes(bool on) {
+	for (auto &h : hosts)
+		h->setKeepStamps(on);
+}
+
+bool FrameRing::frameTimes(uint64_t frame, float out[4]) const {
+	for (const Times &t : times)
+		if (t.frame == frame) {
+			for (int k = 0; k < 4; ++k)
+				out[k] = t.t[k];
+			return true;
+		}
+	return false;
+}
+
+}  // namespace ocrt

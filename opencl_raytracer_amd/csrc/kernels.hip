@@ -892,6 +892,8 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) __attribute__((amdgpu_waves_per
 	const uint32_t wave = threadIdx.x >> 6;
 	const SceneViews scene = make_views(nodes_ptr, tris_ptr, P);
 
+	if (blockIdx.x == 0u && threadIdx.x == 0u)
+		counters->tick_begin = __builtin_amdgcn_s_memrealtime();
 	const uint32_t group = blockIdx.x & (XCD_GROUPS - 1u), seq = blockIdx.x >> 3;
 	const uint32_t strips = (P.tiles_x + 1u) >> 1;
 	const uint32_t row_pairs = (P.local_tile_rows + 1u) >> 1;
@@ -1195,6 +1197,7 @@ __global__ __launch_bounds__(1024) void order_kernel(const uint32_t *__restrict_
 		counters->queue[group].work_tiles = running;
 		counters->queue[group].cost_sum = cost_total;
 		counters->queue[group].head = 0u;
+		atomicMax(&counters->tick_ao_begin, (unsigned long long) __builtin_amdgcn_s_memrealtime());
 #ifdef OCRT_TAIL  // (the AO pass starts right after this kernel: its waves' end times are counted from here)
 		atomicMax(&counters->stamp[7], __builtin_amdgcn_s_memrealtime());
 #endif
@@ -1580,6 +1583,8 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 			}
 		}
 	}
+	if (wave == 0u && fresh_lane() == 0u)  // (nothing kept across the pass: one clock read and one atomic per workgroup)
+		atomicMax(&counters->tick_ao_end, (unsigned long long) __builtin_amdgcn_s_memrealtime());
 #ifdef OCRT_TAIL  // minimal: nothing is kept across the pass, one load and two atomics when the wave ends
 	if (fresh_lane() == 0u) {
 		const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();

@@ -1,0 +1,207 @@
+"""The frame ring (include/rt_hip.h, rt_ring_*) on the GPU: the library itself keeps several render hosts of one scene
+busy on one GPU -- captured hipGraph per host, streams of different priority, frame bookkeeping, and, with a
+communicator attached, the RCCL band gather.  The reference renders one blocking frame per OpenCLHost::operator()()
+(src/opencl_host.cc:137-149); every frame of a ring must be exactly that frame, and the frames must really overlap."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import options_for
+
+pytestmark = pytest.mark.gpu
+
+HEADLINE = "bunny_1080p_s1_a3"
+
+
+def md5_of(rt, u8):
+    return hashlib.md5(rt.pgm_bytes(u8)).hexdigest()
+
+
+def test_ring_frames_are_golden_and_overlap(rt, golden, scene_for):
+    """Three hosts, graph replay.  Every frame is the golden one, the hosts' streams differ, and the frames overlap ON
+    THE DEVICE: in the steady state frame i + 1 has begun before frame i's ambient-occlusion kernel ended (always), and
+    often its ordering step has ended by then too -- its whole primary pass ran beside that kernel (HIP events for a
+    frame's begin and end, the device clock stamped by the kernels themselves for the ambient-occlusion pass)."""
+    c = golden["renders"][HEADLINE]
+    opt = options_for(rt, c)
+    scene, _ = scene_for(c["mesh"], c["bvh"])
+    ring = rt.FrameRing(opt, scene, hosts=3)
+    assert ring.size == 3 and ring.slots == 6 and ring.local_rows == opt.height
+    assert len({h.stream_handle for h in ring.hosts}) == 3 and all(h.stream_handle for h in ring.hosts)
+    frames = []
+    for frame in range(9):  # three in flight at any time from the third on
+        if frame >= 3:
+            frames.append(ring.collect())
+        assert ring.submit() == frame
+    with pytest.raises(rt.RtError) as e:
+        ring.submit()
+    assert e.value.code == rt.api.RT_E_STATE
+    while len(frames) < 9:
+        frames.append(ring.collect())
+    with pytest.raises(rt.RtError):
+        ring.collect()
+    for u8 in frames:
+        assert md5_of(rt, u8) == c["pgm_md5"]
+    for h in ring.hosts:
+        assert hashlib.sha256(h.download().tobytes()).hexdigest() == c["float_sha256"]
+        st = h.stats()
+        assert st["primary_hits"] == c["counters"]["primary_hits"] and st["ao_occluded"] == c["counters"]["ao_occluded"]
+    # a steady stream: one call into the library for 30 frames
+    ring.reset_clock()
+    ring.keep_frame_times(True)
+    first = ring.submit()
+    ring.collect_info()
+    ring.run(30)
+    ring.drain()
+    assert md5_of(rt, ring.download_last()) == c["pgm_md5"]
+    t = {f: ring.frame_times(f) for f in range(first + 4, first + 30)}
+    primary_inside = 0
+    for f in range(first + 4, first + 29):
+        begin, ao_begin, ao_end, end = t[f]
+        assert 0.0 < begin < ao_begin < ao_end <= end, (f, t[f])
+        nxt = t[f + 1]
+        assert nxt[0] < ao_end, (f, t[f], nxt)  # the next frame began while this one's ambient-occlusion pass ran
+        if nxt[1] < ao_end:  # ... and its primary pass + ordering step were over before that pass was
+            primary_inside += 1
+    assert primary_inside >= 8, (primary_inside, t)
+    timers = ring.timers()
+    assert timers["frames"] >= 31 and timers["ao_frames"] >= 31 and 0.0 < timers["ao_ms"] < timers["kernel_ms"]
+    cpu = ring.cpu_times()
+    assert cpu["frames"] == 31
+    ring.close()
+
+
+@pytest.mark.parametrize("graph", [True, False])
+@pytest.mark.parametrize("name", ["bunny_600_defaults", "bunny_101x77_s9_a2", "blob_33x17_s1_a0"])
+def test_ring_of_one_is_the_blocking_frame(rt, golden, scene_for, name, graph):
+    """A ring of one host = the reference's blocking operator(): same floats, same bytes, graph replay or plain
+    launches, also for frames without an ambient-occlusion pass and for odd sizes."""
+    c = golden["renders"][name]
+    opt = options_for(rt, c)
+    scene, _ = scene_for(c["mesh"], c["bvh"])
+    ring = rt.FrameRing(opt, scene, hosts=1)
+    ring.set_graph_mode(graph)
+    for _ in range(3):
+        ring.step()
+        assert ring.in_flight == 0
+        assert md5_of(rt, ring.download_last()) == c["pgm_md5"]
+    assert hashlib.sha256(ring.host(0).download().tobytes()).hexdigest() == c["float_sha256"]
+    ring.close()
+
+
+def test_ring_recaptures_after_a_new_scene(rt, golden, scene_for):
+    """The captured graph bakes the scene's device pointers in: a second upload must lead to a new capture."""
+    a, b = golden["renders"]["blob_128x96_s4_a3"], golden["renders"]["bunny_101x77_s9_a2"]
+    opt = options_for(rt, a)
+    ring = rt.FrameRing(opt, scene_for(a["mesh"], a["bvh"])[0], hosts=2)
+    ring.run(4)
+    ring.drain()
+    assert md5_of(rt, ring.download_last()) == a["pgm_md5"]
+    ring.upload_scene(scene_for(b["mesh"], b["bvh"])[0])  # another mesh under the same options
+    ring.run(4)
+    ring.drain()
+    other = ring.download_last()
+    host = rt.Host(opt, 0)
+    host.upload_scene(scene_for(b["mesh"], b["bvh"])[0])
+    host.render()
+    assert np.array_equal(other, host.download_u8()) and md5_of(rt, other) != a["pgm_md5"]
+    host.close()
+    ring.close()
+
+
+class _DeviceBytes:
+    """A few bytes of device memory straight from the HIP runtime the library itself uses (torch brings its own copy
+    of the runtime, which must be loaded BEFORE the library -- bench.py does that, a test process cannot)."""
+
+    def __init__(self, size):
+        import ctypes as C
+
+        self.hip, self.size, self.ptr = C.CDLL("libamdhip64.so"), size, C.c_void_p()
+        assert self.hip.hipMalloc(C.byref(self.ptr), C.c_size_t(size)) == 0
+        assert self.hip.hipMemset(self.ptr, 0, C.c_size_t(size)) == 0
+
+    def numpy(self, rows, width):
+        import ctypes as C
+
+        out = np.empty((rows, width), dtype=np.uint8)
+        assert self.hip.hipMemcpy(C.c_void_p(out.ctypes.data), self.ptr, C.c_size_t(rows * width), 2) == 0  # device -> host
+        return out
+
+    def free(self):
+        self.hip.hipFree(self.ptr)
+
+
+def test_ring_writes_into_bound_device_memory(rt, golden, scene_for):
+    """rt_ring_bind_output: the frames' bands land in caller-owned device memory (the send buffer of a caller-side
+    collective in bench.py's gloo rehearsal)."""
+    c = golden["renders"]["bunny_600_defaults"]
+    opt = options_for(rt, c)
+    scene, _ = scene_for(c["mesh"], c["bvh"])
+    ring = rt.FrameRing(opt, scene, hosts=2)
+    bands = [_DeviceBytes(ring.local_rows * opt.width) for _ in range(ring.slots + 1)]
+    for k in range(ring.slots):
+        ring.bind_output(k, bands[k].ptr.value)
+    for k in range(0, ring.slots, 2):
+        ring.submit()
+        ring.submit()
+        for j in (k, k + 1):
+            frame, slot, ptr = ring.collect_info()
+            assert (frame, slot, ptr) == (j, j, bands[j].ptr.value)
+            assert md5_of(rt, bands[j].numpy(opt.height, opt.width)) == c["pgm_md5"]
+    ring.submit()
+    assert rt.load_library().rt_ring_collect_into_device(ring._r, bands[-1].ptr.value) == 0
+    assert md5_of(rt, bands[-1].numpy(opt.height, opt.width)) == c["pgm_md5"]
+    ring.close()
+    for b in bands:
+        b.free()
+
+
+@pytest.mark.parametrize("name,nranks", [("interior_4k_s1_a3", 8), ("bunny_1080p_s64_a3", 8), (HEADLINE, 3)])
+def test_full_size_frames_split_over_ranks_reassemble(rt, golden, scene_for, name, nranks):
+    """BASELINE configs 4 and 5 as the driver's 8-GPU run cuts them -- the 4K frame in 270 bands of 8 rows dealt to 8
+    ranks (unevenly: 34 / 33 bands), the 64-spp frame in bands of ONE output row -- rendered rank by rank on the one
+    GPU through rings of two hosts, rows put in place by the partition arithmetic: the golden PGM."""
+    c = golden["renders"][name]
+    opt = options_for(rt, c)
+    scene, _ = scene_for(c["mesh"], c["bvh"])
+    image = np.zeros((opt.height, opt.width), dtype=np.uint8)
+    seen = np.zeros(opt.height, dtype=np.int32)
+    hits = occluded = 0
+    for rank in range(nranks):
+        ring = rt.FrameRing(opt, scene, 0, rank, nranks, hosts=2)
+        rows = rt.partition_rows(opt, rank, nranks)
+        assert ring.local_rows == rows.size
+        ring.submit()
+        ring.submit()
+        ring.collect_info()
+        ring.collect_info()
+        local = ring.host(1).download_u8_local()
+        keep = rows < opt.height
+        image[rows[keep]] = local[keep]
+        seen[rows[keep]] += 1
+        st = ring.host(1).stats()
+        hits += st["primary_hits"]
+        occluded += st["ao_occluded"]
+        ring.close()
+    assert (seen == 1).all()
+    assert md5_of(rt, image) == c["pgm_md5"]
+    assert hits == c["counters"]["primary_hits"] and occluded == c["counters"]["ao_occluded"]
+
+
+def test_ring_gathers_over_rccl_in_a_world_of_one(rt, golden, scene_for):
+    """The library's own RCCL leg on the box: unique id, ncclCommInitRank, a checked grouped self send/recv, and the
+    exchange step behind the frames (with one rank it moves nothing, the assembly kernel still builds the image)."""
+    if not rt.rccl_available():
+        pytest.fail("librccl.so.1 cannot be opened on the GPU box")
+    c = golden["renders"]["bunny_600_defaults"]
+    opt = options_for(rt, c)
+    scene, _ = scene_for(c["mesh"], c["bvh"])
+    ring = rt.FrameRing(opt, scene, hosts=3)
+    ring.attach_rccl(rt.rccl_unique_id())
+    ring.rccl_self_test()
+    ring.run(7)
+    ring.drain()
+    assert ring.last_image_device() != 0
+    assert md5_of(rt, ring.download_last()) == c["pgm_md5"]
+    ring.close()

@@ -34,13 +34,8 @@ for n in ([int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else (1,
         ring = rt.FrameRing(opt, scene, 0, rank, n, hosts=3)
         for phase, frames in (("warm", 9), ("timed", 60)):
             t0 = time.perf_counter()
-            for f in range(frames):
-                if f >= 3:
-                    ring.hosts[f % 3].sync()  # (collect without the download)
-                    ring._open.pop(0)
-                ring.submit()
-            while ring._open:
-                ring._open.pop(0).sync()
+            ring.run(frames)
+            ring.drain()
             dt = (time.perf_counter() - t0) / frames * 1e3
         worst_ring = max(worst_ring, dt)
         ring.close()

@@ -17,12 +17,8 @@ for n in (8, 4, 1):
             ring = rt.FrameRing(opt, scene, 0, rank, n, hosts=hosts)
             for frames in (3 * hosts, 90):
                 t0 = time.perf_counter()
-                for f in range(frames):
-                    if f >= hosts:
-                        ring._open.pop(0).sync()
-                    ring.submit()
-                while ring._open:
-                    ring._open.pop(0).sync()
+                ring.run(frames)  # (one call into the library: submit, collect the oldest beyond hosts - 1 in flight)
+                ring.drain()
                 dt = (time.perf_counter() - t0) / frames * 1e3
             worst = max(worst, dt)
             ring.close()
