@@ -7,9 +7,12 @@
 #include <cstring>
 #include <iostream>
 #include <stdexcept>
+#include <string>
 
+#include "band_gather.h"
 #include "cli_support.h"
 #include "device_renderer.h"
+#include "frame_ring.h"
 #include "scene_pack.h"
 
 using ocrt::cli::Color;
@@ -85,47 +88,172 @@ ocrt::RenderStats HipHost::lastStats() {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-HipHostGroup::HipHostGroup(const RayTracer &rt_, unsigned int devices, int first) : rt(rt_), staging(nullptr), staging_bytes(0) {
-	if (devices == 0)
-		throw std::invalid_argument("--gpus needs at least one device");
-	const int visible = ocrt::visible_device_count();
-	if (visible <= 0)
-		throw std::runtime_error("No device found");
-	if (first < 0) {
-		const char *env = std::getenv("OCRT_DEVICE");
-		first = env ? std::atoi(env) : 0;
-	}
-	const bool share = std::getenv("OCRT_SHARE_DEVICES") != nullptr;
-	if (!share && first + (int) devices > visible)
-		throw std::invalid_argument("more ranks than visible HIP devices (one rank per GPU)");
-	for (unsigned int r = 0; r < devices; ++r) {
-		const int dev = share ? (first + (int) r) % visible : first + (int) r;
-		hosts.emplace_back(new ocrt::DeviceRenderer(rt.options, dev, r, devices));
-		std::cout << Color::WHITE << "Rank " << r << " of " << devices << ": device " << dev << " \"" << hosts.back()->deviceName()
-		          << "\", " << hosts.back()->localRows() << " rows." << Color::RESET << std::endl;
-	}
-	std::cout << std::endl;
+HipHostRing::HipHostRing(const RayTracer &rt_, unsigned int hosts, int device) : rt(rt_), last_host(0) {
+	// std::runtime_error("No device found") propagates, as in the reference; bad arguments end like a device error
 	try {
-		for (auto &h : hosts)
-			staging_bytes += (size_t) h->localRows() * rt.options.width;
-		if (hipSetDevice(hosts[0]->deviceIndex()) != hipSuccess || hipMalloc(&staging, staging_bytes ? staging_bytes : 1) != hipSuccess)
-			throw ocrt::DeviceError("cannot allocate the band staging buffer");
-		// let the first device read its peers' memory directly where the topology allows it (else the copies are staged)
-		for (size_t r = 1; r < hosts.size(); ++r)
-			if (hosts[r]->deviceIndex() != hosts[0]->deviceIndex()) {
-				int can = 0;
-				if (hipDeviceCanAccessPeer(&can, hosts[0]->deviceIndex(), hosts[r]->deviceIndex()) == hipSuccess && can)
-					(void) hipDeviceEnablePeerAccess(hosts[r]->deviceIndex(), 0);
+		ring.reset(new ocrt::FrameRing(rt.options, device, 0, 1, hosts));
+	} catch (const std::invalid_argument &e) {
+		die(e.what());
+	} catch (const ocrt::DeviceError &e) {
+		die(e.what());
+	}
+	std::cout << Color::WHITE << "Using Device \"" << ring->host(0).deviceName() << "\", " << ring->size()
+	          << (ring->size() == 1 ? " render host." : " render hosts taking frames in turn.") << Color::RESET << std::endl
+	          << std::endl;
+}
+
+HipHostRing::~HipHostRing() {}
+
+unsigned int HipHostRing::size() const { return ring->size(); }
+
+void HipHostRing::upload(const std::vector<uint32_t> &faces, const std::vector<uint32_t> &nodes,
+                         const std::vector<Vec3f> &aabbs, const std::vector<Vec3f> &vertices,
+                         const std::vector<Vec3f> &vnormals) {
+	try {
+		const ocrt::PackedScene packed = ocrt::pack_scene(faces, nodes, aabbs, vertices, vnormals);  // once; every host gets it
+		const size_t bytes = ring->upload(packed);
+		std::cout << "Requested " << bytes / 1024 << " kB of memory." << std::endl;
+	} catch (const std::exception &e) {
+		die(e.what());
+	}
+}
+
+bool HipHostRing::operator()() {
+	try {
+		ring->drain();
+		ring->submit();
+		last_host = (unsigned int) (ring->collect().frame % ring->size());
+	} catch (const std::exception &e) {
+		die(e.what());
+	}
+	return true;
+}
+
+bool HipHostRing::frames(unsigned int count) {
+	try {
+		for (unsigned int k = 0; k < count; ++k)
+			ring->step();
+		ring->drain();
+		if (ring->submitted())
+			last_host = (unsigned int) ((ring->submitted() - 1) % ring->size());
+	} catch (const std::exception &e) {
+		die(e.what());
+	}
+	return true;
+}
+
+void HipHostRing::download(float *image) {
+	try {
+		ring->host(last_host).downloadFloat(image);
+	} catch (const std::exception &e) {
+		die(e.what());
+	}
+}
+
+void HipHostRing::downloadResized(unsigned char *image) {
+	try {
+		ring->downloadLast(image);
+	} catch (const std::exception &e) {
+		die(e.what());
+	}
+}
+
+float HipHostRing::lastKernelMs() const { return ring->host(last_host).lastKernelMs(); }
+
+ocrt::RenderStats HipHostRing::lastStats() {
+	try {
+		return ring->host(last_host).stats();
+	} catch (const std::exception &e) {
+		die(e.what());
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+HipHostGroup::HipHostGroup(const RayTracer &rt_, unsigned int devices, int first, const char *gather_choice)
+	: rt(rt_), staging(nullptr), assembled(nullptr), staging_bytes(0) {
+	try {
+		if (devices == 0)
+			throw std::invalid_argument("--gpus needs at least one device");
+		const int visible = ocrt::visible_device_count();
+		if (visible <= 0)
+			throw std::runtime_error("No device found");
+		if (first < 0) {
+			const char *env = std::getenv("OCRT_DEVICE");
+			first = env ? std::atoi(env) : 0;
+		}
+		const bool share = std::getenv("OCRT_SHARE_DEVICES") != nullptr;
+		if (!share && first + (int) devices > visible)
+			throw std::invalid_argument("more ranks than visible HIP devices (one rank per GPU)");
+		std::vector<int> device_of;
+		for (unsigned int r = 0; r < devices; ++r) {
+			const int dev = share ? (first + (int) r) % visible : first + (int) r;
+			device_of.push_back(dev);
+			hosts.emplace_back(new ocrt::DeviceRenderer(rt.options, dev, r, devices));
+			std::cout << Color::WHITE << "Rank " << r << " of " << devices << ": device " << dev << " \"" << hosts.back()->deviceName()
+			          << "\", " << hosts.back()->localRows() << " rows." << Color::RESET << std::endl;
+		}
+		// The exchange step: RCCL where it can be had, else peer copies.
+		const std::string want = gather_choice ? gather_choice : "auto";
+		if (want != "auto" && want != "rccl" && want != "peer")
+			throw std::invalid_argument("the gather is one of rccl, peer, auto");
+		std::string why_not;
+		if (want == "peer") {
+			why_not = "asked for";
+		} else {
+			try {
+				gather.reset(new ocrt::GroupGather(rt.options, device_of));
+			} catch (const ocrt::DeviceError &e) {
+				why_not = e.what();
 			}
-		(void) hipGetLastError();  // (peer access already enabled is not an error)
+		}
+		if (gather) {
+			std::cout << Color::WHITE << "Bands are gathered on device " << device_of[0] << " over RCCL." << Color::RESET << std::endl;
+		} else {
+			if (want == "rccl")
+				throw ocrt::DeviceError(why_not);
+			std::cout << Color::WHITE << "Bands are gathered on device " << device_of[0] << " by peer copies (" << why_not << ")."
+			          << Color::RESET << std::endl;
+			const ocrt::BandPlan plan(rt.options, devices);
+			staging_bytes = plan.stride() * devices;
+			if (hipSetDevice(device_of[0]) != hipSuccess || hipMalloc(&staging, staging_bytes ? staging_bytes : 1) != hipSuccess ||
+			    hipMalloc(&assembled, (size_t) plan.width * plan.height) != hipSuccess)
+				throw ocrt::DeviceError("cannot allocate the band staging buffers");
+			// The copies are enqueued on the SOURCE device's stream and write into the first device's staging buffer:
+			// the source needs access to the first device (and the first device to its peers, for symmetry).
+			for (size_t r = 1; r < hosts.size(); ++r) {
+				if (device_of[r] == device_of[0])
+					continue;
+				int can = 0;
+				if (hipSetDevice(device_of[r]) != hipSuccess)
+					throw ocrt::DeviceError("hipSetDevice failed while enabling peer access");
+				if (hipDeviceCanAccessPeer(&can, device_of[r], device_of[0]) == hipSuccess && can)
+					(void) hipDeviceEnablePeerAccess(device_of[0], 0);
+				(void) hipGetLastError();  // (peer access already enabled is not an error)
+				if (hipSetDevice(device_of[0]) != hipSuccess)
+					throw ocrt::DeviceError("hipSetDevice failed while enabling peer access");
+				if (hipDeviceCanAccessPeer(&can, device_of[0], device_of[r]) == hipSuccess && can)
+					(void) hipDeviceEnablePeerAccess(device_of[r], 0);
+				(void) hipGetLastError();
+			}
+		}
+		std::cout << std::endl;
+	} catch (const std::runtime_error &e) {
+		if (std::string(e.what()) == "No device found")
+			throw;  // as in the reference (src/opencl_host.cc:30-31)
+		die(e.what());
 	} catch (const std::exception &e) {
 		die(e.what());
 	}
 }
 
 HipHostGroup::~HipHostGroup() {
-	if (staging && !hosts.empty() && hipSetDevice(hosts[0]->deviceIndex()) == hipSuccess)
-		(void) hipFree(staging);
+	gather.reset();
+	if (!hosts.empty() && hipSetDevice(hosts[0]->deviceIndex()) == hipSuccess) {
+		if (staging)
+			(void) hipFree(staging);
+		if (assembled)
+			(void) hipFree(assembled);
+	}
 }
 
 void HipHostGroup::upload(const std::vector<uint32_t> &faces, const std::vector<uint32_t> &nodes,
@@ -156,35 +284,45 @@ bool HipHostGroup::operator()() {
 
 void HipHostGroup::downloadResized(unsigned char *image) {
 	try {
-		const size_t width = rt.options.width;
+		const size_t bytes = (size_t) rt.options.width * rt.options.height;
 		for (auto &h : hosts)
 			h->enqueueResize();
-		// every device's bands -> the staging buffer on the first device, on the source device's own stream
-		size_t offset = 0;
-		for (auto &h : hosts) {
-			const size_t bytes = (size_t) h->localRows() * width;
-			if (bytes && hipSetDevice(h->deviceIndex()) == hipSuccess &&
-			    hipMemcpyPeerAsync((char *) staging + offset, hosts[0]->deviceIndex(), h->deviceBands(), h->deviceIndex(),
-			                                bytes, (hipStream_t) h->streamHandle()) != hipSuccess)
-				throw ocrt::DeviceError("hipMemcpyPeerAsync of a device's image bands failed");
-			offset += bytes;
+		const void *result = nullptr;
+		if (gather) {
+			// one grouped send / receive over RCCL, then the row scatter, all on the devices' own streams
+			std::vector<const void *> bands;
+			std::vector<void *> streams;
+			for (auto &h : hosts) {
+				bands.push_back(h->deviceBands());
+				streams.push_back(h->streamHandle());
+			}
+			gather->enqueue(bands, streams);
+			result = gather->image();
+		} else {
+			// every other device's bands -> its stride of the staging buffer on the first device, on the source's stream
+			const ocrt::BandPlan plan(rt.options, (unsigned int) hosts.size());
+			for (size_t r = 1; r < hosts.size(); ++r) {
+				auto &h = hosts[r];
+				if (!plan.bytesOf((unsigned int) r))
+					continue;
+				if (hipSetDevice(h->deviceIndex()) != hipSuccess)
+					throw ocrt::DeviceError("hipSetDevice failed before a band copy");
+				if (hipMemcpyPeerAsync((char *) staging + r * plan.stride(), hosts[0]->deviceIndex(), h->deviceBands(), h->deviceIndex(),
+				                       plan.bytesOf((unsigned int) r), (hipStream_t) h->streamHandle()) != hipSuccess)
+					throw ocrt::DeviceError("hipMemcpyPeerAsync of a device's image bands failed");
+			}
+			for (auto &h : hosts)
+				h->synchronize();
+			if (hipSetDevice(hosts[0]->deviceIndex()) != hipSuccess)
+				throw ocrt::DeviceError("hipSetDevice failed before the row assembly");
+			ocrt::launch_assemble_rows(plan, hosts[0]->deviceBands(), staging, assembled, hosts[0]->streamHandle());
+			result = assembled;
 		}
 		for (auto &h : hosts)
 			h->synchronize();
-		std::vector<unsigned char> stacked(staging_bytes);
 		if (hipSetDevice(hosts[0]->deviceIndex()) != hipSuccess ||
-		    hipMemcpy(stacked.data(), staging, staging_bytes, hipMemcpyDeviceToHost) != hipSuccess)
-			throw ocrt::DeviceError("reading the gathered bands failed");
-		// rows to their place (a device's last band may run past the image: padding rows are dropped)
-		offset = 0;
-		for (auto &h : hosts) {
-			for (uint32_t j = 0; j < h->localRows(); ++j) {
-				const uint32_t y = h->globalRowOf(j);
-				if (y < rt.options.height)
-					std::memcpy(image + (size_t) y * width, stacked.data() + offset + (size_t) j * width, width);
-			}
-			offset += (size_t) h->localRows() * width;
-		}
+		    hipMemcpy(image, result, bytes, hipMemcpyDeviceToHost) != hipSuccess)
+			throw ocrt::DeviceError("reading the assembled image failed");
 	} catch (const std::exception &e) {
 		die(e.what());
 	}

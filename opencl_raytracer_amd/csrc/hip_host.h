@@ -25,7 +25,9 @@
 #include "vec3.h"
 
 namespace ocrt {
-class DeviceRenderer;  // hip_host.cc
+class DeviceRenderer;  // device_renderer.h
+class FrameRing;       // frame_ring.h
+class GroupGather;     // band_gather.h
 }
 
 class HipHost {
@@ -79,16 +81,47 @@ class HipHost {
 		std::unique_ptr<ocrt::DeviceRenderer> impl;
 };
 
+// A steady stream of frames behind the same seam: `hosts` render hosts of one scene on one GPU that take frames in
+// turn (ocrt::FrameRing: own streams in different priority classes, one captured hipGraph per host), so that the next
+// frames' passes fill the wave slots a finishing ambient-occlusion pass frees.  Same member names as HipHost --
+// operator()() is one blocking frame, exactly the reference's (src/opencl_host.cc:137-149) --, plus frames(k).
+class HipHostRing {
+	public:
+		HipHostRing(const RayTracer &rt, unsigned int hosts = 3, int device = -1);
+		~HipHostRing();
+		HipHostRing(const HipHostRing &) = delete;
+		HipHostRing &operator=(const HipHostRing &) = delete;
+
+		void upload(const std::vector<uint32_t> &faces, const std::vector<uint32_t> &nodes,
+		            const std::vector<Vec3f> &aabbs, const std::vector<Vec3f> &vertices,
+		            const std::vector<Vec3f> &vnormals);
+		bool operator()();                            // one frame, blocking
+		bool frames(unsigned int count);              // `count` frames, up to size() - 1 in flight; blocks until all are done
+		void download(float *image);                  // the float image of the last frame
+		void downloadResized(unsigned char *image);   // its 8-bit image (resized on the device as part of the frame)
+		float lastKernelMs() const;                   // kernel time of the last frame (HIP events on its host's stream)
+		ocrt::RenderStats lastStats();
+		unsigned int size() const;
+
+	private:
+		const RayTracer &rt;
+		std::unique_ptr<ocrt::FrameRing> ring;
+		unsigned int last_host;
+};
+
 // One frame on several GPUs of a node, in ONE process (`render --gpus N`): the scene is replicated, the image is cut
 // into bands of whole supersample blocks dealt round-robin to the devices (ocrt::Partition), every device renders and
-// box-filters its own bands, and the 8-bit bands are copied device-to-device over xGMI (hipMemcpyPeerAsync) into a
-// staging buffer on the first device, from where the assembled image is read.  Same member names as HipHost, so the
-// CLI drives either.  New: the reference is single-device (src/opencl_host.cc:16-32).
+// box-filters its own bands, and ONE exchange step brings the 8-bit bands to the first device: an RCCL gather
+// (ncclSend / ncclRecv in one group over xGMI, ocrt::GroupGather) followed by a kernel that moves the rows to their
+// place; where RCCL cannot be used -- the library is absent, or two ranks share a device ($OCRT_SHARE_DEVICES
+// rehearsal) -- device-to-device copies (hipMemcpyPeerAsync) into a staging buffer and the same kernel.  Same member
+// names as HipHost, so the CLI drives either.  New: the reference is single-device (src/opencl_host.cc:16-32).
 class HipHostGroup {
 	public:
 		// `devices` GPUs starting at device `first` (< 0: $OCRT_DEVICE or 0).  More ranks than visible GPUs is an error
 		// unless $OCRT_SHARE_DEVICES is set (rehearsal on a smaller box: ranks are mapped round-robin).
-		HipHostGroup(const RayTracer &rt, unsigned int devices, int first = -1);
+		// `gather`: "rccl", "peer", or "auto" / nullptr (RCCL where it can be set up, else peer copies).
+		HipHostGroup(const RayTracer &rt, unsigned int devices, int first = -1, const char *gather = nullptr);
 		~HipHostGroup();
 		HipHostGroup(const HipHostGroup &) = delete;
 		HipHostGroup &operator=(const HipHostGroup &) = delete;
@@ -101,11 +134,14 @@ class HipHostGroup {
 		float lastKernelMs() const;                   // slowest device's kernel time of the last frame
 		ocrt::RenderStats lastStats();                // summed over the devices
 		unsigned int size() const { return (unsigned int) hosts.size(); }
+		const char *gatherName() const { return gather ? "RCCL gather" : "peer copies"; }
 
 	private:
 		const RayTracer &rt;
 		std::vector<std::unique_ptr<ocrt::DeviceRenderer>> hosts;
-		void *staging;        // on hosts[0]'s device: the devices' band buffers back to back
+		std::unique_ptr<ocrt::GroupGather> gather;  // the exchange step over RCCL, when it could be set up
+		void *staging;        // peer-copy form, on hosts[0]'s device: the ranks' band buffers, one stride apart
+		void *assembled;      // ... and the assembled image
 		size_t staging_bytes;
 };
 

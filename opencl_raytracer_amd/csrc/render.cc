@@ -1,9 +1,10 @@
 // render.cc -- `render [OPTIONS] INPUT_MESH OUTPUT_IMAGE`: the reference's CLI
 // (reference src/render.cc:16-139, flag table :23-30) on the HIP render host.
 // Same flags, defaults, phase lines and PGM format; `-h` is HEIGHT, help is
-// `--help` only.  New: `--device N`, `--gpus N` (one frame on N GPUs of the node, bands gathered over xGMI),
-// `--host-resize` (the reference's own download + RayTracer::resize instead of the fused device resize), and a
-// Mrays/s summary line.
+// `--help` only.  New: `--device N`, `--gpus N` (one frame on N GPUs of the node, bands gathered over RCCL / xGMI;
+// `--gather rccl|peer|auto`), `--frames K` / `--in-flight H` (a steady stream of K frames through a ring of H render
+// hosts on the one GPU: throughput instead of one blocking frame), `--host-resize` (the reference's own download +
+// RayTracer::resize instead of the fused device resize), and a Mrays/s summary line.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -44,6 +45,9 @@ const OptionSpec OPTIONS[] = {
 	{ 'r', "bvh-strategy", "Specifies the strategy of BVH construction (longest|sah)." },
 	{ 0, "device", "Specifies the HIP device index to render on (default: $OCRT_DEVICE or 0)." },
 	{ 0, "gpus", "Renders the frame on this many GPUs of the node (image bands dealt round-robin, gathered over xGMI)." },
+	{ 0, "gather", "How --gpus N brings the image bands together [rccl|peer|auto]." },
+	{ 0, "frames", "Renders the frame this many times in a row (the image written is the last one)." },
+	{ 0, "in-flight", "Render hosts taking those frames in turn on the GPU (default 3 when --frames > 1, else 1)." },
 	{ 0, "host-resize", "Downloads the float image and resizes it on the host, as the reference does [0|1]." },
 };
 
@@ -76,6 +80,8 @@ struct CliOptions : RayTracer::Options {
 	std::string in, out;
 	int device = -1;
 	unsigned int gpus = 1;
+	unsigned int frames = 1, in_flight = 0;
+	std::string gather = "auto";
 	bool host_resize = false;
 
 	CliOptions(int argc, const char **argv) : RayTracer::Options(RayTracer::defaults()) {
@@ -149,6 +155,12 @@ struct CliOptions : RayTracer::Options {
 			device = std::atoi(value);
 		else if (name == "gpus")
 			gpus = (unsigned int) std::atoi(value);
+		else if (name == "frames")
+			frames = (unsigned int) std::atoi(value);
+		else if (name == "in-flight")
+			in_flight = (unsigned int) std::atoi(value);
+		else if (name == "gather")
+			gather = value;
 		else if (name == "host-resize")
 			host_resize = std::atoi(value) != 0;
 		else if (name == "ambient-occlusion-method") {
@@ -170,7 +182,16 @@ struct CliOptions : RayTracer::Options {
 };
 
 void download_floats(HipHost &host, float *image);
+void download_floats(HipHostRing &host, float *image);
 void download_floats(HipHostGroup &host, float *image);
+// `count` frames: one blocking operator()() after the other, or -- a ring -- a steady stream with frames in flight
+template <class Host> bool run_frames(Host &host, unsigned int count) {
+	bool ok = true;
+	for (unsigned int k = 0; k < count && ok; ++k)
+		ok = host();
+	return ok;
+}
+bool run_frames(HipHostRing &host, unsigned int count) { return count == 1 ? host() : host.frames(count); }
 
 // The frame itself, for one device (HipHost) or several (HipHostGroup): the phases of reference src/render.cc:84-128
 // under their own names -- scripts that read the reference's output keep working: "Loading OpenCL kernel" is the
@@ -188,7 +209,8 @@ void render_frame(Host &host, const CliOptions &options, const RayTracer &rt, Me
 	}, true);
 	std::cout << std::endl
 	          << Color::BLUE << "<- " << Info::Palette::SECTION << "Rendering section" << Color::BLUE << " ->" << std::endl;
-	total_time += Info::measure("Rendering image", [&] { return host(); });
+	const std::size_t render_time = Info::measure("Rendering image", [&] { return run_frames(host, options.frames); });
+	total_time += render_time;
 	std::cout << std::endl;
 	if (options.host_resize) {
 		// the reference's flow: float image to the host (:114-117), box filter there (:120-123)
@@ -215,11 +237,17 @@ void render_frame(Host &host, const CliOptions &options, const RayTracer &rt, Me
 	          << host.lastKernelMs() << " ms" << Info::Palette::NORMAL << " = " << Info::Palette::HIGHLIGHT
 	          << (host.lastKernelMs() > 0 ? rays / (host.lastKernelMs() * 1e3) : 0.0) << " Mrays/s" << Color::RESET
 	          << std::endl;
+	if (options.frames > 1)  // (Info::measure counts milliseconds)
+		std::cout << Info::Palette::NORMAL << "Frames: " << Info::Palette::HIGHLIGHT << options.frames << Info::Palette::NORMAL
+		          << " in " << Info::Palette::HIGHLIGHT << render_time << " ms" << Info::Palette::NORMAL << " = "
+		          << Info::Palette::HIGHLIGHT << (render_time ? rays * options.frames / (render_time * 1e3) : 0.0)
+		          << " Mrays/s" << Info::Palette::NORMAL << " over the whole stream" << Color::RESET << std::endl;
 	std::cout << Info::Palette::NORMAL << "Total time (without loading memory and building the BVH): "
 	          << Info::formatTime(total_time) << std::endl;
 }
 
 void download_floats(HipHost &host, float *image) { host.download(image); }
+void download_floats(HipHostRing &host, float *image) { host.download(image); }
 void download_floats(HipHostGroup &, float *) {
 	std::cerr << Info::Palette::WARNING << "--host-resize needs a single device" << Color::RESET << std::endl;
 	std::exit(EXIT_FAILURE);
@@ -265,8 +293,14 @@ int main(int argc, const char **argv) {
 	          << Color::BLUE << "<- " << Info::Palette::SECTION << "Device section" << Color::BLUE << " ->" << std::endl;
 	HipHost::printInfo();
 	std::vector<unsigned char> image((size_t) options.width * options.height);
-	if (options.gpus > 1) {
-		HipHostGroup host(rt, options.gpus, options.device);
+	if (options.gpus == 0 || options.frames == 0 || options.in_flight > 16)
+		usage_error(argv[0], "--gpus and --frames must be positive, --in-flight at most 16");
+	const unsigned int in_flight = options.in_flight ? options.in_flight : options.frames > 1 ? 3u : 1u;
+	if (options.gpus > 1 || options.gather != "auto") {
+		HipHostGroup host(rt, options.gpus, options.device, options.gather.c_str());
+		render_frame(host, options, rt, mesh, bvh, image);
+	} else if (in_flight > 1 || options.frames > 1) {
+		HipHostRing host(rt, in_flight, options.device);
 		render_frame(host, options, rt, mesh, bvh, image);
 	} else {
 		HipHost host(rt, options.device);

@@ -228,7 +228,15 @@ def test_render_cli_writes_the_golden_pgm(rt, golden, tmp_path):
     exe = os.path.join(ROOT, "opencl_raytracer_amd", "bin", "render")
     env = dict(os.environ, OCRT_SHARE_DEVICES="1")
     runs = (("bunny_256_s1_a3", []), ("blob_128x96_s4_a3_sah", ["-r", "sah"]), ("bunny_256_s1_a3", ["--host-resize", "1"]),
-            ("bunny_101x77_s9_a2", ["--gpus", "3"]), ("bunny_600_defaults", ["--gpus=8"]), ("blob_128x96_s4_a3", ["--gpus", "2"]))
+            ("bunny_101x77_s9_a2", ["--gpus", "3"]), ("bunny_600_defaults", ["--gpus=8"]), ("blob_128x96_s4_a3", ["--gpus", "2"]),
+            ("bunny_600_defaults", ["--gpus", "5", "--gather", "peer"]),
+            # the RCCL form of the exchange step (ncclCommInitAll, grouped send / receive, row assembly): RCCL refuses
+            # two ranks on one device, so on a one-GPU box it is the group of one; with two GPUs, of two
+            ("bunny_600_defaults", ["--gpus", "1", "--gather", "rccl"]),
+            ("bunny_256_s1_a3", ["--gpus", str(min(2, rt.device_count())), "--gather", "rccl"]),
+            # a steady stream of frames through a ring of render hosts (HipHostRing)
+            ("bunny_600_defaults", ["--frames", "12"]), ("bunny_101x77_s9_a2", ["--frames=7", "--in-flight", "2"]),
+            ("blob_128x96_s4_a3", ["--in-flight", "4"]))
     for name, extra in runs:
         c = golden["renders"][name]
         out = tmp_path / (name + ".pgm")
@@ -249,7 +257,11 @@ def test_render_cli_writes_the_golden_pgm(rt, golden, tmp_path):
         for line in ("Hardware information", "Max compute units", "Wavefront size", "Using Device" if "--gpus" not in " ".join(extra) else "Rank 0 of"):
             assert line in r.stdout, line
         if "--gpus" in " ".join(extra):
-            assert "Rank 1 of" in r.stdout
+            assert ("Rank 1 of" in r.stdout) == (extra[extra.index("--gpus") + 1] != "1" if "--gpus" in extra else True)
+            if "--gather" in extra:
+                assert ("over RCCL" if "rccl" in extra else "by peer copies") in r.stdout, extra
+        if "--frames" in " ".join(extra):
+            assert "render hosts taking frames in turn" in r.stdout and "over the whole stream" in r.stdout
         assert hashlib.md5(out.read_bytes()).hexdigest() == c["pgm_md5"], (name, extra)
     # more ranks than GPUs without the rehearsal knob: refused, like any other bad device request
     env.pop("OCRT_SHARE_DEVICES")
