@@ -15,20 +15,36 @@ set) any-hit rays per hit sub-pixel.
 `python -m torch.distributed.run`, before this process touches torch or the GPU);
 under an external torchrun (RANK / WORLD_SIZE in the environment) it is a rank.
 
+The frames go through the library's frame ring (include/rt_hip.h, rt_ring_*): several
+render hosts per GPU take them in turn, each replaying its captured hipGraph, and the
+ring itself runs the RCCL gather behind the next frames -- a timed block is ONE call
+into the library (rt_ring_run), Python is not on the per-frame path.  In the same run
+the frame is also timed ONE AT A TIME (a ring of one host = the reference's blocking
+OpenCLHost::operator()(), src/opencl_host.cc:137-149): `blocking` in the line.  Every
+block of K steps is bracketed by barrier + synchronize and repeated until half a second
+of GPU time is covered; the line reports the median block, with min / max beside it.
+
 Rank 0 prints ONE JSON line (contract in the task description) carrying
 `roofline` -- the bound the dominant kernel is actually under (vector-instruction
-issue; the 12 MB scene is cache-resident), with the contractual HBM line of
-SURVEY.md 8d (algorithmic bytes of the REFERENCE traversal over the HIP-event
-kernel time, and the HBM bytes the PMC counters really saw) under `roofline.hbm`
--- and, at N = 1, `cpu_baseline` (the reference's own kernel compiled for x86-64
-when oracle/_ref/ holds it, else this repo's C restatement, on the host cores).
+issue; the 12 MB scene is cache-resident): that kernel's instructions per launch over
+its launch duration, HIP events around the launch with ONE frame at a time; the
+pipelined frame rate in the same units under `roofline.frame_pipelined`; the
+contractual HBM line of SURVEY.md 8d (algorithmic bytes of the REFERENCE traversal over
+the same kernel time, and the HBM bytes the PMC counters really saw) under
+`roofline.hbm` -- and, at N = 1, `cpu_baseline` (the reference's own kernel compiled
+for x86-64 when oracle/_ref/ holds it, else this repo's C restatement, on the host
+cores) and `end_to_end` (the `render` CLI as a child process: every one-off cost).
 """
 from __future__ import annotations
 
 import argparse
 import hashlib
 import json
+import math
 import os
+import re
+import statistics
+import subprocess
 import sys
 import time
 
@@ -135,6 +151,53 @@ def host_cores() -> int:
     return n
 
 
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def end_to_end(w, golden_md5):
+    """One `render` run as a child process, BEFORE this process touches the GPU: the whole drop-in CLI with every
+    one-off cost (HIP start-up overlapped with mesh loading and BVH build, scene packing + upload, one blocking frame,
+    device resize + download, PGM write), by the CLI's own clock (--timings) and by ours around the process."""
+    exe = os.path.join(ROOT, "opencl_raytracer_amd", "bin", "render")
+    out = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"bench_end_to_end_{os.getpid()}.pgm")
+    cmd = [exe, "-w", str(w["width"]), "-h", str(w["height"]), "-s", str(w["ss"]), "-a", str(w["ao"]), "-r", w["bvh"],
+           "--timings", "1", mesh_path(w["mesh"]), out]
+    result = {"command": " ".join(["render"] + cmd[1:-2] + [os.path.basename(cmd[-2]), "out.pgm"])}
+    try:
+        runs = []
+        for _ in range(2):  # (the second run finds the files and the driver warm)
+            t0 = time.perf_counter()
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+            wall = (time.perf_counter() - t0) * 1e3
+            if r.returncode != 0:
+                return dict(result, error=(r.stdout + r.stderr)[-300:])
+            m = re.search(r"Timings \(ms\):(.*)", r.stdout)
+            phases = {}
+            if m:
+                for name, value in re.findall(r"\s*([^,]+?) ([0-9.]+),", m.group(1)):
+                    phases[name.strip().replace(" ", "_").replace("+", "_") + "_ms"] = float(value)
+                tail = re.search(r"wall ([0-9.]+)", m.group(1))
+                if tail:
+                    phases["wall_in_process_ms"] = float(tail.group(1))
+            with open(out, "rb") as f:
+                md5 = hashlib.md5(f.read()).hexdigest()
+            runs.append(dict(phases, process_wall_ms=round(wall, 1), pgm_md5=md5))
+        os.remove(out)
+        best = min(runs, key=lambda x: x["process_wall_ms"])
+        result.update(best, first_run_process_wall_ms=runs[0]["process_wall_ms"],
+                      pgm_matches_golden=(best["pgm_md5"] == golden_md5) if golden_md5 else None)
+    except (OSError, subprocess.SubprocessError) as e:
+        result["error"] = str(e)[-300:]
+    return result
+
+
 def cpu_baseline(opt, scene, gpu_u8, w):
     """Times the CPU checker on the same frame (rank 0, N = 1 only) and checks
     the GPU image against it.  The oracle is used here as the thing to compare
@@ -182,23 +245,30 @@ def cpu_baseline(opt, scene, gpu_u8, w):
     if rows == (0, p.height):
         full_rays = rays
     return {
-        "value": round(rays / seconds / 1e6, 3), "unit": "Mrays/s", "cores": int(used), "kind": kind,
+        "value": round(rays / seconds / 1e6, 3), "unit": "Mrays/s", "cores": int(used), "kind": kind, "cpu_model": cpu_model(),
         "sample": f"rows {rows[0]}..{rows[1]} of {p.height} ({rays} rays, {seconds:.2f} s wall)"
                   + ("; PGM byte-identical to the GPU frame" if rows == (0, p.height) else "; these PGM rows byte-identical to the GPU frame's"),
         "port_value": round(rays / t_port / 1e6, 3),
     }, full_rays
 
 
+def summary(values):
+    return {"median": round(statistics.median(values), 4), "min": round(min(values), 4), "max": round(max(values), 4), "n": len(values)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)  # (a quarter of a second of frames: the pipeline's fill and drain weigh 1-2 % at 50)
+    ap.add_argument("--steps", type=int, default=200)  # (a quarter of a second of frames per block)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--in-flight", type=int, default=0, choices=[0, 1, 2, 3, 4, 5, 6],
-                    help="renderers per GPU taking the frames in turn (1: one frame at a time; 0 = by the number of "
+                    help="render hosts per GPU taking the frames in turn (1: one frame at a time; 0 = by the number of "
                          "ranks: 3 up to two GPUs, 4 at four, 6 at eight)")
+    ap.add_argument("--min-seconds", type=float, default=0.5, help="repeat each block of --steps steps until this much time is covered")
+    ap.add_argument("--plain-launches", action="store_true", help="launch the kernels one by one instead of replaying the captured graph")
     args = ap.parse_args()
 
     launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ  # under torch.distributed.run
@@ -206,7 +276,6 @@ def main():
         # A bare `python bench.py --gpus N`: start the N ranks as FRESH processes.  This process has not imported
         # torch or touched the GPU yet (and must not: a process that initialised HIP may not exec or fork ranks).
         import socket
-        import subprocess
 
         with socket.socket() as sock:
             sock.bind(("127.0.0.1", 0))
@@ -218,6 +287,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     args.gpus = world
+    w = WORKLOADS[args.workload]
+    golden_md5, counters = None, None
+    if w["golden"]:
+        with open(os.path.join(ROOT, "tests", "golden", "golden.json")) as f:
+            g = json.load(f)["renders"][w["golden"]]
+        golden_md5, counters = g["pgm_md5"], g["counters"]
+
+    e2e = None
+    if world == 1 and not args.no_end_to_end:
+        e2e = end_to_end(w, golden_md5)  # (a child process, before this one opens the GPU)
 
     import numpy as np
     import torch
@@ -241,136 +320,180 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
+    reduce_device = device if backend == "nccl" else "cpu"
 
-    w = WORKLOADS[args.workload]
     opt = workload_options(rt, w)
     t0 = time.perf_counter()
-    scene = rt.Scene.load_off(mesh_path(w["mesh"])).build_bvh(opt.bvh_method)
+    scene = rt.Scene.load_off(mesh_path(w["mesh"]))
+    t_load = time.perf_counter() - t0
+    scene.build_bvh(opt.bvh_method)
     t_scene = time.perf_counter() - t0
 
-    # Several renderers of the same scene on this GPU, each on its own stream, take the frames in turn: while frame i's
-    # ambient-occlusion pass runs out (its last quarter runs at falling occupancy: the queues are drained, the
-    # workgroups end one by one) the next frames' passes fill the wave slots it frees, and the latency-bound primary
-    # pass runs beside a vector-issue-bound one.  Headline workload: 1.56 ms per frame with one renderer, 1.35 with
-    # two, 1.27 with three (default), 1.27 with four.  One frame at a time: --in-flight 1.
-    # The smaller a rank's share of the frame, the more of it is start and end of passes: one GPU's eighth of the
-    # headline frame takes 0.48 ms with one renderer, 0.31 with three, 0.29 with four, 0.25 with six; the whole frame
-    # 1.53 / 1.23 / 1.20 / 1.25 (tools/ring_sweep.py).  A step costs the CPU ~0.1 ms (tools/step_overhead_probe.py).
+    # The frame ring (include/rt_hip.h): `in_flight` render hosts of the scene on this GPU, each on its own stream
+    # (consecutive hosts in different priority classes, i.e. hardware queues) with its own captured hipGraph, take the
+    # frames in turn: while frame i's ambient-occlusion pass runs out (its last quarter runs at falling occupancy: the
+    # queues are drained, the workgroups end one by one) the next frames' passes fill the wave slots it frees, and the
+    # latency-bound primary pass runs beside a vector-issue-bound one.  The smaller a rank's share of the frame, the
+    # more of it is start and end of passes, hence more hosts at more ranks (tools/ring_sweep.py).
     in_flight = args.in_flight if args.in_flight > 0 else 3 if world <= 2 else 4 if world <= 4 else 6
-    hosts = [rt.Host(opt, device_index, rank, world) for _ in range(in_flight)]
-    for h in hosts:
-        h.upload_scene(scene)
-        h.set_device_share(len(hosts))
-    # (each host's own stream, created by the library: streams handed out by torch's pool ended up on ONE hardware
-    # queue here -- rocprofv3's kernel trace showed every kernel of both renderers in the same queue, one after the other)
-    render_streams = [torch.cuda.ExternalStream(h.stream_handle, device=device) for h in hosts]
-    host = hosts[0]
-    # The gather and the assembly of the final image run on a third stream (torch.distributed syncs with the current one).
-    stream = torch.cuda.Stream(device)
-    torch.cuda.set_stream(stream)
+    rings = {"pipelined": rt.FrameRing(opt, scene, device_index, rank, world, hosts=in_flight),
+             "blocking": rt.FrameRing(opt, scene, device_index, rank, world, hosts=1)}
+    for ring in rings.values():
+        ring.set_graph_mode(not args.plain_launches)
 
-    # band buffers: equal-sized on every rank so the gather is one collective
+    # The exchange step of a multi-GPU frame: the ring's own RCCL gather (one process per GPU; the unique id is made on
+    # rank 0 and handed round by torch.distributed).  The gloo rehearsal on a one-GPU box cannot use RCCL (it refuses
+    # two ranks on one device): there the ring writes into torch tensors and the gather is torch's, staged through host memory.
     from opencl_raytracer_amd.multi_gpu import BandGatherer, BandLayout
 
     layout = BandLayout(opt, world)
-    assert layout.local_rows(rank) == host.local_rows
-    # One band buffer and one gatherer per renderer: frame i's bands are gathered (RCCL's own stream) and its rows moved
-    # into place on rank 0 while frame i + 1 is rendered -- a frame is finished right after the next one has been
-    # enqueued, and the last one before the closing fence, so K timed steps are K complete frames.
-    slots = len(hosts) if len(hosts) > 1 else 2
-    bands = [torch.zeros((layout.max_rows, opt.width), dtype=torch.uint8, device=device) for _ in range(slots)]
-    staged = launched and backend != "nccl"  # rehearsal path: the gather is staged through host memory
-    gatherers = [BandGatherer(layout, rank, "cpu" if staged else device) for _ in range(slots)]
-    released = [None] * slots  # event: the slot's band and gatherer were last read (its frame was assembled)
-    result = {"frames": 0}
-    open_frames = []  # slots of the frames enqueued and not yet finished, oldest first
+    assert layout.local_rows(rank) == rings["pipelined"].local_rows
+    rccl = launched and backend == "nccl"
+    staged = launched and not rccl
+    bands, gatherers = {}, {}
+    if launched:
+        for name, ring in rings.items():
+            bands[name] = [torch.zeros((layout.max_rows, opt.width), dtype=torch.uint8, device=device) for _ in range(ring.slots)]
+            for k, b in enumerate(bands[name]):
+                ring.bind_output(k, b.data_ptr())
+            gatherers[name] = BandGatherer(layout, rank, "cpu" if staged else device)
+    if rccl:
+        for name, ring in rings.items():
+            uid = torch.zeros(128, dtype=torch.uint8, device=device)
+            if rank == 0:
+                uid = torch.frombuffer(bytearray(rt.rccl_unique_id()), dtype=torch.uint8).to(device)
+            dist.broadcast(uid, 0)
+            ring.attach_rccl(bytes(uid.cpu().numpy().tobytes()))
+            ring.rccl_self_test()
+    last_image = {}
 
-    def finish_oldest():
-        k = open_frames.pop(0)
-        h, rs = hosts[k % len(hosts)], render_streams[k % len(hosts)]
-        if len(hosts) > 1:
-            # The CPU waits for the frame (the next ones are already queued on the other renderers' streams), and only
-            # then issues its gather: a stream-level wait for a frame that has just begun would sit in a hardware
-            # queue as a barrier packet, and HIP streams share hardware queues -- with the collective's stream in
-            # play such a barrier ended up ahead of another renderer's kernels and the frames ran one after the other.
-            h.sync()
-        else:
-            stream.wait_stream(rs)
-        gatherers[k].start(bands[k].cpu() if staged else bands[k])
-        result["final"] = gatherers[k].finish()
-        released[k] = torch.cuda.Event()
-        released[k].record(stream)
+    def run_steps(name, steps):
+        """`steps` frames of a steady stream.  RCCL / single GPU: ONE call into the library."""
+        ring = rings[name]
+        if not staged:
+            ring.run(steps)
+            return
+        hosts = ring.size
+        for _ in range(steps):  # (rehearsal: the gather is torch's, so Python takes part in every frame)
+            ring.submit()
+            while ring.in_flight > max(1, hosts - 1) or (hosts == 1 and ring.in_flight):
+                _, slot, _ = ring.collect_info()
+                last_image[name] = gatherers[name](bands[name][slot].cpu())
 
-    def step():
-        k = result["frames"] % slots
-        h, rs = hosts[k % len(hosts)], render_streams[k % len(hosts)]
-        if released[k] is not None:  # the frame that used this band buffer before has been assembled
-            released[k].synchronize() if len(hosts) > 1 else rs.wait_event(released[k])
-        h.render_async()
-        h.resize_into_device(bands[k].data_ptr())
-        open_frames.append(k)
-        result["frames"] += 1
-        while len(open_frames) > max(1, len(hosts) - 1):  # the oldest frame -- the newer ones are queued behind it
-            finish_oldest()
-
-    def fence():
-        while open_frames:
-            finish_oldest()
+    def fence(name):
+        ring = rings[name]
+        while staged and ring.in_flight:
+            _, slot, _ = ring.collect_info()
+            last_image[name] = gatherers[name](bands[name][slot].cpu())
+        ring.drain()
         torch.cuda.synchronize(device)
         if launched:
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    for h in hosts:
-        h.sync()
-        h.reset_timers()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    for h in hosts:
-        h.sync()  # folds the HIP event pairs into the kernel-time statistics
+    def final_image(name):
+        """The last frame's assembled image on rank 0 (numpy), None elsewhere."""
+        if staged:
+            return last_image[name].numpy() if rank == 0 else None
+        if rccl and rank != 0:
+            return None
+        return rings[name].download_last()
 
-    # whole-job numbers: max time over ranks, sum of rays over ranks
-    st = host.stats()
+    if rccl and world > 1:
+        # The library's own gather against torch.distributed's on the same frame, once, before anything is timed.
+        ring = rings["pipelined"]
+        ring.submit()
+        _, slot, _ = ring.collect_info()
+        ring.drain()
+        torch.cuda.synchronize(device)
+        theirs = gatherers["pipelined"](bands["pipelined"][slot])
+        ok = torch.ones(1, dtype=torch.int32, device=device)
+        if rank == 0 and not np.array_equal(theirs.cpu().numpy(), ring.download_last()):
+            ok[0] = 0
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok[0]) == 0:
+            sys.exit("bench.py: the ring's RCCL gather and torch.distributed's gather disagree")
+
+    def timed_blocks(name):
+        """Warm-up, then blocks of exactly --steps steps, each bracketed by barrier + synchronize, the MAX over ranks
+        of each block's time; repeated until --min-seconds are covered (the count is agreed on across the ranks)."""
+        ring = rings[name]
+        run_steps(name, args.warmup)
+        fence(name)
+        ring.reset_timers()
+        ring.reset_clock()
+        seconds, planned = [], 1
+        while len(seconds) < planned:
+            t0 = time.perf_counter()
+            run_steps(name, args.steps)
+            fence(name)
+            dt = time.perf_counter() - t0
+            if launched:
+                t = torch.tensor([dt], dtype=torch.float64, device=reduce_device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t[0])
+            seconds.append(dt)
+            if len(seconds) == 1:
+                planned = max(1, min(50, math.ceil(args.min_seconds / max(dt, 1e-6))))
+        return seconds
+
+    results = {}
+    for name in ("pipelined", "blocking"):
+        seconds = timed_blocks(name)
+        ring = rings[name]
+        timers, cpu = ring.timers(), ring.cpu_times()
+        results[name] = {"seconds": seconds, "kernel_ms": timers["kernel_ms"] / max(1, timers["frames"]),
+                         "cpu_us": {k: round(cpu[k + "_s"] / max(1, cpu["frames"]) * 1e6, 1) for k in ("submit", "collect", "wait")}}
+    # The dominant kernel ALONE, by HIP events right around its launch on the launch stream (plain launches: the events
+    # of a replayed graph cannot be timed), one frame at a time -- the duration the roofline is quoted for.
+    ring = rings["blocking"]
+    ring.set_graph_mode(False)
+    run_steps("blocking", args.warmup)
+    fence("blocking")
+    ring.reset_timers()
+    run_steps("blocking", max(args.steps, 20))
+    fence("blocking")
+    timers = ring.timers()
+    alone_ao_ms = timers["ao_ms"] / max(1, timers["ao_frames"])
+    alone_kernel_ms = timers["kernel_ms"] / max(1, timers["frames"])
+    ring.set_graph_mode(not args.plain_launches)
+
+    # whole-job numbers: max time over ranks (above), sum of rays over ranks
+    st = rings["pipelined"].host(0).stats()
     my_rays = st["primary_rays"] + st["ao_rays"]
-    launches = max(1, sum(h.kernel_launches for h in hosts))
-    kernel_ms = sum(h.total_kernel_ms for h in hosts) / launches
-    ao_ms = sum(h.total_ao_ms for h in hosts) / launches  # HIP events right around the ao_kernel launch
     if launched:
-        t = torch.tensor([elapsed, kernel_ms, ao_ms], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        t = torch.tensor([alone_ao_ms, alone_kernel_ms, results["pipelined"]["kernel_ms"]], dtype=torch.float64, device=reduce_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, kernel_ms_max, ao_ms_max = float(t[0]), float(t[1]), float(t[2])
-        r = torch.tensor([my_rays, st["primary_hits"], st["ao_occluded"]], dtype=torch.int64,
-                         device=device if backend == "nccl" else "cpu")
+        alone_ao_ms, alone_kernel_ms, results["pipelined"]["kernel_ms"] = (float(x) for x in t)
+        r = torch.tensor([my_rays, st["primary_hits"], st["ao_occluded"]], dtype=torch.int64, device=reduce_device)
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
         total_rays, total_hits, total_occluded = (int(x) for x in r)
     else:
-        kernel_ms_max, ao_ms_max = kernel_ms, ao_ms
         total_rays, total_hits, total_occluded = my_rays, st["primary_hits"], st["ao_occluded"]
+    images = {name: final_image(name) for name in rings}
 
     if rank == 0:
-        final_u8 = result["final"].cpu().numpy()
-        pgm_md5 = hashlib.md5(rt.pgm_bytes(final_u8)).hexdigest()
-        golden_md5, counters = None, None
-        if w["golden"]:
-            with open(os.path.join(ROOT, "tests", "golden", "golden.json")) as f:
-                g = json.load(f)["renders"][w["golden"]]
-            golden_md5, counters = g["pgm_md5"], g["counters"]
-            if pgm_md5 != golden_md5:
-                sys.exit(f"bench.py: PGM md5 {pgm_md5} != golden {golden_md5} -- refusing to report a number")
+        md5 = {name: hashlib.md5(rt.pgm_bytes(img)).hexdigest() for name, img in images.items()}
+        if golden_md5:
+            for name in md5:
+                if md5[name] != golden_md5:
+                    sys.exit(f"bench.py: PGM md5 {md5[name]} ({name}) != golden {golden_md5} -- refusing to report a number")
             if total_hits != counters["primary_hits"] or total_occluded != counters["ao_occluded"]:
-                sys.exit("bench.py: ray statistics differ from the reference traversal")
+                sys.exit(f"bench.py: ray statistics differ from the reference traversal: {total_hits} hit sub-pixels, "
+                         f"{total_occluded} occluded rays against {counters['primary_hits']}, {counters['ao_occluded']}")
+        elif md5["pipelined"] != md5["blocking"]:
+            sys.exit("bench.py: the pipelined and the blocking frame differ")
 
-        ms_per_step = elapsed / args.steps * 1e3
-        value = total_rays / (elapsed / args.steps) / 1e6
+        def per_step_ms(name):
+            return [s / args.steps * 1e3 for s in results[name]["seconds"]]
+
+        pipe_ms, block_ms = per_step_ms("pipelined"), per_step_ms("blocking")
+        ms_per_step = statistics.median(pipe_ms)
+        value = total_rays / (ms_per_step * 1e-3) / 1e6
+        gather = "the ring's RCCL gather to rank 0" if rccl else f"{backend} gather to rank 0 (rehearsal, staged through the host)" if launched else None
         out = {
             # BASELINE.json's metric, verbatim, for the 1920x1080 workloads it is quoted on
-            "metric": "Mrays/s at 1920\u00d71080 (bunny.off, sibenik.off); PGM bit-exact vs CPU" if "1080p" in args.workload
+            "metric": "Mrays/s at 1920×1080 (bunny.off, sibenik.off); PGM bit-exact vs CPU" if "1080p" in args.workload
                       else "Mrays/s; PGM bit-exact vs CPU",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -379,16 +502,27 @@ def main():
                      "synthetic interior scene, stand-in for the missing sibenik.off (tools/make_interior_mesh.py)")
                     + ", fixed camera, no randomness in this path",
             "config": {"workload": w["label"], "rays_per_frame": total_rays, "primary_hits": total_hits,
-                       "parallelism": f"image bands x{world}" + (f", {'RCCL' if backend == 'nccl' else backend} gather to rank 0" if launched else ""),
-                       "frames_in_flight": len(hosts), "pgm_md5": pgm_md5, "pgm_matches_golden": golden_md5 is not None,
-                       "scene_build_s": round(t_scene, 3), "device": torch.cuda.get_device_name(device)},
+                       "parallelism": f"image bands x{world}" + (f", {gather}" if gather else ""),
+                       "frames_in_flight": in_flight, "frame_launch": "plain launches" if args.plain_launches else "hipGraph replay",
+                       "pgm_md5": md5["pipelined"], "pgm_matches_golden": golden_md5 is not None,
+                       "scene_load_s": round(t_load, 3), "scene_build_s": round(t_scene, 3),
+                       "device": torch.cuda.get_device_name(device)},
+            # every block is exactly `steps` steps between barrier + synchronize; `value` / `ms_per_step` are the median block
+            "blocks": dict(summary(pipe_ms), unit="ms per step", seconds_covered=round(sum(results["pipelined"]["seconds"]), 3),
+                           mrays_per_s_min=round(total_rays / (max(pipe_ms) * 1e-3) / 1e6, 1),
+                           mrays_per_s_max=round(total_rays / (min(pipe_ms) * 1e-3) / 1e6, 1)),
+            "cpu_us_per_step": results["pipelined"]["cpu_us"],
+            # the same frames ONE AT A TIME: a ring of one host = the reference's blocking OpenCLHost::operator()()
+            "blocking": dict(value=round(total_rays / (statistics.median(block_ms) * 1e-3) / 1e6, 2), unit="Mrays/s",
+                             ms_per_frame=summary(block_ms), frames_in_flight=1, pgm_md5=md5["blocking"],
+                             kernels_ms_per_frame=round(alone_kernel_ms, 4), cpu_us_per_step=results["blocking"]["cpu_us"]),
         }
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu, _ = cpu_baseline(opt, scene, final_u8, w)
+            cpu, _ = cpu_baseline(opt, scene, images["pipelined"], w)
         has_ao = bool(opt.enable_ao)
         dominant = "ao_kernel" if has_ao else "primary_kernel"
-        dominant_ms = ao_ms_max if has_ao else kernel_ms_max
+        dominant_ms = alone_ao_ms if has_ao else alone_kernel_ms
         seconds = dominant_ms * 1e-3
         pmc = pmc_for(args.workload) if world == 1 else None  # counters are per launch of the WHOLE frame on one GPU
         # The contractual HBM line: algorithmic bytes of the reference traversal over the measured
@@ -402,7 +536,7 @@ def main():
             hbm.update(algorithmic_bytes_per_launch=int(bytes_per_launch),
                        algorithmic_GBps=round(bytes_per_launch / seconds / 1e9, 1),
                        algorithmic_x_peak=round(bytes_per_launch / seconds / 1e9 / HBM_PEAK_GBS, 3),
-                       frame_algorithmic_GBps=round(parts["frame"] / world / (kernel_ms_max * 1e-3) / 1e9, 1))
+                       frame_algorithmic_GBps=round(parts["frame"] / world / (alone_kernel_ms * 1e-3) / 1e9, 1))
         traffic = None
         if pmc is not None:
             traffic = int(pmc["hbm_bytes"])
@@ -410,11 +544,13 @@ def main():
                        measured_frac=round(traffic / seconds / 1e9 / HBM_PEAK_GBS, 4))
         hbm["note"] = ("algorithmic bytes = REFERENCE traversal (36 B/node visit + 60 B/triangle test [+ 48 B/hit + 4 B/"
                        "sub-pixel for the primary pass]); they are served by the scalar cache and L2, not by HBM")
-        # The binding roofline: vector-instruction issue.  Instruction count per launch from the PMC pass of the same
-        # kernel sources (profiles/pmc.json, null if the sources changed since), launch time measured live.
+        # The binding roofline: vector-instruction issue.  ONE scope for achieved / frac: the dominant kernel's
+        # instructions per launch (PMC pass of the same kernel sources, the grid a host alone launches; null if the
+        # sources changed since) over its launch duration with one frame at a time, HIP events, measured live.
         roof = {"bound": "valu", "achieved": None, "peak": VALU_PEAK_PER_CLK_SIMD,
                 "unit": "wave64 VALU instr/clk/SIMD (1024 SIMDs, 2.4 GHz)", "frac": None, "traffic": traffic,
-                "kernel": dominant, "kernel_ms": round(dominant_ms, 4), "frame_kernels_ms": round(kernel_ms_max, 4)}
+                "scope": "dominant kernel alone: its instructions per launch over its launch duration, one frame at a time",
+                "kernel": dominant, "kernel_ms": round(dominant_ms, 4), "frame_kernels_ms": round(alone_kernel_ms, 4)}
         if pmc is not None:
             rate = pmc["valu_insts"] / (seconds * CLOCK_HZ * SIMDS)
             roof.update(achieved=round(rate, 4), frac=round(rate / VALU_PEAK_PER_CLK_SIMD, 4),
@@ -429,38 +565,30 @@ def main():
             if pmc.get("active_inst_valu_quad_cycles") and pmc.get("gui_active_cycles"):
                 roof["valu_nominal_issue_share"] = round(pmc["active_inst_valu_quad_cycles"] * 4.0 / SIMDS /
                                                    (pmc["gui_active_cycles"] / 8.0), 4)
+            # The other scope, under its own key: what the device does per unit of time with frames in flight -- the
+            # vector instructions of a whole frame, every kernel, counted for the grid a host launches when it shares
+            # its GPU, over the measured time per frame of the pipelined blocks.
+            frame_insts = pmc.get("shared_frame_valu_insts") or pmc.get("frame_valu_insts")
+            if frame_insts:
+                frame_rate = frame_insts / (ms_per_step * 1e-3 * CLOCK_HZ * SIMDS)
+                roof["frame_pipelined"] = {
+                    "valu_insts_per_frame": int(frame_insts), "grid": "shared" if pmc.get("shared_frame_valu_insts") else "alone",
+                    "ms_per_frame": round(ms_per_step, 4), "achieved": round(frame_rate, 4),
+                    "frac": round(frame_rate / VALU_PEAK_PER_CLK_SIMD, 4),
+                    "frac_of_measured_ceiling": round(frame_rate / pmc["valu_ceiling_measured"], 4) if pmc.get("valu_ceiling_measured") else None,
+                    "frames_in_flight": in_flight}
         else:
             roof["counters_from"] = None if world > 1 else "profiles/pmc.json is missing or was collected for other kernel sources"
-        # With several frames in flight a launch shares the device with its neighbours' and takes longer than alone
-        # (its event pair spans the time it waits for wave slots): the dominant kernel's instructions over ITS launch
-        # duration then say little about the kernel.  What the device does per unit of time is the vector
-        # instructions of a whole frame -- every kernel, counted by the same PMC pass -- over the measured time per
-        # frame; that is what `achieved` / `frac` hold in this case (`scope` says which), the per-launch figures of
-        # the timed region stay beside them under `launch`, and `--in-flight 1` gives the kernel alone.
-        roof["scope"] = "dominant kernel: its instructions per launch over its launch duration"
-        if pmc is not None and pmc.get("frame_valu_insts"):
-            frame_rate = pmc["frame_valu_insts"] / (ms_per_step * 1e-3 * CLOCK_HZ * SIMDS)
-            frame = {"valu_insts_per_frame": int(pmc["frame_valu_insts"]), "ms_per_frame": round(ms_per_step, 4),
-                     "achieved": round(frame_rate, 4), "frac": round(frame_rate / VALU_PEAK_PER_CLK_SIMD, 4),
-                     "frac_of_measured_ceiling": round(frame_rate / pmc["valu_ceiling_measured"], 4)
-                     if pmc.get("valu_ceiling_measured") else None,
-                     "frames_in_flight": len(hosts)}
-            roof["frame"] = frame
-            if len(hosts) > 1:
-                roof["launch"] = {"kernel": dominant, "kernel_ms_sharing_the_device": roof["kernel_ms"],
-                                  "achieved": roof["achieved"], "frac": roof["frac"],
-                                  "frac_of_measured_ceiling": roof.get("frac_of_measured_ceiling")}
-                roof.update(achieved=frame["achieved"], frac=frame["frac"],
-                            frac_of_measured_ceiling=frame["frac_of_measured_ceiling"],
-                            scope=f"frame: the vector instructions of all its kernels over the time per frame, {len(hosts)} frames in flight")
         roof["hbm"] = hbm
         out["roofline"] = roof
         if cpu is not None:
             out["cpu_baseline"] = cpu
+        if e2e is not None:
+            out["end_to_end"] = e2e
         print(json.dumps(out), flush=True)
 
-    for h in hosts:
-        h.close()
+    for ring in rings.values():
+        ring.close()
     if launched:
         dist.destroy_process_group()
 

@@ -44,6 +44,24 @@ int visible_device_count() {
 	return count;
 }
 
+void warm_up_device(int device) {
+	int count = 0;
+	if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+		return;
+	if (device < 0) {
+		const char *env = std::getenv("OCRT_DEVICE");
+		device = env ? std::atoi(env) : 0;
+	}
+	if (device >= count || hipSetDevice(device) != hipSuccess)
+		return;
+	(void) hipFree(nullptr);  // (forces the context)
+	preload_kernels();
+	void *p = nullptr;        // the allocator's first call is slow too
+	if (hipMalloc(&p, 1 << 20) == hipSuccess)
+		(void) hipFree(p);
+	(void) hipGetLastError();
+}
+
 DeviceRenderer::DeviceRenderer(const RayTracer::Options &options, int device_, unsigned int rank, unsigned int nranks,
                                int ring_slot)
 	: opts(options)
@@ -142,6 +160,10 @@ DeviceRenderer::DeviceRenderer(const RayTracer::Options &options, int device_, u
 	}
 	OCRT_HIP(hipMemsetAsync(d_image, 0, image_bytes, (hipStream_t) stream));
 	OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));
+#ifdef OCRT_DEBUG_KNOBS
+	if (const char *env = std::getenv("OCRT_AO_BLOCKS"))  // workgroups of the persistent ambient-occlusion pass
+		ao_blocks_override = (uint32_t) std::atoi(env);
+#endif
 }
 
 DeviceRenderer::~DeviceRenderer() {
@@ -263,14 +285,15 @@ DeviceRenderer::FrameEvents DeviceRenderer::takeEvents() {
 // The launches of one frame on the stream: counters, primary pass, ordering step + ambient-occlusion pass + resolve
 // (launch_ao), and -- with a destination -- the device resize.  `ao_start` / `ao_stop` bracket the ao_kernel launch.
 void DeviceRenderer::launchFrame(void *device_u8, void *ao_start, void *ao_stop) {
-	hipStream_t s = (hipStream_t) stream;
-	OCRT_HIP(hipMemsetAsync(d_counters, 0, sizeof(FrameCounters), s));
 #ifdef OCRT_STAMPS
-	OCRT_HIP(hipMemsetAsync((char *) d_counters + offsetof(FrameCounters, stamp) + 7 * sizeof(unsigned long long), 0xFF, sizeof(unsigned long long), s));
+	hipStream_t s = (hipStream_t) stream;
 #endif
 	const SceneBuffers scene{ d_nodes, d_walk, d_tris, d_shade, d_ao };
-	launch_primary(scene, (float *) d_image, d_hits, d_occluded, d_tile_hits, d_counters, kp, stream);
+	launch_primary(scene, (float *) d_image, d_hits, d_occluded, d_tile_hits, d_counters, kp, stream);  // (clears the counters first)
 	OCRT_HIP(hipGetLastError());
+#ifdef OCRT_STAMPS  // (instrumented build: the AO pass takes the minimum of its waves' start times into this slot)
+	OCRT_HIP(hipMemsetAsync((char *) d_counters + offsetof(FrameCounters, stamp) + 7 * sizeof(unsigned long long), 0xFF, sizeof(unsigned long long), s));
+#endif
 	launch_ao(scene, (float *) d_image, d_hits, d_occluded, d_tile_hits, d_order, d_counters, kp,
 	          ao_blocks_override ? ao_blocks_override : aoWorkgroups(), stream, ao_start, ao_stop);
 	OCRT_HIP(hipGetLastError());
@@ -527,6 +550,7 @@ RenderStats DeviceRenderer::stats() {
 			std::fprintf(stderr, " %d:%llu", 1 << k, c.stamp[49 + k]);
 	std::fprintf(stderr, "\n   packets in the exact form %llu, wave-time of the jobs holding them %.3f ms\n", c.stamp[63], c.stamp[64] * 1e-5);
 #endif
+#ifdef OCRT_DEBUG_KNOBS
 	if (std::getenv("OCRT_PRINT_COST")) {  // debug knob: the tiles' AO cost classes (leaves the primary packet stopped at)
 		std::vector<uint32_t> th(tile_count);
 		OCRT_HIP(hipMemcpy(th.data(), d_tile_hits, tile_count * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -540,6 +564,7 @@ RenderStats DeviceRenderer::stats() {
 		std::fprintf(stderr, "hit tiles %llu, mean cost class %.2f, mean hits per tile %.1f\n", tiles, tiles ? (double) cost / tiles : 0.0,
 		             tiles ? (double) hits / tiles : 0.0);
 	}
+#endif
 	// Primary rays = sub-pixels of this rank's bands that lie inside the image.
 	const uint32_t tile_rows = (kp.height + TILE_H - 1) / TILE_H;
 	unsigned long long rows = 0;

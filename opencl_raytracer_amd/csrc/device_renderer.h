@@ -21,6 +21,11 @@ struct DeviceError : std::runtime_error {
 
 // Number of visible HIP devices (0 when the runtime reports none or fails).
 int visible_device_count();
+// Initialises the HIP runtime, the device's context and this library's code object on it (device < 0: $OCRT_DEVICE or
+// 0); never fails -- whatever is wrong shows up again, properly reported, when a renderer is created.  These one-off
+// costs (100-200 ms) are independent of the scene: a front end runs this on a second thread while it loads the mesh
+// and builds the BVH (render.cc).
+void warm_up_device(int device);
 
 class DeviceRenderer {
 	public:
@@ -151,6 +156,7 @@ class DeviceRenderer {
 };
 
 // kernels.hip
+void preload_kernels();
 void launch_primary(const SceneBuffers &scene, float *image, void *hits, void *occluded_of, void *tile_hits,
                     void *counters, const KernelParams &P, void *stream);
 void launch_ao(const SceneBuffers &scene, float *image, void *hits, void *occluded_of, void *tile_hits, void *order,

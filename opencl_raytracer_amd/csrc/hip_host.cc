@@ -351,6 +351,8 @@ ocrt::RenderStats HipHostGroup::lastStats() {
 	return total;
 }
 
+void HipHost::warmUp(int device) { ocrt::warm_up_device(device); }
+
 void HipHost::printInfo() {
 	Info info;
 	info.setTitle("Hardware information");

@@ -70,6 +70,10 @@ class HipHost {
 
 		// Device table on stdout (reference src/opencl_host.cc:76-119).
 		static void printInfo();
+		// New: brings up the HIP runtime, the device context and the kernels' code object without creating a host.  A
+		// caller that still has CPU work to do before it needs the host (mesh loading, BVH build: src/render.cc:52-80)
+		// runs this on a second thread; constructing the host afterwards costs milliseconds instead of 100-200 ms.
+		static void warmUp(int device = -1);
 
 		// Milliseconds the ray-casting kernel of the last operator()() took,
 		// measured with HIP events on the launch stream.

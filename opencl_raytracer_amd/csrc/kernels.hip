@@ -33,7 +33,8 @@
 // walk", see shared_box / walk_collect below) -- nodes and triangles arrive by
 // scalar loads, boxes are tested out of SGPRs, nothing diverges and nothing is
 // gathered.  The first generation, in which every lane walked on its own under a
-// wave scheduler, is still here (OCRT_NO_SHARED_WALK=1) for A/B runs.
+// wave scheduler, is only compiled into the A/B build (-DOCRT_DEBUG_KNOBS, where
+// OCRT_NO_SHARED_WALK=1 selects it); the product library does not contain it.
 //
 // What bounds it: the scene (12 MB) is cache-resident, HBM traffic is negligible;
 // the walk is bound by vector-instruction issue (23 per node and packet) and the
@@ -132,21 +133,6 @@ __device__ __forceinline__ bool slab_hit(const float4 lo, const float4 hi, const
 	return !miss & (t_min < max_distance) & (t_max > 0.0f);
 }
 
-// ---------------------------------------------------------------------------
-// Wave-scheduled traversal.
-//
-// A lane walks nodes (T), has hit leaves pending their triangle test (L) or has
-// no ray (I).  Instead of letting every lane run its own nested loops -- where
-// the wave pays for the longest ray and a triangle test runs with a handful of
-// live lanes -- the wave picks, per iteration and with scalar ballots only, the
-// one body worth running: refill idle lanes from the ray queue, run the triangle
-// test for the lanes with a pending leaf, or advance the walking lanes by one
-// node.  Each body is straight-line and predicated, so exec-mask bookkeeping
-// stays out of the hot loop.  A lane keeps up to TWO pending leaves (a FIFO, so
-// the reference's ascending leaf order of the tests is preserved) and goes on
-// walking while the second slot is free: lanes rarely block on a triangle test,
-// and the tests run with more lanes at once.
-// ---------------------------------------------------------------------------
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 
 // Orders this wave's LDS writes before its later LDS reads.  A wave executes in
@@ -158,12 +144,6 @@ __device__ __forceinline__ void wave_lds_sync() {
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// The lane number again, opaque to the optimiser: an address built from it is computed where it is used (per claim,
-// off the hot path) instead of being hoisted out of every loop into registers that the walk then cannot have.
-__device__ __forceinline__ uint32_t cold_lane(uint32_t lane) {
-	asm volatile("" : "+v"(lane));
-	return lane;
-}
 
 // The lane number recomputed (two instructions) where it is needed, opaque to the optimiser (which would otherwise
 // compute it once and hold it in a register across the walks).
@@ -180,24 +160,6 @@ __device__ __forceinline__ uint32_t rank_in(unsigned long long mask) {
 
 // The lanes' predicate as a 64-bit mask, straight from the compare (HIP's __ballot goes through an int).
 __device__ __forceinline__ unsigned long long wave_ballot(bool predicate) { return __builtin_amdgcn_ballot_w64(predicate); }
-
-struct Pending {
-	uint32_t first, second;  // leaf indices in the order they were met; NONE = free
-};
-__device__ __forceinline__ bool can_walk(const Pending &p, uint32_t i, uint32_t count) { return p.second == NONE && i < count; }
-// Thresholds (KernelParams::refill_min / leaf_min, 16 each): refill once that many
-// lanes are idle, run the triangle tests once that many leaves are pending.
-
-// Largest magnitude for which (b - o) cannot overflow.  A ray is "regular" when
-// its origin and its reciprocal direction are finite and within it (so no
-// inf * 0, no inf - inf); for any other ray the reference's own select-based
-// slab test is used instead of the min/max form.
-constexpr float REGULAR_LIMIT = 1.0e37f;
-
-__device__ __forceinline__ bool ray_is_regular(const Ray &r) {
-	return fabsf(r.ox) <= REGULAR_LIMIT && fabsf(r.oy) <= REGULAR_LIMIT && fabsf(r.oz) <= REGULAR_LIMIT &&
-	       fabsf(r.ix) <= REGULAR_LIMIT && fabsf(r.iy) <= REGULAR_LIMIT && fabsf(r.iz) <= REGULAR_LIMIT;
-}
 
 // What the shared walk's fast form needs of a ray: a finite origin within the limit
 // and reciprocal directions that are numbers (infinite is fine -- a zero direction
@@ -223,23 +185,6 @@ __device__ __forceinline__ bool ray_is_selectable(const Ray &r, float origin_lim
 	return origin_ok && numbers && some_finite;
 }
 
-// min/max form of the slab test.  For a regular ray against a regular box
-// (finite, lo <= hi) no NaN can arise, (lo-o)*inv and (hi-o)*inv are ordered by
-// the sign of inv (IEEE rounding is monotonic), and the reference's chain of
-// early-outs (src/intersect_kernel.cl:21-61) reduces to
-//   max(near) <= min(far)  &&  max(near) < max_distance  &&  min(far) > 0,
-// the same comparisons on the same values.  With below = pred(max_distance) and
-// tiny = the smallest positive float, that is  max(near, tiny) <= min(far, below).
-__device__ __forceinline__ bool slab_hit_regular(const float4 lo, const float4 hi, const Ray &r, float below) {
-	const float x0 = (lo.x - r.ox) * r.ix, x1 = (hi.x - r.ox) * r.ix;
-	const float y0 = (lo.y - r.oy) * r.iy, y1 = (hi.y - r.oy) * r.iy;
-	const float z0 = (lo.z - r.oz) * r.iz, z1 = (hi.z - r.oz) * r.iz;
-	const float tiny = __uint_as_float(1u);
-	const float t_near = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tiny));
-	const float t_far = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), below));
-	return t_near <= t_far;
-}
-
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // 128-bit loads through a buffer descriptor (wave-uniform base + 32-bit per-lane
@@ -250,22 +195,6 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 load_f4(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_offset) {
 	const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int) byte_offset, 0, 0);
 	return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
-
-// One node for a lane in state T: box hit -> next node in pre-order (and the leaf,
-// if it is one, becomes pending); miss -> skip the subtree.  Inner nodes carry
-// leaf == NONE, so no leaf/inner branch is needed.
-template <bool REGULAR>
-__device__ __forceinline__ void node_step(__amdgpu_buffer_rsrc_t nodes, const Ray &r, float max_distance,
-                                          float below, uint32_t &i, Pending &pending) {
-	const float4 lo = load_f4(nodes, i * 32u);
-	const float4 hi = load_f4(nodes, i * 32u + 16u);
-	const bool hit = REGULAR ? slab_hit_regular(lo, hi, r, below) : slab_hit(lo, hi, r, max_distance);
-	const uint32_t leaf = hit ? __float_as_uint(hi.w) : NONE;  // NONE unless a leaf's box was hit
-	const bool empty = pending.first == NONE;                  // (this lane walks, so `second` is free)
-	pending.second = empty ? NONE : leaf;
-	pending.first = empty ? leaf : pending.first;
-	i += hit ? 1u : __float_as_uint(lo.w);
 }
 
 __device__ __forceinline__ void normalize3(float &x, float &y, float &z) {
@@ -361,6 +290,74 @@ __device__ __forceinline__ SceneViews make_views(const float4 *nodes_ptr, const 
 	return scene;
 }
 
+#ifdef OCRT_DEBUG_KNOBS  // ---- first generation (A/B build only): every lane walks on its own under a wave scheduler ----
+// ---------------------------------------------------------------------------
+// Wave-scheduled traversal.
+//
+// A lane walks nodes (T), has hit leaves pending their triangle test (L) or has
+// no ray (I).  Instead of letting every lane run its own nested loops -- where
+// the wave pays for the longest ray and a triangle test runs with a handful of
+// live lanes -- the wave picks, per iteration and with scalar ballots only, the
+// one body worth running: refill idle lanes from the ray queue, run the triangle
+// test for the lanes with a pending leaf, or advance the walking lanes by one
+// node.  Each body is straight-line and predicated, so exec-mask bookkeeping
+// stays out of the hot loop.  A lane keeps up to TWO pending leaves (a FIFO, so
+// the reference's ascending leaf order of the tests is preserved) and goes on
+// walking while the second slot is free: lanes rarely block on a triangle test,
+// and the tests run with more lanes at once.
+// ---------------------------------------------------------------------------
+struct Pending {
+	uint32_t first, second;  // leaf indices in the order they were met; NONE = free
+};
+__device__ __forceinline__ bool can_walk(const Pending &p, uint32_t i, uint32_t count) { return p.second == NONE && i < count; }
+// Thresholds (KernelParams::refill_min / leaf_min, 16 each): refill once that many
+// lanes are idle, run the triangle tests once that many leaves are pending.
+
+
+// Largest magnitude for which (b - o) cannot overflow.  A ray is "regular" when
+// its origin and its reciprocal direction are finite and within it (so no
+// inf * 0, no inf - inf); for any other ray the reference's own select-based
+// slab test is used instead of the min/max form.
+constexpr float REGULAR_LIMIT = 1.0e37f;
+
+__device__ __forceinline__ bool ray_is_regular(const Ray &r) {
+	return fabsf(r.ox) <= REGULAR_LIMIT && fabsf(r.oy) <= REGULAR_LIMIT && fabsf(r.oz) <= REGULAR_LIMIT &&
+	       fabsf(r.ix) <= REGULAR_LIMIT && fabsf(r.iy) <= REGULAR_LIMIT && fabsf(r.iz) <= REGULAR_LIMIT;
+}
+
+// min/max form of the slab test.  For a regular ray against a regular box
+// (finite, lo <= hi) no NaN can arise, (lo-o)*inv and (hi-o)*inv are ordered by
+// the sign of inv (IEEE rounding is monotonic), and the reference's chain of
+// early-outs (src/intersect_kernel.cl:21-61) reduces to
+//   max(near) <= min(far)  &&  max(near) < max_distance  &&  min(far) > 0,
+// the same comparisons on the same values.  With below = pred(max_distance) and
+// tiny = the smallest positive float, that is  max(near, tiny) <= min(far, below).
+__device__ __forceinline__ bool slab_hit_regular(const float4 lo, const float4 hi, const Ray &r, float below) {
+	const float x0 = (lo.x - r.ox) * r.ix, x1 = (hi.x - r.ox) * r.ix;
+	const float y0 = (lo.y - r.oy) * r.iy, y1 = (hi.y - r.oy) * r.iy;
+	const float z0 = (lo.z - r.oz) * r.iz, z1 = (hi.z - r.oz) * r.iz;
+	const float tiny = __uint_as_float(1u);
+	const float t_near = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tiny));
+	const float t_far = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), below));
+	return t_near <= t_far;
+}
+
+// One node for a lane in state T: box hit -> next node in pre-order (and the leaf,
+// if it is one, becomes pending); miss -> skip the subtree.  Inner nodes carry
+// leaf == NONE, so no leaf/inner branch is needed.
+template <bool REGULAR>
+__device__ __forceinline__ void node_step(__amdgpu_buffer_rsrc_t nodes, const Ray &r, float max_distance,
+                                          float below, uint32_t &i, Pending &pending) {
+	const float4 lo = load_f4(nodes, i * 32u);
+	const float4 hi = load_f4(nodes, i * 32u + 16u);
+	const bool hit = REGULAR ? slab_hit_regular(lo, hi, r, below) : slab_hit(lo, hi, r, max_distance);
+	const uint32_t leaf = hit ? __float_as_uint(hi.w) : NONE;  // NONE unless a leaf's box was hit
+	const bool empty = pending.first == NONE;                  // (this lane walks, so `second` is free)
+	pending.second = empty ? NONE : leaf;
+	pending.first = empty ? leaf : pending.first;
+	i += hit ? 1u : __float_as_uint(lo.w);
+}
+
 // Advances the lanes in state T by one node: the min/max slab form when every
 // walking lane's ray is regular (the common case), the reference's own form otherwise.
 __device__ __forceinline__ void advance_walkers(const SceneViews &scene, const Ray &r, bool regular, float max_distance,
@@ -374,6 +371,8 @@ __device__ __forceinline__ void advance_walkers(const SceneViews &scene, const R
 			node_step<false>(scene.nodes, r, max_distance, below, i, pending);
 	}
 }
+
+#endif  // OCRT_DEBUG_KNOBS
 
 // ---------------------------------------------------------------------------
 // Shared walk.  The 64 rays of a wave visit the union of their nodes together:
@@ -402,10 +401,9 @@ __device__ __forceinline__ void advance_walkers(const SceneViews &scene, const R
 // tests/test_hip_parity.py::test_zero_normals_on_a_rebuilt_tree covers it.
 // `at` never overtakes a live lane's `mine` because subtree ranges nest.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ bool shared_box(bool exact, const float4 lo, const float4 hi, const Ray &ray, float max_distance,
-                                           float below, bool alive, uint32_t at, uint32_t skip, uint32_t &mine) {
-	if (!exact)
-		return slab_hit_regular(lo, hi, ray, below) & alive;
+// One node of the exact form for a lane: the reference's slab test where the lane's own walk stands (`mine`).
+__device__ __forceinline__ bool exact_box(const float4 lo, const float4 hi, const Ray &ray, float max_distance, bool alive,
+                                          uint32_t at, uint32_t skip, uint32_t &mine) {
 	const bool here = alive && mine == at;
 	const bool box = here && slab_hit(lo, hi, ray, max_distance);
 	mine = here ? (box ? at + 1u : at + skip) : mine;
@@ -879,8 +877,8 @@ __device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ n
 // ---------------------------------------------------------------------------
 constexpr uint32_t PRIMARY_WAVES = 4;
 
-// SHARED: the shared walk (two instantiations, so that the first generation's per-lane state stays out of the
-// default path's register budget).
+// SHARED: the shared walk.  (The A/B build also instantiates the first generation, SHARED = false; two instantiations,
+// so that its per-lane state stays out of the default path's register budget.)
 template <bool SHARED>
 __global__ __launch_bounds__(64 * PRIMARY_WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void primary_kernel(
     const float4 *__restrict__ nodes_ptr, const float4 *__restrict__ walk_ptr, const float4 *__restrict__ tris_ptr,
@@ -921,7 +919,6 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) __attribute__((amdgpu_waves_per
 	float dz = -1.0f;
 	normalize3(dx, dy, dz);
 	const Ray ray = make_ray(0.0f, 0.0f, 2.0f, dx, dy, dz);
-	const bool regular = P.scene_regular && ray_is_regular(ray);
 	Hit best;
 	best.distance = __builtin_inff();
 	best.leaf = 0;
@@ -1038,7 +1035,7 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) __attribute__((amdgpu_waves_per
 				const float4 lo = make_float4(__uint_as_float(node[0]), __uint_as_float(node[1]), __uint_as_float(node[2]), 0.0f);
 				const float4 hi = make_float4(__uint_as_float(node[4]), __uint_as_float(node[5]), __uint_as_float(node[6]), 0.0f);
 				const uint32_t skip = node[3], leaf = node[7];
-				const bool box = shared_box(true, lo, hi, ray, 100000.0f, P.primary_below, active, at, skip, mine);
+				const bool box = exact_box(lo, hi, ray, 100000.0f, active, at, skip, mine);
 				const bool any = wave_ballot(box) != 0ull;
 				if (any && leaf != NONE) {
 					leaf_test(leaf, box);
@@ -1047,7 +1044,10 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) __attribute__((amdgpu_waves_per
 				at = (uint32_t) __builtin_amdgcn_readfirstlane((int) (at + (any ? 1u : skip)));
 			}
 		}
-	} else {
+	}
+#ifdef OCRT_DEBUG_KNOBS
+	if (!SHARED) {
+		const bool regular = P.scene_regular && ray_is_regular(ray);
 		uint32_t i = active ? 0u : count;
 		Pending pending = { NONE, NONE };
 		for (;;) {
@@ -1079,6 +1079,7 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) __attribute__((amdgpu_waves_per
 				advance_walkers(scene, ray, regular, 100000.0f, P.primary_below, count, i, pending);
 		}
 	}
+#endif
 
 	// smooth normal and head-light term, reference :296-304
 	float value = 0.0f;
@@ -1414,12 +1415,14 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 				// order is direction-major, so neighbouring lanes cast the same table direction
 				// from neighbouring pixels. ----
 				const uint32_t total = hit_count * n_dirs;
+				uint32_t h = 0;
+				Ray ray;
+#ifdef OCRT_DEBUG_KNOBS
 				uint32_t next = 0u;  // wave-uniform queue head
 				uint32_t i = count;
 				Pending pending = { NONE, NONE };
-				uint32_t h = 0;
-				Ray ray;
 				bool regular = true;
+#endif
 
 				// ray number `item` of the job -> this lane
 				// `whole` (wave-uniform): the tile is full and the 64 rays are one table direction, `shared_dir`
@@ -1473,9 +1476,12 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 						}
 					}
 					ray = make_ray(sh.frame[0][h], sh.frame[1][h], sh.frame[2][h], rx, ry, rz);
+#ifdef OCRT_DEBUG_KNOBS
 					regular = P.scene_regular && P.ao_regular && ray_is_regular(ray);
+#endif
 				};
 
+#ifdef OCRT_DEBUG_KNOBS
 				// Every lane walks on its own; idle lanes are refilled from the job's rays while
 				// next < total.
 				auto walk_individually = [&]() {
@@ -1515,10 +1521,13 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 							advance_walkers(scene, ray, regular, P.ao_max_distance, P.ao_below, count, i, pending);
 					}
 				};
+#endif
 
-				if (!SHARED) {
+#ifdef OCRT_DEBUG_KNOBS
+				if (!SHARED)
 					walk_individually();
-				} else {
+#endif
+				if (SHARED) {
 					// shared walks (see shared_box) of 64 consecutive rays of the job at a time; a lane
 					// leaves at its first accepted triangle
 					const bool scene_fast = P.fast_walk && P.ao_regular && P.walk_scale > 0.0f;
@@ -1670,11 +1679,31 @@ __global__ __launch_bounds__(256) void resize_kernel(const float *__restrict__ t
 }
 
 // ---- host-callable launchers (keeps the launch syntax inside this TU) ----
+// Makes the runtime load this library's code object for the current device now (it is otherwise loaded at the first
+// launch): called from a warm-up thread while the CPU still builds the scene.
+void preload_kernels() {
+	hipFuncAttributes attr;
+	(void) hipFuncGetAttributes(&attr, (const void *) primary_kernel<true>);
+	(void) hipFuncGetAttributes(&attr, (const void *) ao_kernel<AO_UNIFORM, true>);
+	(void) hipGetLastError();
+}
+
+// Zeroes a frame's counters.  A kernel, not hipMemsetAsync: as a node of a captured graph replayed beside other
+// streams' work (torch.distributed's RCCL kernels), the memset left pointer-like garbage in the counters under the HIP
+// 7.0 runtime that torch bundles (the ray statistics came out wrong, the image did not depend on it); a kernel node
+// has no such problem, and the plain launches take the same path.
+__global__ __launch_bounds__(256) void clear_counters_kernel(FrameCounters *counters) {
+	uint32_t *words = (uint32_t *) counters;
+	for (uint32_t i = threadIdx.x; i < sizeof(FrameCounters) / sizeof(uint32_t); i += blockDim.x)
+		words[i] = 0u;
+}
+
 void launch_primary(const SceneBuffers &scene, float *image, void *hits, void *occluded_of, void *tile_hits,
                     void *counters, const KernelParams &P, void *stream) {
+	hipStream_t s = (hipStream_t) stream;
+	hipLaunchKernelGGL(clear_counters_kernel, dim3(1), dim3(256), 0, s, (FrameCounters *) counters);
 	if (P.tiles_x * P.local_tile_rows == 0)
 		return;
-	hipStream_t s = (hipStream_t) stream;
 	const uint32_t strips = (P.tiles_x + 1u) >> 1, row_pairs = (P.local_tile_rows + 1u) >> 1;
 	const uint32_t blocks = XCD_GROUPS * ((strips + XCD_GROUPS - 1u) >> 3) * row_pairs;
 	auto launch = [&](auto kernel) {
@@ -1682,10 +1711,11 @@ void launch_primary(const SceneBuffers &scene, float *image, void *hits, void *o
 		                   (const float4 *) scene.walk, (const float4 *) scene.tris, (const float4 *) scene.shade, image,
 		                   (HitRec *) hits, (uint32_t *) occluded_of, (uint32_t *) tile_hits, (FrameCounters *) counters, P);
 	};
-	if (P.shared_walk)
-		launch(primary_kernel<true>);
-	else
-		launch(primary_kernel<false>);
+#ifdef OCRT_DEBUG_KNOBS
+	if (!P.shared_walk)
+		return launch(primary_kernel<false>);
+#endif
+	launch(primary_kernel<true>);
 }
 
 void launch_ao(const SceneBuffers &scene, float *image, void *hits, void *occluded_of, void *tile_hits, void *order,
@@ -1700,8 +1730,6 @@ void launch_ao(const SceneBuffers &scene, float *image, void *hits, void *occlud
 	const uint32_t tiles = params.tiles_x * params.local_tile_rows;
 	const uint64_t units = (uint64_t) tiles * params.ao_dirs;
 	uint32_t ao_blocks = workgroups;  // (DeviceRenderer::aoWorkgroups: 8 per CU for a host alone on its GPU)
-	if (const char *env = getenv("OCRT_AO_BLOCKS"))  // debug knob
-		ao_blocks = (uint32_t) atoi(env);
 	if ((units + AO_WAVES - 1) / AO_WAVES < ao_blocks)
 		ao_blocks = (uint32_t) ((units + AO_WAVES - 1) / AO_WAVES);
 	KernelParams P = params;
@@ -1718,17 +1746,18 @@ void launch_ao(const SceneBuffers &scene, float *image, void *hits, void *occlud
 		if (event_after_ao)
 			(void) hipEventRecord((hipEvent_t) event_after_ao, s);
 	};
-	if (P.ao_mode == AO_UNIFORM) {
-		if (P.shared_walk)
-			launch(ao_kernel<AO_UNIFORM, true>);
-		else
+#ifdef OCRT_DEBUG_KNOBS
+	if (!P.shared_walk) {
+		if (P.ao_mode == AO_UNIFORM)
 			launch(ao_kernel<AO_UNIFORM, false>);
-	} else {
-		if (P.shared_walk)
-			launch(ao_kernel<AO_RANDOM, true>);
 		else
 			launch(ao_kernel<AO_RANDOM, false>);
-	}
+	} else
+#endif
+	if (P.ao_mode == AO_UNIFORM)
+		launch(ao_kernel<AO_UNIFORM, true>);
+	else
+		launch(ao_kernel<AO_RANDOM, true>);
 	hipLaunchKernelGGL(resolve_kernel, dim3((tiles * 64u + 255u) / 256u), dim3(256), 0, s, (const HitRec *) hits,
 	                   (const uint32_t *) occluded_of, (const uint32_t *) tile_hits, (FrameCounters *) counters, image,
 	                   tiles, P.ao_divisor);

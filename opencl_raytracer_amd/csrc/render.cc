@@ -5,12 +5,14 @@
 // `--gather rccl|peer|auto`), `--frames K` / `--in-flight H` (a steady stream of K frames through a ring of H render
 // hosts on the one GPU: throughput instead of one blocking frame), `--host-resize` (the reference's own download +
 // RayTracer::resize instead of the fused device resize), and a Mrays/s summary line.
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "bvh.h"
@@ -49,6 +51,8 @@ const OptionSpec OPTIONS[] = {
 	{ 0, "frames", "Renders the frame this many times in a row (the image written is the last one)." },
 	{ 0, "in-flight", "Render hosts taking those frames in turn on the GPU (default 3 when --frames > 1, else 1)." },
 	{ 0, "host-resize", "Downloads the float image and resizes it on the host, as the reference does [0|1]." },
+	{ 0, "timings", "Prints one more line with the phases' wall-clock times in milliseconds [0|1]." },
+	{ 0, "warm-up", "Brings up the HIP device on a second thread while the mesh is loaded and the BVH built [0|1] (default 1)." },
 };
 
 void usage(const char *argv0) {
@@ -83,6 +87,7 @@ struct CliOptions : RayTracer::Options {
 	unsigned int frames = 1, in_flight = 0;
 	std::string gather = "auto";
 	bool host_resize = false;
+	bool timings = false, warm_up = true;
 
 	CliOptions(int argc, const char **argv) : RayTracer::Options(RayTracer::defaults()) {
 		std::vector<std::string> positional;
@@ -163,6 +168,10 @@ struct CliOptions : RayTracer::Options {
 			gather = value;
 		else if (name == "host-resize")
 			host_resize = std::atoi(value) != 0;
+		else if (name == "timings")
+			timings = std::atoi(value) != 0;
+		else if (name == "warm-up")
+			warm_up = std::atoi(value) != 0;
 		else if (name == "ambient-occlusion-method") {
 			if (std::strcmp(value, "uniform") == 0)
 				aoMethod = RayTracer::AmbientOcclusionMethod::UNIFORM;
@@ -180,6 +189,26 @@ struct CliOptions : RayTracer::Options {
 		}
 	}
 };
+
+// Wall-clock phases for --timings (the reference's own phase lines count whole milliseconds).
+struct PhaseClock {
+	using clock = std::chrono::steady_clock;
+	clock::time_point origin = clock::now(), last = origin;
+	std::vector<std::pair<std::string, double>> phases;
+	void mark(const std::string &name) {
+		const clock::time_point now = clock::now();
+		phases.emplace_back(name, std::chrono::duration<double, std::milli>(now - last).count());
+		last = now;
+	}
+	void print() const {
+		std::cout << "Timings (ms):";
+		for (const auto &p : phases)
+			std::printf(" %s %.2f,", p.first.c_str(), p.second);
+		std::fflush(stdout);
+		std::cout << " wall " << std::chrono::duration<double, std::milli>(clock::now() - origin).count() << std::endl;
+	}
+};
+PhaseClock phase_clock;
 
 void download_floats(HipHost &host, float *image);
 void download_floats(HipHostRing &host, float *image);
@@ -199,6 +228,7 @@ bool run_frames(HipHostRing &host, unsigned int count) { return count == 1 ? hos
 template <class Host>
 void render_frame(Host &host, const CliOptions &options, const RayTracer &rt, Mesh &mesh, BVH &bvh,
                   std::vector<unsigned char> &image) {
+	phase_clock.mark("host");
 	std::size_t total_time = 0;
 	total_time += Info::measure("Loading OpenCL kernel", [&] {
 		std::vector<uint32_t> sorted_faces = sort_faces_by_leaf_order(mesh, bvh);
@@ -207,10 +237,12 @@ void render_frame(Host &host, const CliOptions &options, const RayTracer &rt, Me
 		host.upload(sorted_faces, bvh.nodes, bvh.aabbs, mesh.vertices, mesh.vnormals);
 		return true;
 	}, true);
+	phase_clock.mark("upload");
 	std::cout << std::endl
 	          << Color::BLUE << "<- " << Info::Palette::SECTION << "Rendering section" << Color::BLUE << " ->" << std::endl;
 	const std::size_t render_time = Info::measure("Rendering image", [&] { return run_frames(host, options.frames); });
 	total_time += render_time;
+	phase_clock.mark("render");
 	std::cout << std::endl;
 	if (options.host_resize) {
 		// the reference's flow: float image to the host (:114-117), box filter there (:120-123)
@@ -229,6 +261,7 @@ void render_frame(Host &host, const CliOptions &options, const RayTracer &rt, Me
 			return true;
 		});
 	}
+	phase_clock.mark("resize+download");
 	const ocrt::RenderStats stats = host.lastStats();
 	const double rays = (double) stats.primary_rays + (double) stats.ao_rays;
 	std::cout << Info::Palette::NORMAL << "Rays: " << Info::Palette::HIGHLIGHT << stats.primary_rays
@@ -257,11 +290,20 @@ void download_floats(HipHostGroup &, float *) {
 
 int main(int argc, const char **argv) {
 	CliOptions options(argc, argv);
+	// The HIP runtime, the device context and the kernels' code object cost 100-200 ms and do not depend on the scene:
+	// they come up on a second thread while this one reads the mesh and builds the BVH (reference order of the output
+	// kept: nothing is printed from that thread).
+	std::thread warm_up;
+	if (options.warm_up)
+		warm_up = std::thread([&options] { HipHost::warmUp(options.device); });
+	phase_clock.mark("options");
 	std::cout << Color::BLUE << "<- " << Info::Palette::SECTION << "BVH section" << Color::BLUE << " ->" << std::endl;
 	std::cout << Info::Palette::NORMAL << "Reading input mesh\xE2\x80\xA6" << std::endl;
 	Mesh mesh;
 	load_off_mesh(options.in, &mesh);
+	phase_clock.mark("load");
 	compute_vertex_normals(&mesh);
+	phase_clock.mark("normals");
 	std::cout << Color::BLUE << "- " << Info::Palette::NORMAL << "Vertices: " << Info::Palette::HIGHLIGHT
 	          << mesh.vertices.size() << std::endl
 	          << Color::BLUE << "- " << Info::Palette::NORMAL << "Triangles: " << Info::Palette::HIGHLIGHT
@@ -289,9 +331,14 @@ int main(int argc, const char **argv) {
 		bvh.buildBVH(mesh);
 		return true;
 	});
+	phase_clock.mark("bvh");
+	if (warm_up.joinable())
+		warm_up.join();
+	phase_clock.mark("wait for the device");
 	std::cout << std::endl
 	          << Color::BLUE << "<- " << Info::Palette::SECTION << "Device section" << Color::BLUE << " ->" << std::endl;
 	HipHost::printInfo();
+	phase_clock.mark("device table");
 	std::vector<unsigned char> image((size_t) options.width * options.height);
 	if (options.gpus == 0 || options.frames == 0 || options.in_flight > 16)
 		usage_error(argv[0], "--gpus and --frames must be positive, --in-flight at most 16");
@@ -314,5 +361,8 @@ int main(int argc, const char **argv) {
 	std::fprintf(out, "P5 %u %u 255\n", options.width, options.height);
 	std::fwrite(image.data(), 1, image.size(), out);
 	std::fclose(out);
+	phase_clock.mark("write");
+	if (options.timings)
+		phase_clock.print();
 	return 0;
 }

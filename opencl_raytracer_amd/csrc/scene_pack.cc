@@ -4,12 +4,28 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <future>
 #include <limits>
 #include <sstream>
 #include <stdexcept>
 #include <string>
 
 namespace ocrt {
+
+namespace {
+
+// Debug knobs are environment variables that only the A/B build reads (make EXTRA_DEFS=-DOCRT_DEBUG_KNOBS): the
+// product library never looks at the environment for them.  None changes results.
+const char *debug_knob(const char *name) {
+#ifdef OCRT_DEBUG_KNOBS
+	return std::getenv(name);
+#else
+	(void) name;
+	return nullptr;
+#endif
+}
+
+}  // namespace
 
 PackedScene pack_scene(const std::vector<uint32_t> &faces, const std::vector<uint32_t> &nodes,
                        const std::vector<Vec3f> &aabbs, const std::vector<Vec3f> &vertices,
@@ -78,13 +94,18 @@ PackedScene pack_scene(const std::vector<uint32_t> &faces, const std::vector<uin
 	}
 
 	// The walk may use any tree over the same leaves (walk_tree.h): take a binned-SAH one when it is cheaper
-	// than what was uploaded.  (Damaged arrays keep their tree: the exact form of the walk follows it.)
-	if (out.regular && out.nested && !std::getenv("OCRT_KEEP_TREE")) {  // (debug knob)
+	// than what was uploaded.  (Damaged arrays keep their tree: the exact form of the walk follows it.)  The rebuild
+	// is half of what an upload costs the CPU and independent of the triangle records packed below: it runs beside them.
+	std::future<std::vector<NodeRec>> rebuilding;
+	if (out.regular && out.nested && !debug_knob("OCRT_KEEP_TREE")) {
 		double threshold = 0.5;
-		if (const char *env = std::getenv("OCRT_CONTRACT"))  // debug knob: area ratio above which an inner node is dropped
+		if (const char *env = debug_knob("OCRT_CONTRACT"))  // area ratio above which an inner node is dropped
 			threshold = std::atof(env);
-		std::vector<NodeRec> rebuilt = contract_walk_tree(rebuild_walk_tree(out.nodes), threshold);
-		if (!rebuilt.empty() && tree_cost(rebuilt) < tree_cost(out.nodes)) {
+		const std::vector<NodeRec> &uploaded = out.nodes;  // (not touched until the future is collected)
+		rebuilding = std::async(std::launch::async, [&uploaded, threshold, tri_count]() -> std::vector<NodeRec> {
+			std::vector<NodeRec> rebuilt = contract_walk_tree(rebuild_walk_tree(uploaded), threshold);
+			if (rebuilt.empty() || !(tree_cost(rebuilt) < tree_cost(uploaded)))
+				return {};
 			// The flags above were computed on the uploaded array; the kernels walk this one, so it has to
 			// earn them again: an inner node may have more than two children here (contraction), what the
 			// shared walk needs is that sibling subtrees tile their parent's index range, every leaf index
@@ -118,11 +139,10 @@ PackedScene pack_scene(const std::vector<uint32_t> &faces, const std::vector<uin
 					}
 				}
 			}
-			if (ranges && leaves == tri_count && regular && nested) {
-				out.nodes.swap(rebuilt);
-				out.rebuilt = true;
-			}
-		}
+			if (ranges && leaves == tri_count && regular && nested)
+				return rebuilt;
+			return {};
+		});
 	}
 
 	out.tris.resize(tri_count);
@@ -155,7 +175,14 @@ PackedScene pack_scene(const std::vector<uint32_t> &faces, const std::vector<uin
 			dst[c][3] = 0.0f;
 		}
 	}
-	// the leaf's own box, exactly as uploaded, next to its triangle
+	if (rebuilding.valid()) {
+		std::vector<NodeRec> rebuilt = rebuilding.get();
+		if (!rebuilt.empty()) {
+			out.nodes.swap(rebuilt);
+			out.rebuilt = true;
+		}
+	}
+	// the leaf's own box, exactly as uploaded, next to its triangle (leaf indices are the same in either tree)
 	for (const NodeRec &n : out.nodes)
 		if (n.skip == 1)
 			for (unsigned k = 0; k < 3; ++k) {
@@ -228,6 +255,18 @@ float walk_scale_for(float max_distance) {
 	return r;
 }
 
+// The scaled reciprocals meet origins up to `origin_limit`: oi' = -(o * inv') must stay finite for the largest
+// stand-in of an infinite reciprocal (2^100 * scale) and for the largest finite one the packets admit (1e30 * scale);
+// an overflow to +-inf would make every fma on that axis +-inf and the ray reject real boxes -- not conservative.
+// (Scenes of extent 1e6 with a max_distance below ~0.01: the any-hit rays then take the exact form.)
+bool walk_scale_usable(float scale, float origin_limit) {
+	if (!(scale > 0.0f))
+		return false;
+	const double worst = (double) origin_limit * (double) scale;
+	const double room = 0.25 * (double) std::numeric_limits<float>::max();
+	return worst * std::ldexp(1.0, 100) < room && worst * 1.0e30 < room;
+}
+
 WalkArray make_walk_array(const PackedScene &scene, float ao_max_distance) {
 	WalkArray out;
 	const std::vector<NodeRec> &nodes = scene.nodes;
@@ -244,6 +283,8 @@ WalkArray make_walk_array(const PackedScene &scene, float ao_max_distance) {
 	// ray origins: the camera at (0, 0, 2) and hit points, which lie in the root box up to the triangle test's slack
 	out.origin_limit = 2.0f * extent + 4.0f;
 	out.ao_scale = walk_scale_for(ao_max_distance);
+	if (!walk_scale_usable(out.ao_scale, out.origin_limit))
+		out.ao_scale = 0.0f;
 	const float scaled_reach = out.ao_scale > 0.0f ? ao_max_distance * 1.001f : 0.0f;
 	const double camera[3] = { 0.0, 0.0, 2.0 };  // reference src/intersect_kernel.cl:284
 	out.nodes.resize(nodes.size() + 2);
@@ -352,23 +393,24 @@ KernelParams make_kernel_params(const RayTracer &rt, uint32_t node_count, uint32
 	p.origin_limit = walk ? walk->origin_limit : 0.0f;
 	// (the array's margins hold for the max_distance it was made for: the renderer re-makes it when that changes)
 	p.walk_scale = (walk && walk->ao_scale > 0.0f && walk->ao_scale == walk_scale_for(p.ao_max_distance) &&
-	                !std::getenv("OCRT_NO_SCALED_WALK")) ? walk->ao_scale : 0.0f;  // (debug knob)
-	p.fast_walk = (walk && !walk->nodes.empty() && !std::getenv("OCRT_FORCE_EXACT_WALK")) ? 1 : 0;  // (debug knob)
+	                walk_scale_usable(walk->ao_scale, walk->origin_limit) &&
+	                !debug_knob("OCRT_NO_SCALED_WALK")) ? walk->ao_scale : 0.0f;  // (debug knob)
+	p.fast_walk = (walk && !walk->nodes.empty() && !debug_knob("OCRT_FORCE_EXACT_WALK")) ? 1 : 0;  // (debug knob)
 	p.scene_regular = (scene && scene->regular) ? 1 : 0;
-	p.scene_nested = (scene && scene->nested && !std::getenv("OCRT_FORCE_EXACT_WALK")) ? 1 : 0;  // (debug knob)
-	p.shared_walk = (scene && scene->binary_tree && !std::getenv("OCRT_NO_SHARED_WALK")) ? 1 : 0;  // (debug knob)
-	p.debug_no_sort = std::getenv("OCRT_NO_SORT") ? 1 : 0;
-	const char *refill_min = std::getenv("OCRT_REFILL_MIN"), *leaf_min = std::getenv("OCRT_LEAF_MIN");
+	p.scene_nested = (scene && scene->nested && !debug_knob("OCRT_FORCE_EXACT_WALK")) ? 1 : 0;  // (debug knob)
+	p.shared_walk = (scene && scene->binary_tree && !debug_knob("OCRT_NO_SHARED_WALK")) ? 1 : 0;  // (debug knob)
+	p.debug_no_sort = debug_knob("OCRT_NO_SORT") ? 1 : 0;
+	const char *refill_min = debug_knob("OCRT_REFILL_MIN"), *leaf_min = debug_knob("OCRT_LEAF_MIN");
 	p.refill_min = refill_min ? (uint32_t) std::atoi(refill_min) : 16u;
 	p.leaf_min = leaf_min ? (uint32_t) std::atoi(leaf_min) : 16u;
-	const char *guide = std::getenv("OCRT_AO_GUIDE");  // debug knob
+	const char *guide = debug_knob("OCRT_AO_GUIDE");  // debug knob
 	p.ao_guide = guide && std::atoi(guide) > 0 ? (uint32_t) std::atoi(guide) : 0u;  // (0: claims never shrink, the default)
-	const char *claim_max = std::getenv("OCRT_AO_CLAIM_MAX");  // debug knob
+	const char *claim_max = debug_knob("OCRT_AO_CLAIM_MAX");  // debug knob
 	p.ao_claim_max = claim_max && std::atoi(claim_max) > 0 ? (uint32_t) std::atoi(claim_max) : 0u;
 	p.ao_claim_div = 1u;
-	const char *batch_below = std::getenv("OCRT_BATCH_BELOW");  // debug knob
+	const char *batch_below = debug_knob("OCRT_BATCH_BELOW");  // debug knob
 	p.batch_below = batch_below ? (uint32_t) std::atoi(batch_below) : 32u;
-	const char *cost_shift = std::getenv("OCRT_COST_SHIFT");  // debug knob
+	const char *cost_shift = debug_knob("OCRT_COST_SHIFT");  // debug knob
 	p.cost_shift = cost_shift ? (uint32_t) std::atoi(cost_shift) & 31u : 5u;
 	p.ao_regular = (p.ao_max_distance > 0.0f && std::isfinite(p.ao_max_distance)) ? 1 : 0;
 	p.primary_below = std::nextafterf(100000.0f, 0.0f);

@@ -54,6 +54,9 @@ float padded_bound(float b, float origin_bound, bool upper, float scaled_reach =
 // r * max_distance * (1 + 2^-23) <= 1, or 0 where the scaled form must not be used (max_distance not a positive
 // number within 2^-20 .. 2^20).
 float walk_scale_for(float max_distance);
+// ... and whether origins up to `origin_limit` keep o * (2^100 * scale) and o * (1e30 * scale) finite (make_walk_array
+// drops the scaled form otherwise).
+bool walk_scale_usable(float scale, float origin_limit);
 
 // The value a float option has once it went through the reference's -D string:
 // printed with 6 significant digits ("-DNAME=0.2f", reference

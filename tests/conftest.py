@@ -39,6 +39,33 @@ def rt():
     return rt_mod
 
 
+@pytest.fixture(scope="session")
+def rt_knobs():
+    """A second, independent binding on the A/B build of the library (make EXTRA_DEFS=-DOCRT_DEBUG_KNOBS ->
+    opencl_raytracer_amd/lib_knobs): the only build that reads the OCRT_* scheduling knobs from the environment and
+    that still holds the first-generation kernels.  The product library contains neither."""
+    import importlib.util
+
+    path = os.path.join(ROOT, "opencl_raytracer_amd", "lib_knobs", "libocrt_hip.so")
+    if not os.path.exists(path):
+        pytest.fail("opencl_raytracer_amd/lib_knobs/libocrt_hip.so is missing: run __graft_entry__.build()")
+    spec = importlib.util.spec_from_file_location("ocrt_api_knobs", os.path.join(ROOT, "opencl_raytracer_amd", "api.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = mod
+    old = os.environ.get("OCRT_LIB_DIR")
+    os.environ["OCRT_LIB_DIR"] = "lib_knobs"
+    try:
+        spec.loader.exec_module(mod)
+        mod.load_library()
+        assert mod.lib_path() == path
+    finally:
+        if old is None:
+            del os.environ["OCRT_LIB_DIR"]
+        else:
+            os.environ["OCRT_LIB_DIR"] = old
+    return mod
+
+
 def mesh_file(name: str) -> str:
     from tools.meshes import bunny_path, interior_path
 
@@ -63,6 +90,24 @@ def scene_for(rt):
             sc = rt.Scene.load_off(mesh_file(mesh)).build_bvh(0 if bvh == "longest" else 1)
             _SCENES[key] = (sc, orc.SceneArrays.from_scene(sc))
         return _SCENES[key]
+
+    return get
+
+
+_KNOB_SCENES = {}
+
+
+@pytest.fixture(scope="session")
+def scene_for_knobs(rt_knobs):
+    """scene_for, through the A/B build's own binding (handles are not shared between two copies of the library)."""
+    import orc
+
+    def get(mesh: str, bvh: str):
+        key = (mesh, bvh)
+        if key not in _KNOB_SCENES:
+            sc = rt_knobs.Scene.load_off(mesh_file(mesh)).build_bvh(0 if bvh == "longest" else 1)
+            _KNOB_SCENES[key] = (sc, orc.SceneArrays.from_scene(sc))
+        return _KNOB_SCENES[key]
 
     return get
 

@@ -206,6 +206,13 @@ def ref_kernel(p: OrcParams, n_super_samples: int, build: bool = True) -> Option
 
 
 # ---- the reference kernel compiled for the MI355X itself (oracle/Makefile: ref-kernel-gfx950) ----
+# Golden cases the reference's own kernel is compiled for gfx950 and launched for (tests/test_refkernel_gpu.py;
+# __graft_entry__.build() makes the code objects): those whose NDRange the reference's 16 x 16 work-groups divide
+# (SURVEY fact 0.8), and the headline frame, whose height 1080 they do not divide: launched with 16 x 8 work-groups.
+REFKERNEL_CASES_16 = ["bunny_256_s1_a0", "bunny_256_s1_a3", "blob_128x96_s4_a3", "ties_64_s4_a3", "bunny_600_defaults"]
+REFKERNEL_CASES_OTHER = {"bunny_1080p_s1_a0": (16, 8), "bunny_1080p_s1_a3": (16, 8)}
+REFKERNEL_ALL_CASES = REFKERNEL_CASES_16 + sorted(REFKERNEL_CASES_OTHER)
+
 GFX950_MODES = ("default", "strict", "ieee_dot", "ieee_cross", "ieee_normalize", "ieee_length", "ieee_geom", "ieee_all")
 
 

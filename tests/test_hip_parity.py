@@ -357,12 +357,13 @@ def test_zero_direction_components(rt, oracle, scene_for):
 
 
 @pytest.mark.parametrize("name", ["blob_128x96_s4_a3", "ties_64_s4_a3", "bunny_256_s1_a3"])
-def test_lane_by_lane_walk_still_matches(rt, golden, scene_for, name, monkeypatch):
+def test_lane_by_lane_walk_still_matches(rt_knobs, golden, scene_for_knobs, name, monkeypatch):
     """OCRT_NO_SHARED_WALK=1 selects the kernels in which every lane walks the
-    tree on its own (the first generation, kept for A/B runs)."""
+    tree on its own (the first generation; only the A/B build of the library holds it)."""
     monkeypatch.setenv("OCRT_NO_SHARED_WALK", "1")
+    rt = rt_knobs
     case = golden["renders"][name]
-    scene, _ = scene_for(case["mesh"], case["bvh"])
+    scene, _ = scene_for_knobs(case["mesh"], case["bvh"])
     host = render_hip(rt, scene, options_for(rt, case))
     assert host.stats()["ao_occluded"] == case["counters"]["ao_occluded"]
     assert hashlib.sha256(host.download().tobytes()).hexdigest() == case["float_sha256"]
@@ -381,18 +382,71 @@ def test_lane_by_lane_walk_still_matches(rt, golden, scene_for, name, monkeypatc
     {"OCRT_KEEP_TREE": "1"},            # walk the uploaded tree instead of the rebuilt one
     {"OCRT_KEEP_TREE": "1", "OCRT_NO_SHARED_WALK": "1"},
 ])
-def test_scheduling_knobs_do_not_change_the_image(rt, golden, scene_for, knobs, monkeypatch):
-    """Claim sizes, tile order, batching thresholds and the form of the walk only change who does what when."""
+def test_scheduling_knobs_do_not_change_the_image(rt_knobs, golden, scene_for_knobs, knobs, monkeypatch):
+    """Claim sizes, tile order, batching thresholds and the form of the walk only change who does what when.  (The
+    knobs exist in the A/B build of the library only.)"""
     for key, value in knobs.items():
         monkeypatch.setenv(key, value)
+    rt = rt_knobs
     for name in ("bunny_256_s1_a3", "bunny_101x77_s9_a2", "ties_64_s4_a3"):
         case = golden["renders"][name]
-        scene, _ = scene_for(case["mesh"], case["bvh"])
+        scene, _ = scene_for_knobs(case["mesh"], case["bvh"])
         host = render_hip(rt, scene, options_for(rt, case))
         assert hashlib.sha256(host.download().tobytes()).hexdigest() == case["float_sha256"], (name, knobs)
         assert host.stats()["ao_occluded"] == case["counters"]["ao_occluded"]
         host.close()
 
+
+
+def test_product_library_ignores_the_knobs(rt, golden, scene_for, monkeypatch):
+    """The product library reads no scheduling knob from the environment: with OCRT_AO_BLOCKS=3 and the first
+    generation asked for, a frame takes the time it always takes (three workgroups would need 100x as long)."""
+    c = golden["renders"]["bunny_600_defaults"]
+    scene, _ = scene_for(c["mesh"], c["bvh"])
+    plain = render_hip(rt, scene, options_for(rt, c))
+    plain.render()
+    monkeypatch.setenv("OCRT_AO_BLOCKS", "3")
+    monkeypatch.setenv("OCRT_NO_SHARED_WALK", "1")
+    knobbed = render_hip(rt, scene, options_for(rt, c))
+    knobbed.render()
+    assert knobbed.last_kernel_ms < 3.0 * plain.last_kernel_ms + 0.5
+    assert hashlib.sha256(knobbed.download().tobytes()).hexdigest() == c["float_sha256"]
+    import subprocess
+
+    from conftest import ROOT
+    import os
+
+    symbols = subprocess.run(["nm", "-C", os.path.join(ROOT, "opencl_raytracer_amd", "lib", "libocrt_hip.so")],
+                             capture_output=True, text=True).stdout
+    assert "primary_kernel<true>" in symbols and "primary_kernel<false>" not in symbols
+    plain.close()
+    knobbed.close()
+
+
+FUZZ_SLICE = 64
+
+
+@pytest.mark.parametrize("index", range(FUZZ_SLICE))
+def test_fuzz_slice(rt, rt_knobs, oracle, index):
+    """A seeded slice of tools/fuzz_parity.py (random size, supersampling, AO rings / distance / angles incl. distances
+    the scaled node test refuses, focal length, mesh incl. bunny and the interior scene, tree, hosts that share the
+    GPU, rings of hosts replaying their graph): floats and statistics equal the oracle's bit for bit.  Cases without a
+    scheduling knob run on the product library, the others on the A/B build."""
+    import random
+
+    import orc
+    from tools import fuzz_parity
+
+    rng = random.Random(20261004)
+    for _ in range(index + 1):
+        case = fuzz_parity.draw_case(rng)
+    binding = rt_knobs if case["knobs"] else rt
+    scenes = _FUZZ_SCENES.setdefault(id(binding), {})
+    same, stats_ok = fuzz_parity.run_case(binding, orc, oracle, scenes, case)
+    assert same and stats_ok, case
+
+
+_FUZZ_SCENES = {}
 
 
 def test_three_renderers_in_flight_give_the_golden_frames(rt, golden, scene_for):

@@ -13,7 +13,9 @@ def test_host_scene_build_under_asan_ubsan(tmp_path):
     srcs = [os.path.join(ROOT, "tests", "host_sanitize.cc")] + [os.path.join(CSRC, f) for f in
                                                                ("mesh.cc", "bvh.cc", "ray_tracer.cc", "scene_pack.cc", "walk_tree.cc")]
     subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-ffp-contract=off",
-                    "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-I", CSRC, "-o", exe] + srcs,
+                    "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-pthread",
+                    "-DOCRT_DEBUG_KNOBS",  # (the program compares the rebuilt walk tree with the kept one: OCRT_KEEP_TREE)
+                    "-I", CSRC, "-o", exe] + srcs,
                    check=True)
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1")
     r = subprocess.run([exe] + [mesh_file(m) for m in ("single", "ties", "blob", "bunny")], capture_output=True,

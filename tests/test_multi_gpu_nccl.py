@@ -19,17 +19,26 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _run_bench(nproc, extra_env=None, bare=False):
+def _free_port():
+    import socket
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def _run_bench(nproc, extra_env=None, bare=False, extra_args=()):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.update(extra_env or {})
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    args = ["--gpus", str(nproc), "--steps", "3", "--warmup", "1", "--workload", "bunny_600_defaults", "--no-cpu-baseline"]
+    args = ["--gpus", str(nproc), "--steps", "3", "--warmup", "1", "--workload", "bunny_600_defaults", "--no-cpu-baseline",
+            "--no-end-to-end", "--min-seconds", "0.05"] + list(extra_args)
     if bare:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr",
-               "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py")] + args
+               "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + args
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -40,6 +49,7 @@ def _run_bench(nproc, extra_env=None, bare=False):
 def test_rccl_world_of_one_runs_the_gather(golden):
     out = _run_bench(1)
     assert out["n_gpus"] == 1 and "RCCL gather" in out["config"]["parallelism"]
+    assert out["blocking"]["pgm_md5"] == golden["renders"]["bunny_600_defaults"]["pgm_md5"] and out["blocking"]["value"] > 0
     assert out["config"]["pgm_md5"] == golden["renders"]["bunny_600_defaults"]["pgm_md5"]
     assert out["config"]["pgm_matches_golden"] is True and out["value"] > 0
 
@@ -66,3 +76,15 @@ def test_bare_gpus_flag_starts_its_own_ranks(golden):
         out = _run_bench(2, bare=True)
         assert out["n_gpus"] == 2 and "RCCL" in out["config"]["parallelism"]
     assert out["config"]["pgm_md5"] == golden["renders"]["bunny_600_defaults"]["pgm_md5"]
+
+
+def test_five_gloo_ranks_rehearse_the_eight_gpu_run(golden):
+    """The shape of the driver's 8-GPU run on the one GPU of the box, as far as its process limit allows: five ranks
+    (gloo: RCCL refuses two ranks on one device), each with the six render hosts per GPU that bench.py uses beyond four
+    ranks and a blocking ring beside them, bands of 4 rows dealt round-robin, the gather, barriers and all-reduces of
+    the timing contract.  The assembled PGM is the golden one in both modes."""
+    out = _run_bench(5, extra_env={"OCRT_BENCH_BACKEND": "gloo"}, bare=True)
+    assert out["n_gpus"] == 5 and out["config"]["frames_in_flight"] == 6
+    assert out["config"]["pgm_md5"] == golden["renders"]["bunny_600_defaults"]["pgm_md5"]
+    assert out["blocking"]["pgm_md5"] == golden["renders"]["bunny_600_defaults"]["pgm_md5"]
+    assert out["config"]["rays_per_frame"] == 1440000 + 28 * golden["renders"]["bunny_600_defaults"]["counters"]["primary_hits"]

@@ -29,11 +29,12 @@ from conftest import ROOT, bits, options_for
 
 pytestmark = pytest.mark.gpu
 
-# golden cases whose NDRange the reference's 16 x 16 work-groups divide ...
-CASES_16 = ["bunny_256_s1_a0", "bunny_256_s1_a3", "blob_128x96_s4_a3", "ties_64_s4_a3", "bunny_600_defaults"]
-# ... and the headline frame, whose height 1080 they do not divide: launched with 16 x 8 work-groups
-CASES_OTHER = {"bunny_1080p_s1_a0": (16, 8), "bunny_1080p_s1_a3": (16, 8)}
-ALL_CASES = CASES_16 + sorted(CASES_OTHER)
+from orc import REFKERNEL_ALL_CASES as ALL_CASES, REFKERNEL_CASES_OTHER as CASES_OTHER  # noqa: E402
+
+# What the real-library builds measured on the MI355X when the table was committed (profiles/r02_refkernel_gfx950.json):
+# the reference kernel is deterministic, so a run must land on these numbers; the bound below allows twice as much.
+with open(os.path.join(ROOT, "tests", "golden", "refkernel_gfx950_distance.json")) as _f:
+    COMMITTED_DISTANCE = json.load(_f)
 
 REPORT = {}
 
@@ -109,4 +110,6 @@ def test_reference_kernel_on_gfx950_vs_oracle(rt, oracle, golden, scene_for, ref
     # difference, not a different image (silhouette pixels may flip between hit and miss).
     for mode in ("default", "strict"):
         if mode in ran:
-            assert ran[mode]["pixels_differ_by_more_than_1"] <= 0.002 * ran[mode]["pixels"] + 4, (mode, ran[mode])
+            was = COMMITTED_DISTANCE[name][mode]
+            for key in ("pixels_differ", "pixels_differ_by_more_than_1", "hit_miss_flips"):
+                assert ran[mode][key] <= 2 * was[key] + 2, (mode, key, ran[mode][key], was[key])

@@ -19,6 +19,7 @@
 namespace ocrt {
 float padded_bound(float b, float origin_bound, bool upper, float scaled_reach);  // libocrt_hip.so
 float walk_scale_for(float max_distance);
+bool walk_scale_usable(float scale, float origin_limit);
 }
 
 namespace {
@@ -89,6 +90,23 @@ bool scaled_slab(const float plo[3], const float phi[3], const float o[3], const
 int main(int argc, char **argv) {
 	const long cases = argc > 1 ? std::atol(argv[1]) : 20000000L;
 	const bool unpadded = argc > 2 && std::atoi(argv[2]) != 0;  // self-check: without the margin misses MUST show up
+	// The corner the scaled form must refuse: a scene of extent 1e6 (origins up to 2e6 + 4) with a max_distance so small
+	// that origin * 2^100 * scale overflows -- every fma on a zero-direction axis would be +-inf and real boxes rejected.
+	if (ocrt::walk_scale_usable(ocrt::walk_scale_for(0.007f), 2.0e6f + 4.0f) ||
+	    ocrt::walk_scale_usable(ocrt::walk_scale_for(1.0e-6f), 2.0e6f + 4.0f) ||
+	    !ocrt::walk_scale_usable(ocrt::walk_scale_for(0.2f), 24.0f) || !ocrt::walk_scale_usable(ocrt::walk_scale_for(0.5f), 4100.0f)) {
+		std::printf("walk_scale_usable: wrong answer in the overflow corner\n");
+		return 1;
+	}
+	for (float scale : { ocrt::walk_scale_for(0.007f), ocrt::walk_scale_for(3.0f), ocrt::walk_scale_for(1.0e-6f) })
+		for (float limit : { 24.0f, 4100.0f, 2.0e6f + 4.0f })
+			if (ocrt::walk_scale_usable(scale, limit)) {
+				const float worst = limit * (0x1.0p+100f * scale), finite = limit * (1.0e30f * scale);
+				if (!(worst < INF) || !(finite < INF)) {
+					std::printf("walk_scale_usable accepted an overflowing pair: scale %a limit %a\n", scale, limit);
+					return 1;
+				}
+			}
 	std::mt19937_64 rng(20261004);
 	std::uniform_real_distribution<float> unit(-1.0f, 1.0f);
 	std::uniform_int_distribution<int> pick(0, 15);
