@@ -7,18 +7,27 @@ the build when a hot kernel would spill vector registers to scratch or run at fe
 kernels pinned to a 64-VGPR budget (`amdgpu_waves_per_eu(8, 8)`), so growth in live VGPRs
 would otherwise turn into silent scratch traffic in the hottest loop.
 
-    check_kernel_resources.py <remarks.txt> [--table out.txt] [--report-only]
+    check_kernel_resources.py <remarks.txt> [--table out.txt] [--isa kernels.s] [--report-only]
 
 Hot kernels (must have VGPR spill 0, scratch 0, occupancy 8): the default path, i.e. the
 shared-walk instantiations primary_kernel<true> and ao_kernel<1, true> (1 = UNIFORM).  The
 first-generation instantiations (<.., false>, debug knob OCRT_NO_SHARED_WALK) and the RANDOM
 mode (ao_kernel<2, ..>, outside the bit-exact contract) must keep the occupancy; their
-spills are reported, not fatal.  SGPR spills go to VGPR lanes
-(v_writelane / v_readlane outside the loops), not to memory; they are reported too.
+spills are reported, not fatal.  SGPR spills go to VGPR lanes (v_writelane / v_readlane), not
+to memory -- but those are vector instructions, the very resource the walk is bound by, so
+WHERE they land matters: with `--isa` (the device assembly of the same translation unit,
+`hipcc --cuda-device-only -S`) the tool locates every lane operation of the hot kernels by
+loop depth and fails the build when one sits inside the hand-scheduled node loop (the asm
+blocks between .Lw_miss_a and .Lw_out), when the loop around it -- one turn per leaf stop or
+batch -- holds more than LANE_OPS_PER_WALK_TURN of them, or when the per-packet code holds more
+than LANE_OPS_PER_PACKET.
 """
 import re
 import subprocess
 import sys
+
+LANE_OPS_PER_WALK_TURN = 8   # v_readlane / v_writelane per turn of the loop around walk_collect, i.e. per leaf stop or batch (measured: 6 primary, 2 AO)
+LANE_OPS_PER_PACKET = 40     # ... in the per-packet code around that loop (measured: ~24 of ~700 vector instructions)
 
 FIELDS = ("TotalSGPRs", "VGPRs", "AGPRs", "ScratchSize [bytes/lane]", "Occupancy [waves/SIMD]", "SGPRs Spill",
           "VGPRs Spill", "LDS Size [bytes/block]")
@@ -46,6 +55,46 @@ def parse(text: str):
     return kernels
 
 
+def lane_ops_by_place(isa_text: str):
+    """Per kernel of the device assembly: where its v_readlane / v_writelane (SGPR spill traffic) sit.  Returns
+    {demangled name: {"total", "in_node_loop", "walk_turn", "per_packet", "depths": {depth: count}}}."""
+    lines = isa_text.split("\n")
+    out, name, start = {}, None, 0
+    for i, line in enumerate(lines):
+        m = re.match(r"^(_Z\w+):", line)
+        if m and name is None:
+            name, start = m.group(1), i
+        if line.startswith(".Lfunc_end") and name is not None:
+            body = lines[start:i]
+            regions, begin = [], None  # the hand-scheduled node loops: .Lw_miss_a_N ... .Lw_out_N
+            for j, text in enumerate(body):
+                if re.search(r"\.Lw_miss_a_\d+:", text):
+                    begin = j
+                if re.search(r"\.Lw_out_\d+:", text) and begin is not None:
+                    regions.append((begin, j))
+                    begin = None
+            if regions:
+                # loop depth of a line = the depth noted at the last basic-block label before it
+                depth, depths = 0, []
+                for text in body:
+                    m = re.match(r"^\.LBB\d+_\d+:(.*)", text)
+                    if m:
+                        d = re.search(r"Depth=(\d+)", m.group(1))
+                        depth = int(d.group(1)) if d else 0
+                    depths.append(depth)
+                lane = [j for j, text in enumerate(body) if "v_writelane" in text or "v_readlane" in text]
+                walk_depth = max(depths[a] for a, _ in regions)  # the loop that holds the asm blocks
+                by_depth = {}
+                for j in lane:
+                    by_depth[depths[j]] = by_depth.get(depths[j], 0) + 1
+                out[demangle(name)] = {
+                    "total": len(lane), "in_node_loop": sum(1 for j in lane if any(a <= j <= b for a, b in regions)),
+                    "walk_turn": by_depth.get(walk_depth, 0), "per_packet": by_depth.get(walk_depth - 1, 0),
+                    "depths": dict(sorted(by_depth.items())), "walk_depth": walk_depth}
+            name = None
+    return out
+
+
 def main():
     if len(sys.argv) < 2:
         sys.exit(__doc__)
@@ -68,6 +117,22 @@ def main():
         if hot and (k.get("VGPRs Spill") != "0" or k.get("ScratchSize [bytes/lane]") != "0"):
             errors.append(f"{name}: VGPR spill {k.get('VGPRs Spill')}, scratch {k.get('ScratchSize [bytes/lane]')} B/lane "
                           "in a hot kernel (walk_collect's fixed registers v56-v62 need the 64-VGPR budget to hold)")
+    if "--isa" in sys.argv:
+        places = lane_ops_by_place(open(sys.argv[sys.argv.index("--isa") + 1]).read())
+        lines.append("")
+        lines.append("SGPR spill traffic (v_readlane / v_writelane) by place: kernel, total, inside the hand-scheduled node loop, "
+                     "per turn of the loop around it, per packet, by loop depth")
+        for kname, p in places.items():
+            short = kname.replace("ocrt::", "").replace("void ", "")
+            lines.append(f"{short:44s} {p['total']:5d} {p['in_node_loop']:5d} {p['walk_turn']:5d} {p['per_packet']:5d}   {p['depths']}")
+            if not (short.startswith("primary_kernel<true>") or short.startswith("ao_kernel<1, true>")):
+                continue
+            if p["in_node_loop"]:
+                errors.append(f"{short}: {p['in_node_loop']} SGPR spill instructions inside the node loop")
+            if p["walk_turn"] > LANE_OPS_PER_WALK_TURN:
+                errors.append(f"{short}: {p['walk_turn']} SGPR spill instructions per turn of the loop around the node loop (limit {LANE_OPS_PER_WALK_TURN})")
+            if p["per_packet"] > LANE_OPS_PER_PACKET:
+                errors.append(f"{short}: {p['per_packet']} SGPR spill instructions in the per-packet code (limit {LANE_OPS_PER_PACKET})")
     table = "\n".join(lines) + "\n"
     if "--table" in sys.argv:
         with open(sys.argv[sys.argv.index("--table") + 1], "w") as f:
