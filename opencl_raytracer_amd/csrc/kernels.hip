@@ -878,8 +878,8 @@ __device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ n
 #ifndef OCRT_PRIMARY_WAVES
 #define OCRT_PRIMARY_WAVES 4
 #endif
-constexpr uint32_t PRIMARY_WAVES = OCRT_PRIMARY_WAVES;  // 1, 2 or 4: the waves of a 2 x 2 block of tiles that share a workgroup
-constexpr uint32_t PRIMARY_SPLIT = 4u / PRIMARY_WAVES;  // workgroups per 2 x 2 block
+constexpr uint32_t PRIMARY_WAVES = OCRT_PRIMARY_WAVES;  // 4, 8 or 16: a workgroup covers a block of tiles 2 wide and PRIMARY_WAVES / 2 high
+constexpr uint32_t PRIMARY_ROWS = PRIMARY_WAVES / 2u;
 
 // SHARED: the shared walk.  (The A/B build also instantiates the first generation, SHARED = false; two instantiations,
 // so that its per-lane state stays out of the default path's register budget.)
@@ -896,17 +896,16 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) __attribute__((amdgpu_waves_per
 
 	if (blockIdx.x == 0u && threadIdx.x == 0u)
 		counters->tick_begin = __builtin_amdgcn_s_memrealtime();
-	const uint32_t group = blockIdx.x & (XCD_GROUPS - 1u);
-	const uint32_t seq = (blockIdx.x >> 3) / PRIMARY_SPLIT, quad = ((blockIdx.x >> 3) % PRIMARY_SPLIT) * PRIMARY_WAVES + wave;
+	const uint32_t group = blockIdx.x & (XCD_GROUPS - 1u), seq = blockIdx.x >> 3;
 	const uint32_t strips = (P.tiles_x + 1u) >> 1;
-	const uint32_t row_pairs = (P.local_tile_rows + 1u) >> 1;
+	const uint32_t row_blocks = (P.local_tile_rows + PRIMARY_ROWS - 1u) / PRIMARY_ROWS;
 	const uint32_t strips_here = (strips + XCD_GROUPS - 1u - group) >> 3;
-	if (seq >= strips_here * row_pairs)
+	if (seq >= strips_here * row_blocks)
 		return;
-	const uint32_t strip_index = seq / row_pairs;
-	const uint32_t row_pair = seq - strip_index * row_pairs;
-	const uint32_t tile_x = 2u * (group + XCD_GROUPS * strip_index) + (quad & 1u);
-	const uint32_t local_row = 2u * row_pair + (quad >> 1);
+	const uint32_t strip_index = seq / row_blocks;
+	const uint32_t row_block = seq - strip_index * row_blocks;
+	const uint32_t tile_x = 2u * (group + XCD_GROUPS * strip_index) + (wave & 1u);
+	const uint32_t local_row = PRIMARY_ROWS * row_block + (wave >> 1);
 	if (tile_x >= P.tiles_x || local_row >= P.local_tile_rows)
 		return;  // the waves of a workgroup never synchronise
 	const uint32_t tile = local_row * P.tiles_x + tile_x;
@@ -1709,8 +1708,8 @@ void launch_primary(const SceneBuffers &scene, float *image, void *hits, void *o
 	hipLaunchKernelGGL(clear_counters_kernel, dim3(1), dim3(256), 0, s, (FrameCounters *) counters);
 	if (P.tiles_x * P.local_tile_rows == 0)
 		return;
-	const uint32_t strips = (P.tiles_x + 1u) >> 1, row_pairs = (P.local_tile_rows + 1u) >> 1;
-	const uint32_t blocks = XCD_GROUPS * ((strips + XCD_GROUPS - 1u) >> 3) * row_pairs * PRIMARY_SPLIT;
+	const uint32_t strips = (P.tiles_x + 1u) >> 1, row_blocks = (P.local_tile_rows + PRIMARY_ROWS - 1u) / PRIMARY_ROWS;
+	const uint32_t blocks = XCD_GROUPS * ((strips + XCD_GROUPS - 1u) >> 3) * row_blocks;
 	auto launch = [&](auto kernel) {
 		hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64 * PRIMARY_WAVES), 0, s, (const float4 *) scene.nodes,
 		                   (const float4 *) scene.walk, (const float4 *) scene.tris, (const float4 *) scene.shade, image,

@@ -83,75 +83,83 @@ struct Builder {
 	// Partitions leaves[begin, end) at the cheapest of the 3 x 15 bin boundaries; equal halves by
 	// index when the centres do not separate.
 	size_t split(size_t begin, size_t end) {
+		// one pass: the centres' bounds, the box of all leaves and the largest leaf
 		float c_lo[3], c_hi[3];
 		for (int k = 0; k < 3; ++k) {
 			c_lo[k] = std::numeric_limits<float>::infinity();
 			c_hi[k] = -std::numeric_limits<float>::infinity();
 		}
-		for (size_t i = begin; i < end; ++i)
+		Box all;
+		all.reset();
+		double largest = -1.0;
+		size_t giant = begin;
+		for (size_t i = begin; i < end; ++i) {
+			const Leaf &l = leaves[i];
 			for (int k = 0; k < 3; ++k) {
-				c_lo[k] = std::fmin(c_lo[k], leaves[i].centre[k]);
-				c_hi[k] = std::fmax(c_hi[k], leaves[i].centre[k]);
+				c_lo[k] = std::fmin(c_lo[k], l.centre[k]);
+				c_hi[k] = std::fmax(c_hi[k], l.centre[k]);
 			}
+			all.grow(l.lo, l.hi);
+			const double dx = (double) l.hi[0] - l.lo[0], dy = (double) l.hi[1] - l.lo[1], dz = (double) l.hi[2] - l.lo[2];
+			const double a = dx < 0.0 ? 0.0 : 2.0 * (dx * dy + dy * dz + dz * dx);
+			if (a > largest) {
+				largest = a;
+				giant = i;
+			}
+		}
 		// A leaf more than half as large as the whole node (a ground plane under a small model) would
 		// drag every box it stays in up to its own size; centre-based bins cannot set it apart and the
 		// greedy cost does not see far enough to want to.  It gets a node of its own.
-		if (end - begin > 2) {
-			Box all;
-			all.reset();
-			double largest = -1.0;
-			size_t giant = begin;
-			for (size_t i = begin; i < end; ++i) {
-				all.grow(leaves[i].lo, leaves[i].hi);
-				Box one;
-				one.reset();
-				one.grow(leaves[i].lo, leaves[i].hi);
-				const double a = one.area();
-				if (a > largest) {
-					largest = a;
-					giant = i;
-				}
-			}
-			if (largest >= 0.5 * all.area()) {
-				std::swap(leaves[begin], leaves[giant]);
-				return begin + 1;
+		if (end - begin > 2 && largest >= 0.5 * all.area()) {
+			std::swap(leaves[begin], leaves[giant]);
+			return begin + 1;
+		}
+		// one more pass: the leaves into the bins of all three axes
+		float scale[3];
+		bool usable[3];
+		Box bin_box[3][BINS];
+		size_t bin_count[3][BINS] = { { 0 } };
+		for (int axis = 0; axis < 3; ++axis) {
+			const float extent = c_hi[axis] - c_lo[axis];
+			usable[axis] = extent > 0.0f && std::isfinite(extent);
+			scale[axis] = usable[axis] ? (float) BINS / extent : 0.0f;
+			for (Box &b : bin_box[axis])
+				b.reset();
+		}
+		for (size_t i = begin; i < end; ++i) {
+			const Leaf &l = leaves[i];
+			for (int axis = 0; axis < 3; ++axis) {
+				if (!usable[axis])
+					continue;
+				const int b = bin_of(l.centre[axis], c_lo[axis], scale[axis]);
+				bin_box[axis][b].grow(l.lo, l.hi);
+				++bin_count[axis][b];
 			}
 		}
 		double best_cost = std::numeric_limits<double>::infinity();
 		int best_axis = -1, best_bin = 0;
 		float best_scale = 0.0f;
 		for (int axis = 0; axis < 3; ++axis) {
-			const float extent = c_hi[axis] - c_lo[axis];
-			if (!(extent > 0.0f) || !std::isfinite(extent))
+			if (!usable[axis])
 				continue;
-			const float scale = (float) BINS / extent;
-			Box bin_box[BINS];
-			size_t bin_count[BINS] = { 0 };
-			for (Box &b : bin_box)
-				b.reset();
-			for (size_t i = begin; i < end; ++i) {
-				const int b = bin_of(leaves[i].centre[axis], c_lo[axis], scale);
-				bin_box[b].grow(leaves[i].lo, leaves[i].hi);
-				++bin_count[b];
-			}
 			double right_area[BINS];
 			size_t right_count[BINS];
 			Box sweep;
 			sweep.reset();
 			size_t n = 0;
 			for (int b = BINS - 1; b >= 1; --b) {
-				if (bin_count[b])
-					sweep.grow(bin_box[b].lo, bin_box[b].hi);
-				n += bin_count[b];
+				if (bin_count[axis][b])
+					sweep.grow(bin_box[axis][b].lo, bin_box[axis][b].hi);
+				n += bin_count[axis][b];
 				right_area[b] = sweep.area();
 				right_count[b] = n;
 			}
 			sweep.reset();
 			n = 0;
 			for (int b = 1; b < BINS; ++b) {  // split between bins b-1 and b
-				if (bin_count[b - 1])
-					sweep.grow(bin_box[b - 1].lo, bin_box[b - 1].hi);
-				n += bin_count[b - 1];
+				if (bin_count[axis][b - 1])
+					sweep.grow(bin_box[axis][b - 1].lo, bin_box[axis][b - 1].hi);
+				n += bin_count[axis][b - 1];
 				if (n == 0 || right_count[b] == 0)
 					continue;
 				const double cost = sweep.area() * (double) n + right_area[b] * (double) right_count[b];
@@ -159,7 +167,7 @@ struct Builder {
 					best_cost = cost;
 					best_axis = axis;
 					best_bin = b;
-					best_scale = scale;
+					best_scale = scale[axis];
 				}
 			}
 		}
