@@ -180,6 +180,15 @@ def test_no_device_behaviour(rt):
     with pytest.raises(rt.RtError) as e:
         rt.Host(rt.Options.defaults())
     assert e.value.code == -2 and "No device found" in e.value.message
+    with pytest.raises(rt.RtError) as e:  # the frame ring ends the same way (reference src/opencl_host.cc:30-31)
+        rt.FrameRing(rt.Options.defaults(), hosts=3)
+    assert e.value.code == -2 and "No device found" in e.value.message
+    with pytest.raises(rt.RtError) as e:
+        rt.FrameRing(rt.Options.defaults(), hosts=0)
+    assert e.value.code in (-1, -2)
+    assert rt.rccl_available() in (True, False)  # (opened at run time; never a load-time dependency of the library)
+    needed = subprocess.run(["readelf", "-d", rt.lib_path()], capture_output=True, text=True).stdout
+    assert "rccl" not in needed
 
 
 def render_binary():

@@ -32,7 +32,7 @@ def main():
     out_dir, workloads = sys.argv[1], sys.argv[2:]
     result = {
         "kernel_source_sha256": kernel_source_sha(),
-        "source": "profiles/r02_pmc_<workload>.txt (rocprofv3 --pmc, one pass per counter group, tools/pmc_collect.sh)",
+        "source": "profiles/r03_pmc_<workload>.txt (rocprofv3 --pmc, one pass per counter group, tools/pmc_collect.sh)",
         "units": "per launch of the dominant kernel; SQ_*_CYCLES and SQ_WAIT_* count quad-cycles",
         "workloads": {},
     }
@@ -70,6 +70,14 @@ def main():
             # v_fma / v_mul / v_add / v_mov on registers reach the guide's 2 cycles (2.3 measured).
             "valu_ceiling_measured": round(1.0 / 3.15, 3) if WORKLOADS[w]["ao"] else round(1.0 / 3.24, 3),
         }
+        shared_path = os.path.join(out_dir, f"pmc_{w}__shared.txt")
+        if os.path.exists(shared_path):  # the same frame with the grid of a host that shares its GPU
+            shared = parse(shared_path)
+            names = [k for k in shared if want in k]
+            if names:
+                entry["shared_valu_insts"] = shared[names[0]].get("SQ_INSTS_VALU")
+                entry["shared_waves"] = shared[names[0]].get("SQ_WAVES")
+                entry["shared_frame_valu_insts"] = sum(k.get("SQ_INSTS_VALU", 0.0) for name, k in shared.items() if "ocrt::" in name)
         result["workloads"][w] = entry
     json.dump(result, sys.stdout, indent=1)
     print()

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--workload", default="bunny_1080p_ao", choices=sorted(WORKLOADS))
     ap.add_argument("--frames", type=int, default=3)
     ap.add_argument("--bvh", default=None, choices=[None, "longest", "sah"])
+    ap.add_argument("--share", type=int, default=1, help="tell the host that this many hosts share its GPU (the grid of a ring's hosts)")
     args = ap.parse_args()
     w = dict(WORKLOADS[args.workload])
     if args.bvh:
@@ -28,6 +29,7 @@ def main():
     scene = rt.Scene.load_off(mesh_path(w["mesh"])).build_bvh(opt.bvh_method)
     host = rt.Host(opt, 0)
     host.upload_scene(scene)
+    host.set_device_share(args.share)
     for _ in range(args.frames):
         host.render()
     st = host.stats()
