@@ -271,10 +271,7 @@ void BandGather::selfTest() {
 GroupGather::GroupGather(const RayTracer::Options &options, const std::vector<int> &devices_)
 	: layout(options, (unsigned int) devices_.size()), devices(devices_), stacked(nullptr), final_image(nullptr) {
 	const Rccl &api = rccl_or_throw();
-	for (size_t i = 0; i < devices.size(); ++i)
-		for (size_t j = i + 1; j < devices.size(); ++j)
-			if (devices[i] == devices[j])
-				throw DeviceError("RCCL needs one device per rank (a device is listed twice)");
+	// (RCCL itself refuses a device that is listed twice -- "duplicate GPU" --: the caller then falls back to peer copies)
 	std::vector<ncclComm_t> c(devices.size(), nullptr);
 	OCRT_NCCL(api.CommInitAll(c.data(), (int) devices.size(), devices.data()));
 	for (ncclComm_t x : c)
