@@ -106,6 +106,7 @@ class HipHostRing {
 		float lastKernelMs() const;                   // kernel time of the last frame (HIP events on its host's stream)
 		ocrt::RenderStats lastStats();
 		unsigned int size() const;
+		static void printInfo() { HipHost::printInfo(); }
 
 	private:
 		const RayTracer &rt;
@@ -149,5 +150,11 @@ class HipHostGroup {
 		size_t staging_bytes;
 };
 
-// Source compatibility with callers written against the reference.
+// Source compatibility with callers written against the reference.  (-DOCRT_DROPIN_RING: the same callers on a frame
+// ring instead -- their operator()() is one blocking frame either way; oracle/Makefile builds the reference's main()
+// both ways.)
+#ifdef OCRT_DROPIN_RING
+using OpenCLHost = HipHostRing;
+#else
 using OpenCLHost = HipHost;
+#endif

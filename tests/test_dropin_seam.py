@@ -20,6 +20,7 @@ from conftest import ROOT, mesh_file
 
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 DROPIN = os.path.join(ORACLE_DIR, "_ref", "ref_render_dropin")
+DROPIN_RING = os.path.join(ORACLE_DIR, "_ref", "ref_render_dropin_ring")  # the same main() with OpenCLHost = HipHostRing
 LIB = os.path.join(ROOT, "opencl_raytracer_amd", "lib", "libocrt_hip.so")
 
 
@@ -51,6 +52,8 @@ def test_reference_render_cc_builds_unmodified_against_the_drop_in(dropin_built)
     out = subprocess.run(["nm", "-C", dropin_built], capture_output=True, text=True, check=True).stdout
     assert " T main" in out
     assert "HipHost::upload" in out and "HipHost::operator()()" in out
+    ring = subprocess.run(["nm", "-C", DROPIN_RING], capture_output=True, text=True, check=True).stdout
+    assert " T main" in ring and "HipHostRing::upload" in ring and "HipHostRing::operator()()" in ring
 
 
 def test_no_symbol_is_defined_twice(dropin_built):
@@ -77,9 +80,11 @@ def test_without_a_gpu_it_ends_like_the_reference(dropin_built, tmp_path):
 
 
 @pytest.mark.gpu
-def test_reference_main_renders_the_golden_pgm_on_the_hip_host(golden, tmp_path):
+@pytest.mark.parametrize("binary", [DROPIN, DROPIN_RING], ids=["HipHost", "HipHostRing"])
+def test_reference_main_renders_the_golden_pgm_on_the_hip_host(golden, tmp_path, binary):
+    DROPIN = binary  # noqa: N806 (the reference's own main(), on the plain host and on the frame ring)
     if not os.path.exists(DROPIN):
-        pytest.skip("oracle/_ref/ref_render_dropin not built (needs the reference tree at build time)")
+        pytest.skip("oracle/_ref/ref_render_dropin* not built (needs the reference tree at build time)")
     # (no `-r` / `-m` here: the reference's own option parser returns a reference to a temporary for enum options,
     # include/args.h:233 -- g++ warns about it -- and its main() then crashes at -O2 before any of our code runs)
     for name, extra in (("bunny_256_s1_a3", []), ("bunny_600_defaults", []), ("blob_128x96_s4_a3", [])):
