@@ -14,8 +14,8 @@
 //                   the smooth normal and head-light term.  Sub-pixels that need
 //                   no ambient occlusion are final; the tile's other hits are
 //                   ballot-compacted into the tile's 64 slots of the hit list.
-//   order_kernel    counting sort of the non-empty tiles by AO cost class, heaviest
-//                   first, per XCD group.
+//   order_kernel    counting sort of the non-empty tiles by AO cost class, the costly
+//                   ones first, per XCD group.
 //   ao_kernel       persistent waves claim runs of (tile, table direction) units in
 //                   that order.  A wave rebuilds the tile's tangent frames in its
 //                   LDS slice and casts one packet of 64 any-hit rays per
@@ -27,7 +27,7 @@
 // Why not one fused launch (it was, see profiles/r01_notes.md): cost per tile
 // varies 30x (background vs model, 29 rays per hit sub-pixel), so the frame used
 // to end on a long tail of half-empty CUs.  With the tiles' costs known after the
-// primary pass, longest-first claiming packs them almost perfectly.
+// primary pass, claiming the costly blocks first packs them almost perfectly.
 //
 // How rays walk the tree: the 64 rays of a wave share ONE node index ("shared
 // walk", see shared_box / walk_collect below) -- nodes and triangles arrive by
@@ -1134,9 +1134,10 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) __attribute__((amdgpu_waves_per
 
 // ---------------------------------------------------------------------------
 // Ordering step: per XCD group, blocks of 64 neighbouring tiles sorted by their AO
-// cost (sum of the tiles' cost classes from primary_kernel), costliest first; the
-// tiles of a block stay together and in spatial order (counting sort, one workgroup
-// per group, one wave per block).
+// cost (sum of the tiles' cost classes from primary_kernel >> KernelParams::cost_shift,
+// capped: the costly blocks share the top key and keep their spatial order, the cheap ones
+// follow by cost -- scene_pack.cc says why); the tiles of a block stay together and in
+// spatial order (counting sort, one workgroup per group, one wave per block).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void order_kernel(const uint32_t *__restrict__ tile_hits,
                                                      uint32_t *__restrict__ order, FrameCounters *__restrict__ counters,

@@ -409,9 +409,17 @@ KernelParams make_kernel_params(const RayTracer &rt, uint32_t node_count, uint32
 	p.ao_claim_max = claim_max && std::atoi(claim_max) > 0 ? (uint32_t) std::atoi(claim_max) : 0u;
 	p.ao_claim_div = 1u;
 	const char *batch_below = debug_knob("OCRT_BATCH_BELOW");  // debug knob
-	p.batch_below = batch_below ? (uint32_t) std::atoi(batch_below) : 32u;
+	// (32 until round 3; with the coarser ordering key below 40 ... 56 measure alike and 1-2 % better, profiles/r03_notes.md)
+	p.batch_below = batch_below ? (uint32_t) std::atoi(batch_below) : 48u;
 	const char *cost_shift = debug_knob("OCRT_COST_SHIFT");  // debug knob
-	p.cost_shift = cost_shift ? (uint32_t) std::atoi(cost_shift) & 31u : 5u;
+	// Ordering key of a block of 64 tiles = 1 + (sum of its tiles' cost classes >> 2), capped at 64: every block whose
+	// tiles average four leaf stops or more -- the model -- shares the top key and is claimed first IN SPATIAL ORDER
+	// (neighbouring claims walk the same part of the tree: the scalar cache and the XCD's L2 see it again), the cheap
+	// blocks after them by cost.  A finer key for the costly blocks (>> 5 until round 3: costliest first) shortened the
+	// tail of a pass that runs alone by a little and cost the locality: -3 % ... -7 % per frame on every workload with
+	// frames in flight, -6 ... -10 % for the pass alone at 600 x 600 -s 4 and on the interior scene, +0.5 % for the
+	// headline pass alone (profiles/r03_notes.md).
+	p.cost_shift = cost_shift ? (uint32_t) std::atoi(cost_shift) & 31u : 2u;
 	p.ao_regular = (p.ao_max_distance > 0.0f && std::isfinite(p.ao_max_distance)) ? 1 : 0;
 	p.primary_below = std::nextafterf(100000.0f, 0.0f);
 	p.ao_below = std::nextafterf(p.ao_max_distance, -std::numeric_limits<float>::infinity());

@@ -6,7 +6,7 @@ that box drift hits every variant alike:
         ms per frame, of which primary pass + ordering step, ao_kernel
     a steady stream (a ring of three hosts, graph replay)      ms per frame by the wall clock
 
-    python3 tools/ab_variants.py lib lib_x lib_y -- bunny_1080p_ao interior_1080p_ao [--frames 120]
+    python3 tools/ab_variants.py lib lib_x lib_knobs:OCRT_COST_SHIFT=3 -- bunny_1080p_ao interior_1080p_ao [--frames 120]
 """
 import os
 import statistics
@@ -52,7 +52,7 @@ def one(workload, frames):
         walls.append((time.perf_counter() - t0) / frames * 1e3)
     ring.close()
     pipe = min(walls)
-    print(f"{os.environ.get('OCRT_LIB_DIR', 'lib'):14s} {workload:20s} blocking {total:7.4f} ms (primary+order {primary:7.4f}, ao {ao:7.4f})  "
+    print(f"{os.environ.get('OCRT_AB_LABEL', os.environ.get('OCRT_LIB_DIR', 'lib')):34s} {workload:20s} blocking {total:7.4f} ms (primary+order {primary:7.4f}, ao {ao:7.4f})  "
           f"stream {pipe:7.4f} ms = {rays / pipe / 1e3:8.1f} Mrays/s", flush=True)
 
 
@@ -64,12 +64,23 @@ def main():
     if "--frames" in args:
         frames = int(args[args.index("--frames") + 1])
         del args[args.index("--frames"):args.index("--frames") + 2]
+    if "--reps" in args:
+        reps_value = int(args[args.index("--reps") + 1])
+        del args[args.index("--reps"):args.index("--reps") + 2]
+        args += ["--reps", str(reps_value)]
     split = args.index("--")
-    variants, workloads = args[:split], args[split + 1:]
-    for rep in range(2):
+    variants, workloads = args[:split], [a for a in args[split + 1:] if not a.startswith("--") and not a.isdigit()]
+    reps = 2
+    if "--reps" in args:
+        reps = int(args[args.index("--reps") + 1])
+    for rep in range(reps):
         for w in workloads:
-            for v in variants:
-                env = dict(os.environ, OCRT_LIB_DIR=v)
+            for v in variants:  # "lib_dir" or "lib_dir:KNOB=value,KNOB=value" (knobs: the A/B build lib_knobs reads them)
+                lib_dir, _, knobs = v.partition(":")
+                env = dict(os.environ, OCRT_LIB_DIR=lib_dir, OCRT_AB_LABEL=v)
+                for item in filter(None, knobs.split(",")):
+                    key, _, value = item.partition("=")
+                    env[key] = value
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one", w, str(frames)], env=env, capture_output=True, text=True)
                 out = [ln for ln in r.stdout.splitlines() if "blocking" in ln]
                 print(out[0] if out else f"{v} {w}: FAILED {r.stderr[-300:]}", flush=True)
