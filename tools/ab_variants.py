@@ -4,7 +4,7 @@ that box drift hits every variant alike:
 
     one frame at a time (a ring of one host, plain launches: HIP events around the passes)
         ms per frame, of which primary pass + ordering step, ao_kernel
-    a steady stream (a ring of three hosts, graph replay)      ms per frame by the wall clock
+    a steady stream (a ring of four hosts -- OCRT_AB_HOSTS --, graph replay)      ms per frame by the wall clock
 
     python3 tools/ab_variants.py lib lib_x lib_knobs:OCRT_COST_SHIFT=3 -- bunny_1080p_ao interior_1080p_ao [--frames 120]
 """
@@ -41,7 +41,7 @@ def one(workload, frames):
     st = ring.host(0).stats()
     rays = st["primary_rays"] + st["ao_rays"]
     ring.close()
-    ring = rt.FrameRing(opt, scene, hosts=3)
+    ring = rt.FrameRing(opt, scene, hosts=int(os.environ.get("OCRT_AB_HOSTS", "4")))  # (a tool's own variable: hosts of the stream's ring)
     ring.run(30)
     ring.drain()
     walls = []
