@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 
@@ -28,11 +29,34 @@ namespace {
 
 }  // namespace
 
+namespace {
+
+// The render host that HipHost::warmUp(rt, device) created ahead of time, waiting to be adopted.
+std::mutex prepared_mutex;
+std::unique_ptr<ocrt::DeviceRenderer> prepared;
+int prepared_device = -1;
+
+bool same_options(const RayTracer::Options &a, const RayTracer::Options &b) {
+	return a.width == b.width && a.height == b.height && a.focalLength == b.focalLength && a.nSuperSamples == b.nSuperSamples &&
+	       a.enableShading == b.enableShading && a.enableAO == b.enableAO && a.aoMaxDistance == b.aoMaxDistance &&
+	       a.aoNumSamples == b.aoNumSamples && a.aoMethod == b.aoMethod && a.aoAlphaMin == b.aoAlphaMin &&
+	       a.aoAlphaMax == b.aoAlphaMax && a.bvhMethod == b.bvhMethod;
+}
+
+}  // namespace
+
 HipHost::HipHost(const RayTracer &rt_, int device) : HipHost(rt_, device, 0, 1) {}
 
 HipHost::HipHost(const RayTracer &rt_, int device, unsigned int rank, unsigned int nranks) : rt(rt_) {
+	if (rank == 0 && nranks == 1) {
+		std::lock_guard<std::mutex> lock(prepared_mutex);
+		if (prepared && prepared_device == device && same_options(prepared->rayTracer().options, rt.options))
+			impl = std::move(prepared);
+		prepared.reset();
+	}
 	// std::runtime_error("No device found") propagates, as in the reference.
-	impl.reset(new ocrt::DeviceRenderer(rt.options, device, rank, nranks));
+	if (!impl)
+		impl.reset(new ocrt::DeviceRenderer(rt.options, device, rank, nranks));
 	std::cout << Color::WHITE << "Using Device \"" << impl->deviceName() << "\"." << Color::RESET << std::endl
 	          << std::endl;
 }
@@ -44,6 +68,15 @@ void HipHost::upload(const std::vector<uint32_t> &faces, const std::vector<uint3
                      const std::vector<Vec3f> &vnormals) {
 	try {
 		const ocrt::PackedScene packed = ocrt::pack_scene(faces, nodes, aabbs, vertices, vnormals);
+		const size_t bytes = impl->upload(packed);
+		std::cout << "Requested " << bytes / 1024 << " kB of memory." << std::endl;
+	} catch (const std::exception &e) {
+		die(e.what());
+	}
+}
+
+void HipHost::upload(const ocrt::PackedScene &packed) {
+	try {
 		const size_t bytes = impl->upload(packed);
 		std::cout << "Requested " << bytes / 1024 << " kB of memory." << std::endl;
 	} catch (const std::exception &e) {
@@ -111,6 +144,15 @@ void HipHostRing::upload(const std::vector<uint32_t> &faces, const std::vector<u
                          const std::vector<Vec3f> &vnormals) {
 	try {
 		const ocrt::PackedScene packed = ocrt::pack_scene(faces, nodes, aabbs, vertices, vnormals);  // once; every host gets it
+		const size_t bytes = ring->upload(packed);
+		std::cout << "Requested " << bytes / 1024 << " kB of memory." << std::endl;
+	} catch (const std::exception &e) {
+		die(e.what());
+	}
+}
+
+void HipHostRing::upload(const ocrt::PackedScene &packed) {
+	try {
 		const size_t bytes = ring->upload(packed);
 		std::cout << "Requested " << bytes / 1024 << " kB of memory." << std::endl;
 	} catch (const std::exception &e) {
@@ -270,6 +312,17 @@ void HipHostGroup::upload(const std::vector<uint32_t> &faces, const std::vector<
 	}
 }
 
+void HipHostGroup::upload(const ocrt::PackedScene &packed) {
+	try {
+		size_t bytes = 0;
+		for (auto &h : hosts)
+			bytes += h->upload(packed);
+		std::cout << "Requested " << bytes / 1024 << " kB of memory on " << hosts.size() << " devices." << std::endl;
+	} catch (const std::exception &e) {
+		die(e.what());
+	}
+}
+
 bool HipHostGroup::operator()() {
 	try {
 		for (auto &h : hosts)  // (launches are asynchronous: the devices work at the same time)
@@ -352,6 +405,17 @@ ocrt::RenderStats HipHostGroup::lastStats() {
 }
 
 void HipHost::warmUp(int device) { ocrt::warm_up_device(device); }
+
+void HipHost::warmUp(const RayTracer &rt, int device) {
+	ocrt::warm_up_device(device);
+	try {  // (whatever goes wrong here goes wrong again, and is reported, when the host proper is constructed)
+		std::unique_ptr<ocrt::DeviceRenderer> host(new ocrt::DeviceRenderer(rt.options, device, 0, 1));
+		std::lock_guard<std::mutex> lock(prepared_mutex);
+		prepared = std::move(host);
+		prepared_device = device;
+	} catch (const std::exception &) {
+	}
+}
 
 void HipHost::printInfo() {
 	Info info;

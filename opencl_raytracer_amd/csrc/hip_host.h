@@ -25,6 +25,7 @@
 #include "vec3.h"
 
 namespace ocrt {
+struct PackedScene;    // scene_pack.h
 class DeviceRenderer;  // device_renderer.h
 class FrameRing;       // frame_ring.h
 class GroupGather;     // band_gather.h
@@ -56,6 +57,10 @@ class HipHost {
 		            const std::vector<Vec3f> &aabbs, const std::vector<Vec3f> &vertices,
 		            const std::vector<Vec3f> &vnormals);
 
+		// New: the same with the arrays already validated and packed (ocrt::pack_scene, scene_pack.h) -- the CPU half of
+		// an upload, which a caller can run while the device is still coming up (HipHost::warmUp).
+		void upload(const ocrt::PackedScene &packed);
+
 		// Renders the whole frame (this rank's bands) and blocks until it is done;
 		// false means the caller should exit (reference src/opencl_host.cc:137-149).
 		bool operator()();
@@ -74,6 +79,9 @@ class HipHost {
 		// caller that still has CPU work to do before it needs the host (mesh loading, BVH build: src/render.cc:52-80)
 		// runs this on a second thread; constructing the host afterwards costs milliseconds instead of 100-200 ms.
 		static void warmUp(int device = -1);
+		// ... and also creates the render host's device state for `rt` (streams, image and hit-list buffers): the next
+		// HipHost(rt', device) whose options equal rt's adopts it instead of allocating its own.
+		static void warmUp(const RayTracer &rt, int device);
 
 		// Milliseconds the ray-casting kernel of the last operator()() took,
 		// measured with HIP events on the launch stream.
@@ -99,6 +107,7 @@ class HipHostRing {
 		void upload(const std::vector<uint32_t> &faces, const std::vector<uint32_t> &nodes,
 		            const std::vector<Vec3f> &aabbs, const std::vector<Vec3f> &vertices,
 		            const std::vector<Vec3f> &vnormals);
+		void upload(const ocrt::PackedScene &packed);
 		bool operator()();                            // one frame, blocking
 		bool frames(unsigned int count);              // `count` frames, up to size() - 1 in flight; blocks until all are done
 		void download(float *image);                  // the float image of the last frame
@@ -134,6 +143,7 @@ class HipHostGroup {
 		void upload(const std::vector<uint32_t> &faces, const std::vector<uint32_t> &nodes,
 		            const std::vector<Vec3f> &aabbs, const std::vector<Vec3f> &vertices,
 		            const std::vector<Vec3f> &vnormals);
+		void upload(const ocrt::PackedScene &packed);
 		bool operator()();                            // all devices render their bands; blocks until every one is done
 		void downloadResized(unsigned char *image);   // resize on every device, gather, assemble width x height bytes
 		float lastKernelMs() const;                   // slowest device's kernel time of the last frame

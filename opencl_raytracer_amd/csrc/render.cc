@@ -20,6 +20,7 @@
 #include "hip_host.h"
 #include "mesh.h"
 #include "ray_tracer.h"
+#include "scene_pack.h"
 
 using ocrt::cli::Color;
 using ocrt::cli::Info;
@@ -226,15 +227,12 @@ bool run_frames(HipHostRing &host, unsigned int count) { return count == 1 ? hos
 // under their own names -- scripts that read the reference's output keep working: "Loading OpenCL kernel" is the
 // face sort + scene upload there as well (:86-105), whatever its name says.
 template <class Host>
-void render_frame(Host &host, const CliOptions &options, const RayTracer &rt, Mesh &mesh, BVH &bvh,
+void render_frame(Host &host, const CliOptions &options, const RayTracer &rt, const ocrt::PackedScene &packed,
                   std::vector<unsigned char> &image) {
 	phase_clock.mark("host");
 	std::size_t total_time = 0;
 	total_time += Info::measure("Loading OpenCL kernel", [&] {
-		std::vector<uint32_t> sorted_faces = sort_faces_by_leaf_order(mesh, bvh);
-		mesh.faces.clear();
-		bvh.triangles.clear();
-		host.upload(sorted_faces, bvh.nodes, bvh.aabbs, mesh.vertices, mesh.vnormals);
+		host.upload(packed);  // (the face sort and the packing of the scene ran while the device came up, main())
 		return true;
 	}, true);
 	phase_clock.mark("upload");
@@ -293,9 +291,16 @@ int main(int argc, const char **argv) {
 	// The HIP runtime, the device context and the kernels' code object cost 100-200 ms and do not depend on the scene:
 	// they come up on a second thread while this one reads the mesh and builds the BVH (reference order of the output
 	// kept: nothing is printed from that thread).
+	const RayTracer rt(options);
+	const bool plain_host = options.gpus == 1 && options.gather == "auto" && options.frames == 1 && options.in_flight <= 1;
 	std::thread warm_up;
 	if (options.warm_up)
-		warm_up = std::thread([&options] { HipHost::warmUp(options.device); });
+		warm_up = std::thread([&options, &rt, plain_host] {
+			if (plain_host)
+				HipHost::warmUp(rt, options.device);  // (... and the host's own buffers: main() adopts them below)
+			else
+				HipHost::warmUp(options.device);
+		});
 	phase_clock.mark("options");
 	std::cout << Color::BLUE << "<- " << Info::Palette::SECTION << "BVH section" << Color::BLUE << " ->" << std::endl;
 	std::cout << Info::Palette::NORMAL << "Reading input mesh\xE2\x80\xA6" << std::endl;
@@ -308,7 +313,6 @@ int main(int argc, const char **argv) {
 	          << mesh.vertices.size() << std::endl
 	          << Color::BLUE << "- " << Info::Palette::NORMAL << "Triangles: " << Info::Palette::HIGHLIGHT
 	          << (mesh.faces.size() / 3) << Color::RESET << std::endl;
-	RayTracer rt(options);
 	if (options.enableAO && options.aoMethod == RayTracer::AmbientOcclusionMethod::UNIFORM) {
 		// the reference's notice and its own ray estimate (:63-74; it prints 25 for the default three rings, the
 		// kernel casts 28: the inner loop there runs to ray_count inclusive, src/intersect_kernel.cl:242)
@@ -332,6 +336,22 @@ int main(int argc, const char **argv) {
 		return true;
 	});
 	phase_clock.mark("bvh");
+	// The CPU half of the upload -- faces into leaf order (reference src/render.cc:88-95), validation, device records,
+	// the walk tree -- needs no device: it runs here, beside the warm-up thread.  Malformed arrays end the run as they
+	// would inside upload(): message + exit(EXIT_FAILURE) (the reference's check(), include/opencl_host.h:21-26).
+	ocrt::PackedScene packed;
+	try {
+		std::vector<uint32_t> sorted_faces = sort_faces_by_leaf_order(mesh, bvh);
+		mesh.faces.clear();
+		bvh.triangles.clear();
+		packed = ocrt::pack_scene(sorted_faces, bvh.nodes, bvh.aabbs, mesh.vertices, mesh.vnormals);
+	} catch (const std::exception &e) {
+		if (warm_up.joinable())
+			warm_up.join();
+		std::cerr << "HIP error: " << e.what() << std::endl;
+		std::exit(EXIT_FAILURE);
+	}
+	phase_clock.mark("pack");
 	if (warm_up.joinable())
 		warm_up.join();
 	phase_clock.mark("wait for the device");
@@ -345,13 +365,13 @@ int main(int argc, const char **argv) {
 	const unsigned int in_flight = options.in_flight ? options.in_flight : options.frames > 1 ? 3u : 1u;
 	if (options.gpus > 1 || options.gather != "auto") {
 		HipHostGroup host(rt, options.gpus, options.device, options.gather.c_str());
-		render_frame(host, options, rt, mesh, bvh, image);
+		render_frame(host, options, rt, packed, image);
 	} else if (in_flight > 1 || options.frames > 1) {
 		HipHostRing host(rt, in_flight, options.device);
-		render_frame(host, options, rt, mesh, bvh, image);
+		render_frame(host, options, rt, packed, image);
 	} else {
 		HipHost host(rt, options.device);
-		render_frame(host, options, rt, mesh, bvh, image);
+		render_frame(host, options, rt, packed, image);
 	}
 	std::FILE *out = std::fopen(options.out.c_str(), "wb");
 	if (!out) {
