@@ -158,6 +158,15 @@ BandGather::BandGather(const RayTracer::Options &options, unsigned int rank_, un
 	ncclComm_t c = nullptr;
 	OCRT_NCCL(api.CommInitRank(&c, (int) nranks, id, (int) rank));
 	comm = c;
+	try {
+		allocate(slots);
+	} catch (...) {
+		release();
+		throw;
+	}
+}
+
+void BandGather::allocate(unsigned int slots) {
 	// Its own stream, HIGHEST priority class: the transfer and the row scatter are a few microseconds of work that a
 	// frame's consumer waits for, while the ring's persistent ambient-occlusion passes would keep a low-priority
 	// kernel waiting for wave slots until one of them ends (measured: +4 % per frame with the lowest class).
@@ -180,23 +189,30 @@ BandGather::BandGather(const RayTracer::Options &options, unsigned int rank_, un
 	}
 }
 
-BandGather::~BandGather() {
+BandGather::~BandGather() { release(); }
+
+void BandGather::release() {
 	if (hipSetDevice(device) != hipSuccess)
 		return;
 	if (stream)
 		(void) hipStreamSynchronize((hipStream_t) stream);
 	if (comm && rccl().CommDestroy)
 		(void) rccl().CommDestroy((ncclComm_t) comm);
+	comm = nullptr;
 	for (void *e : done)
 		(void) hipEventDestroy((hipEvent_t) e);
+	done.clear();
 	for (void *p : stacked)
 		if (p)
 			(void) hipFree(p);
+	stacked.clear();
 	for (void *p : final_image)
 		if (p)
 			(void) hipFree(p);
+	final_image.clear();
 	if (stream)
 		(void) hipStreamDestroy((hipStream_t) stream);
+	stream = nullptr;
 }
 
 void BandGather::enqueue(unsigned int slot, const void *device_bands) {

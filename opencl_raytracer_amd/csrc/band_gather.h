@@ -58,6 +58,8 @@ class BandGather {
 		void selfTest();
 
 	private:
+		void allocate(unsigned int slots);  // stream, events, rank 0's buffers
+		void release();
 		BandPlan layout;
 		unsigned int rank, nranks;
 		int device;

@@ -234,7 +234,10 @@ size_t DeviceRenderer::upload(const PackedScene &scene) {
 		}
 	}
 	const bool ao_on = opts.enableAO && opts.aoNumSamples > 0;
-	const WalkArray walk = make_walk_array(scene, ao_on ? kernel_float(opts.aoMaxDistance) : 0.0f);
+	const float walk_distance = ao_on ? kernel_float(opts.aoMaxDistance) : 0.0f;
+	const std::shared_ptr<const WalkArray> made = (scene.walk && scene.walk_max_distance == walk_distance)
+	                                                  ? scene.walk : std::make_shared<const WalkArray>(make_walk_array(scene, walk_distance));
+	const WalkArray &walk = *made;
 	kp = make_kernel_params(rt, (uint32_t) scene.nodes.size(), (uint32_t) scene.tris.size(), ao_dirs, part, &scene, &walk);
 	kp.shared_device = device_share > 1u ? 1 : 0;
 	const size_t nodes_bytes = scene.nodes.size() * sizeof(NodeRec);

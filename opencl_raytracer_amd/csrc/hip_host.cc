@@ -32,8 +32,10 @@ namespace {
 namespace {
 
 // The render host that HipHost::warmUp(rt, device) created ahead of time, waiting to be adopted.
+// (A plain pointer on purpose: a host that is never adopted -- the run ended early -- is left to the process's exit
+// rather than destroyed by a static destructor after the HIP runtime may have shut down.)
 std::mutex prepared_mutex;
-std::unique_ptr<ocrt::DeviceRenderer> prepared;
+ocrt::DeviceRenderer *prepared = nullptr;
 int prepared_device = -1;
 
 bool same_options(const RayTracer::Options &a, const RayTracer::Options &b) {
@@ -51,8 +53,10 @@ HipHost::HipHost(const RayTracer &rt_, int device, unsigned int rank, unsigned i
 	if (rank == 0 && nranks == 1) {
 		std::lock_guard<std::mutex> lock(prepared_mutex);
 		if (prepared && prepared_device == device && same_options(prepared->rayTracer().options, rt.options))
-			impl = std::move(prepared);
-		prepared.reset();
+			impl.reset(prepared);
+		else
+			delete prepared;
+		prepared = nullptr;
 	}
 	// std::runtime_error("No device found") propagates, as in the reference.
 	if (!impl)
@@ -409,9 +413,10 @@ void HipHost::warmUp(int device) { ocrt::warm_up_device(device); }
 void HipHost::warmUp(const RayTracer &rt, int device) {
 	ocrt::warm_up_device(device);
 	try {  // (whatever goes wrong here goes wrong again, and is reported, when the host proper is constructed)
-		std::unique_ptr<ocrt::DeviceRenderer> host(new ocrt::DeviceRenderer(rt.options, device, 0, 1));
+		ocrt::DeviceRenderer *host = new ocrt::DeviceRenderer(rt.options, device, 0, 1);
 		std::lock_guard<std::mutex> lock(prepared_mutex);
-		prepared = std::move(host);
+		delete prepared;
+		prepared = host;
 		prepared_device = device;
 	} catch (const std::exception &) {
 	}

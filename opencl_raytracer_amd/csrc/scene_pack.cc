@@ -313,6 +313,11 @@ WalkArray make_walk_array(const PackedScene &scene, float ao_max_distance) {
 	return out;
 }
 
+void prepare_walk_array(PackedScene &scene, float ao_max_distance) {
+	scene.walk = std::make_shared<const WalkArray>(make_walk_array(scene, ao_max_distance));
+	scene.walk_max_distance = ao_max_distance;
+}
+
 float kernel_float(float v) {
 	if (!std::isfinite(v))
 		return v;

@@ -2,6 +2,7 @@
 // records of device_types.h and derives the launch constants.  Host only.
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <vector>
 
 #include "device_types.h"
@@ -10,6 +11,17 @@
 
 namespace ocrt {
 
+// What the fast form of the shared walk reads: the same tree as PackedScene::nodes with every box pushed outward by
+// the margin derived at padded_bound(), the subtree size as a BYTE offset and two END records behind the last node
+// (kernels.hip, walk_collect).  The outward margin makes the walk's 6-FMA box test conservative, so a ray can only
+// visit MORE boxes than the reference's own test would let it; which triangles count is decided by the exact test on
+// the leaf's own box (TriRec::lo / hi).  `nodes` is empty when the scene does not qualify (irregular or non-nested
+// boxes, extent beyond 1e6): the kernels then only use the exact form.
+struct WalkArray {
+	std::vector<NodeRec> nodes;
+	float origin_limit = 0.0f;  // rays whose origin exceeds this magnitude on some axis take the exact form
+	float ao_scale = 0.0f;      // walk_scale_for(ao_max_distance) the margins were sized for (0: none)
+};
 struct PackedScene {
 	std::vector<NodeRec> nodes;
 	std::vector<TriRec> tris;
@@ -23,6 +35,11 @@ struct PackedScene {
 	bool nested = false;       // ... and every node's box contains its children's boxes (true for any tree built by
 	                           // uniting child boxes; arbitrary uploaded arrays need not be)
 	bool rebuilt = false;      // `nodes` is the rebuilt tree, not the uploaded one
+	// Optional: the walk array made ahead of the upload (prepare_walk_array) for this AO_MAX_DISTANCE -- CPU work that a
+	// caller can do before it has a device; DeviceRenderer::upload makes its own when this one is absent or was made for
+	// another distance.
+	std::shared_ptr<const WalkArray> walk;
+	float walk_max_distance = -1.0f;
 };
 
 // Validates the arrays against each other (every index and skip count is
@@ -32,20 +49,11 @@ PackedScene pack_scene(const std::vector<uint32_t> &faces, const std::vector<uin
                        const std::vector<Vec3f> &aabbs, const std::vector<Vec3f> &vertices,
                        const std::vector<Vec3f> &vnormals);
 
-// What the fast form of the shared walk reads: the same tree as PackedScene::nodes with every box pushed outward by
-// the margin derived at padded_bound(), the subtree size as a BYTE offset and two END records behind the last node
-// (kernels.hip, walk_collect).  The outward margin makes the walk's 6-FMA box test conservative, so a ray can only
-// visit MORE boxes than the reference's own test would let it; which triangles count is decided by the exact test on
-// the leaf's own box (TriRec::lo / hi).  `nodes` is empty when the scene does not qualify (irregular or non-nested
-// boxes, extent beyond 1e6): the kernels then only use the exact form.
-struct WalkArray {
-	std::vector<NodeRec> nodes;
-	float origin_limit = 0.0f;  // rays whose origin exceeds this magnitude on some axis take the exact form
-	float ao_scale = 0.0f;      // walk_scale_for(ao_max_distance) the margins were sized for (0: none)
-};
 // `ao_max_distance`: the kernel's AO_MAX_DISTANCE (bounds how far from a box an ambient-occlusion ray that hits it
 // can start; <= 0 or not finite: no ambient occlusion, or no usable bound).
 WalkArray make_walk_array(const PackedScene &scene, float ao_max_distance);
+// make_walk_array into scene.walk (see PackedScene::walk).
+void prepare_walk_array(PackedScene &scene, float ao_max_distance);
 // The margin itself: the padded value of a box's lower (upper = false) or upper bound `b` for ray origins of
 // magnitude up to `origin_bound` on that axis; always < b resp. > b.
 // `scaled_reach`: the max_distance (x 1.001) of the rays that use the SCALED node test on this array, 0 if none do.
