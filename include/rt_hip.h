@@ -187,6 +187,11 @@ uint32_t rt_ring_in_flight(const rt_ring *r);   /* frames submitted and not yet 
 rt_host *rt_ring_host(rt_ring *r, uint32_t slot);
 /* 1 (default): a frame is one replay of the host's captured hipGraph; 0: the same launches one by one. */
 int rt_ring_set_graph_mode(rt_ring *r, int on);
+/* Pacing of the submissions: a frame is enqueued no sooner than beta x (the running mean of the time per finished frame)
+ * after the previous one, so that frames which finished together do not start their successors together and keep the
+ * ring in lockstep.  Default 0.3; 0 switches it off.  (The reference submits one frame and waits for it:
+ * src/opencl_host.cc:137-149; nothing to pace there.) */
+int rt_ring_set_pacing(rt_ring *r, float beta);
 /* Band buffer `slot` (< rt_ring_slots) is caller-owned DEVICE memory from now on (rt_ring_local_rows * width bytes;
  * NULL: the ring's own again), e.g. the send buffer of a caller-side collective. */
 int rt_ring_bind_output(rt_ring *r, uint32_t slot, void *device_u8);

@@ -138,6 +138,7 @@ _SIGNATURES = {
     "rt_ring_in_flight": (C.c_uint32, [C.c_void_p]),
     "rt_ring_host": (C.c_void_p, [C.c_void_p, C.c_uint32]),
     "rt_ring_set_graph_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "rt_ring_set_pacing": (C.c_int, [C.c_void_p, C.c_float]),
     "rt_ring_bind_output": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
     "rt_ring_submit": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "rt_ring_collect": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_void_p)]),
@@ -477,6 +478,10 @@ class FrameRing:
 
     def set_graph_mode(self, on: bool) -> None:
         _check(load_library().rt_ring_set_graph_mode(self._r, int(on)))
+
+    def set_pacing(self, beta: float) -> None:
+        """0: submit as soon as a host is free; default 0.3 (include/rt_hip.h, rt_ring_set_pacing)."""
+        _check(load_library().rt_ring_set_pacing(self._r, float(beta)))
 
     def bind_output(self, slot: int, device_ptr: int) -> None:
         _check(load_library().rt_ring_bind_output(self._r, slot, device_ptr))

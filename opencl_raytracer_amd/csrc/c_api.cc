@@ -415,6 +415,13 @@ int rt_ring_set_graph_mode(rt_ring *r, int on) {
 	return guarded([&] { r->ring->setGraphMode(on != 0); });
 }
 
+int rt_ring_set_pacing(rt_ring *r, float beta) {
+	if (!r)
+		return fail(RT_E_INVALID, "null ring");
+	r->ring->setPacing(beta);
+	return RT_OK;
+}
+
 int rt_ring_bind_output(rt_ring *r, uint32_t slot, void *device_u8) {
 	if (!r)
 		return fail(RT_E_INVALID, "null ring");

@@ -4,6 +4,7 @@
 
 #include <chrono>
 #include <sstream>
+#include <thread>
 
 namespace ocrt {
 
@@ -23,7 +24,8 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 }  // namespace
 
 FrameRing::FrameRing(const RayTracer::Options &options, int device, unsigned int rank, unsigned int nranks, unsigned int count)
-	: next_frame(0), last{ 0, 0, nullptr }, have_last(false), epoch(nullptr) {
+	: next_frame(0), last{ 0, 0, nullptr }, have_last(false), epoch(nullptr), pacing(0.3f), period_s(0.0), last_collect_s(0.0),
+	  last_submit_s(0.0) {
 	if (count == 0 || count > 16)
 		throw std::invalid_argument("a frame ring holds 1 to 16 renderers");
 	for (unsigned int k = 0; k < count; ++k) {
@@ -99,7 +101,19 @@ uint64_t FrameRing::submit() {
 	if (open.size() >= hosts.size())
 		throw std::logic_error("frame ring: every renderer has a frame in flight, collect one first");
 	const unsigned int slot = (unsigned int) (next_frame % bound.size());
+	if (pacing > 0.0f && hosts.size() > 1 && period_s > 0.0 && !open.empty()) {
+		// (see setPacing: keep the frames of the ring out of step)
+		const double t_pace = now_s(), due = last_submit_s + (double) pacing * period_s;
+		if (due > t_pace && due - t_pace < 0.05) {
+			if (due - t_pace > 200e-6)
+				std::this_thread::sleep_for(std::chrono::duration<double>(due - t_pace - 100e-6));
+			while (now_s() < due)
+				std::this_thread::yield();
+			cpu.wait_s += now_s() - t_pace;
+		}
+	}
 	const double t0 = now_s();
+	last_submit_s = t0;
 	waitSlotFree(slot);  // (its gather was enqueued size() frames ago: long done)
 	hosts[next_frame % hosts.size()]->enqueueFrame(bufferOf(slot));
 	open.push_back(Collected{ next_frame, slot, nullptr });
@@ -128,6 +142,13 @@ FrameRing::Collected FrameRing::collect() {
 	}
 	last = c;
 	have_last = true;
+	// the time per finished frame, while frames follow each other without the ring running empty
+	const double t_done = now_s();
+	if (last_collect_s > 0.0 && !open.empty()) {
+		const double dt = t_done - last_collect_s;
+		period_s = period_s > 0.0 ? 0.9 * period_s + 0.1 * dt : dt;
+	}
+	last_collect_s = open.empty() ? 0.0 : t_done;
 	cpu.wait_s += t1 - t0;
 	cpu.collect_s += now_s() - t1;
 	++cpu.frames;

@@ -34,6 +34,12 @@ class FrameRing {
 		unsigned int size() const { return (unsigned int) hosts.size(); }
 		DeviceRenderer &host(unsigned int slot) { return *hosts.at(slot); }
 		void setGraphMode(bool on);
+		// Pacing: a frame is submitted no sooner than `beta` x the running mean of the time per finished frame after the
+		// previous submission.  Frames that finish together would otherwise start their successors together, and the
+		// ring falls into lockstep -- every host in its primary pass at once, then every host at the falling end of its
+		// ambient-occlusion pass at once --, which is exactly what several hosts are there to avoid (interior scene,
+		// three hosts: 1.52 -> 1.33 ms per frame; headline +-0; profiles/r03_notes.md).  0 switches it off; default 0.3.
+		void setPacing(float beta) { pacing = beta < 0.0f ? 0.0f : beta > 1.0f ? 1.0f : beta; }
 
 		// Frames write their 8-bit bands (the device resize) into slots() = 2 x size() band buffers in turn: frame f
 		// is rendered by renderer f % size() into buffer f % slots(), so a frame's bands -- and, with a gather, its
@@ -111,6 +117,10 @@ class FrameRing {
 		static constexpr size_t kept_times = 256;
 		std::deque<Times> times;
 		CpuTimes cpu;
+		float pacing;
+		double period_s;        // running mean of the time between finished frames while the ring stays busy (0: unknown)
+		double last_collect_s;  // when the previous frame was collected (0: the ring ran empty since)
+		double last_submit_s;
 };
 
 }  // namespace ocrt

@@ -42,6 +42,8 @@ def one(workload, frames):
     rays = st["primary_rays"] + st["ao_rays"]
     ring.close()
     ring = rt.FrameRing(opt, scene, hosts=int(os.environ.get("OCRT_AB_HOSTS", "4")))  # (a tool's own variable: hosts of the stream's ring)
+    if "OCRT_AB_PACING" in os.environ:  # (a tool's own variable: the ring's pacing factor, 0 = off)
+        ring.set_pacing(float(os.environ["OCRT_AB_PACING"]))
     ring.run(30)
     ring.drain()
     walls = []
