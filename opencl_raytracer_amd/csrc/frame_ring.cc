@@ -2,6 +2,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <sstream>
 #include <thread>
@@ -101,10 +102,10 @@ uint64_t FrameRing::submit() {
 	if (open.size() >= hosts.size())
 		throw std::logic_error("frame ring: every renderer has a frame in flight, collect one first");
 	const unsigned int slot = (unsigned int) (next_frame % bound.size());
-	if (pacing > 0.0f && hosts.size() > 1 && period_s > 0.0 && !open.empty()) {
+	if (pacing > 0.0f && hosts.size() > 1 && period_s > 0.0 && open.size() + 1 >= hosts.size()) {
 		// (see setPacing: keep the frames of the ring out of step)
 		const double t_pace = now_s(), due = last_submit_s + (double) pacing * period_s;
-		if (due > t_pace && due - t_pace < 0.05) {
+		if (due > t_pace && due - t_pace < 0.25) {
 			if (due - t_pace > 200e-6)
 				std::this_thread::sleep_for(std::chrono::duration<double>(due - t_pace - 100e-6));
 			while (now_s() < due)
@@ -145,8 +146,19 @@ FrameRing::Collected FrameRing::collect() {
 	// the time per finished frame, while frames follow each other without the ring running empty
 	const double t_done = now_s();
 	if (last_collect_s > 0.0 && !open.empty()) {
-		const double dt = t_done - last_collect_s;
-		period_s = period_s > 0.0 ? 0.9 * period_s + 0.1 * dt : dt;
+		// The MEAN of the last eight intervals (frames in lockstep finish in bursts: short and long intervals alternate,
+		// and their mean is the time per frame), each capped at four times the current estimate (the first frames of a
+		// ring include graph captures, and a caller may pause between two collects).
+		double dt = t_done - last_collect_s;
+		if (period_s > 0.0 && dt > 4.0 * period_s)
+			dt = 4.0 * period_s;
+		intervals.push_back(dt);
+		if (intervals.size() > 8)
+			intervals.pop_front();
+		double sum = 0.0;
+		for (double v : intervals)
+			sum += v;
+		period_s = sum / (double) intervals.size();
 	}
 	last_collect_s = open.empty() ? 0.0 : t_done;
 	cpu.wait_s += t1 - t0;

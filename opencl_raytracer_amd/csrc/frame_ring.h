@@ -34,8 +34,8 @@ class FrameRing {
 		unsigned int size() const { return (unsigned int) hosts.size(); }
 		DeviceRenderer &host(unsigned int slot) { return *hosts.at(slot); }
 		void setGraphMode(bool on);
-		// Pacing: a frame is submitted no sooner than `beta` x the running mean of the time per finished frame after the
-		// previous submission.  Frames that finish together would otherwise start their successors together, and the
+		// Pacing: with the ring about to be full again, a frame is submitted no sooner than `beta` x the time per finished
+		// frame (the mean over the last eight) after the previous submission.  Frames that finish together would otherwise start their successors together, and the
 		// ring falls into lockstep -- every host in its primary pass at once, then every host at the falling end of its
 		// ambient-occlusion pass at once --, which is exactly what several hosts are there to avoid (interior scene,
 		// three hosts: 1.52 -> 1.33 ms per frame; headline +-0; profiles/r03_notes.md).  0 switches it off; default 0.3.
@@ -118,7 +118,8 @@ class FrameRing {
 		std::deque<Times> times;
 		CpuTimes cpu;
 		float pacing;
-		double period_s;        // running mean of the time between finished frames while the ring stays busy (0: unknown)
+		double period_s;        // mean of the last eight times between finished frames while the ring stays busy (0: unknown)
+		std::deque<double> intervals;
 		double last_collect_s;  // when the previous frame was collected (0: the ring ran empty since)
 		double last_submit_s;
 };
