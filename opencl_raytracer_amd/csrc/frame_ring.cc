@@ -2,7 +2,6 @@
 
 #include <hip/hip_runtime.h>
 
-#include <algorithm>
 #include <chrono>
 #include <sstream>
 #include <thread>
@@ -25,8 +24,7 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 }  // namespace
 
 FrameRing::FrameRing(const RayTracer::Options &options, int device, unsigned int rank, unsigned int nranks, unsigned int count)
-	: next_frame(0), last{ 0, 0, nullptr }, have_last(false), epoch(nullptr), pacing(0.3f), period_s(0.0), last_collect_s(0.0),
-	  last_submit_s(0.0) {
+	: next_frame(0), last{ 0, 0, nullptr }, have_last(false), epoch(nullptr), pacing(0.3f), period_s(0.0), last_submit_s(0.0) {
 	if (count == 0 || count > 16)
 		throw std::invalid_argument("a frame ring holds 1 to 16 renderers");
 	for (unsigned int k = 0; k < count; ++k) {
@@ -143,24 +141,15 @@ FrameRing::Collected FrameRing::collect() {
 	}
 	last = c;
 	have_last = true;
-	// the time per finished frame, while frames follow each other without the ring running empty
-	const double t_done = now_s();
-	if (last_collect_s > 0.0 && !open.empty()) {
-		// The MEAN of the last eight intervals (frames in lockstep finish in bursts: short and long intervals alternate,
-		// and their mean is the time per frame), each capped at four times the current estimate (the first frames of a
-		// ring include graph captures, and a caller may pause between two collects).
-		double dt = t_done - last_collect_s;
-		if (period_s > 0.0 && dt > 4.0 * period_s)
-			dt = 4.0 * period_s;
-		intervals.push_back(dt);
-		if (intervals.size() > 8)
-			intervals.pop_front();
-		double sum = 0.0;
-		for (double v : intervals)
-			sum += v;
-		period_s = sum / (double) intervals.size();
+	// The time per finished frame, from the DEVICE's clock: the frame took lastKernelMs() from its first to its last kernel
+	// (HIP events on its host's stream) while sharing the device with the frames still in flight -- so one frame is
+	// finished every (that time / frames in flight) in the steady state.  (The CPU's clock between two collects would
+	// also hold graph captures and whatever the caller did in between.)
+	{
+		const double sample = (double) h.lastKernelMs() * 1e-3 / (double) (open.size() + 1);
+		if (sample > 0.0)
+			period_s = period_s > 0.0 ? 0.75 * period_s + 0.25 * sample : sample;
 	}
-	last_collect_s = open.empty() ? 0.0 : t_done;
 	cpu.wait_s += t1 - t0;
 	cpu.collect_s += now_s() - t1;
 	++cpu.frames;

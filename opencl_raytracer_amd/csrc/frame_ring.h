@@ -35,7 +35,7 @@ class FrameRing {
 		DeviceRenderer &host(unsigned int slot) { return *hosts.at(slot); }
 		void setGraphMode(bool on);
 		// Pacing: with the ring about to be full again, a frame is submitted no sooner than `beta` x the time per finished
-		// frame (the mean over the last eight) after the previous submission.  Frames that finish together would otherwise start their successors together, and the
+		// frame (a frame's time on the device over the frames it shared it with, smoothed) after the previous submission.  Frames that finish together would otherwise start their successors together, and the
 		// ring falls into lockstep -- every host in its primary pass at once, then every host at the falling end of its
 		// ambient-occlusion pass at once --, which is exactly what several hosts are there to avoid (interior scene,
 		// three hosts: 1.52 -> 1.33 ms per frame; headline +-0; profiles/r03_notes.md).  0 switches it off; default 0.3.
@@ -118,9 +118,7 @@ class FrameRing {
 		std::deque<Times> times;
 		CpuTimes cpu;
 		float pacing;
-		double period_s;        // mean of the last eight times between finished frames while the ring stays busy (0: unknown)
-		std::deque<double> intervals;
-		double last_collect_s;  // when the previous frame was collected (0: the ring ran empty since)
+		double period_s;        // time per finished frame: a frame's time on the device / the frames it shared it with, smoothed (0: unknown)
 		double last_submit_s;
 };
 

@@ -20,9 +20,10 @@ def md5_of(rt, u8):
 
 def test_ring_frames_are_golden_and_overlap(rt, golden, scene_for):
     """Three hosts, graph replay.  Every frame is the golden one, the hosts' streams differ, and the frames overlap ON
-    THE DEVICE: in the steady state frame i + 1 has begun before frame i's ambient-occlusion kernel ended (always), and
-    often its ordering step has ended by then too -- its whole primary pass ran beside that kernel (HIP events for a
-    frame's begin and end, the device clock stamped by the kernels themselves for the ambient-occlusion pass)."""
+    THE DEVICE: in the steady state another frame is on the device for at least half of every frame's ambient-occlusion
+    pass, and often the next frame's ordering step has ended before that pass has -- its whole primary pass ran beside
+    it (HIP events for a frame's begin and end, the device clock stamped by the kernels themselves for the
+    ambient-occlusion pass)."""
     c = golden["renders"][HEADLINE]
     opt = options_for(rt, c)
     scene, _ = scene_for(c["mesh"], c["bvh"])
@@ -57,14 +58,16 @@ def test_ring_frames_are_golden_and_overlap(rt, golden, scene_for):
     assert md5_of(rt, ring.download_last()) == c["pgm_md5"]
     t = {f: ring.frame_times(f) for f in range(first + 4, first + 30)}
     primary_inside = 0
-    for f in range(first + 4, first + 29):
+    for f in range(first + 10, first + 29):  # (the first frames after the blocking one are the ring filling up)
         begin, ao_begin, ao_end, end = t[f]
         assert 0.0 < begin < ao_begin < ao_end <= end, (f, t[f])
+        # another frame was on the device for at least half of this frame's ambient-occlusion pass
+        shared = max(min(ao_end, t[g][3]) - max(ao_begin, t[g][0]) for g in t if g != f)
+        assert shared >= 0.5 * (ao_end - ao_begin), (f, t[f], shared)
         nxt = t[f + 1]
-        assert nxt[0] < ao_end, (f, t[f], nxt)  # the next frame began while this one's ambient-occlusion pass ran
-        if nxt[1] < ao_end:  # ... and its primary pass + ordering step were over before that pass was
+        if nxt[1] < ao_end:  # ... and the next frame's primary pass + ordering step were over before that pass was
             primary_inside += 1
-    assert primary_inside >= 8, (primary_inside, t)
+    assert primary_inside >= 6, (primary_inside, t)
     timers = ring.timers()
     assert timers["frames"] >= 31 and timers["ao_frames"] >= 31 and 0.0 < timers["ao_ms"] < timers["kernel_ms"]
     cpu = ring.cpu_times()
