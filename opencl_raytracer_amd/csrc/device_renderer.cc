@@ -330,23 +330,10 @@ void DeviceRenderer::dropFrameGraphs() {
 	frame_graphs.clear();
 }
 
-void DeviceRenderer::enqueueFrame(void *device_u8) {
-	if (!scene_ready)
-		throw std::logic_error("render called before upload");
-	useDevice();
-	void *dst = device_u8 ? device_u8 : d_u8;
+// The captured frame for `dst` (captured now if there is none yet).
+const DeviceRenderer::FrameGraph *DeviceRenderer::frameGraphFor(void *dst) {
 	const bool has_ao = kp.ao_mode != AO_NONE && kp.ao_dirs > 0 && tile_count > 0;
 	hipStream_t s = (hipStream_t) stream;
-	if (!graph_mode) {
-		FrameEvents ev = takeEvents();
-		OCRT_HIP(hipEventRecord((hipEvent_t) ev.start, s));
-		ev.ao_timed = has_ao;
-		launchFrame(dst, ev.ao_start, ev.ao_stop);
-		OCRT_HIP(hipEventRecord((hipEvent_t) ev.stop, s));
-		pending_events.push_back(ev);
-		frame_ready = true;
-		return;
-	}
 	// The captured frame for this destination; everything else a graph bakes in (scene, stream, share of the device)
 	// invalidates all of them.
 	if (!frame_graphs.empty()) {
@@ -398,6 +385,35 @@ void DeviceRenderer::enqueueFrame(void *device_u8) {
 		frame_graphs.push_back(fresh);
 		g = &frame_graphs.back();
 	}
+	return g;
+}
+
+void DeviceRenderer::prepareFrame(void *device_u8) {
+	if (!scene_ready)
+		throw std::logic_error("prepare called before upload");
+	useDevice();
+	if (graph_mode)
+		(void) frameGraphFor(device_u8 ? device_u8 : d_u8);
+}
+
+void DeviceRenderer::enqueueFrame(void *device_u8) {
+	if (!scene_ready)
+		throw std::logic_error("render called before upload");
+	useDevice();
+	void *dst = device_u8 ? device_u8 : d_u8;
+	const bool has_ao = kp.ao_mode != AO_NONE && kp.ao_dirs > 0 && tile_count > 0;
+	hipStream_t s = (hipStream_t) stream;
+	if (!graph_mode) {
+		FrameEvents ev = takeEvents();
+		OCRT_HIP(hipEventRecord((hipEvent_t) ev.start, s));
+		ev.ao_timed = has_ao;
+		launchFrame(dst, ev.ao_start, ev.ao_stop);
+		OCRT_HIP(hipEventRecord((hipEvent_t) ev.stop, s));
+		pending_events.push_back(ev);
+		frame_ready = true;
+		return;
+	}
+	const FrameGraph *g = frameGraphFor(dst);
 	FrameEvents ev = takeEvents();
 	OCRT_HIP(hipEventRecord((hipEvent_t) ev.start, s));
 	OCRT_HIP(hipGraphLaunch((hipGraphExec_t) g->exec, s));

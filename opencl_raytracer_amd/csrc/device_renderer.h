@@ -51,7 +51,11 @@ class DeviceRenderer {
 		// (setGraphMode(false): as the same sequence of launches).  The graph is captured at the first call and again
 		// whenever what it bakes in has changed (scene, destination, stream, share of the device).
 		void enqueueFrame(void *device_u8 = nullptr);
+		// Captures the frame for that destination now (graph mode; a few milliseconds), so that the first enqueueFrame for
+		// it is a replay like every later one.
+		void prepareFrame(void *device_u8 = nullptr);
 		void setGraphMode(bool on) { graph_mode = on; }
+		bool sceneReady() const { return scene_ready; }
 		bool graphMode() const { return graph_mode; }
 		// Waits for everything enqueued so far and folds pending event pairs into
 		// the kernel-time statistics.
@@ -143,6 +147,7 @@ class DeviceRenderer {
 			bool valid = false, ao_events = false;
 		};
 		std::vector<FrameGraph> frame_graphs;  // one per destination seen lately (a ring alternates between two per renderer)
+		const FrameGraph *frameGraphFor(void *dst);
 		void dropFrameGraphs();
 		bool graph_mode;
 		uint64_t scene_version;

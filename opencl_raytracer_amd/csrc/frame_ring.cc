@@ -2,6 +2,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <sstream>
 #include <thread>
@@ -24,7 +25,7 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 }  // namespace
 
 FrameRing::FrameRing(const RayTracer::Options &options, int device, unsigned int rank, unsigned int nranks, unsigned int count)
-	: next_frame(0), last{ 0, 0, nullptr }, have_last(false), epoch(nullptr), pacing(0.3f), period_s(0.0), last_submit_s(0.0) {
+	: next_frame(0), last{ 0, 0, nullptr, 1 }, have_last(false), epoch(nullptr), pacing(0.3f), period_s(0.0), last_submit_s(0.0) {
 	if (count == 0 || count > 16)
 		throw std::invalid_argument("a frame ring holds 1 to 16 renderers");
 	for (unsigned int k = 0; k < count; ++k) {
@@ -65,6 +66,9 @@ size_t FrameRing::upload(const PackedScene &scene) {
 	size_t bytes = 0;
 	for (auto &h : hosts)
 		bytes += h->upload(scene);
+	// every host's two frames are captured now, not in the middle of the stream that follows
+	for (unsigned int slot = 0; slot < bound.size(); ++slot)
+		hosts[slot % hosts.size()]->prepareFrame(bufferOf(slot));
 	return bytes;
 }
 
@@ -80,6 +84,9 @@ void FrameRing::bindOutput(unsigned int slot, void *device_u8) {
 		if (c.slot == slot)
 			throw std::logic_error("frame ring: the slot has a frame in flight");
 	bound[slot] = device_u8;
+	DeviceRenderer &h = *hosts[slot % hosts.size()];
+	if (h.sceneReady())
+		h.prepareFrame(bufferOf(slot));
 }
 
 void FrameRing::attachGather(std::unique_ptr<BandGather> g) {
@@ -115,7 +122,7 @@ uint64_t FrameRing::submit() {
 	last_submit_s = t0;
 	waitSlotFree(slot);  // (its gather was enqueued size() frames ago: long done)
 	hosts[next_frame % hosts.size()]->enqueueFrame(bufferOf(slot));
-	open.push_back(Collected{ next_frame, slot, nullptr });
+	open.push_back(Collected{ next_frame, slot, nullptr, (unsigned int) open.size() + 1u });
 	cpu.submit_s += now_s() - t0;
 	return next_frame++;
 }
@@ -146,7 +153,8 @@ FrameRing::Collected FrameRing::collect() {
 	// finished every (that time / frames in flight) in the steady state.  (The CPU's clock between two collects would
 	// also hold graph captures and whatever the caller did in between.)
 	{
-		const double sample = (double) h.lastKernelMs() * 1e-3 / (double) (open.size() + 1);
+		const size_t sharing = std::max<size_t>(c.in_flight_at_submit, open.size() + 1);  // (a ring that is draining: as it began)
+		const double sample = (double) h.lastKernelMs() * 1e-3 / (double) sharing;
 		if (sample > 0.0)
 			period_s = period_s > 0.0 ? 0.75 * period_s + 0.25 * sample : sample;
 	}

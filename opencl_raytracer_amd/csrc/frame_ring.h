@@ -62,6 +62,7 @@ class FrameRing {
 			uint64_t frame;
 			unsigned int slot;         // the band buffer it was rendered into
 			const void *device_bands;  // localRows() x width bytes; valid until frame + slots() is submitted
+			unsigned int in_flight_at_submit = 1;  // frames on the device when this one joined them (itself included)
 		};
 		// Waits (on the CPU: a stream-level wait for a frame that has just begun would sit in a hardware queue as a
 		// barrier packet ahead of whatever else shares that queue) for the OLDEST frame in flight.
