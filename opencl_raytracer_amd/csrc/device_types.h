@@ -26,7 +26,7 @@ constexpr uint32_t WALK_END = 0xFFFFFFFEu;
 // the host with the SAME float operations the kernel would execute, so the bits are identical.
 struct TriRec {
 	float lo[3], pad0;  // the leaf's box
-	float hi[3], pad1;
+	float hi[3], inv_d;  // ... and RN(1 / D), or NaN where that is no use: tri_predicate.h
 	float ta[3];
 	float u[3];   // tb - ta
 	float v[3];   // tc - ta

@@ -45,6 +45,8 @@
 #include <cstdlib>
 
 #include "device_types.h"
+#include "exact_reciprocal.h"
+#include "tri_predicate.h"
 
 namespace ocrt {
 
@@ -107,9 +109,17 @@ __device__ __forceinline__ Ray make_ray(float ox, float oy, float oz, float dx, 
 	Ray r;
 	r.ox = ox; r.oy = oy; r.oz = oz;
 	r.dx = dx; r.dy = dy; r.dz = dz;
-	r.ix = 1.0f / dx;
-	r.iy = 1.0f / dy;
-	r.iz = 1.0f / dz;
+	// 1 / direction: the short form where every lane's three components allow it (exact_reciprocal.h: the same bits as
+	// the division, proven for every such float), the division for the packet otherwise (a zero component, say)
+	if (__builtin_amdgcn_ballot_w64(!reciprocals_are_short(dx, dy, dz)) == 0ull) {
+		r.ix = short_reciprocal(dx);
+		r.iy = short_reciprocal(dy);
+		r.iz = short_reciprocal(dz);
+	} else {
+		r.ix = 1.0f / dx;
+		r.iy = 1.0f / dy;
+		r.iz = 1.0f / dz;
+	}
 	return r;
 }
 
@@ -264,6 +274,35 @@ __device__ __forceinline__ TriResult tri_eval(const float4 q0, const float4 q1, 
 		out.distance = sqrtf(dot3(ex, ey, ez, ex, ey, ez));
 	}
 	return out;
+}
+
+// The any-hit form of the test: the same plane half (a, b, r = a / b, the point, wu, wv -- the reference's operations
+// in the reference's order), then the parametric half as a predicate on products by TriRec::inv_d, with the
+// reference's two divisions only for the lanes too close to a threshold to be decided that way (tri_predicate.h:
+// the decision is the reference's in every case; 9 vector instructions instead of 27).
+__device__ __forceinline__ bool tri_any_hit(const float4 q0, const float4 q1, const float4 q2, const float4 q3, float inv_d,
+                                            const Ray &r) {
+	const float tax = q0.x, tay = q0.y, taz = q0.z;
+	const float ux = q0.w, uy = q1.x, uz = q1.y;
+	const float vx = q1.z, vy = q1.w, vz = q2.x;
+	const float nx = q2.y, ny = q2.z, nz = q2.w;
+	const float uu = q3.x, uv = q3.y, vv = q3.z, D = q3.w;
+	const float a = -dot3(nx, ny, nz, r.ox - tax, r.oy - tay, r.oz - taz);
+	const float b = dot3(nx, ny, nz, r.dx, r.dy, r.dz);
+	const float rr = a / b;
+	const bool reject = (fabsf(b) < 0.000001f) | (rr < 0.0f);
+	if (wave_ballot(!reject) == 0ull)
+		return false;
+	const float ipx = r.ox + rr * r.dx, ipy = r.oy + rr * r.dy, ipz = r.oz + rr * r.dz;
+	const float wx = ipx - tax, wy = ipy - tay, wz = ipz - taz;
+	const float wu = dot3(ux, uy, uz, wx, wy, wz);
+	const float wv = dot3(wx, wy, wz, vx, vy, vz);
+	const float X = uv * wv - vv * wu, Y = uv * wu - uu * wv;  // the numerators of s and t
+	const unsigned int zone = tri_zone(X, Y, inv_d);
+	bool accepted = zone == 1u;
+	if (wave_ballot(!reject & (zone == 2u)) != 0ull)  // (about one test in 10^4)
+		accepted = zone == 2u ? tri_accepts_exact(X, Y, D) : accepted;
+	return accepted & !reject;
 }
 
 // Leaf records are 96 bytes: the leaf's own box (float4 0, 1), then the triangle (float4 2..5).
@@ -712,10 +751,11 @@ constexpr uint32_t INF_BITS = 0x7F800000u;
 // Any-hit shared walk of one packet (AO): a lane leaves at its first accepted
 // triangle and bumps *occluded (reference :251 only uses the boolean).
 // EXACT walks `nodes_ptr` (exact boxes); the fast form walks `walk_ptr` (padded boxes) and gates every candidate
-// leaf with its own box, the head of its leaf record (by pointer for a leaf tested on the spot, by descriptor in a batch).
+// leaf with its own box, the head of its leaf record (scalar loads for a leaf tested on the spot; in a batch each lane
+// loads its pair's record relative to the same scalar base: no buffer descriptor held across the walk).
 template <bool EXACT>
 __device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ nodes_ptr, const float4 *__restrict__ walk_ptr,
-                                                    const float4 *__restrict__ tris_ptr, __amdgpu_buffer_rsrc_t tris_rsrc,
+                                                    const float4 *__restrict__ tris_ptr,
                                                     uint32_t count, const Ray &ray_in, const float (&frame)[12][64], uint32_t h,
                                                     float max_distance, float below, float walk_scale, bool alive,
                                                     unsigned int *occluded, LeafBatch &batch, uint32_t batch_below,
@@ -757,15 +797,15 @@ __device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ n
 			if (lane < n) {
 				// the pair is a candidate of the padded walk: the leaf's own box decides whether the reference tests it
 				const uint32_t pair_leaf = pair & 0x03FFFFFFu;
-				const float4 lo = load_f4(tris_rsrc, pair_leaf * LEAF_BYTES), hi = load_f4(tris_rsrc, pair_leaf * LEAF_BYTES + 16u);
+				const float4 *rec = (const float4 *) ((const char *) tris_ptr + pair_leaf * LEAF_BYTES);  // (scalar base + 32-bit lane offset)
+				const float4 lo = rec[0], hi = rec[1];
 				const bool gate = exact_leaf_gate(lo, hi, theirs, below);
 #ifdef OCRT_STAMPS
 				prof[5] += n;  // candidate pairs / pairs whose own box passes
 				prof[6] += (unsigned long long) __popcll(wave_ballot(gate));
 #endif
 				if (gate) {
-					const TriResult tr = tri_test<false>(tris_rsrc, pair_leaf, theirs);
-					if (tr.accepted)
+					if (tri_any_hit(rec[2], rec[3], rec[4], rec[5], hi.w, theirs))
 						atomicOr(&batch.occluded_bits[owner >> 5], 1u << (owner & 31));
 				}
 			}
@@ -811,8 +851,7 @@ __device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ n
 				const float4 lo = rec[0], hi = rec[1], q0 = rec[2], q1 = rec[3], q2 = rec[4], q3 = rec[5];
 				const Ray ray = with_origin();
 				if (((hit_mask >> fresh_lane()) & 1ull) && exact_leaf_gate(lo, hi, ray, below)) {
-					const TriResult tr = tri_eval<false>(q0, q1, q2, q3, ray);
-					if (tr.accepted) {
+					if (tri_any_hit(q0, q1, q2, q3, hi.w, ray)) {
 						atomicAdd(occluded, 1u);
 						alive = false;
 					}
@@ -1554,11 +1593,11 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 						job_exact += exact ? 1u : 0u;
 #endif
 						if (exact)
-							shared_walk_any_hit<true>(nodes_ptr, walk_ptr, tris_ptr, scene.tris, count, ray, sh.frame, h,
+							shared_walk_any_hit<true>(nodes_ptr, walk_ptr, tris_ptr, count, ray, sh.frame, h,
 							                          P.ao_max_distance, P.ao_below, P.walk_scale, alive, &sh.occluded[h], sh.batch,
 							                          P.batch_below, walk_prof);
 						else
-							shared_walk_any_hit<false>(nodes_ptr, walk_ptr, tris_ptr, scene.tris, count, ray, sh.frame, h,
+							shared_walk_any_hit<false>(nodes_ptr, walk_ptr, tris_ptr, count, ray, sh.frame, h,
 							                           P.ao_max_distance, P.ao_below, P.walk_scale, alive, &sh.occluded[h], sh.batch,
 							                           P.batch_below, walk_prof);
 					}

@@ -1,5 +1,6 @@
 #include "scene_pack.h"
 
+#include "tri_predicate.h"
 #include "walk_tree.h"
 
 #include <cmath>
@@ -160,11 +161,12 @@ PackedScene pack_scene(const std::vector<uint32_t> &faces, const std::vector<uin
 			r.v[k] = v[k];
 			r.n[k] = n[k];
 		}
-		r.pad0 = r.pad1 = 0.0f;
+		r.pad0 = 0.0f;
 		r.uu = u.dot(u);
 		r.uv = u.dot(v);
 		r.vv = v.dot(v);
 		r.D = r.uv * r.uv - r.uu * r.vv;
+		r.inv_d = tri_inverse_d(r.D);
 		ShadeRec &s = out.shade[t];
 		const Vec3f *src[3] = { &vnormals[i0], &vnormals[i1], &vnormals[i2] };
 		float *dst[3] = { s.n0, s.n1, s.n2 };

@@ -300,7 +300,7 @@ def test_random_ao_statistical_parity(rt, oracle, scene_for, mesh, samples):
 
 
 @pytest.mark.parametrize("damage", ["inverted_box", "nan_leaf_box", "huge_box", "inf_box", "nan_vertex",
-                                    "child_outside_parent"])
+                                    "child_outside_parent", "collinear_triangle"])
 def test_irregular_scene_arrays_match_oracle(rt, oracle, scene_for, damage):
     """Scene arrays a BVH builder would never emit (inverted / NaN / infinite /
     overflowing boxes, a NaN vertex, a parent box that does not contain its
@@ -310,7 +310,7 @@ def test_irregular_scene_arrays_match_oracle(rt, oracle, scene_for, damage):
     import orc
 
     _, arrays = scene_for("blob", "longest")
-    nodes, aabbs, verts = arrays.nodes.copy(), arrays.aabbs.copy(), arrays.vertices.copy()
+    nodes, aabbs, verts, faces = arrays.nodes.copy(), arrays.aabbs.copy(), arrays.vertices.copy(), arrays.faces.copy()
     inner = int(np.flatnonzero(nodes > 8)[5])
     leaf = int(np.flatnonzero(nodes == 1)[40])
     if damage == "inverted_box":
@@ -328,7 +328,11 @@ def test_irregular_scene_arrays_match_oracle(rt, oracle, scene_for, damage):
     elif damage == "child_outside_parent":
         # finite, lo <= hi, but the node's box is now a sliver its children stick out of
         aabbs[2 * inner + 1, 0] = aabbs[2 * inner, 0] + 1.0e-3
-    damaged = orc.SceneArrays(arrays.faces, nodes, aabbs, verts, arrays.normals)
+    elif damage == "collinear_triangle":
+        # two equal corners: D = 0, so the record carries no reciprocal of it (TriRec::inv_d is a NaN, tri_predicate.h)
+        for face in (17, 40, 41):
+            faces[3 * face + 2] = faces[3 * face + 1]
+    damaged = orc.SceneArrays(faces, nodes, aabbs, verts, arrays.normals)
     opt = rt.Options.defaults(width=96, height=64, n_super_samples=1, ao_num_samples=2, ao_max_distance=0.5)
     host = rt.Host(opt, 0)
     host.upload(damaged.faces, damaged.nodes, damaged.aabbs, damaged.vertices, damaged.normals)
@@ -476,3 +480,38 @@ def test_three_renderers_in_flight_give_the_golden_frames(rt, golden, scene_for)
         st = h.stats()
         assert st["primary_hits"] == c["counters"]["primary_hits"] and st["ao_occluded"] == c["counters"]["ao_occluded"]
     ring.close()
+
+
+def _device_check(tmp_path, source):
+    """Compiles one of the tests' device programs against the product's headers and runs it: its JSON line, exit status."""
+    import json
+    import os
+    import subprocess
+
+    from conftest import ROOT
+
+    exe = tmp_path / "check"
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-ffp-contract=off", "-w", "-I",
+                    os.path.join(ROOT, "opencl_raytracer_amd", "csrc"), "-o", str(exe), os.path.join(ROOT, "tests", source)], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode in (0, 1), r.stderr[-1000:]
+    return json.loads(r.stdout.strip().splitlines()[-1]), r.returncode
+
+
+def test_fast_reciprocal_is_exact_for_every_float(tmp_path):
+    """csrc/exact_reciprocal.h (the ray set-up's 1 / direction): v_rcp_f32 + one Newton step in fma form has the bits of
+    the IEEE division for every float its gate lets through, and the gate lets through exactly the biased exponents
+    1 ... 252 -- all 2^32 bit patterns, on the device (tests/reciprocal_check.hip)."""
+    out, status = _device_check(tmp_path, "reciprocal_check.hip")
+    assert status == 0 and out["wrong_bits"] == 0 and out["gate_differs"] == 0, out
+    assert out["inputs"] == 2 ** 32 and out["let_through"] == 2 * 252 * 2 ** 23
+
+
+def test_triangle_zones_never_contradict_the_divisions(tmp_path):
+    """csrc/tri_predicate.h (the any-hit triangle test): wherever the products by TriRec::inv_d decide, the reference's
+    two divisions decide the same -- 2^32 (X, Y, D) triples, most of them within 1e-10 ... 1e-4 of a threshold or a zone
+    edge, plus infinities, NaNs, subnormals and unusable D (tests/tri_predicate_check.hip).  At least a third of the
+    triples must have been decided without a division, or the sweep says nothing about the short form."""
+    out, status = _device_check(tmp_path, "tri_predicate_check.hip")
+    assert status == 0 and out["said_in_but_rejected"] == 0 and out["said_out_but_accepted"] == 0 and out["nan_inverse_decided"] == 0, out
+    assert out["triples"] == 2 ** 32 and out["decided_without_division"] > out["triples"] // 3 and out["undecided"] > 2 ** 24

@@ -76,6 +76,17 @@ def test_padded_walk_boxes_never_lose_a_pair_the_reference_accepts(rt, tmp_path)
     assert r.returncode == 0, "the unpadded self-check found no miss: the test has no teeth\n" + r.stdout[-500:]
 
 
+def test_packed_triangles_carry_the_reciprocal_of_d(rt, tmp_path):
+    """tests/tri_inverse_check.cc: TriRec::inv_d is RN(1 / D) where the short form of the any-hit triangle test may use
+    it and a NaN elsewhere (zero-area, huge, tiny triangles), through pack_scene; tri_inverse_d's boundaries."""
+    exe = tmp_path / "tri_inverse_check"
+    lib_dir = os.path.join(ROOT, "opencl_raytracer_amd", "lib")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-I", os.path.join(ROOT, "opencl_raytracer_amd", "csrc"), "-o", str(exe),
+                    os.path.join(ROOT, "tests", "tri_inverse_check.cc"), "-L" + lib_dir, "-locrt_hip", "-Wl,-rpath," + lib_dir], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0 and "tri_inverse_check: ok" in r.stdout, r.stdout[-2000:]
+
+
 def test_loader_rejects_truncated_and_oversized_headers(rt, tmp_path):
     """A header that promises more than the file holds must fail, not reserve memory for it or pad with zeros."""
     huge = tmp_path / "huge.off"
