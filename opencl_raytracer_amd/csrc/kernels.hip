@@ -1319,7 +1319,7 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
     uint32_t *__restrict__ occluded_of, const uint32_t *__restrict__ order, FrameCounters *__restrict__ counters,
     KernelParams P) {
 	__shared__ TileShared shared_tiles[AO_WAVES];
-	__shared__ unsigned int wg_claim[2];  // the workgroup's current claim: first unit, units per wave
+	__shared__ unsigned int wg_claim[4];  // the workgroup's current claim: first unit, units per wave, end (if dealt by cursor), cursor
 	const uint32_t wave = (uint32_t) __builtin_amdgcn_readfirstlane((int) threadIdx.x) >> 6;  // (scalar)
 	TileShared &sh = shared_tiles[wave];
 	const SceneViews scene = make_views(nodes_ptr, tris_ptr, P);
@@ -1368,34 +1368,50 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 			OCRT_STAMP(t_claim);
 			// The WORKGROUP claims (thread 0: a plain load first -- most visits to a foreign group find its queue
 			// drained, and a load does not queue up behind the other workgroups' atomics --, then one returning
-			// atomic), and its four waves take consecutive quarters of the claim: they then work on the same tile,
-			// or on neighbouring ones, at the same time, and share its nodes in the CU's scalar cache (63 % of the
-			// scalar loads of the per-wave claims missed it, profiles/r02_notes.md) and its hit records in L2.
-			// A wave's share is claim_max units to the end of the queue.  (Guided self-scheduling -- the share
+			// atomic), and its four waves share the claim: they then work on the same tile, or on neighbouring
+			// ones, at the same time, and share its nodes in the CU's scalar cache (63 % of the scalar loads of the
+			// per-wave claims missed it, profiles/r02_notes.md) and its hit records in L2.  A claim is four times
+			// claim_max units, to the end of the queue; how the waves divide it is decided below.  (Guided self-scheduling -- the share
 			// shrinking to 1/ao_guide of what is left per wave of the group -- is kept behind OCRT_AO_GUIDE: the
 			// single directions it hands out at the end cost a claim each, two barriers and a tile set-up, and
 			// lengthened the pass by 3-5 %; the costly tiles are claimed first anyway, order_kernel.)
+			uint32_t per_wave = 0u, first = units;  // (thread 0's; in registers until the siblings are done with the last claim)
 			if (wave == 0u && fresh_lane() == 0u) {
 				const uint32_t seen = __hip_atomic_load(&counters->queue[group].head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				uint32_t per_wave = 0u, first = units;
 				if (seen < units) {
 					per_wave = P.ao_guide ? (units - seen) / P.ao_guide : claim_max;
 					per_wave = per_wave < 1u ? 1u : per_wave > claim_max ? claim_max : per_wave;
 					first = atomicAdd(&counters->queue[group].head, per_wave * AO_WAVES);
 				}
+			}
+			__syncthreads();  // (everybody is done with the previous claim: its words in LDS, the cursor among them, are free)
+			if (wave == 0u && fresh_lane() == 0u) {
+				// A claim that lies in ONE tile (the rule: four quarters of a tile's directions) is not dealt out in fixed
+				// quarters: the four waves take its directions from a cursor in LDS, a packet's worth at a time, so that they
+				// finish within a packet of each other -- with fixed quarters a wave spent 12-18 % of its life waiting for the
+				// slowest sibling at the barrier (profiles/r02_notes.md; what the cursor buys and where it does not:
+				// profiles/r03_notes.md).  Other claims (whole tiles per wave, the short ones of scarce work) keep fixed shares.
+				// wg_claim[2] = the claim's end, 0 for fixed shares.
+				const uint32_t end = first + per_wave * AO_WAVES < units ? first + per_wave * AO_WAVES : units;
+				const bool one_tile = SHARED && first < units && first / P.ao_dirs == (end - 1u) / P.ao_dirs && P.ao_dirs < 0x8000u;
 				wg_claim[0] = first;
 				wg_claim[1] = per_wave;
+				wg_claim[2] = one_tile ? end : 0u;
+				// the cursor, in directions of the tile: end << 16 | next (both 0 for fixed shares: nothing to take)
+				const uint32_t base = first - first / P.ao_dirs * P.ao_dirs;
+				wg_claim[3] = one_tile ? (base + (end - first)) << 16 | base : 0u;
 			}
 			__syncthreads();
 			const uint32_t wg_claimed = (uint32_t) __builtin_amdgcn_readfirstlane((int) wg_claim[0]);
 			const uint32_t want = (uint32_t) __builtin_amdgcn_readfirstlane((int) wg_claim[1]);
-			__syncthreads();  // (everybody has read the claim before thread 0 writes the next one)
 			if (wg_claimed >= units)
 				break;  // (the same for all four waves)
-			const uint32_t claimed = wg_claimed + wave * want;
+			// fixed shares: this wave's quarter; a claim with a cursor: one job, the tile, for every wave
+			const bool dealt_by_cursor = __builtin_amdgcn_readfirstlane((int) wg_claim[2]) != 0;
+			const uint32_t claimed = dealt_by_cursor ? wg_claimed : wg_claimed + wave * want;
 			if (claimed >= units)
 				continue;  // nothing left for this wave; it meets the others again at the next claim
-			const uint32_t claim_end = claimed + want < units ? claimed + want : units;
+			const uint32_t claim_end = dealt_by_cursor ? claimed + 1u : claimed + want < units ? claimed + want : units;
 			OCRT_STAMP(t_claimed);
 			OCRT_STAMP_ADD(0, t_claimed - t_claim);
 #ifdef OCRT_STAMPS
@@ -1406,12 +1422,41 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 				// job = (tile, direction range); a claim that runs over a tile's last direction goes on in
 				// the next tile.  Neighbouring claims work on the same tile: its hit records are shared in L2.
 				const uint32_t tile_index = unit / P.ao_dirs;
-				const uint32_t dir0 = unit - tile_index * P.ao_dirs;
+				uint32_t dir0 = unit - tile_index * P.ao_dirs;
 				const uint32_t n_dirs = P.ao_dirs - dir0 < claim_end - unit ? P.ao_dirs - dir0 : claim_end - unit;
 				unit += n_dirs;
 				const uint32_t entry = order[segment + tile_index];
 				const uint32_t tile = entry & 0x03FFFFFFu;
 				const uint32_t hit_count = (entry >> 26) + 1u;
+				uint32_t total = hit_count * n_dirs;  // the rays of this piece of the job: directions dir0 ...
+				// A claim dealt by the cursor: the next piece of the tile's directions -- enough to fill a packet, twice that
+				// at most (64 >> floor(log2(hit_count)) directions) -- or nothing, if the siblings have taken them all.
+				auto take_from_cursor = [&]() {
+					const uint32_t chunk = 64u >> (31u - (uint32_t) __builtin_clz(hit_count));
+					// one LDS atomic, issued by lane 0 alone: the word holds the claim's end above its cursor (directions of the tile)
+					uint32_t word, scratch;
+					unsigned long long saved;
+					asm volatile("s_mov_b64 %[saved], exec\n\t"
+					             "s_mov_b64 exec, 1\n\t"
+					             "v_mov_b32 %[scratch], %[address]\n\t"
+					             "v_mov_b32 %[word], %[chunk]\n\t"
+					             "ds_add_rtn_u32 %[word], %[scratch], %[word]\n\t"
+					             "s_waitcnt lgkmcnt(0)\n\t"
+					             "s_mov_b64 exec, %[saved]"
+					             : [word] "=&v"(word), [scratch] "=&v"(scratch), [saved] "=&s"(saved)
+					             : [address] "s"((uint32_t) (uintptr_t) &wg_claim[3]), [chunk] "s"(chunk)
+					             : "memory");
+					word = (uint32_t) __builtin_amdgcn_readfirstlane((int) word);
+					const uint32_t at = word & 0xFFFFu, end = word >> 16;
+					const uint32_t left = at < end ? end - at : 0u;
+					dir0 = at;
+					total = hit_count * (left < chunk ? left : chunk);
+				};
+				if (SHARED && __builtin_amdgcn_readfirstlane((int) wg_claim[2]) != 0) {
+					take_from_cursor();
+					if (total == 0u)
+						continue;  // (not even the tile's table is needed)
+				}
 
 				// ---- the tile's tangent frames -> this wave's LDS slice (reference :215-236) ----
 				{
@@ -1458,7 +1503,6 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 				// ---- the tile's hit_count * ao_dirs any-hit rays (reference :237-255).  Queue
 				// order is direction-major, so neighbouring lanes cast the same table direction
 				// from neighbouring pixels. ----
-				const uint32_t total = hit_count * n_dirs;
 				uint32_t h = 0;
 				Ray ray;
 #ifdef OCRT_DEBUG_KNOBS
@@ -1578,6 +1622,8 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 #ifdef OCRT_STAMPS
 					uint32_t job_exact = 0u;
 #endif
+					do {  // (once per piece: fixed shares are one piece, the cursor hands out the others)
+					OCRT_STAMP_ADD(5, (total + 63u) / 64u);
 					for (uint32_t base = 0u; base < total; base += 64u) {
 						const uint32_t lane = fresh_lane();
 						bool alive = base + lane < total;
@@ -1601,6 +1647,8 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 							                           P.ao_max_distance, P.ao_below, P.walk_scale, alive, &sh.occluded[h], sh.batch,
 							                           P.batch_below, walk_prof);
 					}
+					take_from_cursor();  // (fixed shares: the cursor holds nothing)
+					} while (total != 0u);
 #ifdef OCRT_STAMPS
 					if (fresh_lane() == 0u && job_exact) {
 						atomicAdd(&counters->stamp[63], (unsigned long long) job_exact);  // packets that took the exact form
@@ -1612,7 +1660,6 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 				OCRT_STAMP(t_walked);
 				OCRT_STAMP_ADD(2, t_walked - t_frames);
 				OCRT_STAMP_ADD(4, 1);
-				OCRT_STAMP_ADD(5, (total + 63u) / 64u);
 
 				// ---- this job's share of the occlusion counts ----
 				{

@@ -26,7 +26,8 @@ import re
 import subprocess
 import sys
 
-LANE_OPS_PER_WALK_TURN = 8   # v_readlane / v_writelane per turn of the loop around walk_collect, i.e. per leaf stop or batch (measured: 6 primary, 7 AO)
+LANE_OPS_PER_WALK_TURN = 10  # v_readlane / v_writelane per turn of the loop around walk_collect, i.e. per leaf stop or batch (measured: 6 primary;
+                             # 9 AO: four in the batch block, five single reloads on paths that exclude each other)
 LANE_OPS_PER_PACKET = 40     # ... in the per-packet code around that loop (measured: 38 of ~700 vector instructions)
 
 FIELDS = ("TotalSGPRs", "VGPRs", "AGPRs", "ScratchSize [bytes/lane]", "Occupancy [waves/SIMD]", "SGPRs Spill",
