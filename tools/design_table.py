@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Prints the rows of DESIGN.md's measurement table from profiles/<round>_bench_lines.json (what tools/final_measure.sh +
+tools/install_profiles.py left there), so that the table is the committed bench lines and nothing else.
+
+    python3 tools/design_table.py r03
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROWS = [  # workload, label, (round 2, round 1) one-frame-at-a-time Mrays/s
+    ("bunny_1080p_ao", "**bunny 1080p `-s 1 -a 3`** (headline)", "21 890 / 15 533"),
+    ("bunny_1080p_primary", "bunny 1080p primary only", "6 730 / 7 900"),
+    ("bunny_600_defaults", "bunny 600² CLI defaults", "20 177 / 13 500"),
+    ("bunny_1080p_s64", "bunny 1080p `-s 64` (2.2 G rays)", "41 392 / 36 900"),
+    ("interior_1080p_ao", "interior stand-in 1080p", "34 774 / 22 900"),
+    ("interior_4k_ao", "interior stand-in 4K", "41 351 / 34 200"),
+]
+
+
+def thousands(x):
+    return f"{x:,.0f}".replace(",", " ")
+
+
+def main():
+    prefix = sys.argv[1] if len(sys.argv) > 1 else "r03"
+    lines = json.load(open(os.path.join(ROOT, "profiles", f"{prefix}_bench_lines.json")))
+    for key, label, earlier in ROWS:
+        b = lines[key]
+        r, p = b["roofline"], b["roofline"]["frame_pipelined"]
+        blocks = b.get("blocks", {})
+        spread = f" ({thousands(blocks['mrays_per_s_min'])}–{thousands(blocks['mrays_per_s_max'])})" if blocks.get("n", 0) > 1 else ""
+        value = f"**{thousands(b['value'])}**" if key == "bunny_1080p_ao" else thousands(b["value"])
+        print(f"| {label} | {value}{spread} | {b['ms_per_step']:.3f} | {thousands(b['blocking']['value'])} ({earlier}) | "
+              f"{b['blocking']['ms_per_frame']['median']:.3f} | {r['kernel_ms']:.3f} | {r['achieved']:.3f} ({r['frac']:.2f}; {r['frac_of_measured_ceiling']:.2f}) | "
+              f"{p['achieved']:.3f} ({p['frac']:.2f}; {p['frac_of_measured_ceiling']:.2f}) | {100 * r['hbm']['measured_frac']:.1f} % |")
+    c = lines["bunny_1080p_ao"]["cpu_baseline"]
+    print(f"| CPU beside it (same run; {c['cpu_model'].replace(' 64-Core Processor', '')}, {c['cores']} host cores) | | | reference kernel {c['value']:.1f}, "
+          f"oracle {c['port_value']:.1f}; PGM byte-identical | | | | | |")
+
+
+if __name__ == "__main__":
+    main()
