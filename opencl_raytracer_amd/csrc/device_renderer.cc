@@ -218,16 +218,12 @@ size_t DeviceRenderer::upload(const PackedScene &scene) {
 	std::vector<float> table;
 	if (opts.enableAO && opts.aoNumSamples > 0) {
 		if (opts.aoMethod == RayTracer::AmbientOcclusionMethod::UNIFORM) {
-			const std::vector<float> ring_major = uniform_ao_table(opts.aoNumSamples, opts.aoAlphaMin, opts.aoAlphaMax);
-			ao_dirs = (uint32_t) (ring_major.size() / 4);
-			// The occlusion count of a hit is a sum over the directions: their order is free.  The reference's order is
-			// ring by ring -- 12 grazing directions first, the steep ones last --, and the four waves of a workgroup
-			// take consecutive quarters of a tile's directions and wait for each other at the next claim: dealt
-			// round-robin, every quarter holds directions of every ring and the quarters cost about the same.
-			table.reserve(ring_major.size());
-			for (uint32_t r = 0; r < AO_WORKGROUP_WAVES; ++r)
-				for (uint32_t i = r; i < ao_dirs; i += AO_WORKGROUP_WAVES)
-					table.insert(table.end(), ring_major.begin() + 4 * i, ring_major.begin() + 4 * i + 4);
+			// The reference's order, ring by ring.  (The occlusion count of a hit is a sum over the directions, so the order is
+			// free: while a workgroup's four waves took FIXED quarters of a tile's directions the table was dealt round-robin
+			// to the quarters so that they cost about the same; with the claim's cursor -- kernels.hip, ao_kernel -- the waves
+			// balance themselves, and neighbouring directions cast at the same time are worth 0.5-2 %.)
+			table = uniform_ao_table(opts.aoNumSamples, opts.aoAlphaMin, opts.aoAlphaMax);
+			ao_dirs = (uint32_t) (table.size() / 4);
 		} else {
 			// RANDOM casts the normal ray plus AO_NUM_SAMPLES + 1 random ones (reference :260-275)
 			ao_dirs = opts.aoNumSamples + 2;
