@@ -266,7 +266,7 @@ def main():
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--in-flight", type=int, default=0, choices=[0, 1, 2, 3, 4, 5, 6],
                     help="render hosts per GPU taking the frames in turn (1: one frame at a time; 0 = by the number of "
-                         "ranks: 3 up to two GPUs, 4 at four, 6 at eight)")
+                         "ranks: 3 up to four GPUs, 6 at eight)")
     ap.add_argument("--min-seconds", type=float, default=0.5, help="repeat each block of --steps steps until this much time is covered")
     ap.add_argument("--plain-launches", action="store_true", help="launch the kernels one by one instead of replaying the captured graph")
     args = ap.parse_args()
@@ -334,8 +334,10 @@ def main():
     # frames in turn: while frame i's ambient-occlusion pass runs out (its last quarter runs at falling occupancy: the
     # queues are drained, the workgroups end one by one) the next frames' passes fill the wave slots it frees, and the
     # latency-bound primary pass runs beside a vector-issue-bound one.  The smaller a rank's share of the frame, the
-    # more of it is start and end of passes, hence more hosts at more ranks (tools/ring_sweep.py).
-    in_flight = args.in_flight if args.in_flight > 0 else 3 if world <= 2 else 4 if world <= 4 else 6
+    # more of it is start and end of passes, hence more hosts at eight ranks -- an eighth of the headline frame on one
+    # GPU takes 0.455 / 0.217 / 0.248 / 0.210 ms per frame with 1 / 3 / 4 / 6 hosts, a quarter 0.649 / 0.340 / 0.363 / 0.339: four
+    # is the one count that loses everywhere (tools/ring_sweep.py on round 3's final kernels).
+    in_flight = args.in_flight if args.in_flight > 0 else 3 if world <= 4 else 6
     rings = {"pipelined": rt.FrameRing(opt, scene, device_index, rank, world, hosts=in_flight),
              "blocking": rt.FrameRing(opt, scene, device_index, rank, world, hosts=1)}
     for ring in rings.values():
