@@ -23,7 +23,7 @@
 //                   surface points -- that stop at the first accepted triangle;
 //                   occlusion counts are LDS atomics, flushed to a per-hit counter
 //                   when the claim is done.
-//   resolve_kernel  one thread per hit: value * (1 - occluded / n) -> image.
+//   resolve_kernel  a thread per hit-list slot, grid-stride: value * (1 - occluded / n) -> image.
 // Why not one fused launch (it was, see profiles/r01_notes.md): cost per tile
 // varies 30x (background vs model, 29 rays per hit sub-pixel), so the frame used
 // to end on a long tail of half-empty CUs.  With the tiles' costs known after the
@@ -1716,7 +1716,9 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 #endif
 }
 
-// Pass 3: value *= 1 - hits / n (reference :256 and :305-307), one thread per hit-list slot.
+// Pass 3: value *= 1 - hits / n (reference :256 and :305-307), a thread per hit-list slot, the grid striding over the
+// list (launch_resolve: what the chip holds).  The frame's occlusion count is summed per lane, then per wave by
+// cross-lane adds, per workgroup in LDS, and reaches the counter with one atomic per workgroup.
 __global__ __launch_bounds__(256) void resolve_kernel(const HitRec *__restrict__ hits,
                                                       const uint32_t *__restrict__ occluded_of,
                                                       const uint32_t *__restrict__ tile_hits,
@@ -1726,15 +1728,21 @@ __global__ __launch_bounds__(256) void resolve_kernel(const HitRec *__restrict__
 	if (threadIdx.x == 0)
 		block_total = 0u;
 	__syncthreads();
-	const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-	const uint32_t tile = slot >> 6;
-	if (tile < tiles && (slot & 63u) < (tile_hits[tile] & 0xFFu)) {
-		const uint32_t occluded = occluded_of[slot];
-		const HitRec rec = hits[slot];
-		image[rec.pixel] = rec.value * (1.0f - ((float) occluded / (float) ao_divisor));
-		if (occluded)
-			atomicAdd(&block_total, occluded);
+	uint32_t mine = 0u;
+	const float divisor = (float) ao_divisor;
+	// (64-bit: tiles * 64 may come close to 2^32, the upload allows 2^26 tiles)
+	for (unsigned long long slot = blockIdx.x * blockDim.x + threadIdx.x; (slot >> 6) < tiles; slot += gridDim.x * blockDim.x) {
+		if ((slot & 63ull) < (tile_hits[slot >> 6] & 0xFFu)) {
+			const uint32_t occluded = occluded_of[slot];
+			const HitRec rec = hits[slot];
+			image[rec.pixel] = rec.value * (1.0f - ((float) occluded / divisor));
+			mine += occluded;
+		}
 	}
+	for (int offset = 32; offset > 0; offset >>= 1)
+		mine += (uint32_t) __shfl_down((int) mine, offset);
+	if ((threadIdx.x & 63u) == 0u && mine)
+		atomicAdd(&block_total, mine);
 	__syncthreads();
 	if (threadIdx.x == 0 && block_total)
 		atomicAdd(&counters->occluded, (unsigned long long) block_total);
@@ -1849,7 +1857,8 @@ void launch_ao(const SceneBuffers &scene, float *image, void *hits, void *occlud
 		launch(ao_kernel<AO_UNIFORM, true>);
 	else
 		launch(ao_kernel<AO_RANDOM, true>);
-	hipLaunchKernelGGL(resolve_kernel, dim3((tiles * 64u + 255u) / 256u), dim3(256), 0, s, (const HitRec *) hits,
+	const uint32_t resolve_blocks = (tiles * 64u + 255u) / 256u;
+	hipLaunchKernelGGL(resolve_kernel, dim3(resolve_blocks < 4096u ? resolve_blocks : 4096u), dim3(256), 0, s, (const HitRec *) hits,
 	                   (const uint32_t *) occluded_of, (const uint32_t *) tile_hits, (FrameCounters *) counters, image,
 	                   tiles, P.ao_divisor);
 }
