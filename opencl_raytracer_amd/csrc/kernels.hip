@@ -941,13 +941,8 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) __attribute__((amdgpu_waves_per
 	const uint32_t strips_here = (strips + XCD_GROUPS - 1u - group) >> 3;
 	if (seq >= strips_here * row_blocks)
 		return;
-#ifdef OCRT_PRIMARY_ROW_MAJOR
-	const uint32_t row_block = seq / strips_here;
-	const uint32_t strip_index = seq - row_block * strips_here;
-#else
 	const uint32_t strip_index = seq / row_blocks;
 	const uint32_t row_block = seq - strip_index * row_blocks;
-#endif
 	const uint32_t tile_x = 2u * (group + XCD_GROUPS * strip_index) + (wave & 1u);
 	const uint32_t local_row = PRIMARY_ROWS * row_block + (wave >> 1);
 	if (tile_x >= P.tiles_x || local_row >= P.local_tile_rows)
