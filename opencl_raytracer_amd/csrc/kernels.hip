@@ -16,8 +16,9 @@
 //                   ballot-compacted into the tile's 64 slots of the hit list.
 //   order_kernel    counting sort of the non-empty tiles by AO cost class, the costly
 //                   ones first, per XCD group.
-//   ao_kernel       persistent waves claim runs of (tile, table direction) units in
-//                   that order.  A wave rebuilds the tile's tangent frames in its
+//   ao_kernel       persistent workgroups claim runs of (tile, table direction) units in
+//                   that order -- a tile at a time, whose directions the four waves take
+//                   from a cursor in LDS.  A wave rebuilds the tile's tangent frames in its
 //                   LDS slice and casts one packet of 64 any-hit rays per
 //                   direction -- one table direction from the tile's neighbouring
 //                   surface points -- that stop at the first accepted triangle;
@@ -30,16 +31,16 @@
 // primary pass, claiming the costly blocks first packs them almost perfectly.
 //
 // How rays walk the tree: the 64 rays of a wave share ONE node index ("shared
-// walk", see shared_box / walk_collect below) -- nodes and triangles arrive by
+// walk", see walk_collect below) -- nodes and triangles arrive by
 // scalar loads, boxes are tested out of SGPRs, nothing diverges and nothing is
 // gathered.  The first generation, in which every lane walked on its own under a
 // wave scheduler, is only compiled into the A/B build (-DOCRT_DEBUG_KNOBS, where
 // OCRT_NO_SHARED_WALK=1 selects it); the product library does not contain it.
 //
 // What bounds it: the scene (12 MB) is cache-resident, HBM traffic is negligible;
-// the walk is bound by vector-instruction issue (23 per node and packet) and the
-// latency of the one scalar load per node -- see DESIGN.md section 5 and
-// profiles/r01_notes.md for the counters and the microbenchmarks.
+// the walk is bound by vector-instruction issue (9 to 17 per node and packet) and the
+// latency of the one scalar load per pair of nodes -- see DESIGN.md section 5 and
+// profiles/r0*_notes.md for the counters and the microbenchmarks.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -1616,7 +1617,7 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 					walk_individually();
 #endif
 				if (SHARED) {
-					// shared walks (see shared_box) of 64 consecutive rays of the job at a time; a lane
+					// shared walks (see walk_collect) of 64 consecutive rays of the job at a time; a lane
 					// leaves at its first accepted triangle
 					const bool scene_fast = P.fast_walk && P.ao_regular && P.walk_scale > 0.0f;
 #ifdef OCRT_STAMPS
