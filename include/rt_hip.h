@@ -189,7 +189,7 @@ rt_host *rt_ring_host(rt_ring *r, uint32_t slot);
 int rt_ring_set_graph_mode(rt_ring *r, int on);
 /* Pacing of the submissions: a frame is enqueued no sooner than beta x (the running mean of the time per finished frame)
  * after the previous one, so that frames which finished together do not start their successors together and keep the
- * ring in lockstep.  Default 0.3; 0 switches it off.  (The reference submits one frame and waits for it:
+ * ring in lockstep.  Default 0.5; 0 switches it off.  (The reference submits one frame and waits for it:
  * src/opencl_host.cc:137-149; nothing to pace there.) */
 int rt_ring_set_pacing(rt_ring *r, float beta);
 /* Band buffer `slot` (< rt_ring_slots) is caller-owned DEVICE memory from now on (rt_ring_local_rows * width bytes;

@@ -480,7 +480,7 @@ class FrameRing:
         _check(load_library().rt_ring_set_graph_mode(self._r, int(on)))
 
     def set_pacing(self, beta: float) -> None:
-        """0: submit as soon as a host is free; default 0.3 (include/rt_hip.h, rt_ring_set_pacing)."""
+        """0: submit as soon as a host is free; default 0.5 (include/rt_hip.h, rt_ring_set_pacing)."""
         _check(load_library().rt_ring_set_pacing(self._r, float(beta)))
 
     def bind_output(self, slot: int, device_ptr: int) -> None:

@@ -25,7 +25,7 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 }  // namespace
 
 FrameRing::FrameRing(const RayTracer::Options &options, int device, unsigned int rank, unsigned int nranks, unsigned int count)
-	: next_frame(0), last{ 0, 0, nullptr, 1 }, have_last(false), epoch(nullptr), pacing(0.3f), period_s(0.0), last_submit_s(0.0) {
+	: next_frame(0), last{ 0, 0, nullptr, 1 }, have_last(false), epoch(nullptr), pacing(0.5f), period_s(0.0), last_submit_s(0.0) {
 	if (count == 0 || count > 16)
 		throw std::invalid_argument("a frame ring holds 1 to 16 renderers");
 	for (unsigned int k = 0; k < count; ++k) {

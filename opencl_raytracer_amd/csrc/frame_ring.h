@@ -38,7 +38,8 @@ class FrameRing {
 		// frame (a frame's time on the device over the frames it shared it with, smoothed) after the previous submission.  Frames that finish together would otherwise start their successors together, and the
 		// ring falls into lockstep -- every host in its primary pass at once, then every host at the falling end of its
 		// ambient-occlusion pass at once --, which is exactly what several hosts are there to avoid (interior scene,
-		// three hosts: 1.52 -> 1.33 ms per frame; headline +-0; profiles/r03_notes.md).  0 switches it off; default 0.3.
+		// three hosts: 1.52 -> 1.33 ms per frame; profiles/r03_notes.md).  0 switches it off; default 0.5 (0.3 until the
+		// AO pass dealt its claims by cursor; on those kernels 0.4-0.5 is 2-3 % better on the bunny frames, the interior's alike).
 		void setPacing(float beta) { pacing = beta < 0.0f ? 0.0f : beta > 1.0f ? 1.0f : beta; }
 
 		// Frames write their 8-bit bands (the device resize) into slots() = 2 x size() band buffers in turn: frame f
