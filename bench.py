@@ -269,6 +269,7 @@ def main():
                          "ranks: 3 up to four GPUs, 6 at eight)")
     ap.add_argument("--min-seconds", type=float, default=0.5, help="repeat each block of --steps steps until this much time is covered")
     ap.add_argument("--plain-launches", action="store_true", help="launch the kernels one by one instead of replaying the captured graph")
+    ap.add_argument("--pacing", type=float, default=-1.0, help="the ring's pacing factor (rt_ring_set_pacing); default: the library's")
     args = ap.parse_args()
 
     launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ  # under torch.distributed.run
@@ -342,6 +343,8 @@ def main():
              "blocking": rt.FrameRing(opt, scene, device_index, rank, world, hosts=1)}
     for ring in rings.values():
         ring.set_graph_mode(not args.plain_launches)
+        if args.pacing >= 0.0:
+            ring.set_pacing(args.pacing)
 
     # The exchange step of a multi-GPU frame: the ring's own RCCL gather (one process per GPU; the unique id is made on
     # rank 0 and handed round by torch.distributed).  The gloo rehearsal on a one-GPU box cannot use RCCL (it refuses
