@@ -76,11 +76,12 @@ __device__ __forceinline__ float walk_reciprocal(float i) {
 }
 // `scale`: 1 for the plain form (t in ray units); the SCALED form of the node test (walk_collect<true>) measures t in
 // units of the ray's max_distance, scale = KernelParams::walk_scale ~ 1 / max_distance.
-__device__ __forceinline__ WalkRay make_walk_ray(const Ray &r, float scale) {
+// `tame`: no reciprocal is infinite (ray_is_tame held for the packet).
+__device__ __forceinline__ WalkRay make_walk_ray(const Ray &r, float scale, bool tame = false) {
 	WalkRay w;
-	w.ix = walk_reciprocal(r.ix) * scale;
-	w.iy = walk_reciprocal(r.iy) * scale;
-	w.iz = walk_reciprocal(r.iz) * scale;
+	w.ix = (tame ? r.ix : walk_reciprocal(r.ix)) * scale;
+	w.iy = (tame ? r.iy : walk_reciprocal(r.iy)) * scale;
+	w.iz = (tame ? r.iz : walk_reciprocal(r.iz)) * scale;
 	w.oix = -(r.ox * w.ix);
 	w.oiy = -(r.oy * w.iy);
 	w.oiz = -(r.oz * w.iz);
@@ -194,6 +195,17 @@ __device__ __forceinline__ bool ray_is_selectable(const Ray &r, float origin_lim
 	                     (az <= RECIPROCAL_LIMIT || az == inf) && fminf(fminf(ax, ay), az) >= 0.5f;
 	const bool some_finite = ax <= RECIPROCAL_LIMIT || ay <= RECIPROCAL_LIMIT || az <= RECIPROCAL_LIMIT;
 	return origin_ok && numbers && some_finite;
+}
+
+// The common case in nine instructions: a finite origin within the limit and direction components that are numbers of
+// magnitude 2^-99 ... 2.  Every reciprocal is then a normal number in [0.5, 2^99] (< RECIPROCAL_LIMIT): the short
+// reciprocal has the division's bits (exact_reciprocal.h: exponents 1 ... 252), ray_is_selectable holds and there is no
+// infinite reciprocal for the walk to replace.  (NaN fails: v_cmp_o for the direction, `<=` for the origin.)
+__device__ __forceinline__ bool ray_is_tame(float ox, float oy, float oz, float dx, float dy, float dz, float origin_limit) {
+	const float smallest = fminf(fminf(fabsf(dx), fabsf(dy)), fabsf(dz)), largest = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
+	const bool numbers = !__builtin_isunordered(dx, dy) && !__builtin_isunordered(dz, dz);
+	return numbers && smallest >= 0x1.0p-99f && largest <= 2.0f && fabsf(ox) <= origin_limit && fabsf(oy) <= origin_limit &&
+	       fabsf(oz) <= origin_limit;
 }
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -559,22 +571,25 @@ __device__ __forceinline__ u32x8 scalar_load_node(const float4 *nodes_ptr, uint3
 	"\tv_max3_f32 v56, v56, v57, v58\n"                   \
 	"\tv_min3_f32 v59, v59, v60, v61\n"                   \
 	"\tv_cmp_lt_f32 vcc, v56, v59\n"
-#define OCRT_TEST_MIXED_SCALED(LX, LY, LZ, HX, HY, HZ) \
-	"\tv_fma_f32 v56, " LX ", %[ix], %[oix]\n"         \
-	"\tv_fma_f32 v57, " HX ", %[ix], %[oix]\n"         \
-	"\tv_fma_f32 v58, " LY ", %[iy], %[oiy]\n"         \
-	"\tv_fma_f32 v59, " HY ", %[iy], %[oiy]\n"         \
-	"\tv_fma_f32 v60, " LZ ", %[iz], %[oiz] clamp\n"   \
-	"\tv_fma_f32 v61, " HZ ", %[iz], %[oiz] clamp\n"   \
-	"\tv_cndmask_b32 v62, v57, v56, %[px]\n"           \
-	"\tv_cndmask_b32 v56, v56, v57, %[px]\n"           \
-	"\tv_cndmask_b32 v57, v59, v58, %[py]\n"           \
-	"\tv_cndmask_b32 v58, v58, v59, %[py]\n"           \
-	"\tv_cndmask_b32 v59, v61, v60, %[pz]\n"           \
-	"\tv_cndmask_b32 v60, v60, v61, %[pz]\n"           \
-	"\tv_max3_f32 v62, v62, v57, v59\n"                \
-	"\tv_min3_f32 v56, v56, v58, v60\n"                \
-	"\tv_cmp_lt_f32 vcc, v62, v56\n"
+// Mixed packets of the SCALED form read the CENTRE / HALF-EXTENT copy of the walk array (scene_pack.cc, ce_record:
+// c in the lo fields, e in the hi fields; the copy lies behind the plane form's records and their END records):
+// t_c = fma(c, inv, oi), near = fma(-e, |inv|, t_c), far = fma(e, |inv|, t_c) -- right for either sign of inv, so no
+// selects: 9 v_fma + max3 + min3 + cmp = 12 vector instructions, nine of them of the fast class (the select form
+// took 15, nine of them of the slow class: tools/microbench/valu_rate_probe.hip).  Conservative like the plane form
+// (the half-extent carries the rounding of t_c: proof at ce_record).
+#define OCRT_TEST_CE_SCALED(CX, CY, CZ, EX, EY, EZ)       \
+	"\tv_fma_f32 v56, " CX ", %[ix], %[oix]\n"           \
+	"\tv_fma_f32 v57, " CY ", %[iy], %[oiy]\n"           \
+	"\tv_fma_f32 v58, " CZ ", %[iz], %[oiz]\n"           \
+	"\tv_fma_f32 v59, -" EX ", |%[ix]|, v56\n"           \
+	"\tv_fma_f32 v56, " EX ", |%[ix]|, v56\n"            \
+	"\tv_fma_f32 v60, -" EY ", |%[iy]|, v57\n"           \
+	"\tv_fma_f32 v57, " EY ", |%[iy]|, v57\n"            \
+	"\tv_fma_f32 v61, -" EZ ", |%[iz]|, v58 clamp\n"     \
+	"\tv_fma_f32 v58, " EZ ", |%[iz]|, v58 clamp\n"      \
+	"\tv_max3_f32 v59, v59, v60, v61\n"                  \
+	"\tv_min3_f32 v56, v56, v57, v58\n"                  \
+	"\tv_cmp_lt_f32 vcc, v59, v56\n"
 // (LEAF: the s-register holding the node's leaf field; NEXT: where the walk goes on after an append)
 #define OCRT_WALK_LEAF(LEAF, NOW, NEXT)                 \
 	"\ts_cmp_eq_u32 " LEAF ", -2\n"                     \
@@ -659,7 +674,7 @@ __device__ __forceinline__ u32x8 scalar_load_node(const float4 *nodes_ptr, uint3
 	             : [at] "+s"(at), [waiting] "+s"(waiting), [stops] "+s"(leaf_stops), [hit] "=&s"(hit_mask),               \
 	               [leaf] "=&s"(leaf), [status] "=&s"(status)                                                            \
 	             : [base] "s"(walk_ptr), [alive] "s"(alive_mask), [below] "s"(below), [batch_below] "s"(batch_below),     \
-	               [list] "v"(list_lds_address), [tag] "v"(lane_tag), [ix] "v"(ray.ix), [iy] "v"(ray.iy), [iz] "v"(ray.iz), \
+	               [list] "s"(list_lds_address), [tag] "v"(lane_tag), [ix] "v"(ray.ix), [iy] "v"(ray.iy), [iz] "v"(ray.iz), \
 	               [oix] "v"(ray.oix), [oiy] "v"(ray.oiy), [oiz] "v"(ray.oiz)                                             \
 	             : OCRT_WALK_CLOBBERS)
 
@@ -668,7 +683,16 @@ __device__ __forceinline__ u32x8 scalar_load_node(const float4 *nodes_ptr, uint3
 	             : [at] "+s"(at), [waiting] "+s"(waiting), [stops] "+s"(leaf_stops), [hit] "=&s"(hit_mask),               \
 	               [leaf] "=&s"(leaf), [status] "=&s"(status)                                                            \
 	             : [base] "s"(walk_ptr), [alive] "s"(alive_mask), [below] "s"(below), [batch_below] "s"(batch_below),     \
-	               [px] "s"(sign.x), [py] "s"(sign.y), [pz] "s"(sign.z), [list] "v"(list_lds_address), [tag] "v"(lane_tag), \
+	               [px] "s"(sign.x), [py] "s"(sign.y), [pz] "s"(sign.z), [list] "s"(list_lds_address), [tag] "v"(lane_tag), \
+	               [ix] "v"(ray.ix), [iy] "v"(ray.iy), [iz] "v"(ray.iz), [oix] "v"(ray.oix), [oiy] "v"(ray.oiy),          \
+	               [oiz] "v"(ray.oiz)                                                                                    \
+	             : OCRT_WALK_CLOBBERS)
+#define OCRT_WALK_MIXED_CE(TEST)                                                                                          \
+	asm volatile(OCRT_WALK_ASM(TEST("s48", "s49", "s50", "s52", "s53", "s54"), TEST("s56", "s57", "s58", "s60", "s61", "s62")) \
+	             : [at] "+s"(at), [waiting] "+s"(waiting), [stops] "+s"(leaf_stops), [hit] "=&s"(hit_mask),               \
+	               [leaf] "=&s"(leaf), [status] "=&s"(status)                                                            \
+	             : [base] "s"(walk_ptr), [alive] "s"(alive_mask), [below] "s"(below), [batch_below] "s"(batch_below),     \
+	               [list] "s"(list_lds_address), [tag] "v"(lane_tag),                                                      \
 	               [ix] "v"(ray.ix), [iy] "v"(ray.iy), [iz] "v"(ray.iz), [oix] "v"(ray.oix), [oiy] "v"(ray.oiy),          \
 	               [oiz] "v"(ray.oiz)                                                                                    \
 	             : OCRT_WALK_CLOBBERS)
@@ -682,7 +706,7 @@ __device__ __forceinline__ u32x8 scalar_load_node(const float4 *nodes_ptr, uint3
 	case 5u: OCRT_WALK_COHERENT(COHERENT_TEST, P, N, P); break;         \
 	case 6u: OCRT_WALK_COHERENT(COHERENT_TEST, N, P, P); break;         \
 	case 7u: OCRT_WALK_COHERENT(COHERENT_TEST, P, P, P); break;         \
-	default: OCRT_WALK_MIXED(MIXED_TEST); break;                        \
+	default: MIXED_TEST; break;                                         \
 	}
 
 // `variant`: 0..7 = sign octant of a coherent packet (bit 0: x reciprocals >= 0, bit 1: y, bit 2: z), 8 = mixed.
@@ -696,9 +720,10 @@ __device__ __forceinline__ uint32_t walk_collect(uint32_t variant, const float4 
                                                  uint32_t batch_below) {
 	uint32_t status;
 	if (SCALED) {
-		OCRT_WALK_SWITCH(OCRT_TEST_COHERENT_SCALED, OCRT_TEST_MIXED_SCALED)
+		(void) sign;  // (mixed packets: the caller starts `at` in the centre / half-extent copy of the array)
+		OCRT_WALK_SWITCH(OCRT_TEST_COHERENT_SCALED, OCRT_WALK_MIXED_CE(OCRT_TEST_CE_SCALED))
 	} else {
-		OCRT_WALK_SWITCH(OCRT_TEST_COHERENT, OCRT_TEST_MIXED)
+		OCRT_WALK_SWITCH(OCRT_TEST_COHERENT, OCRT_WALK_MIXED(OCRT_TEST_MIXED))
 	}
 	return status;
 }
@@ -758,7 +783,7 @@ template <bool EXACT>
 __device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ nodes_ptr, const float4 *__restrict__ walk_ptr,
                                                     const float4 *__restrict__ tris_ptr,
                                                     uint32_t count, const Ray &ray_in, const float (&frame)[12][64], uint32_t h,
-                                                    float max_distance, float below, float walk_scale, bool alive,
+                                                    float max_distance, float below, float walk_scale, bool alive, bool tame,
                                                     unsigned int *occluded, LeafBatch &batch, uint32_t batch_below,
                                                     unsigned long long *prof) {
 	(void) prof;  // (-DOCRT_STAMPS builds: time in the node loop / in batches, loop entries, batches, leaf stops)
@@ -825,12 +850,14 @@ __device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ n
 			prof[3] += 1;
 #endif
 		};
-		uint32_t at = 0u;  // byte offset of the node (count < 2^27, checked at upload)
-		const uint32_t end = count * 32u;
-		const uint32_t list_lds_address = (uint32_t) (uintptr_t) &batch.entry[0];  // (low half of the flat address)
+		const uint32_t list_lds_address = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (uintptr_t) &batch.entry[0]);  // (low half of the flat address; scalar)
 		const SignMasks sign = sign_masks(ray_in);
 		const uint32_t variant = walk_variant(sign, alive_mask);  // (lanes only leave: a coherent packet stays coherent)
-		const WalkRay walk_ray = make_walk_ray(with_origin(), walk_scale);
+		// byte offset of the node; a mixed packet walks the centre / half-extent copy of the records, which lies behind
+		// the plane form's and its two END records (scene_pack.cc, make_walk_array: 2 * (count + 2) * 32 < 2^32)
+		uint32_t at = variant == WALK_MIXED ? (count + 2u) * 32u : 0u;
+		const uint32_t end = at + count * 32u;
+		const WalkRay walk_ray = tame ? make_walk_ray(with_origin(), walk_scale, true) : make_walk_ray(with_origin(), walk_scale);  // (wave-uniform)
 		const uint32_t lane_tag = fresh_lane() << 26;
 		while (alive_mask != 0ull && at < end) {
 			uint32_t leaf = 0u;
@@ -1025,7 +1052,7 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) __attribute__((amdgpu_waves_per
 			const SignMasks sign = sign_masks(ray);
 			const uint32_t variant = walk_variant(sign, alive_mask);
 			const WalkRay walk_ray = make_walk_ray(ray, 1.0f);
-			const uint32_t list_lds_address = (uint32_t) (uintptr_t) &cb.entry[0];  // (low half of the flat address)
+			const uint32_t list_lds_address = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (uintptr_t) &cb.entry[0]);  // (low half of the flat address; scalar)
 			const uint32_t end = count * 32u;
 			uint32_t at = 0u;  // byte offset
 			while (alive_mask != 0ull && at < end) {
@@ -1313,19 +1340,50 @@ struct TileShared {
 #define OCRT_STAMP_ADD(slot, value)
 #endif
 
+// The pass's arguments as ONE block.  The walks leave the kernel some 40 scalar registers for everything it holds across
+// them (80 per wave at 8 waves per SIMD, 22 of them the node loop's own and 14 its operands), and what does not fit is
+// spilled to VGPR lanes: v_writelane / v_readlane -- VECTOR instructions, the resource the pass is bound by (round 3:
+// 33 per packet and 9 per leaf stop or batch, a tenth of the pass's vector instructions).  So only what every leaf stop
+// needs is held in registers (the two pointers at the head, node_count, ao_below, batch_below); every other argument is
+// READ AGAIN from the kernel-argument segment where it is used -- one scalar load (asm volatile: the compiler can neither
+// hoist it out of a loop nor merge it with another) that hits the scalar cache and costs no vector issue slot.
+struct AoArgs {
+	const float4 *walk_ptr, *tris_ptr;
+	const float4 *nodes_ptr, *ao_table;
+	const HitRec *hits;
+	uint32_t *occluded_of;
+	const uint32_t *order;
+	FrameCounters *counters;
+	KernelParams P;
+};
+template <uint32_t OFFSET>
+__device__ __forceinline__ uint32_t cold_u32() {
+	uint32_t v;
+	asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "i"(OFFSET));
+	return v;
+}
+template <uint32_t OFFSET>
+__device__ __forceinline__ unsigned long long cold_u64() {
+	unsigned long long v;
+	asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "i"(OFFSET));
+	return v;
+}
+#define OCRT_COLD_U32(FIELD) cold_u32<(uint32_t) offsetof(AoArgs, FIELD)>()
+#define OCRT_COLD_F32(FIELD) __uint_as_float(cold_u32<(uint32_t) offsetof(AoArgs, FIELD)>())
+#define OCRT_COLD_PTR(TYPE, FIELD) ((TYPE) cold_u64<(uint32_t) offsetof(AoArgs, FIELD)>())
+
 template <int MODE, bool SHARED>
-__global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void ao_kernel(
-    const float4 *__restrict__ nodes_ptr, const float4 *__restrict__ walk_ptr, const float4 *__restrict__ tris_ptr,
-    const float4 *__restrict__ ao_table, const HitRec *__restrict__ hits,
-    uint32_t *__restrict__ occluded_of, const uint32_t *__restrict__ order, FrameCounters *__restrict__ counters,
-    KernelParams P) {
+__global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void ao_kernel(AoArgs A) {
 	__shared__ TileShared shared_tiles[AO_WAVES];
 	__shared__ unsigned int wg_claim[4];  // the workgroup's current claim: first unit, units per wave, end (if dealt by cursor), cursor
 	const uint32_t wave = (uint32_t) __builtin_amdgcn_readfirstlane((int) threadIdx.x) >> 6;  // (scalar)
 	TileShared &sh = shared_tiles[wave];
-	const SceneViews scene = make_views(nodes_ptr, tris_ptr, P);
-	const uint32_t count = P.node_count;
-	const uint32_t strips = (P.tiles_x + 1u) >> 1;
+	const float4 *__restrict__ const walk_ptr = A.walk_ptr, *__restrict__ const tris_ptr = A.tris_ptr;
+	const uint32_t count = A.P.node_count;
+#ifdef OCRT_DEBUG_KNOBS  // (the first-generation walk of the A/B build uses the arguments freely: its register budget is nobody's concern)
+	const KernelParams &P = A.P;
+	const SceneViews scene = make_views(A.nodes_ptr, A.tris_ptr, A.P);
+#endif
 
 #ifndef OCRT_STAMPS
 	unsigned long long *walk_prof = nullptr;
@@ -1342,28 +1400,40 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 	for (uint32_t turn = 0; turn < XCD_GROUPS; ++turn) {
 		const uint32_t group = (home + turn) & (XCD_GROUPS - 1u);
 		uint32_t segment = 0u;
-		for (uint32_t g = 0; g < group; ++g)
-			segment += ((strips + XCD_GROUPS - 1u - g) >> 3) * 2u * P.local_tile_rows;
+		{
+			const uint32_t strips = (OCRT_COLD_U32(P.tiles_x) + 1u) >> 1, rows = OCRT_COLD_U32(P.local_tile_rows);
+			for (uint32_t g = 0; g < group; ++g)
+				segment += ((strips + XCD_GROUPS - 1u - g) >> 3) * 2u * rows;
+		}
 		// the group's work in units of (tile, table direction), tile-major
-		const uint32_t units = counters->queue[group].work_tiles * P.ao_dirs;
+		uint32_t units, claim_max;
+		{
+		FrameCounters *const counters = OCRT_COLD_PTR(FrameCounters *, counters);
+		const uint32_t ao_dirs = OCRT_COLD_U32(P.ao_dirs);
+		// (loads through a re-read pointer are vector loads -- the compiler cannot know the memory to be constant --: what they
+		// return is made scalar again by hand)
+		const uint32_t queued_tiles = (uint32_t) __builtin_amdgcn_readfirstlane((int) counters->queue[group].work_tiles);
+		units = queued_tiles * ao_dirs;
 		// A wave's largest claim.  A quarter of a tile's directions, so that the workgroup's four waves take ONE tile
 		// together (the best locality, and the finest balance); whole tiles per wave where packets are cheap and
 		// plentiful -- a tile's mean cost class (the leaves its primary packet stopped at) below 8 and 512 or more
 		// units per wave: 16+ samples per pixel -- because there the ~12 us of set-up per claim (hit records,
 		// tangent frames) weigh more than the locality.  Swept per workload: profiles/r02_notes.md.
-		uint32_t claim_max = P.ao_claim_max;
+		claim_max = OCRT_COLD_U32(P.ao_claim_max);
 		if (claim_max == 0u) {
-			const uint32_t tiles = counters->queue[group].work_tiles, cost = counters->queue[group].cost_sum;
-			const bool cheap_and_plenty = cost < 8u * tiles && units >= 512u * P.ao_claim_div;
-			const uint32_t quarter = (P.ao_dirs + AO_WAVES - 1u) / AO_WAVES;
+			const uint32_t tiles = queued_tiles, cost = (uint32_t) __builtin_amdgcn_readfirstlane((int) counters->queue[group].cost_sum);
+			const uint32_t claim_div = OCRT_COLD_U32(P.ao_claim_div);
+			const bool cheap_and_plenty = cost < 8u * tiles && units >= 512u * claim_div;
+			const uint32_t quarter = (ao_dirs + AO_WAVES - 1u) / AO_WAVES;
 			// ... and less than a quarter where work is scarce (one GPU's share of a frame split eight ways holds 8
 			// units per wave): half a quarter below 24 units per wave, a third below 12 -- the frame then ends when its
 			// heaviest tile does, and more waves should share that one (tools/partition_probe.py: -13 % at 1/8).  Not
 			// where other frames run beside this one: what a pass leaves idle at its end is theirs, and the smaller
 			// claims only cost (an eighth of the headline frame, six frames in flight: 0.25 ms with them, 0.21 without).
-			const uint32_t per_wave = P.shared_device ? 24u : units / P.ao_claim_div;
-			claim_max = cheap_and_plenty ? P.ao_dirs : per_wave < 12u ? quarter / 3u : per_wave < 24u ? (quarter + 1u) / 2u : quarter;
+			const uint32_t per_wave = OCRT_COLD_U32(P.shared_device) ? 24u : units / claim_div;
+			claim_max = cheap_and_plenty ? ao_dirs : per_wave < 12u ? quarter / 3u : per_wave < 24u ? (quarter + 1u) / 2u : quarter;
 			claim_max = claim_max < 1u ? 1u : claim_max;
+		}
 		}
 		for (;;) {
 			OCRT_STAMP(t_claim);
@@ -1376,13 +1446,21 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 			// shrinking to 1/ao_guide of what is left per wave of the group -- is kept behind OCRT_AO_GUIDE: the
 			// single directions it hands out at the end cost a claim each, two barriers and a tile set-up, and
 			// lengthened the pass by 3-5 %; the costly tiles are claimed first anyway, order_kernel.)
-			uint32_t per_wave = 0u, first = units;  // (thread 0's; in registers until the siblings are done with the last claim)
-			if (wave == 0u && fresh_lane() == 0u) {
-				const uint32_t seen = __hip_atomic_load(&counters->queue[group].head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			uint32_t per_wave = 0u, first = units;  // (wave 0's, scalar; in registers until the siblings are done with the last claim)
+			if (wave == 0u) {
+				FrameCounters *const counters = OCRT_COLD_PTR(FrameCounters *, counters);
+				uint32_t seen = 0u;
+				if (fresh_lane() == 0u)
+					seen = __hip_atomic_load(&counters->queue[group].head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				seen = (uint32_t) __builtin_amdgcn_readfirstlane((int) seen);
 				if (seen < units) {
-					per_wave = P.ao_guide ? (units - seen) / P.ao_guide : claim_max;
+					const uint32_t guide = OCRT_COLD_U32(P.ao_guide);
+					per_wave = guide ? (units - seen) / guide : claim_max;
 					per_wave = per_wave < 1u ? 1u : per_wave > claim_max ? claim_max : per_wave;
-					first = atomicAdd(&counters->queue[group].head, per_wave * AO_WAVES);
+					uint32_t got = 0u;
+					if (fresh_lane() == 0u)
+						got = atomicAdd(&counters->queue[group].head, per_wave * AO_WAVES);
+					first = (uint32_t) __builtin_amdgcn_readfirstlane((int) got);
 				}
 			}
 			__syncthreads();  // (everybody is done with the previous claim: its words in LDS, the cursor among them, are free)
@@ -1394,12 +1472,13 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 				// profiles/r03_notes.md).  Other claims (whole tiles per wave, the short ones of scarce work) keep fixed shares.
 				// wg_claim[2] = the claim's end, 0 for fixed shares.
 				const uint32_t end = first + per_wave * AO_WAVES < units ? first + per_wave * AO_WAVES : units;
-				const bool one_tile = SHARED && first < units && first / P.ao_dirs == (end - 1u) / P.ao_dirs && P.ao_dirs < 0x8000u;
+				const uint32_t ao_dirs = OCRT_COLD_U32(P.ao_dirs);
+				const bool one_tile = SHARED && first < units && first / ao_dirs == (end - 1u) / ao_dirs && ao_dirs < 0x8000u;
 				wg_claim[0] = first;
 				wg_claim[1] = per_wave;
 				wg_claim[2] = one_tile ? end : 0u;
 				// the cursor, in directions of the tile: end << 16 | next (both 0 for fixed shares: nothing to take)
-				const uint32_t base = first - first / P.ao_dirs * P.ao_dirs;
+				const uint32_t base = first - first / ao_dirs * ao_dirs;
 				wg_claim[3] = one_tile ? (base + (end - first)) << 16 | base : 0u;
 			}
 			__syncthreads();
@@ -1422,11 +1501,15 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 				OCRT_STAMP(t_job);
 				// job = (tile, direction range); a claim that runs over a tile's last direction goes on in
 				// the next tile.  Neighbouring claims work on the same tile: its hit records are shared in L2.
-				const uint32_t tile_index = unit / P.ao_dirs;
-				uint32_t dir0 = unit - tile_index * P.ao_dirs;
-				const uint32_t n_dirs = P.ao_dirs - dir0 < claim_end - unit ? P.ao_dirs - dir0 : claim_end - unit;
+				uint32_t tile_index, dir0, n_dirs;
+				{
+					const uint32_t ao_dirs = OCRT_COLD_U32(P.ao_dirs);
+					tile_index = unit / ao_dirs;
+					dir0 = unit - tile_index * ao_dirs;
+					n_dirs = ao_dirs - dir0 < claim_end - unit ? ao_dirs - dir0 : claim_end - unit;
+				}
 				unit += n_dirs;
-				const uint32_t entry = order[segment + tile_index];
+				const uint32_t entry = (uint32_t) __builtin_amdgcn_readfirstlane((int) OCRT_COLD_PTR(const uint32_t *, order)[segment + tile_index]);
 				const uint32_t tile = entry & 0x03FFFFFFu;
 				const uint32_t hit_count = (entry >> 26) + 1u;
 				uint32_t total = hit_count * n_dirs;  // the rays of this piece of the job: directions dir0 ...
@@ -1464,8 +1547,9 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 				const uint32_t lane = fresh_lane();  // (recomputed where it is needed: no register held across the walks)
 				if (lane < hit_count) {
 					const size_t slot = (size_t) tile * 64u + lane;
-					const float4 q0 = ((const float4 *) hits)[2 * slot];
-					const float4 q1 = ((const float4 *) hits)[2 * slot + 1];
+					const float4 *const hits = OCRT_COLD_PTR(const float4 *, hits);
+					const float4 q0 = hits[2 * slot];
+					const float4 q1 = hits[2 * slot + 1];
 					float nx = q1.x, ny = q1.y, nz = q1.z;
 					// p = point + normal * (1.0f / 100000.0f)
 					const float eps = 1.0f / 100000.0f;
@@ -1506,6 +1590,7 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 				// from neighbouring pixels. ----
 				uint32_t h = 0;
 				Ray ray;
+				bool tame = false;  // (wave-uniform) every ray of the packet set up last is "tame": ray_is_tame
 #ifdef OCRT_DEBUG_KNOBS
 				uint32_t next = 0u;  // wave-uniform queue head
 				uint32_t i = count;
@@ -1526,7 +1611,7 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 						k = item / hit_count;
 						h = item - k * hit_count;
 						if (MODE == AO_UNIFORM) {
-							const float4 dir = ao_table[dir0 + k];
+							const float4 dir = OCRT_COLD_PTR(const float4 *, ao_table)[dir0 + k];
 							xs = dir.x; ys = dir.y; zs = dir.z;
 						}
 					}
@@ -1537,9 +1622,9 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 						const uint32_t j = dir0 + k;
 						along_normal = j == 0u;
 						// the generator is seeded with the sub-pixel's index in the WHOLE image (reference :169, :279-281)
-						const uint32_t local_y = sh.pixel[h] / P.width, x = sh.pixel[h] - local_y * P.width;
-						const uint32_t y = global_tile_row(P.part, local_y / TILE_H) * TILE_H + (local_y & (TILE_H - 1u));
-						Rng rng = rng_seed(536870923u * (y * P.width + x));
+						const uint32_t local_y = sh.pixel[h] / A.P.width, x = sh.pixel[h] - local_y * A.P.width;
+						const uint32_t y = global_tile_row(A.P.part, local_y / TILE_H) * TILE_H + (local_y & (TILE_H - 1u));
+						Rng rng = rng_seed(536870923u * (y * A.P.width + x));
 						for (uint32_t skip = 1; skip < j; ++skip) {
 							rng_next(rng);
 							rng_next(rng);
@@ -1560,11 +1645,22 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 						normalize3(rx, ry, rz);
 						if (along_normal) {
 							// the un-normalised shading normal itself (:263), kept in the hit record
-							const float4 q1 = ((const float4 *) hits)[2 * ((size_t) tile * 64u + h) + 1];
+							const float4 q1 = ((const float4 *) A.hits)[2 * ((size_t) tile * 64u + h) + 1];
 							rx = q1.x; ry = q1.y; rz = q1.z;
 						}
 					}
-					ray = make_ray(sh.frame[0][h], sh.frame[1][h], sh.frame[2][h], rx, ry, rz);
+					const float ox = sh.frame[0][h], oy = sh.frame[1][h], oz = sh.frame[2][h];
+					// (only the lanes with a ray are here: the ballot is over the packet's live lanes)
+					tame = MODE == AO_UNIFORM && wave_ballot(!ray_is_tame(ox, oy, oz, rx, ry, rz, OCRT_COLD_F32(P.origin_limit))) == 0ull;
+					if (tame) {
+						ray.ox = ox; ray.oy = oy; ray.oz = oz;
+						ray.dx = rx; ray.dy = ry; ray.dz = rz;
+						ray.ix = short_reciprocal(rx); ray.iy = short_reciprocal(ry); ray.iz = short_reciprocal(rz);
+					} else {  // (rare: a zero or tiny direction component, a NaN from a zero-length normal)
+						ray.ox = ox; ray.oy = oy; ray.oz = oz;
+						ray.dx = rx; ray.dy = ry; ray.dz = rz;
+						ray.ix = 1.0f / rx; ray.iy = 1.0f / ry; ray.iz = 1.0f / rz;
+					}
 #ifdef OCRT_DEBUG_KNOBS
 					regular = P.scene_regular && P.ao_regular && ray_is_regular(ray);
 #endif
@@ -1619,7 +1715,7 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 				if (SHARED) {
 					// shared walks (see walk_collect) of 64 consecutive rays of the job at a time; a lane
 					// leaves at its first accepted triangle
-					const bool scene_fast = P.fast_walk && P.ao_regular && P.walk_scale > 0.0f;
+					const bool scene_fast = OCRT_COLD_U32(P.fast_walk) && OCRT_COLD_U32(P.ao_regular) && OCRT_COLD_F32(P.walk_scale) > 0.0f;
 #ifdef OCRT_STAMPS
 					uint32_t job_exact = 0u;
 #endif
@@ -1632,28 +1728,28 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 						const bool whole = hit_count == 64u;
 						float4 shared_dir = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 						if (whole && MODE == AO_UNIFORM)
-							shared_dir = ao_table[dir0 + (base >> 6)];
+							shared_dir = OCRT_COLD_PTR(const float4 *, ao_table)[dir0 + (base >> 6)];
 						if (alive)
 							setup_ray(base + lane, whole, shared_dir);
-						const bool exact = !scene_fast || wave_ballot(alive && !ray_is_selectable(ray, P.origin_limit)) != 0ull;
+						const bool exact = !scene_fast || (!tame && wave_ballot(alive && !ray_is_selectable(ray, OCRT_COLD_F32(P.origin_limit))) != 0ull);
 #ifdef OCRT_STAMPS
 						job_exact += exact ? 1u : 0u;
 #endif
 						if (exact)
-							shared_walk_any_hit<true>(nodes_ptr, walk_ptr, tris_ptr, count, ray, sh.frame, h,
-							                          P.ao_max_distance, P.ao_below, P.walk_scale, alive, &sh.occluded[h], sh.batch,
-							                          P.batch_below, walk_prof);
+							shared_walk_any_hit<true>(OCRT_COLD_PTR(const float4 *, nodes_ptr), walk_ptr, tris_ptr, count, ray, sh.frame, h,
+							                          OCRT_COLD_F32(P.ao_max_distance), A.P.ao_below, 0.0f, alive, false, &sh.occluded[h], sh.batch,
+							                          A.P.batch_below, walk_prof);
 						else
-							shared_walk_any_hit<false>(nodes_ptr, walk_ptr, tris_ptr, count, ray, sh.frame, h,
-							                           P.ao_max_distance, P.ao_below, P.walk_scale, alive, &sh.occluded[h], sh.batch,
-							                           P.batch_below, walk_prof);
+							shared_walk_any_hit<false>(nullptr, walk_ptr, tris_ptr, count, ray, sh.frame, h,
+							                           0.0f, A.P.ao_below, OCRT_COLD_F32(P.walk_scale), alive, tame, &sh.occluded[h], sh.batch,
+							                           A.P.batch_below, walk_prof);
 					}
 					take_from_cursor();  // (fixed shares: the cursor holds nothing)
 					} while (total != 0u);
 #ifdef OCRT_STAMPS
 					if (fresh_lane() == 0u && job_exact) {
-						atomicAdd(&counters->stamp[63], (unsigned long long) job_exact);  // packets that took the exact form
-						atomicAdd(&counters->stamp[64], (__builtin_amdgcn_s_memrealtime() - t_frames));  // ... and the time of the jobs holding them
+						atomicAdd(&A.counters->stamp[63], (unsigned long long) job_exact);  // packets that took the exact form
+						atomicAdd(&A.counters->stamp[64], (__builtin_amdgcn_s_memrealtime() - t_frames));  // ... and the time of the jobs holding them
 					}
 #endif
 				}
@@ -1668,7 +1764,7 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 					if (lane < hit_count) {
 						const uint32_t occluded = sh.occluded[lane];
 						if (occluded)
-							atomicAdd(&occluded_of[(size_t) tile * 64u + lane], occluded);
+							atomicAdd(&OCRT_COLD_PTR(uint32_t *, occluded_of)[(size_t) tile * 64u + lane], occluded);
 					}
 				}
 				wave_lds_sync();
@@ -1678,41 +1774,41 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 				if (fresh_lane() == 0u) {  // jobs by duration: bucket k holds those of 2^k .. 2^(k+1) microseconds
 					const unsigned long long us = (t_flushed - t_job) / 100ull;
 					const int bucket = us == 0ull ? 0 : 63 - __builtin_clzll(us);
-					atomicAdd(&counters->stamp[49 + (bucket > 15 ? 15 : bucket)], 1ull);
+					atomicAdd(&A.counters->stamp[49 + (bucket > 15 ? 15 : bucket)], 1ull);
 				}
 #endif
 			}
 		}
 	}
 	if (wave == 0u && fresh_lane() == 0u)  // (nothing kept across the pass: one clock read and one atomic per workgroup)
-		atomicMax(&counters->tick_ao_end, (unsigned long long) __builtin_amdgcn_s_memrealtime());
+		atomicMax(&OCRT_COLD_PTR(FrameCounters *, counters)->tick_ao_end, (unsigned long long) __builtin_amdgcn_s_memrealtime());
 #ifdef OCRT_TAIL  // minimal: nothing is kept across the pass, one load and two atomics when the wave ends
 	if (fresh_lane() == 0u) {
 		const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
-		const unsigned long long origin = __hip_atomic_load(&counters->stamp[7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const unsigned long long origin = __hip_atomic_load(&A.counters->stamp[7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		const unsigned long long end_bucket = (t_end - origin) / 5000ull;  // 0.05 ms
-		atomicAdd(&counters->stamp[10 + (end_bucket > 31 ? 31 : end_bucket)], 1ull);
-		atomicMax(&counters->stamp[8], t_end);
+		atomicAdd(&A.counters->stamp[10 + (end_bucket > 31 ? 31 : end_bucket)], 1ull);
+		atomicMax(&A.counters->stamp[8], t_end);
 	}
 #endif
 #ifdef OCRT_STAMPS
 	if (fresh_lane() == 0u) {
 		const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
 		for (int k = 0; k < 6; ++k)
-			atomicAdd(&counters->stamp[k], stamp_acc[k]);           // claim, frames, walks, flush (10 ns ticks); jobs, packets
-		atomicAdd(&counters->stamp[6], t_end - t_begin);            // sum of wave lifetimes
-		atomicMin(&counters->stamp[7], t_begin);                     // first start
-		atomicMax(&counters->stamp[8], t_end);                       // last end
+			atomicAdd(&A.counters->stamp[k], stamp_acc[k]);           // claim, frames, walks, flush (10 ns ticks); jobs, packets
+		atomicAdd(&A.counters->stamp[6], t_end - t_begin);            // sum of wave lifetimes
+		atomicMin(&A.counters->stamp[7], t_begin);                     // first start
+		atomicMax(&A.counters->stamp[8], t_end);                       // last end
 		if (stamp_acc[4])
-			atomicAdd(&counters->stamp[9], 1ull);                    // waves that got any work
+			atomicAdd(&A.counters->stamp[9], 1ull);                    // waves that got any work
 		for (int k = 0; k < 7; ++k)
-			atomicAdd(&counters->stamp[42 + k], walk_prof_store[k]);  // time in the node loop, in batches; loop entries, batches, leaf stops
+			atomicAdd(&A.counters->stamp[42 + k], walk_prof_store[k]);  // time in the node loop, in batches; loop entries, batches, leaf stops
 		// when this wave ended, counted from the first wave's start (settled long before any wave ends), 0.1 ms buckets:
 		// how the occupancy decays towards the end of the launch
 		(void) t_last_claim;
-		const unsigned long long first = __hip_atomic_load(&counters->stamp[7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const unsigned long long first = __hip_atomic_load(&A.counters->stamp[7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		const unsigned long long end_bucket = (t_end - (first < t_begin ? first : t_begin)) / 10000ull;
-		atomicAdd(&counters->stamp[10 + (end_bucket > 31 ? 31 : end_bucket)], 1ull);
+		atomicAdd(&A.counters->stamp[10 + (end_bucket > 31 ? 31 : end_bucket)], 1ull);
 	}
 #endif
 }
@@ -1840,9 +1936,17 @@ void launch_ao(const SceneBuffers &scene, float *image, void *hits, void *occlud
 		// (the events bracket the ao_kernel launch alone: its duration is the one the roofline is quoted for)
 		if (event_before_ao)
 			(void) hipEventRecord((hipEvent_t) event_before_ao, s);
-		hipLaunchKernelGGL(kernel, dim3(ao_blocks), dim3(64 * AO_WAVES), 0, s, (const float4 *) scene.nodes,
-		                   (const float4 *) scene.walk, (const float4 *) scene.tris, (const float4 *) scene.ao_table, (const HitRec *) hits, (uint32_t *) occluded_of,
-		                   (const uint32_t *) order, (FrameCounters *) counters, P);
+		AoArgs args;
+		args.walk_ptr = (const float4 *) scene.walk;
+		args.tris_ptr = (const float4 *) scene.tris;
+		args.nodes_ptr = (const float4 *) scene.nodes;
+		args.ao_table = (const float4 *) scene.ao_table;
+		args.hits = (const HitRec *) hits;
+		args.occluded_of = (uint32_t *) occluded_of;
+		args.order = (const uint32_t *) order;
+		args.counters = (FrameCounters *) counters;
+		args.P = P;
+		hipLaunchKernelGGL(kernel, dim3(ao_blocks), dim3(64 * AO_WAVES), 0, s, args);
 		if (event_after_ao)
 			(void) hipEventRecord((hipEvent_t) event_after_ao, s);
 	};

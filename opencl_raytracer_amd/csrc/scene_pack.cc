@@ -269,6 +269,35 @@ bool walk_scale_usable(float scale, float origin_limit) {
 	return worst * std::ldexp(1.0, 100) < room && worst * 1.0e30 < room;
 }
 
+// A padded walk record (lo', hi': already conservative for the plane form, padded_bound) as centre c and half-extent e
+// (stored in the lo / hi fields).  The kernel computes t_c = fl(c * inv + oi) and then near = fl(t_c - e |inv|),
+// far = fl(t_c + e |inv|), each by ONE fma.  With T(x) = x * inv + oi as a real (oi as the kernel rounded it), the plane
+// form's values are fl(T(lo')) and fl(T(hi')) (for inv > 0; mirrored otherwise).  |t_c - T(c)| <= u |T(c)| <=
+// u (|c| + |o| (1 + u)) |inv|, hence
+//     e >= max(c - lo', hi' - c) + u (|c| + 1.01 O)      (O >= |o|: the bound padded_bound was given for this box and axis)
+// gives  t_c - e |inv| <= T(c) - (c - lo') |inv| = T(lo')  and  t_c + e |inv| >= T(hi')  as reals, and rounding being
+// monotone the fma's results lie at or outside the plane form's: whatever passes there passes here.  The z axis' clamp
+// is monotone too.  Nothing depends on the magnitude of inv (2^100 for an infinite reciprocal included: the bound scales
+// with |inv|); e is computed in double and rounded up.  tests/walk_margin_check.cc throws the same pairs at this form.
+void padded_centre_extent(float padded_lo, float padded_hi, float origin_bound, float *centre, float *half_extent) {
+	const double lo = padded_lo, hi = padded_hi;
+	const float c = (float) (0.5 * lo + 0.5 * hi);
+	const double half = std::fmax((double) c - lo, hi - (double) c);
+	const double want = (half + std::ldexp(std::fabs((double) c) + 1.01 * (double) origin_bound, -24)) * (1.0 + 1.0e-12) + 1.0e-38;
+	float e = (float) want;
+	if ((double) e < want)
+		e = std::nextafterf(e, std::numeric_limits<float>::infinity());
+	*centre = c;
+	*half_extent = e;
+}
+
+static NodeRec ce_record(const NodeRec &padded, const double origin_bound[3]) {
+	NodeRec r = padded;
+	for (unsigned k = 0; k < 3; ++k)
+		padded_centre_extent(padded.lo[k], padded.hi[k], (float) origin_bound[k], &r.lo[k], &r.hi[k]);
+	return r;
+}
+
 WalkArray make_walk_array(const PackedScene &scene, float ao_max_distance) {
 	WalkArray out;
 	const std::vector<NodeRec> &nodes = scene.nodes;
@@ -312,6 +341,32 @@ WalkArray make_walk_array(const PackedScene &scene, float ao_max_distance) {
 	end.leaf = WALK_END;
 	out.nodes[nodes.size()] = end;
 	out.nodes[nodes.size() + 1] = end;
+	// The same records once more in CENTRE / HALF-EXTENT form, behind the END records, for the packets whose rays do not
+	// agree on the sign of their direction (kernels.hip, OCRT_TEST_CE_SCALED): with t_c = fma(c, inv, oi) the two planes
+	// of an axis are fma(-e, |inv|, t_c) and fma(e, |inv|, t_c) whatever the sign of inv -- nine fmas and no selects.
+	// Only the scaled form (the any-hit rays) uses it.  Why it stays conservative: ce_record() below.
+	const size_t records = nodes.size() + 2;
+	if (2 * records * sizeof(NodeRec) >= (size_t) 1 << 32)
+		out.ao_scale = 0.0f;  // (no room for the copy below 2^32 bytes: the any-hit rays of such a scene take the exact form)
+	if (out.ao_scale > 0.0f) {
+		out.ce_offset = (uint32_t) (records * sizeof(NodeRec));
+		out.nodes.resize(2 * records);
+		for (size_t i = 0; i < nodes.size(); ++i) {
+			double origin[3];
+			for (unsigned k = 0; k < 3; ++k) {
+				const double box = std::fmax(std::fabs((double) nodes[i].lo[k]), std::fabs((double) nodes[i].hi[k]));
+				origin[k] = std::fmin((double) out.origin_limit, std::fmax(camera[k], box + reach));
+			}
+			out.nodes[records + i] = ce_record(out.nodes[i], origin);
+		}
+		NodeRec ce_end = end;  // centre 0, half-extent +inf: near = -inf, far = +inf for every finite ray
+		for (unsigned k = 0; k < 3; ++k) {
+			ce_end.lo[k] = 0.0f;
+			ce_end.hi[k] = std::numeric_limits<float>::infinity();
+		}
+		out.nodes[records + nodes.size()] = ce_end;
+		out.nodes[records + nodes.size() + 1] = ce_end;
+	}
 	return out;
 }
 

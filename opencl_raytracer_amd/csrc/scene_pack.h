@@ -21,6 +21,7 @@ struct WalkArray {
 	std::vector<NodeRec> nodes;
 	float origin_limit = 0.0f;  // rays whose origin exceeds this magnitude on some axis take the exact form
 	float ao_scale = 0.0f;      // walk_scale_for(ao_max_distance) the margins were sized for (0: none)
+	uint32_t ce_offset = 0;     // byte offset of the same records in centre / half-extent form (0: none; ao_scale > 0 only)
 };
 struct PackedScene {
 	std::vector<NodeRec> nodes;
@@ -58,6 +59,9 @@ void prepare_walk_array(PackedScene &scene, float ao_max_distance);
 // magnitude up to `origin_bound` on that axis; always < b resp. > b.
 // `scaled_reach`: the max_distance (x 1.001) of the rays that use the SCALED node test on this array, 0 if none do.
 float padded_bound(float b, float origin_bound, bool upper, float scaled_reach = 0.0f);
+// One axis of a padded box as centre and half-extent for the select-free form of the scaled node test (kernels.hip,
+// OCRT_TEST_CE_SCALED): the half-extent also covers the rounding of t at the centre (scene_pack.cc, ce_record).
+void padded_centre_extent(float padded_lo, float padded_hi, float origin_bound, float *centre, float *half_extent);
 // The factor the scaled node test multiplies the reciprocal directions with: the largest float r with
 // r * max_distance * (1 + 2^-23) <= 1, or 0 where the scaled form must not be used (max_distance not a positive
 // number within 2^-20 .. 2^20).

@@ -20,6 +20,7 @@ namespace ocrt {
 float padded_bound(float b, float origin_bound, bool upper, float scaled_reach);  // libocrt_hip.so
 float walk_scale_for(float max_distance);
 bool walk_scale_usable(float scale, float origin_limit);
+void padded_centre_extent(float padded_lo, float padded_hi, float origin_bound, float *centre, float *half_extent);
 }
 
 namespace {
@@ -85,6 +86,24 @@ bool scaled_slab(const float plo[3], const float phi[3], const float o[3], const
 	return n < f;  // strictly: a box behind the origin on z (far clamped to 0) must fail
 }
 
+// kernels.hip, OCRT_TEST_CE_SCALED (mixed packets): centre / half-extent records, t_c = fma(c, inv, oi), the planes
+// fma(-e, |inv|, t_c) and fma(e, |inv|, t_c), z clamped, compared strictly
+bool ce_slab(const float c[3], const float e[3], const float o[3], const float d[3], float scale) {
+	float near[3], far[3];
+	for (int k = 0; k < 3; ++k) {
+		const float inv = 1.0f / d[k];
+		const float wi = walk_reciprocal(inv) * scale;
+		const float oi = -(o[k] * wi);
+		const float tc = std::fmaf(c[k], wi, oi);
+		near[k] = std::fmaf(-e[k], std::fabs(wi), tc);
+		far[k] = std::fmaf(e[k], std::fabs(wi), tc);
+		if (k == 2) { near[k] = clamp01(near[k]); far[k] = clamp01(far[k]); }
+	}
+	const float n = std::fmax(std::fmax(near[0], near[1]), near[2]);
+	const float f = std::fmin(std::fmin(far[0], far[1]), far[2]);
+	return n < f;
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
@@ -110,7 +129,7 @@ int main(int argc, char **argv) {
 	std::mt19937_64 rng(20261004);
 	std::uniform_real_distribution<float> unit(-1.0f, 1.0f);
 	std::uniform_int_distribution<int> pick(0, 15);
-	long accepted = 0, failures = 0, scaled_cases = 0, scaled_failures = 0;
+	long accepted = 0, failures = 0, scaled_cases = 0, scaled_failures = 0, ce_failures = 0;
 	for (long c = 0; c < cases; ++c) {
 		const float extent = std::ldexp(1.0f, pick(rng) - 4);         // scene extents 1/16 .. 2048
 		const float max_distance = (c & 1) ? 100000.0f : extent * std::ldexp(1.0f, -(pick(rng) % 6));  // primary / AO rays
@@ -179,12 +198,18 @@ int main(int argc, char **argv) {
 		// the scaled form serves the ambient-occlusion rays where walk_scale_for() allows it
 		const float scale = (c & 1) == 0 ? ocrt::walk_scale_for(max_distance) : 0.0f;
 		const float scaled_reach = scale > 0.0f ? max_distance * 1.001f : 0.0f;
-		float plo[3], phi[3];
+		float plo[3], phi[3], centre[3], half[3];
 		for (int k = 0; k < 3; ++k) {
 			const double box = std::fmax(std::fabs((double) lo[k]), std::fabs((double) hi[k]));
 			const double origin = std::fmin(2.0 * scene + 4.0, std::fmax(camera[k], box + reach));
 			plo[k] = unpadded ? lo[k] : ocrt::padded_bound(lo[k], (float) origin, false, scaled_reach);
 			phi[k] = unpadded ? hi[k] : ocrt::padded_bound(hi[k], (float) origin, true, scaled_reach);
+			if (unpadded) {
+				centre[k] = 0.5f * lo[k] + 0.5f * hi[k];
+				half[k] = std::fmax(centre[k] - lo[k], hi[k] - centre[k]);
+			} else {
+				ocrt::padded_centre_extent(plo[k], phi[k], (float) origin, &centre[k], &half[k]);
+			}
 		}
 		if (scale > 0.0f) {
 			bool unit_like = true;  // (ray_is_selectable: finite reciprocals are those of a unit vector's components)
@@ -195,6 +220,9 @@ int main(int argc, char **argv) {
 				if (!scaled_slab(plo, phi, o, d, scale) && ++scaled_failures <= 10 && !unpadded)
 					std::printf("MISSED (scaled): o %a %a %a d %a %a %a lo %a %a %a hi %a %a %a md %a\n", o[0], o[1], o[2], d[0], d[1],
 					            d[2], lo[0], lo[1], lo[2], hi[0], hi[1], hi[2], max_distance);
+				if (!ce_slab(centre, half, o, d, scale) && ++ce_failures <= 10 && !unpadded)
+					std::printf("MISSED (centre / half-extent): o %a %a %a d %a %a %a lo %a %a %a hi %a %a %a md %a\n", o[0], o[1], o[2], d[0],
+					            d[1], d[2], lo[0], lo[1], lo[2], hi[0], hi[1], hi[2], max_distance);
 			}
 		}
 		const float below = std::nextafter(max_distance, -INF);
@@ -205,8 +233,9 @@ int main(int argc, char **argv) {
 		}
 	}
 	std::printf("%ld pairs accepted by the reference's box test, %ld of them missed by the conservative test\n", accepted, failures);
-	std::printf("%ld of those through the scaled test as well, %ld of them missed\n", scaled_cases, scaled_failures);
+	std::printf("%ld of those through the scaled test as well, %ld of them missed; %ld missed by its centre / half-extent form\n",
+	            scaled_cases, scaled_failures, ce_failures);
 	if (unpadded)
-		return failures > 0 && scaled_failures > 0 ? 0 : 1;
-	return failures == 0 && scaled_failures == 0 && accepted > cases / 100 && scaled_cases > cases / 400 ? 0 : 1;
+		return failures > 0 && scaled_failures > 0 && ce_failures > 0 ? 0 : 1;
+	return failures == 0 && scaled_failures == 0 && ce_failures == 0 && accepted > cases / 100 && scaled_cases > cases / 400 ? 0 : 1;
 }
