@@ -176,6 +176,10 @@ void rt_ring_destroy(rt_ring *r);
 int rt_ring_upload(rt_ring *r, const uint32_t *faces, uint32_t num_faces, const uint32_t *nodes, uint32_t num_nodes,
                    const float *aabbs, const float *vertices, uint32_t num_vertices, const float *vnormals);
 int rt_ring_upload_scene(rt_ring *r, const rt_scene *s);
+/* What the last upload put on the device: the bytes of the scene's arrays, how many copies of them exist among the
+ * ring's hosts (ONE: the hosts share the arrays, like the single upload of src/opencl_host.cc:120-136) and the bytes
+ * of everything requested, per-host frame buffers included.  Out pointers may be NULL. */
+int rt_ring_device_bytes(const rt_ring *r, uint64_t *scene_bytes, uint32_t *scene_copies, uint64_t *total_bytes);
 uint32_t rt_ring_size(const rt_ring *r);        /* hosts */
 /* Band buffers: frame f is rendered by host f % size into buffer f % slots, slots = 2 * size, so that a frame's bands
  * (and, with a communicator, its assembled image) stay untouched while the next `size` frames are submitted. */

@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 import os
 from typing import Optional
 
@@ -132,6 +133,7 @@ _SIGNATURES = {
     "rt_ring_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                  C.c_uint32, C.c_void_p]),
     "rt_ring_upload_scene": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rt_ring_device_bytes": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
     "rt_ring_size": (C.c_uint32, [C.c_void_p]),
     "rt_ring_slots": (C.c_uint32, [C.c_void_p]),
     "rt_ring_local_rows": (C.c_uint32, [C.c_void_p]),
@@ -177,7 +179,14 @@ def load_library() -> C.CDLL:
             )
         lib = C.CDLL(path)
         for name, (restype, argtypes) in _SIGNATURES.items():
-            fn = getattr(lib, name)
+            try:
+                fn = getattr(lib, name)
+            except AttributeError:
+                # an OLDER build of the library loaded on purpose for an A/B run (OCRT_LIB_DIR): it may lack the newest
+                # entry points, which such a run does not call; the product library must export every one of them
+                if os.environ.get("OCRT_LIB_DIR"):
+                    continue
+                raise
             fn.restype = restype
             fn.argtypes = argtypes
         _LIB = lib
@@ -303,9 +312,11 @@ class Host:
             _raise_last()
 
     @classmethod
-    def _borrowed(cls, options: Options, handle: int) -> "Host":
+    def _borrowed(cls, options: Options, handle: int, owner=None) -> "Host":
+        """A view of a host that `owner` (a FrameRing) owns: it keeps the owner alive, and the owner's close() takes the
+        handle away (`_h = None`: every later call then fails with RtError / returns 0 instead of touching freed memory)."""
         h = cls.__new__(cls)
-        h.options, h._h, h._owned = options, handle, False
+        h.options, h._h, h._owned, h._owner = options, handle, False, owner
         return h
 
     def close(self) -> None:
@@ -436,6 +447,13 @@ class FrameRing:
 
     def close(self) -> None:
         if getattr(self, "_r", None):
+            # the hosts handed out by host() point into the ring: they die with it
+            for ref in getattr(self, "_lent", []):
+                h = ref()
+                if h is not None:
+                    h._h = None
+                    h._owner = None
+            self._lent = []
             load_library().rt_ring_destroy(self._r)
             self._r = None
 
@@ -447,6 +465,12 @@ class FrameRing:
 
     def upload_scene(self, scene: "Scene") -> None:
         _check(load_library().rt_ring_upload_scene(self._r, scene._h))
+
+    def device_bytes(self):
+        """(bytes of the scene's arrays on the device, copies of them among the hosts -- one --, bytes of everything requested)."""
+        a, c, t = C.c_uint64(), C.c_uint32(), C.c_uint64()
+        _check(load_library().rt_ring_device_bytes(self._r, C.byref(a), C.byref(c), C.byref(t)))
+        return int(a.value), int(c.value), int(t.value)
 
     @property
     def size(self) -> int:
@@ -470,7 +494,12 @@ class FrameRing:
         h = load_library().rt_ring_host(self._r, slot)
         if not h:
             raise IndexError(slot)
-        return Host._borrowed(self.options, h)
+        host = Host._borrowed(self.options, h, owner=self)  # (the view keeps the ring alive)
+        if not hasattr(self, "_lent"):
+            self._lent = []
+        self._lent = [r for r in self._lent if r() is not None]
+        self._lent.append(weakref.ref(host))
+        return host
 
     @property
     def hosts(self):

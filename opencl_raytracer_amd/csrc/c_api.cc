@@ -1,6 +1,7 @@
 // c_api.cc -- the extern "C" boundary declared in include/rt_hip.h.
 #include "../../include/rt_hip.h"
 
+#include <algorithm>
 #include <hip/hip_runtime.h>
 
 #include <cstring>
@@ -294,6 +295,8 @@ uint32_t rt_partition_global_row(const rt_options *o, uint32_t rank, uint32_t nr
 }
 
 uint32_t rt_local_to_global_row(const rt_host *h, uint32_t local_row) {
+	if (!h)
+		return 0xFFFFFFFFu;
 	const ocrt::KernelParams &p = h->dev->params();
 	const RayTracer::Options &ro = h->dev->rayTracer().options;
 	rt_options o{};
@@ -400,6 +403,25 @@ int rt_ring_upload_scene(rt_ring *r, const rt_scene *s) {
 		return fail(RT_E_STATE, "scene has no BVH yet (call rt_scene_build_bvh)");
 	return guarded([&] {
 		r->ring->upload(ocrt::pack_scene(s->sorted_faces, s->bvh.nodes, s->bvh.aabbs, s->mesh.vertices, s->mesh.vnormals));
+	});
+}
+
+int rt_ring_device_bytes(const rt_ring *r, uint64_t *scene_bytes, uint32_t *scene_copies, uint64_t *total_bytes) {
+	if (!r)
+		return fail(RT_E_INVALID, "null argument");
+	return guarded([&] {
+		std::vector<const ocrt::DeviceScene *> seen;
+		for (uint32_t k = 0; k < r->ring->size(); ++k) {
+			const ocrt::DeviceScene *s = r->ring->host(k).deviceScene().get();
+			if (s && std::find(seen.begin(), seen.end(), s) == seen.end())
+				seen.push_back(s);
+		}
+		if (scene_bytes)
+			*scene_bytes = seen.empty() ? 0 : seen.front()->bytes();
+		if (scene_copies)
+			*scene_copies = (uint32_t) seen.size();
+		if (total_bytes)
+			*total_bytes = r->ring->uploadedBytes();
 	});
 }
 

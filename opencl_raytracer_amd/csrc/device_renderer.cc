@@ -71,11 +71,6 @@ DeviceRenderer::DeviceRenderer(const RayTracer::Options &options, int device_, u
 	, local_out_rows(0)
 	, own_stream(nullptr)
 	, stream(nullptr)
-	, d_nodes(nullptr)
-	, d_walk(nullptr)
-	, d_tris(nullptr)
-	, d_shade(nullptr)
-	, d_ao(nullptr)
 	, d_image(nullptr)
 	, d_u8(nullptr)
 	, d_hits(nullptr)
@@ -119,7 +114,7 @@ DeviceRenderer::DeviceRenderer(const RayTracer::Options &options, int device_, u
 	part.rank = rank;
 	part.nranks = nranks;
 	part.band_tile_rows = band_tile_rows_for(grid);
-	kp = make_kernel_params(rt, 0, 0, 0, part, nullptr, nullptr);
+	kp = make_kernel_params(rt, 0, 0, 0, part, nullptr);
 	local_out_rows = kp.local_tile_rows * TILE_H / grid;
 	tile_count = (size_t) kp.tiles_x * kp.local_tile_rows;
 
@@ -153,6 +148,7 @@ DeviceRenderer::DeviceRenderer(const RayTracer::Options &options, int device_, u
 	d_tile_hits = device_alloc(tile_count * sizeof(uint32_t));
 	d_order = device_alloc(order_slots * sizeof(uint32_t));
 	d_counters = device_alloc(sizeof(FrameCounters));
+	OCRT_HIP(hipMemsetAsync(d_counters, 0, sizeof(FrameCounters), (hipStream_t) stream));  // (once: the kernels keep it clean, device_types.h)
 	{
 		hipDeviceProp_t prop;
 		OCRT_HIP(hipGetDeviceProperties(&prop, device));
@@ -195,11 +191,7 @@ DeviceRenderer::~DeviceRenderer() {
 void DeviceRenderer::useDevice() const { OCRT_HIP(hipSetDevice(device)); }
 
 void DeviceRenderer::freeScene() {
-	device_free(d_nodes);
-	device_free(d_walk);
-	device_free(d_tris);
-	device_free(d_shade);
-	device_free(d_ao);
+	scene_on_device.reset();  // (the arrays go when the last renderer lets go of them)
 	scene_ready = false;
 }
 
@@ -210,58 +202,105 @@ std::string DeviceRenderer::deviceName() const {
 	return prop.name;
 }
 
-size_t DeviceRenderer::upload(const PackedScene &scene) {
-	useDevice();
-	synchronize();
-	freeScene();
-	uint32_t ao_dirs = 0;
+std::shared_ptr<const DeviceScene> DeviceScene::create(int device, const PackedScene &scene, const RayTracer::Options &opts) {
+	OCRT_HIP(hipSetDevice(device));
+	std::shared_ptr<DeviceScene> out(new DeviceScene());
+	out->device_index = device;
 	std::vector<float> table;
-	if (opts.enableAO && opts.aoNumSamples > 0) {
+	out->ao_on = opts.enableAO && opts.aoNumSamples > 0;
+	out->ao_method = (int) opts.aoMethod;
+	out->ao_samples = opts.aoNumSamples;
+	out->ao_alpha_min = opts.aoAlphaMin;
+	out->ao_alpha_max = opts.aoAlphaMax;
+	if (out->ao_on) {
 		if (opts.aoMethod == RayTracer::AmbientOcclusionMethod::UNIFORM) {
 			// The reference's order, ring by ring.  (The occlusion count of a hit is a sum over the directions, so the order is
 			// free: while a workgroup's four waves took FIXED quarters of a tile's directions the table was dealt round-robin
 			// to the quarters so that they cost about the same; with the claim's cursor -- kernels.hip, ao_kernel -- the waves
 			// balance themselves, and neighbouring directions cast at the same time are worth 0.5-2 %.)
 			table = uniform_ao_table(opts.aoNumSamples, opts.aoAlphaMin, opts.aoAlphaMax);
-			ao_dirs = (uint32_t) (table.size() / 4);
+			out->ao_dirs = (uint32_t) (table.size() / 4);
 		} else {
 			// RANDOM casts the normal ray plus AO_NUM_SAMPLES + 1 random ones (reference :260-275)
-			ao_dirs = opts.aoNumSamples + 2;
+			out->ao_dirs = opts.aoNumSamples + 2;
 		}
 	}
-	const bool ao_on = opts.enableAO && opts.aoNumSamples > 0;
-	const float walk_distance = ao_on ? kernel_float(opts.aoMaxDistance) : 0.0f;
-	const std::shared_ptr<const WalkArray> made = (scene.walk && scene.walk_max_distance == walk_distance)
-	                                                  ? scene.walk : std::make_shared<const WalkArray>(make_walk_array(scene, walk_distance));
+	out->walk_distance = out->ao_on ? kernel_float(opts.aoMaxDistance) : 0.0f;
+	const std::shared_ptr<const WalkArray> made = (scene.walk && scene.walk_max_distance == out->walk_distance)
+	                                                  ? scene.walk : std::make_shared<const WalkArray>(make_walk_array(scene, out->walk_distance));
 	const WalkArray &walk = *made;
-	kp = make_kernel_params(rt, (uint32_t) scene.nodes.size(), (uint32_t) scene.tris.size(), ao_dirs, part, &scene, &walk);
-	kp.shared_device = device_share > 1u ? 1 : 0;
+	out->scene_facts_ = scene_facts(scene, walk);
+	out->node_count = (uint32_t) scene.nodes.size();
+	out->tri_count = (uint32_t) scene.tris.size();
 	const size_t nodes_bytes = scene.nodes.size() * sizeof(NodeRec);
 	const size_t tris_bytes = scene.tris.size() * sizeof(TriRec);
 	const size_t shade_bytes = scene.shade.size() * sizeof(ShadeRec);
 	const size_t ao_bytes = table.size() * sizeof(float);
 	// one node of zero padding: the shared walk fetches a node together with its successor
-	d_nodes = device_alloc(nodes_bytes + sizeof(NodeRec));
-	OCRT_HIP(hipMemset((char *) d_nodes + nodes_bytes, 0, sizeof(NodeRec)));
+	out->d_nodes = device_alloc(nodes_bytes + sizeof(NodeRec));
+	OCRT_HIP(hipMemset((char *) out->d_nodes + nodes_bytes, 0, sizeof(NodeRec)));
 	const size_t walk_bytes = walk.nodes.size() * sizeof(NodeRec);
 	if (walk_bytes) {
-		d_walk = device_alloc(walk_bytes);
-		OCRT_HIP(hipMemcpy(d_walk, walk.nodes.data(), walk_bytes, hipMemcpyHostToDevice));
+		out->d_walk = device_alloc(walk_bytes);
+		OCRT_HIP(hipMemcpy(out->d_walk, walk.nodes.data(), walk_bytes, hipMemcpyHostToDevice));
 	}
-	d_tris = device_alloc(tris_bytes);
-	d_shade = device_alloc(shade_bytes);
-	d_ao = device_alloc(ao_bytes);
-	OCRT_HIP(hipMemcpy(d_nodes, scene.nodes.data(), nodes_bytes, hipMemcpyHostToDevice));
-	OCRT_HIP(hipMemcpy(d_tris, scene.tris.data(), tris_bytes, hipMemcpyHostToDevice));
-	OCRT_HIP(hipMemcpy(d_shade, scene.shade.data(), shade_bytes, hipMemcpyHostToDevice));
+	out->d_tris = device_alloc(tris_bytes);
+	out->d_shade = device_alloc(shade_bytes);
+	out->d_ao = device_alloc(ao_bytes);
+	OCRT_HIP(hipMemcpy(out->d_nodes, scene.nodes.data(), nodes_bytes, hipMemcpyHostToDevice));
+	OCRT_HIP(hipMemcpy(out->d_tris, scene.tris.data(), tris_bytes, hipMemcpyHostToDevice));
+	OCRT_HIP(hipMemcpy(out->d_shade, scene.shade.data(), shade_bytes, hipMemcpyHostToDevice));
 	if (ao_bytes)
-		OCRT_HIP(hipMemcpy(d_ao, table.data(), ao_bytes, hipMemcpyHostToDevice));
+		OCRT_HIP(hipMemcpy(out->d_ao, table.data(), ao_bytes, hipMemcpyHostToDevice));
 	OCRT_HIP(hipDeviceSynchronize());
+	out->device_bytes = nodes_bytes + walk_bytes + tris_bytes + shade_bytes + ao_bytes;
+	return out;
+}
+
+DeviceScene::~DeviceScene() {
+	if (hipSetDevice(device_index) != hipSuccess)
+		return;
+	device_free(d_nodes);
+	device_free(d_walk);
+	device_free(d_tris);
+	device_free(d_shade);
+	device_free(d_ao);
+}
+
+bool DeviceScene::servesOptions(const RayTracer::Options &opts) const {
+	const bool on = opts.enableAO && opts.aoNumSamples > 0;
+	if (on != ao_on)
+		return false;
+	if (!on)
+		return true;
+	return (int) opts.aoMethod == ao_method && opts.aoNumSamples == ao_samples && opts.aoAlphaMin == ao_alpha_min &&
+	       opts.aoAlphaMax == ao_alpha_max && kernel_float(opts.aoMaxDistance) == walk_distance;
+}
+
+size_t DeviceRenderer::upload(const PackedScene &scene) {
+	useDevice();
+	synchronize();
+	freeScene();
+	std::shared_ptr<const DeviceScene> made = DeviceScene::create(device, scene, opts);
+	const size_t scene_bytes = made->bytes();
+	return scene_bytes + adopt(std::move(made));
+}
+
+size_t DeviceRenderer::adopt(std::shared_ptr<const DeviceScene> scene) {
+	if (!scene || scene->device() != device)
+		throw std::invalid_argument("the scene lives on another device than the renderer");
+	if (!scene->servesOptions(opts))
+		throw std::invalid_argument("the scene on the device was made for other ambient-occlusion options than the renderer's");
+	useDevice();
+	synchronize();
+	freeScene();
+	kp = make_kernel_params(rt, scene->nodeCount(), scene->triCount(), scene->aoDirs(), part, &scene->facts());
+	kp.shared_device = device_share > 1u ? 1 : 0;
+	scene_on_device = std::move(scene);
 	scene_ready = true;
 	++scene_version;  // (a captured frame bakes the scene's pointers and launch constants in)
-	return nodes_bytes + walk_bytes + tris_bytes + shade_bytes + ao_bytes + image_bytes +
-	       (size_t) local_out_rows * opts.width + tile_count * (64 * (sizeof(HitRec) + sizeof(uint32_t)) + 2 * sizeof(uint32_t)) +
-	       sizeof(FrameCounters);
+	return image_bytes + (size_t) local_out_rows * opts.width +
+	       tile_count * (64 * (sizeof(HitRec) + sizeof(uint32_t)) + 2 * sizeof(uint32_t)) + sizeof(FrameCounters);
 }
 
 DeviceRenderer::FrameEvents DeviceRenderer::takeEvents() {
@@ -281,25 +320,24 @@ DeviceRenderer::FrameEvents DeviceRenderer::takeEvents() {
 	return ev;
 }
 
-// The launches of one frame on the stream: counters, primary pass, ordering step + ambient-occlusion pass + resolve
-// (launch_ao), and -- with a destination -- the device resize.  `ao_start` / `ao_stop` bracket the ao_kernel launch.
+// The launches of one frame on the stream: primary pass (with the ordering step in its tail), ambient-occlusion pass,
+// finishing kernel (AO factor into the float image and -- with a destination -- the device resize in the same sweep).
+// `ao_start` / `ao_stop` bracket the ao_kernel launch.
 void DeviceRenderer::launchFrame(void *device_u8, void *ao_start, void *ao_stop) {
 #ifdef OCRT_STAMPS
 	hipStream_t s = (hipStream_t) stream;
 #endif
-	const SceneBuffers scene{ d_nodes, d_walk, d_tris, d_shade, d_ao };
-	launch_primary(scene, (float *) d_image, d_hits, d_occluded, d_tile_hits, d_counters, kp, stream);  // (clears the counters first)
+	const SceneBuffers scene = scene_on_device->buffers();
+	launch_primary(scene, (float *) d_image, d_hits, d_occluded, d_tile_hits, d_order, d_counters, kp, stream);
 	OCRT_HIP(hipGetLastError());
 #ifdef OCRT_STAMPS  // (instrumented build: the AO pass takes the minimum of its waves' start times into this slot)
 	OCRT_HIP(hipMemsetAsync((char *) d_counters + offsetof(FrameCounters, stamp) + 7 * sizeof(unsigned long long), 0xFF, sizeof(unsigned long long), s));
 #endif
-	launch_ao(scene, (float *) d_image, d_hits, d_occluded, d_tile_hits, d_order, d_counters, kp,
-	          ao_blocks_override ? ao_blocks_override : aoWorkgroups(), stream, ao_start, ao_stop);
+	launch_ao(scene, d_hits, d_occluded, d_order, d_counters, kp, ao_blocks_override ? ao_blocks_override : aoWorkgroups(), stream,
+	          ao_start, ao_stop);
 	OCRT_HIP(hipGetLastError());
-	if (device_u8) {
-		launch_resize((const float *) d_image, (unsigned char *) device_u8, kp, opts.width, grid, local_out_rows, stream);
-		OCRT_HIP(hipGetLastError());
-	}
+	launch_finish((float *) d_image, d_hits, d_occluded, d_counters, (unsigned char *) device_u8, kp, opts.width, grid, local_out_rows, stream);
+	OCRT_HIP(hipGetLastError());
 }
 
 void DeviceRenderer::enqueueRender() {
@@ -452,8 +490,11 @@ void DeviceRenderer::synchronize() {
 			OCRT_HIP(hipEventElapsedTime(&ao_ms, (hipEvent_t) ev.ao_start, (hipEvent_t) ev.ao_stop));
 			OCRT_HIP(hipEventElapsedTime(&ao_begin_after_start, (hipEvent_t) ev.start, (hipEvent_t) ev.ao_start));
 		} else if (ev.graph_ao && newest && keep_stamps) {
-			unsigned long long tick[3] = { 0, 0, 0 };
-			OCRT_HIP(hipMemcpy(tick, (const char *) d_counters + offsetof(FrameCounters, tick_begin), sizeof tick, hipMemcpyDeviceToHost));
+			FrameCounters c{};
+			OCRT_HIP(hipMemcpy(&c, d_counters, sizeof c, hipMemcpyDeviceToHost));
+			unsigned long long tick[3] = { c.tick_begin, 0, c.tick_ao_end };
+			for (const GroupQueue &q : c.queue)  // the ambient-occlusion pass may begin when the last group is ordered
+				tick[1] = q.tick_ordered > tick[1] ? q.tick_ordered : tick[1];
 			if (tick[2] >= tick[1] && tick[1] >= tick[0] && tick[0] != 0) {
 				ao_ms = (float) ((double) (tick[2] - tick[1]) * 1e-5);  // 100 MHz clock -> ms
 				ao_begin_after_start = (float) ((double) (tick[1] - tick[0]) * 1e-5);
@@ -538,8 +579,9 @@ RenderStats DeviceRenderer::stats() {
 	synchronize();
 	FrameCounters c{};
 	OCRT_HIP(hipMemcpy(&c, d_counters, sizeof c, hipMemcpyDeviceToHost));
-	out.primary_hits = c.primary_hits;
-	out.ao_occluded = c.occluded;
+	for (const GroupQueue &q : c.queue)
+		out.primary_hits += q.hits;
+	out.ao_occluded = kp.ao_mode != AO_NONE && kp.ao_dirs > 0 ? c.occluded : 0;
 #ifdef OCRT_TAIL
 	std::fprintf(stderr, "AO pass: last wave ended %.3f ms after the ordering step; waves by the time they ended at (0.05 ms buckets):", (c.stamp[8] - c.stamp[7]) * 1e-5);
 	for (int k = 0; k < 32; ++k)

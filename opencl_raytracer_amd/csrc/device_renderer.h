@@ -5,6 +5,7 @@
 // return codes) decide what to do with them.
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -27,6 +28,45 @@ int visible_device_count();
 // and builds the BVH (render.cc).
 void warm_up_device(int device);
 
+// One uploaded scene on one GPU: node arrays, leaf records, normals, direction table.  Immutable once made and
+// reference-counted, so that every renderer of that GPU that renders the scene -- the hosts of a frame ring -- walks
+// the SAME arrays: one upload, one copy in HBM, and the frames that overlap on the device find each other's nodes in
+// the XCDs' L2 and the scalar caches instead of competing for them with identical copies (the reference uploads a scene
+// once, src/opencl_host.cc:120-136).  Holds what the launch constants need to know of it as well.
+class DeviceScene {
+	public:
+		// Blocking upload; `options`: the direction table (AO samples, angles, method) and the any-hit rays' reach
+		// (AO_MAX_DISTANCE, which sizes the walk array's margins) are baked in -- servesOptions() says whether another
+		// renderer's options agree.
+		static std::shared_ptr<const DeviceScene> create(int device, const PackedScene &scene, const RayTracer::Options &options);
+		~DeviceScene();
+		DeviceScene(const DeviceScene &) = delete;
+		DeviceScene &operator=(const DeviceScene &) = delete;
+		bool servesOptions(const RayTracer::Options &options) const;
+
+		SceneBuffers buffers() const { return SceneBuffers{ d_nodes, d_walk, d_tris, d_shade, d_ao }; }
+		int device() const { return device_index; }
+		size_t bytes() const { return device_bytes; }  // requested on the device
+		uint32_t nodeCount() const { return node_count; }
+		uint32_t triCount() const { return tri_count; }
+		uint32_t aoDirs() const { return ao_dirs; }
+		const SceneFacts &facts() const { return scene_facts_; }
+
+	private:
+		DeviceScene() = default;
+		int device_index = 0;
+		void *d_nodes = nullptr, *d_walk = nullptr, *d_tris = nullptr, *d_shade = nullptr, *d_ao = nullptr;
+		size_t device_bytes = 0;
+		uint32_t node_count = 0, tri_count = 0, ao_dirs = 0;
+		SceneFacts scene_facts_;
+		// what of the options went into it
+		bool ao_on = false;
+		int ao_method = 0;
+		unsigned int ao_samples = 0;
+		int ao_alpha_min = 0, ao_alpha_max = 0;
+		float walk_distance = 0.0f;
+};
+
 class DeviceRenderer {
 	public:
 		// `ring_slot`: this renderer's index among the renderers that take frames in turn on its GPU (FrameRing), -1 for
@@ -36,8 +76,12 @@ class DeviceRenderer {
 		DeviceRenderer(const DeviceRenderer &) = delete;
 		DeviceRenderer &operator=(const DeviceRenderer &) = delete;
 
-		// Blocking upload of a packed scene; returns the bytes requested on the device.
+		// Blocking upload of a packed scene; returns the bytes requested on the device (scene + this renderer's buffers).
 		size_t upload(const PackedScene &scene);
+		// Renders a scene that is on the device already (DeviceScene::create on this renderer's device, for options that
+		// agree with this renderer's: std::invalid_argument otherwise); returns the bytes of this renderer's own buffers.
+		size_t adopt(std::shared_ptr<const DeviceScene> scene);
+		const std::shared_ptr<const DeviceScene> &deviceScene() const { return scene_on_device; }
 
 		// Enqueues the ray-casting kernel for this rank's bands on the stream.
 		void enqueueRender();
@@ -124,7 +168,8 @@ class DeviceRenderer {
 		uint32_t grid;            // supersample grid side
 		uint32_t local_out_rows;
 		void *own_stream, *stream;
-		void *d_nodes, *d_walk, *d_tris, *d_shade, *d_ao, *d_image, *d_u8, *d_hits, *d_occluded, *d_tile_hits, *d_order, *d_counters;
+		std::shared_ptr<const DeviceScene> scene_on_device;
+		void *d_image, *d_u8, *d_hits, *d_occluded, *d_tile_hits, *d_order, *d_counters;
 		size_t image_bytes;  // float image of this rank's bands
 		size_t tile_count;
 		uint32_t compute_units;
@@ -162,11 +207,12 @@ class DeviceRenderer {
 
 // kernels.hip
 void preload_kernels();
-void launch_primary(const SceneBuffers &scene, float *image, void *hits, void *occluded_of, void *tile_hits,
+void launch_primary(const SceneBuffers &scene, float *image, void *hits, void *occluded_of, void *tile_hits, void *order,
                     void *counters, const KernelParams &P, void *stream);
-void launch_ao(const SceneBuffers &scene, float *image, void *hits, void *occluded_of, void *tile_hits, void *order,
-               void *counters, const KernelParams &P, uint32_t workgroups, void *stream, void *event_before_ao,
-               void *event_after_ao);
+void launch_ao(const SceneBuffers &scene, void *hits, void *occluded_of, void *order, void *counters, const KernelParams &P,
+               uint32_t workgroups, void *stream, void *event_before_ao, void *event_after_ao);
+void launch_finish(float *image, const void *hits, const void *occluded_of, void *counters, unsigned char *out,
+                   const KernelParams &P, uint32_t out_width, uint32_t n, uint32_t local_out_rows, void *stream);
 void launch_resize(const float *tmp, unsigned char *out, const KernelParams &P, uint32_t out_width, uint32_t n,
                    uint32_t local_out_rows, void *stream);
 

@@ -63,12 +63,17 @@ FrameRing::~FrameRing() {
 
 size_t FrameRing::upload(const PackedScene &scene) {
 	drain();
-	size_t bytes = 0;
+	// ONE copy of the scene on the GPU, whatever the number of hosts: they all walk the same arrays
 	for (auto &h : hosts)
-		bytes += h->upload(scene);
+		h->synchronize();
+	std::shared_ptr<const DeviceScene> on_device = DeviceScene::create(hosts.front()->deviceIndex(), scene, hosts.front()->rayTracer().options);
+	size_t bytes = on_device->bytes();
+	for (auto &h : hosts)
+		bytes += h->adopt(on_device);
 	// every host's two frames are captured now, not in the middle of the stream that follows
 	for (unsigned int slot = 0; slot < bound.size(); ++slot)
 		hosts[slot % hosts.size()]->prepareFrame(bufferOf(slot));
+	uploaded_bytes = bytes;
 	return bytes;
 }
 

@@ -31,6 +31,7 @@ class FrameRing {
 		FrameRing &operator=(const FrameRing &) = delete;
 
 		size_t upload(const PackedScene &scene);  // every renderer of the ring; returns the bytes requested on the device
+		size_t uploadedBytes() const { return uploaded_bytes; }  // what the last upload() returned
 		unsigned int size() const { return (unsigned int) hosts.size(); }
 		DeviceRenderer &host(unsigned int slot) { return *hosts.at(slot); }
 		void setGraphMode(bool on);
@@ -109,6 +110,7 @@ class FrameRing {
 		std::unique_ptr<BandGather> gather;
 		std::vector<bool> gather_pending; // per slot: a gather of this slot's bands was enqueued and not yet waited for
 		uint64_t next_frame;
+		size_t uploaded_bytes = 0;
 		Collected last;
 		bool have_last;
 		void *epoch;  // hipEvent_t

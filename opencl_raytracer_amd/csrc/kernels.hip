@@ -611,6 +611,18 @@ __device__ __forceinline__ u32x8 scalar_load_node(const float4 *nodes_ptr, uint3
 	"\ts_cmp_ge_u32 %[waiting], 64\n"                   \
 	"\ts_cbranch_scc1 .Lw_full_%=\n"                    \
 	"\ts_branch " NEXT "\n"
+// (experiment, -DOCRT_PREFETCH=1|2|3: once a pair has arrived, touch the line the walk goes to if `a` is missed (1), the
+// line behind the pair (2), or both (3), with a one-dword scalar load nobody reads: the next turn's load then finds it
+// in the scalar cache or on its way)
+#if defined(OCRT_PREFETCH) && OCRT_PREFETCH == 1
+#define OCRT_WALK_PREFETCH "\ts_add_u32 s46, %[at], s51\n\ts_load_dword s47, %[base], s46\n"
+#elif defined(OCRT_PREFETCH) && OCRT_PREFETCH == 2
+#define OCRT_WALK_PREFETCH "\ts_add_u32 s46, %[at], 64\n\ts_load_dword s47, %[base], s46\n"
+#elif defined(OCRT_PREFETCH) && OCRT_PREFETCH == 3
+#define OCRT_WALK_PREFETCH "\ts_add_u32 s46, %[at], s51\n\ts_load_dword s47, %[base], s46\n\ts_add_u32 s46, %[at], 64\n\ts_load_dword s47, %[base], s46\n"
+#else
+#define OCRT_WALK_PREFETCH
+#endif
 #define OCRT_WALK_ASM(TEST_A, TEST_B)                       \
 	"\ts_branch .Lw_node_%=\n"                              \
 	".Lw_miss_a_%=:\n"                                      \
@@ -618,6 +630,7 @@ __device__ __forceinline__ u32x8 scalar_load_node(const float4 *nodes_ptr, uint3
 	".Lw_node_%=:\n"                                        \
 	"\ts_load_dwordx16 s[48:63], %[base], %[at]\n"          \
 	"\ts_waitcnt lgkmcnt(0)\n"                              \
+	OCRT_WALK_PREFETCH                                      \
 	TEST_A                                                  \
 	"\ts_and_b64 s[44:45], vcc, %[alive]\n"                 \
 	"\ts_cbranch_scc0 .Lw_miss_a_%=\n"                      \
@@ -939,42 +952,54 @@ __device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ n
 // neighbouring workgroups of a group touch the same BVH region, while every
 // group still sees the whole image height.
 
-// ---------------------------------------------------------------------------
-// Pass 1: primary rays.  Four independent waves per workgroup, one tile each.
-// ---------------------------------------------------------------------------
-#ifndef OCRT_PRIMARY_WAVES
-#define OCRT_PRIMARY_WAVES 4
-#endif
-constexpr uint32_t PRIMARY_WAVES = OCRT_PRIMARY_WAVES;  // 4, 8 or 16: a workgroup covers a block of tiles 2 wide and PRIMARY_WAVES / 2 high
-constexpr uint32_t PRIMARY_ROWS = PRIMARY_WAVES / 2u;
+// Kernel arguments that are READ AGAIN from the kernel-argument segment where they are used -- one scalar load each
+// (asm volatile: the compiler can neither hoist it out of a loop nor merge it with another) -- instead of being held in
+// scalar registers, and spilled from them to VGPR lanes, across the walks (see AoArgs).
+template <uint32_t OFFSET>
+__device__ __forceinline__ uint32_t cold_u32() {
+	uint32_t v;
+	asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "i"(OFFSET));
+	return v;
+}
+template <uint32_t OFFSET>
+__device__ __forceinline__ unsigned long long cold_u64() {
+	unsigned long long v;
+	asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "i"(OFFSET));
+	return v;
+}
+
+// The primary pass's arguments as one block (see AoArgs for why): the walk holds the two pointers at the head,
+// node_count, primary_below and batch_below in registers; what the tile's epilogue and the kernel's tail need is read
+// again there.
+struct PrimaryArgs {
+	const float4 *walk_ptr, *tris_ptr;
+	const float4 *nodes_ptr, *shade;
+	float *image;
+	HitRec *hits;
+	uint32_t *occluded_of, *tile_hits, *order;
+	FrameCounters *counters;
+	KernelParams P;
+};
+#define OCRT_PCOLD_U32(FIELD) cold_u32<(uint32_t) offsetof(PrimaryArgs, FIELD)>()
+#define OCRT_PCOLD_PTR(TYPE, FIELD) ((TYPE) cold_u64<(uint32_t) offsetof(PrimaryArgs, FIELD)>())
+
+// A hit sub-pixel that still waits for its ambient-occlusion factor holds, in the float image, a TAG instead of a value:
+// a negative quiet NaN whose low six bits are the sub-pixel's slot in its tile's part of the hit list (no value the
+// path computes is a NaN: the head-light term is clamped to [0, 1]).  The finishing kernel puts the value there.
+constexpr uint32_t PENDING_TAG = 0xFFC00000u;
+__device__ __forceinline__ bool is_pending(uint32_t bits) { return (bits & 0xFFFFFFC0u) == PENDING_TAG; }
 
 // SHARED: the shared walk.  (The A/B build also instantiates the first generation, SHARED = false; two instantiations,
 // so that its per-lane state stays out of the default path's register budget.)
+// One tile of the primary pass, one wave.
 template <bool SHARED>
-__global__ __launch_bounds__(64 * PRIMARY_WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void primary_kernel(
-    const float4 *__restrict__ nodes_ptr, const float4 *__restrict__ walk_ptr, const float4 *__restrict__ tris_ptr,
-    const float4 *__restrict__ shade,
-    float *__restrict__ image, HitRec *__restrict__ hits, uint32_t *__restrict__ occluded_of,
-    uint32_t *__restrict__ tile_hits, FrameCounters *__restrict__ counters, KernelParams P) {
-	__shared__ ClosestBatch closest_batches[PRIMARY_WAVES];
+__device__ __forceinline__ void primary_tile(const PrimaryArgs &A, ClosestBatch *closest_batches, uint32_t tile_x, uint32_t local_row) {
+	const KernelParams &P = A.P;  // (fields used BEFORE or IN the walk only; the epilogue reads its own again)
+	const float4 *__restrict__ const walk_ptr = A.walk_ptr, *__restrict__ const tris_ptr = A.tris_ptr;
+	const float4 *__restrict__ const nodes_ptr = A.nodes_ptr;  // (exact form and first-generation walk only)
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t wave = threadIdx.x >> 6;
 	const SceneViews scene = make_views(nodes_ptr, tris_ptr, P);
-
-	if (blockIdx.x == 0u && threadIdx.x == 0u)
-		counters->tick_begin = __builtin_amdgcn_s_memrealtime();
-	const uint32_t group = blockIdx.x & (XCD_GROUPS - 1u), seq = blockIdx.x >> 3;
-	const uint32_t strips = (P.tiles_x + 1u) >> 1;
-	const uint32_t row_blocks = (P.local_tile_rows + PRIMARY_ROWS - 1u) / PRIMARY_ROWS;
-	const uint32_t strips_here = (strips + XCD_GROUPS - 1u - group) >> 3;
-	if (seq >= strips_here * row_blocks)
-		return;
-	const uint32_t strip_index = seq / row_blocks;
-	const uint32_t row_block = seq - strip_index * row_blocks;
-	const uint32_t tile_x = 2u * (group + XCD_GROUPS * strip_index) + (wave & 1u);
-	const uint32_t local_row = PRIMARY_ROWS * row_block + (wave >> 1);
-	if (tile_x >= P.tiles_x || local_row >= P.local_tile_rows)
-		return;  // the waves of a workgroup never synchronise
 	const uint32_t tile = local_row * P.tiles_x + tile_x;
 	const uint32_t tile_y = global_tile_row(P.part, local_row);
 	const uint32_t x = tile_x * TILE_W + (lane & 7u);
@@ -1156,6 +1181,7 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) __attribute__((amdgpu_waves_per
 	float value = 0.0f;
 	float nx = 0.0f, ny = 0.0f, nz = 0.0f;
 	if (hit) {
+		const float4 *const shade = OCRT_PCOLD_PTR(const float4 *, shade);
 		const float4 n0 = shade[3 * (size_t) best.leaf + 0];
 		const float4 n1 = shade[3 * (size_t) best.leaf + 1];
 		const float4 n2 = shade[3 * (size_t) best.leaf + 2];
@@ -1165,16 +1191,17 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) __attribute__((amdgpu_waves_per
 		nz = (n0.z * b0 + n1.z * b1) + n2.z * b2;
 		normalize3(nx, ny, nz);
 		value = 1.0f;
-		if (P.shading)
+		if (OCRT_PCOLD_U32(P.shading))
 			value = fminf(fmaxf(-dot3(nx, ny, nz, dx, dy, dz), 0.0f), 1.0f);
 	}
-	const bool want_ao = P.ao_mode != AO_NONE && P.ao_dirs > 0;
-	if (active && !(hit && want_ao))
-		image[(size_t) local_y * P.width + x] = value;  // final already
-
+	const bool want_ao = OCRT_PCOLD_U32(P.ao_mode) != (uint32_t) AO_NONE && OCRT_PCOLD_U32(P.ao_dirs) > 0u;
+	const uint32_t image_width = OCRT_PCOLD_U32(P.width);
 	// the tile's hits go into the tile's own 64 slots of the hit list, compacted
 	const unsigned long long hit_mask = wave_ballot(hit);
 	const uint32_t hit_count = (uint32_t) __popcll(hit_mask);
+	const uint32_t slot_in_tile = rank_in(hit_mask);
+	if (active)  // final already, or the tag that says which slot will bring the ambient-occlusion factor
+		OCRT_PCOLD_PTR(float *, image)[(size_t) local_y * image_width + x] = (hit && want_ao) ? __uint_as_float(PENDING_TAG | slot_in_tile) : value;
 	if (lane == 0u) {
 		// hit count, and above it the tile's AO cost class 1..64 for the ordering step: its 28 AO packets
 		// walk about as far as the primary packet did (correlation 0.8-0.9, tools/analysis/packet_union.cc).
@@ -1183,79 +1210,93 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) __attribute__((amdgpu_waves_per
 		uint32_t cost = SHARED ? leaf_stops : hit_count;
 		cost = cost < 1u ? 1u : cost;
 		cost = cost > 64u ? 64u : cost;
-		tile_hits[tile] = (want_ao && hit_count) ? (hit_count | (cost << 8)) : 0u;
-		if (hit_count)
-			atomicAdd(&counters->primary_hits, hit_count);
+		// (a store that is coherent across the device: the workgroup that orders the group's tiles at the end of this very
+		// kernel reads the word with a load of the same kind -- primary_kernel's tail)
+		__hip_atomic_store(&OCRT_PCOLD_PTR(uint32_t *, tile_hits)[tile], hit_count | ((want_ao && hit_count) ? cost << 8 : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	}
 	if (hit && want_ao) {
 		HitRec rec;
 		rec.ox = best.px; rec.oy = best.py; rec.oz = best.pz;
 		rec.value = value;
 		rec.nx = nx; rec.ny = ny; rec.nz = nz;
-		rec.pixel = local_y * P.width + x;  // index into this rank's band image
-		const size_t slot = (size_t) tile * 64u + rank_in(hit_mask);
-		hits[slot] = rec;
-		occluded_of[slot] = 0u;
+		rec.pixel = local_y * image_width + x;  // index into this rank's band image
+		const size_t slot = (size_t) tile * 64u + slot_in_tile;
+		OCRT_PCOLD_PTR(HitRec *, hits)[slot] = rec;
+		OCRT_PCOLD_PTR(uint32_t *, occluded_of)[slot] = 0u;
 	}
 }
 
 // ---------------------------------------------------------------------------
-// Ordering step: per XCD group, blocks of 64 neighbouring tiles sorted by their AO
-// cost (sum of the tiles' cost classes from primary_kernel >> KernelParams::cost_shift,
-// capped: the costly blocks share the top key and keep their spatial order, the cheap ones
-// follow by cost -- scene_pack.cc says why); the tiles of a block stay together and in
-// spatial order (counting sort, one workgroup per group, one wave per block).
+// Ordering step of one XCD group, run by the LAST workgroup of the primary pass that finishes in the group (below):
+// blocks of 64 neighbouring tiles sorted by their AO cost (sum of the tiles' cost classes >> KernelParams::cost_shift,
+// capped: the costly blocks share the top key and keep their spatial order, the cheap ones follow by cost --
+// scene_pack.cc says why); the tiles of a block stay together and in spatial order (counting sort, one wave per
+// block).  Also sums the group's hit sub-pixels.  Every tile word is read with a device-coherent load: the words were
+// written by other workgroups of this kernel.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void order_kernel(const uint32_t *__restrict__ tile_hits,
-                                                     uint32_t *__restrict__ order, FrameCounters *__restrict__ counters,
-                                                     KernelParams P) {
-	__shared__ unsigned int bucket[65];  // non-empty tiles per key, then the keys' write cursors
-	__shared__ unsigned int cost_total;  // sum of the group's tiles' cost classes
-	const uint32_t group = blockIdx.x;
+struct OrderScratch {
+	unsigned int bucket[65];  // non-empty tiles per key, then the keys' write cursors
+	unsigned int cost_total;  // sum of the group's tiles' cost classes
+	unsigned int hit_total;   // hit sub-pixels of the group
+	unsigned int last;        // (primary_kernel's tail: this workgroup is the group's last)
+};
+__device__ __forceinline__ void order_group(const uint32_t *__restrict__ tile_hits, uint32_t *__restrict__ order,
+                                            FrameCounters *__restrict__ counters, uint32_t tiles_x, uint32_t local_tile_rows,
+                                            bool no_sort, uint32_t cost_shift, uint32_t group, OrderScratch &scratch, uint32_t waves) {
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-	const uint32_t strips = (P.tiles_x + 1u) >> 1;
+	const uint32_t strips = (tiles_x + 1u) >> 1;
 	const uint32_t strips_here = (strips + XCD_GROUPS - 1u - group) >> 3;
-	const uint32_t tiles_here = strips_here * 2u * P.local_tile_rows;  // incl. a possible column past the image
+	const uint32_t tiles_here = strips_here * 2u * local_tile_rows;  // incl. a possible column past the image
 	// this group's segment of `order` starts where the previous groups' capacity ends
 	uint32_t segment = 0u;
 	for (uint32_t g = 0; g < group; ++g)
-		segment += ((strips + XCD_GROUPS - 1u - g) >> 3) * 2u * P.local_tile_rows;
+		segment += ((strips + XCD_GROUPS - 1u - g) >> 3) * 2u * local_tile_rows;
 	if (threadIdx.x < 65u)
-		bucket[threadIdx.x] = 0u;
-	if (threadIdx.x == 0u)
-		cost_total = 0u;
+		scratch.bucket[threadIdx.x] = 0u;
+	if (threadIdx.x == 0u) {
+		scratch.cost_total = 0u;
+		scratch.hit_total = 0u;
+	}
 	__syncthreads();
-	// tile e of the group: strip (e / (2 * rows)), then row-major 2-wide; returns its cost class (0: no work)
-	auto class_of = [&](uint32_t e, uint32_t &tile) -> uint32_t {
+	// tile e of the group: strip (e / (2 * rows)), then row-major 2-wide; returns its word (0: nothing there)
+	auto word_of = [&](uint32_t e, uint32_t &tile) -> uint32_t {
 		if (e >= tiles_here)
 			return 0u;
-		const uint32_t per_strip = 2u * P.local_tile_rows;
+		const uint32_t per_strip = 2u * local_tile_rows;
 		const uint32_t strip_index = e / per_strip, within = e - strip_index * per_strip;
 		const uint32_t tile_x = 2u * (group + XCD_GROUPS * strip_index) + (within & 1u);
 		const uint32_t local_row = within >> 1;
-		tile = local_row * P.tiles_x + tile_x;
-		if (tile_x >= P.tiles_x)
+		tile = local_row * tiles_x + tile_x;
+		if (tile_x >= tiles_x)
 			return 0u;
-		return tile_hits[tile] >> 8;
+		return __hip_atomic_load(&tile_hits[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	};
 	// One wave per block of 64 spatially consecutive tiles (2 wide, 32 high).  key: the block's cost, 1..64.
 	const uint32_t n_blocks = (tiles_here + 63u) >> 6;
-	auto block_key = [&](uint32_t block, uint32_t &tile, uint32_t &cls, unsigned long long &work_mask, uint32_t &cost) -> uint32_t {
-		cls = class_of(block * 64u + lane, tile);
+	auto block_key = [&](uint32_t block, uint32_t &tile, uint32_t &word, unsigned long long &work_mask, uint32_t &cost) -> uint32_t {
+		word = word_of(block * 64u + lane, tile);
+		const uint32_t cls = word >> 8;
 		work_mask = wave_ballot(cls != 0u);
 		cost = cls;
 		for (int offset = 32; offset >= 1; offset >>= 1)
 			cost += (uint32_t) __shfl_xor((int) cost, offset);
-		const uint32_t key = P.debug_no_sort ? 1u : 1u + (cost >> P.cost_shift);
+		const uint32_t key = no_sort ? 1u : 1u + (cost >> cost_shift);
 		return key > 64u ? 64u : key;
 	};
-	for (uint32_t block = wave; block < n_blocks; block += 16u) {
-		uint32_t tile = 0u, cls, cost;
+	for (uint32_t block = wave; block < n_blocks; block += waves) {
+		uint32_t tile = 0u, word, cost;
 		unsigned long long work_mask;
-		const uint32_t key = block_key(block, tile, cls, work_mask, cost);
-		if (lane == 0u && work_mask != 0ull) {
-			atomicAdd(&bucket[key], (uint32_t) __popcll(work_mask));
-			atomicAdd(&cost_total, cost);
+		const uint32_t key = block_key(block, tile, word, work_mask, cost);
+		uint32_t hit_sum = word & 0xFFu;
+		for (int offset = 32; offset >= 1; offset >>= 1)
+			hit_sum += (uint32_t) __shfl_xor((int) hit_sum, offset);
+		if (lane == 0u) {
+			if (work_mask != 0ull) {
+				atomicAdd(&scratch.bucket[key], (uint32_t) __popcll(work_mask));
+				atomicAdd(&scratch.cost_total, cost);
+			}
+			if (hit_sum)
+				atomicAdd(&scratch.hit_total, hit_sum);
 		}
 	}
 	__syncthreads();
@@ -1263,34 +1304,98 @@ __global__ __launch_bounds__(1024) void order_kernel(const uint32_t *__restrict_
 		// exclusive prefix over descending keys: costly regions first, so that the frame ends on short claims
 		uint32_t running = 0u;
 		for (int k = 64; k >= 1; --k) {
-			const uint32_t n = bucket[k];
-			bucket[k] = running;
+			const uint32_t n = scratch.bucket[k];
+			scratch.bucket[k] = running;
 			running += n;
 		}
 		counters->queue[group].work_tiles = running;
-		counters->queue[group].cost_sum = cost_total;
+		counters->queue[group].cost_sum = scratch.cost_total;
+		counters->queue[group].hits = scratch.hit_total;
 		counters->queue[group].head = 0u;
-		atomicMax(&counters->tick_ao_begin, (unsigned long long) __builtin_amdgcn_s_memrealtime());
-#ifdef OCRT_TAIL  // (the AO pass starts right after this kernel: its waves' end times are counted from here)
-		atomicMax(&counters->stamp[7], __builtin_amdgcn_s_memrealtime());
-#endif
 	}
 	__syncthreads();
-	for (uint32_t block = wave; block < n_blocks; block += 16u) {
-		uint32_t tile = 0u, cls, cost;
+	for (uint32_t block = wave; block < n_blocks; block += waves) {
+		uint32_t tile = 0u, word, cost;
 		unsigned long long work_mask;
-		const uint32_t key = block_key(block, tile, cls, work_mask, cost);
+		const uint32_t key = block_key(block, tile, word, work_mask, cost);
 		if (work_mask == 0ull)
 			continue;
 		uint32_t base = 0u;
 		if (lane == 0u)
-			base = atomicAdd(&bucket[key], (uint32_t) __popcll(work_mask));
+			base = atomicAdd(&scratch.bucket[key], (uint32_t) __popcll(work_mask));
 		base = (uint32_t) __builtin_amdgcn_readfirstlane((int) base);
 		// entry = tile (26 bits: at most 2^32 sub-pixels per frame) | hit count - 1 (6 bits); inside a block
 		// the tiles keep their spatial order
-		if (cls)
-			order[segment + base + rank_in(work_mask)] = tile | (((tile_hits[tile] & 0xFFu) - 1u) << 26);
+		if (word >> 8)
+			order[segment + base + rank_in(work_mask)] = tile | (((word & 0xFFu) - 1u) << 26);
 	}
+	if (threadIdx.x == 0) {
+		counters->queue[group].tick_ordered = (unsigned long long) __builtin_amdgcn_s_memrealtime();
+#ifdef OCRT_TAIL  // (the AO pass starts right after this kernel: its waves' end times are counted from here)
+		atomicMax(&counters->stamp[7], __builtin_amdgcn_s_memrealtime());
+#endif
+	}
+}
+
+// ---------------------------------------------------------------------------
+// Pass 1: primary rays, then -- the last workgroup of each XCD group -- the group's ordering step.  Four waves per
+// workgroup, one tile each; they meet once, at the end.
+//
+// Why the ordering step lives here and not in a kernel of its own: it is 8 workgroups of work, and as a kernel it cost
+// a frame that shares its GPU ~0.2 ms of waiting (a launch boundary on either side, and workgroups of 1024 threads that
+// need 16 free wave slots on one CU while other frames' persistent passes hold them).  The hand-over inside the kernel:
+// every wave's tile word is a device-coherent store (primary_tile), drained (s_waitcnt vmcnt(0)) before the workgroup's
+// barrier; then ONE returning atomic per workgroup on the group's `done` counter -- whoever takes it to the number of
+// the group's workgroups is the last, reads the words with device-coherent loads and puts the counter back to 0 for the
+// next frame.  (MI355X_MICROARCH.md, inter-workgroup visibility: sc1 stores drained before the counter, sc1 loads after it.)
+// ---------------------------------------------------------------------------
+#ifndef OCRT_PRIMARY_WAVES
+#define OCRT_PRIMARY_WAVES 4
+#endif
+constexpr uint32_t PRIMARY_WAVES = OCRT_PRIMARY_WAVES;  // 4, 8 or 16: a workgroup covers a block of tiles 2 wide and PRIMARY_WAVES / 2 high
+constexpr uint32_t PRIMARY_ROWS = PRIMARY_WAVES / 2u;
+
+template <bool SHARED>
+__global__ __launch_bounds__(64 * PRIMARY_WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void primary_kernel(PrimaryArgs A) {
+	__shared__ ClosestBatch closest_batches[PRIMARY_WAVES];
+	__shared__ OrderScratch scratch;
+	const uint32_t wave = threadIdx.x >> 6;
+	if (blockIdx.x == 0u && threadIdx.x == 0u) {
+		FrameCounters *const counters = A.counters;
+		counters->tick_begin = __builtin_amdgcn_s_memrealtime();
+		// the sums the LATER kernels of this frame add to (nobody touches them before this kernel has ended)
+		counters->occluded = 0ull;
+		counters->tick_ao_end = 0ull;
+	}
+	const uint32_t group = blockIdx.x & (XCD_GROUPS - 1u), seq = blockIdx.x >> 3;
+	{
+		const uint32_t strips = (A.P.tiles_x + 1u) >> 1;
+		const uint32_t row_blocks = (A.P.local_tile_rows + PRIMARY_ROWS - 1u) / PRIMARY_ROWS;
+		const uint32_t strips_here = (strips + XCD_GROUPS - 1u - group) >> 3;
+		const uint32_t strip_index = seq / row_blocks;
+		const uint32_t row_block = seq - strip_index * row_blocks;
+		const uint32_t tile_x = 2u * (group + XCD_GROUPS * strip_index) + (wave & 1u);
+		const uint32_t local_row = PRIMARY_ROWS * row_block + (wave >> 1);
+		if (seq < strips_here * row_blocks && tile_x < A.P.tiles_x && local_row < A.P.local_tile_rows)
+			primary_tile<SHARED>(A, closest_batches, tile_x, local_row);
+	}
+	// ---- the tail: is this the group's last workgroup? ----
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (this wave's tile word has left)
+	__syncthreads();
+	if (threadIdx.x == 0u) {
+		FrameCounters *const counters = OCRT_PCOLD_PTR(FrameCounters *, counters);
+		const uint32_t before = __hip_atomic_fetch_add(&counters->queue[group].done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		scratch.last = before + 1u == gridDim.x / XCD_GROUPS ? 1u : 0u;
+	}
+	__syncthreads();
+	if (scratch.last == 0u)
+		return;
+	FrameCounters *const counters = OCRT_PCOLD_PTR(FrameCounters *, counters);
+	order_group(OCRT_PCOLD_PTR(const uint32_t *, tile_hits), OCRT_PCOLD_PTR(uint32_t *, order), counters, OCRT_PCOLD_U32(P.tiles_x),
+	            OCRT_PCOLD_U32(P.local_tile_rows), OCRT_PCOLD_U32(P.debug_no_sort) != 0u, OCRT_PCOLD_U32(P.cost_shift), group, scratch,
+	            PRIMARY_WAVES);
+	if (threadIdx.x == 0u)
+		__hip_atomic_store(&counters->queue[group].done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // xorshift128 of the RANDOM hemisphere sampler, reference src/intersect_kernel.cl:128-152.
@@ -1356,18 +1461,6 @@ struct AoArgs {
 	FrameCounters *counters;
 	KernelParams P;
 };
-template <uint32_t OFFSET>
-__device__ __forceinline__ uint32_t cold_u32() {
-	uint32_t v;
-	asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "i"(OFFSET));
-	return v;
-}
-template <uint32_t OFFSET>
-__device__ __forceinline__ unsigned long long cold_u64() {
-	unsigned long long v;
-	asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "i"(OFFSET));
-	return v;
-}
 #define OCRT_COLD_U32(FIELD) cold_u32<(uint32_t) offsetof(AoArgs, FIELD)>()
 #define OCRT_COLD_F32(FIELD) __uint_as_float(cold_u32<(uint32_t) offsetof(AoArgs, FIELD)>())
 #define OCRT_COLD_PTR(TYPE, FIELD) ((TYPE) cold_u64<(uint32_t) offsetof(AoArgs, FIELD)>())
@@ -1813,28 +1906,51 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 #endif
 }
 
-// Pass 3: value *= 1 - hits / n (reference :256 and :305-307), a thread per hit-list slot, the grid striding over the
-// list (launch_resolve: what the chip holds).  The frame's occlusion count is summed per lane, then per wave by
-// cross-lane adds, per workgroup in LDS, and reaches the counter with one atomic per workgroup.
-__global__ __launch_bounds__(256) void resolve_kernel(const HitRec *__restrict__ hits,
-                                                      const uint32_t *__restrict__ occluded_of,
-                                                      const uint32_t *__restrict__ tile_hits,
-                                                      FrameCounters *__restrict__ counters, float *__restrict__ image,
-                                                      uint32_t tiles, uint32_t ao_divisor) {
+// Pass 3, the frame's last kernel: value *= 1 - hits / n (reference :256 and :305-307) for the sub-pixels that wait
+// for it, and the supersample box filter + 8-bit quantisation (reference src/ray_tracer.cc:3-16) in the same sweep
+// over the float image.  One thread per OUTPUT pixel of this rank's bands: it visits its n x n sub-pixels in the
+// reference's order (ssY-major, ssX-minor), replaces every pending tag (primary_tile) by
+// value * (1 - occluded / n_dirs) -- value and count from the tile's slot of the hit list --, WRITES THAT BACK (the float
+// image is what `download` hands out, reference src/opencl_host.cc:150-153) and sums.  `out` may be null (a frame
+// without the device resize).  The frame's occlusion count is summed per lane, per wave by cross-lane adds, per
+// workgroup in LDS, and reaches the counter with one atomic per workgroup.
+// Band layout as in resize_kernel below.
+__global__ __launch_bounds__(256) void finish_kernel(float *__restrict__ image, const HitRec *__restrict__ hits,
+                                                     const uint32_t *__restrict__ occluded_of,
+                                                     FrameCounters *__restrict__ counters, unsigned char *__restrict__ out,
+                                                     uint32_t width, uint32_t height, uint32_t total_width, uint32_t n,
+                                                     uint32_t tiles_x, Partition part, uint32_t rows_per_band, uint32_t ao_divisor) {
 	__shared__ unsigned int block_total;
 	if (threadIdx.x == 0)
 		block_total = 0u;
 	__syncthreads();
+	const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t j = blockIdx.y;
+	const uint32_t band_local = j / rows_per_band;
+	const uint32_t y = (band_local * part.nranks + part.rank) * rows_per_band + (j - band_local * rows_per_band);
 	uint32_t mine = 0u;
-	const float divisor = (float) ao_divisor;
-	// (64-bit: tiles * 64 may come close to 2^32, the upload allows 2^26 tiles)
-	for (unsigned long long slot = blockIdx.x * blockDim.x + threadIdx.x; (slot >> 6) < tiles; slot += gridDim.x * blockDim.x) {
-		if ((slot & 63ull) < (tile_hits[slot >> 6] & 0xFFu)) {
-			const uint32_t occluded = occluded_of[slot];
-			const HitRec rec = hits[slot];
-			image[rec.pixel] = rec.value * (1.0f - ((float) occluded / divisor));
-			mine += occluded;
+	if (x < width) {
+		const float divisor = (float) ao_divisor;
+		float total = 0.0f;
+		for (uint32_t sy = 0; sy < n; ++sy) {
+			const uint32_t row_index = j * n + sy;
+			float *row = image + (size_t) row_index * total_width + (size_t) x * n;
+			for (uint32_t sx = 0; sx < n; ++sx) {
+				float v = row[sx];
+				const uint32_t bits = __float_as_uint(v);
+				if (is_pending(bits)) {
+					const uint32_t column = x * n + sx;
+					const size_t slot = ((size_t) (row_index / TILE_H) * tiles_x + column / TILE_W) * 64u + (bits & 63u);
+					const uint32_t occluded = occluded_of[slot];
+					v = hits[slot].value * (1.0f - ((float) occluded / divisor));
+					row[sx] = v;
+					mine += occluded;
+				}
+				total += v;
+			}
 		}
+		if (out)
+			out[(size_t) j * width + x] = y < height ? (unsigned char) ((total / (float) (n * n)) * 255.0f) : (unsigned char) 0;
 	}
 	for (int offset = 32; offset > 0; offset >>= 1)
 		mine += (uint32_t) __shfl_down((int) mine, offset);
@@ -1884,28 +2000,40 @@ void preload_kernels() {
 	(void) hipGetLastError();
 }
 
-// Zeroes a frame's counters.  A kernel, not hipMemsetAsync: as a node of a captured graph replayed beside other
-// streams' work (torch.distributed's RCCL kernels), the memset left pointer-like garbage in the counters under the HIP
-// 7.0 runtime that torch bundles (the ray statistics came out wrong, the image did not depend on it); a kernel node
-// has no such problem, and the plain launches take the same path.
-__global__ __launch_bounds__(256) void clear_counters_kernel(FrameCounters *counters) {
-	uint32_t *words = (uint32_t *) counters;
-	for (uint32_t i = threadIdx.x; i < sizeof(FrameCounters) / sizeof(uint32_t); i += blockDim.x)
-		words[i] = 0u;
+#if defined(OCRT_STAMPS) || defined(OCRT_TAIL)
+// (instrumented builds only: the debug stamps are sums and need zeroing; the frame's own counters do not -- device_types.h)
+__global__ __launch_bounds__(256) void clear_stamps_kernel(FrameCounters *counters) {
+	for (uint32_t i = threadIdx.x; i < sizeof(counters->stamp) / sizeof(counters->stamp[0]); i += blockDim.x)
+		counters->stamp[i] = 0ull;
 }
+#endif
 
-void launch_primary(const SceneBuffers &scene, float *image, void *hits, void *occluded_of, void *tile_hits,
+// The frame is three kernels (two without ambient occlusion): primary pass (+ ordering step in its tail), the
+// ambient-occlusion pass, the finishing kernel (AO factor + box filter + quantisation).
+void launch_primary(const SceneBuffers &scene, float *image, void *hits, void *occluded_of, void *tile_hits, void *order,
                     void *counters, const KernelParams &P, void *stream) {
 	hipStream_t s = (hipStream_t) stream;
-	hipLaunchKernelGGL(clear_counters_kernel, dim3(1), dim3(256), 0, s, (FrameCounters *) counters);
+#if defined(OCRT_STAMPS) || defined(OCRT_TAIL)
+	hipLaunchKernelGGL(clear_stamps_kernel, dim3(1), dim3(256), 0, s, (FrameCounters *) counters);
+#endif
 	if (P.tiles_x * P.local_tile_rows == 0)
 		return;
 	const uint32_t strips = (P.tiles_x + 1u) >> 1, row_blocks = (P.local_tile_rows + PRIMARY_ROWS - 1u) / PRIMARY_ROWS;
 	const uint32_t blocks = XCD_GROUPS * ((strips + XCD_GROUPS - 1u) >> 3) * row_blocks;
 	auto launch = [&](auto kernel) {
-		hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64 * PRIMARY_WAVES), 0, s, (const float4 *) scene.nodes,
-		                   (const float4 *) scene.walk, (const float4 *) scene.tris, (const float4 *) scene.shade, image,
-		                   (HitRec *) hits, (uint32_t *) occluded_of, (uint32_t *) tile_hits, (FrameCounters *) counters, P);
+		PrimaryArgs args;
+		args.walk_ptr = (const float4 *) scene.walk;
+		args.tris_ptr = (const float4 *) scene.tris;
+		args.nodes_ptr = (const float4 *) scene.nodes;
+		args.shade = (const float4 *) scene.shade;
+		args.image = image;
+		args.hits = (HitRec *) hits;
+		args.occluded_of = (uint32_t *) occluded_of;
+		args.tile_hits = (uint32_t *) tile_hits;
+		args.order = (uint32_t *) order;
+		args.counters = (FrameCounters *) counters;
+		args.P = P;
+		hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64 * PRIMARY_WAVES), 0, s, args);
 	};
 #ifdef OCRT_DEBUG_KNOBS
 	if (!P.shared_walk)
@@ -1914,14 +2042,11 @@ void launch_primary(const SceneBuffers &scene, float *image, void *hits, void *o
 	launch(primary_kernel<true>);
 }
 
-void launch_ao(const SceneBuffers &scene, float *image, void *hits, void *occluded_of, void *tile_hits, void *order,
-               void *counters, const KernelParams &params, uint32_t workgroups, void *stream, void *event_before_ao,
-               void *event_after_ao) {
+void launch_ao(const SceneBuffers &scene, void *hits, void *occluded_of, void *order, void *counters,
+               const KernelParams &params, uint32_t workgroups, void *stream, void *event_before_ao, void *event_after_ao) {
 	if (params.tiles_x * params.local_tile_rows == 0 || params.ao_mode == AO_NONE || params.ao_dirs == 0)
 		return;
 	hipStream_t s = (hipStream_t) stream;
-	hipLaunchKernelGGL(order_kernel, dim3(XCD_GROUPS), dim3(1024), 0, s, (const uint32_t *) tile_hits,
-	                   (uint32_t *) order, (FrameCounters *) counters, params);
 	// persistent grid: what the chip holds, or one wave per (tile, direction) when the image is small
 	const uint32_t tiles = params.tiles_x * params.local_tile_rows;
 	const uint64_t units = (uint64_t) tiles * params.ao_dirs;
@@ -1962,10 +2087,20 @@ void launch_ao(const SceneBuffers &scene, float *image, void *hits, void *occlud
 		launch(ao_kernel<AO_UNIFORM, true>);
 	else
 		launch(ao_kernel<AO_RANDOM, true>);
-	const uint32_t resolve_blocks = (tiles * 64u + 255u) / 256u;
-	hipLaunchKernelGGL(resolve_kernel, dim3(resolve_blocks < 4096u ? resolve_blocks : 4096u), dim3(256), 0, s, (const HitRec *) hits,
-	                   (const uint32_t *) occluded_of, (const uint32_t *) tile_hits, (FrameCounters *) counters, image,
-	                   tiles, P.ao_divisor);
+}
+
+// `out`: this rank's 8-bit bands (local_out_rows x out_width), or null for a frame without the device resize.
+void launch_finish(float *image, const void *hits, const void *occluded_of, void *counters, unsigned char *out,
+                   const KernelParams &P, uint32_t out_width, uint32_t n, uint32_t local_out_rows, void *stream) {
+	if (local_out_rows == 0 || out_width == 0 || n == 0)
+		return;
+	const bool has_ao = P.ao_mode != AO_NONE && P.ao_dirs > 0;
+	if (!has_ao && !out)
+		return;  // (nothing pending, nothing to filter)
+	const uint32_t rows_per_band = P.part.band_tile_rows * TILE_H / n;
+	hipLaunchKernelGGL(finish_kernel, dim3((out_width + 255) / 256, local_out_rows), dim3(256), 0, (hipStream_t) stream, image,
+	                   (const HitRec *) hits, (const uint32_t *) occluded_of, (FrameCounters *) counters, out, out_width, P.height / n,
+	                   P.width, n, P.tiles_x, P.part, rows_per_band, P.ao_divisor ? P.ao_divisor : 1u);
 }
 
 void launch_resize(const float *tmp, unsigned char *out, const KernelParams &P, uint32_t out_width, uint32_t n,

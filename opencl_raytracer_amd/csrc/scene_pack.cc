@@ -367,6 +367,8 @@ WalkArray make_walk_array(const PackedScene &scene, float ao_max_distance) {
 		out.nodes[records + nodes.size()] = ce_end;
 		out.nodes[records + nodes.size() + 1] = ce_end;
 	}
+	// (two records of slack behind everything: a scalar load that touches the line behind the last pair stays in the array)
+	out.nodes.resize(out.nodes.size() + 2, NodeRec{});
 	return out;
 }
 
@@ -433,8 +435,19 @@ uint32_t local_tile_rows_for(uint32_t total_height, const Partition &part) {
 	return mine;
 }
 
+SceneFacts scene_facts(const PackedScene &scene, const WalkArray &walk) {
+	SceneFacts f;
+	f.regular = scene.regular;
+	f.nested = scene.nested;
+	f.binary_tree = scene.binary_tree;
+	f.has_walk = !walk.nodes.empty();
+	f.origin_limit = walk.origin_limit;
+	f.ao_scale = walk.ao_scale;
+	return f;
+}
+
 KernelParams make_kernel_params(const RayTracer &rt, uint32_t node_count, uint32_t tri_count, uint32_t ao_dirs,
-                                const Partition &part, const PackedScene *scene, const WalkArray *walk) {
+                                const Partition &part, const SceneFacts *facts) {
 	KernelParams p{};
 	p.width = rt.totalWidth;
 	p.height = rt.totalHeight;
@@ -452,15 +465,15 @@ KernelParams make_kernel_params(const RayTracer &rt, uint32_t node_count, uint32
 	p.ao_max_distance = kernel_float(rt.options.aoMaxDistance);
 	p.ao_dirs = ao_dirs;
 	p.ao_divisor = p.ao_mode == AO_RANDOM ? ao_dirs - 1 : ao_dirs;
-	p.origin_limit = walk ? walk->origin_limit : 0.0f;
+	p.origin_limit = facts ? facts->origin_limit : 0.0f;
 	// (the array's margins hold for the max_distance it was made for: the renderer re-makes it when that changes)
-	p.walk_scale = (walk && walk->ao_scale > 0.0f && walk->ao_scale == walk_scale_for(p.ao_max_distance) &&
-	                walk_scale_usable(walk->ao_scale, walk->origin_limit) &&
-	                !debug_knob("OCRT_NO_SCALED_WALK")) ? walk->ao_scale : 0.0f;  // (debug knob)
-	p.fast_walk = (walk && !walk->nodes.empty() && !debug_knob("OCRT_FORCE_EXACT_WALK")) ? 1 : 0;  // (debug knob)
-	p.scene_regular = (scene && scene->regular) ? 1 : 0;
-	p.scene_nested = (scene && scene->nested && !debug_knob("OCRT_FORCE_EXACT_WALK")) ? 1 : 0;  // (debug knob)
-	p.shared_walk = (scene && scene->binary_tree && !debug_knob("OCRT_NO_SHARED_WALK")) ? 1 : 0;  // (debug knob)
+	p.walk_scale = (facts && facts->ao_scale > 0.0f && facts->ao_scale == walk_scale_for(p.ao_max_distance) &&
+	                walk_scale_usable(facts->ao_scale, facts->origin_limit) &&
+	                !debug_knob("OCRT_NO_SCALED_WALK")) ? facts->ao_scale : 0.0f;  // (debug knob)
+	p.fast_walk = (facts && facts->has_walk && !debug_knob("OCRT_FORCE_EXACT_WALK")) ? 1 : 0;  // (debug knob)
+	p.scene_regular = (facts && facts->regular) ? 1 : 0;
+	p.scene_nested = (facts && facts->nested && !debug_knob("OCRT_FORCE_EXACT_WALK")) ? 1 : 0;  // (debug knob)
+	p.shared_walk = (facts && facts->binary_tree && !debug_knob("OCRT_NO_SHARED_WALK")) ? 1 : 0;  // (debug knob)
 	p.debug_no_sort = debug_knob("OCRT_NO_SORT") ? 1 : 0;
 	const char *refill_min = debug_knob("OCRT_REFILL_MIN"), *leaf_min = debug_knob("OCRT_LEAF_MIN");
 	p.refill_min = refill_min ? (uint32_t) std::atoi(refill_min) : 16u;

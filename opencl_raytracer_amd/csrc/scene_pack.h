@@ -87,7 +87,14 @@ uint32_t band_tile_rows_for(unsigned int grid);
 // Number of tile rows rank `rank` owns for an image of `total_height` rows.
 uint32_t local_tile_rows_for(uint32_t total_height, const Partition &part);
 
+// What the launch constants need to know of an uploaded scene (the arrays themselves stay on the device).
+struct SceneFacts {
+	bool regular = false, nested = false, binary_tree = false;  // PackedScene's flags
+	bool has_walk = false;                                       // the padded walk array exists
+	float origin_limit = 0.0f, ao_scale = 0.0f;                  // WalkArray's
+};
+SceneFacts scene_facts(const PackedScene &scene, const WalkArray &walk);
 KernelParams make_kernel_params(const RayTracer &rt, uint32_t node_count, uint32_t tri_count, uint32_t ao_dirs,
-                                const Partition &part, const PackedScene *scene, const WalkArray *walk);
+                                const Partition &part, const SceneFacts *facts);
 
 }  // namespace ocrt

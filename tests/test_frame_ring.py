@@ -113,6 +113,48 @@ def test_ring_recaptures_after_a_new_scene(rt, golden, scene_for):
     ring.close()
 
 
+def test_ring_holds_one_copy_of_the_scene(rt, golden, scene_for):
+    """The reference uploads a scene once (src/opencl_host.cc:120-136).  A ring's hosts share ONE set of scene arrays on
+    the device: the bytes of the scene do not depend on the number of hosts, only the per-host frame buffers do, and
+    the frames are the golden ones whichever host renders them."""
+    case = golden["renders"]["bunny_101x77_s9_a2"]
+    opt = options_for(rt, case)
+    scene = scene_for(case["mesh"], case["bvh"])[0]
+    seen = {}
+    for hosts in (1, 3, 6):
+        ring = rt.FrameRing(opt, scene, hosts=hosts)
+        scene_bytes, copies, total = ring.device_bytes()
+        assert copies == 1 and scene_bytes > 0
+        seen[hosts] = (scene_bytes, total)
+        ring.run(2 * hosts + 1)  # every host and every band buffer at least once
+        ring.drain()
+        assert md5_of(rt, ring.download_last()) == case["pgm_md5"]
+        ring.close()
+    assert seen[1][0] == seen[3][0] == seen[6][0]
+    per_host = seen[1][1] - seen[1][0]
+    assert seen[3][1] == seen[3][0] + 3 * per_host and seen[6][1] == seen[6][0] + 6 * per_host
+
+
+def test_a_borrowed_host_cannot_outlive_its_ring(rt, golden, scene_for):
+    """FrameRing.host() hands out views into the ring: a view keeps the ring alive, and once the ring is closed every
+    call on it fails cleanly instead of touching freed memory."""
+    import gc
+
+    case = golden["renders"]["blob_128x96_s4_a3"]
+    opt = options_for(rt, case)
+    view = rt.FrameRing(opt, scene_for(case["mesh"], case["bvh"])[0], hosts=2).host(0)  # the ring itself is a temporary
+    gc.collect()
+    assert view.stats()["primary_rays"] == 0  # nothing rendered yet; the call reaches a live host
+    ring = view._owner
+    ring.run(2)
+    ring.drain()
+    assert view.stats()["primary_rays"] > 0
+    ring.close()
+    with pytest.raises(rt.RtError):
+        view.stats()
+    assert view.last_kernel_ms == 0.0
+
+
 class _DeviceBytes:
     """A few bytes of device memory straight from the HIP runtime the library itself uses (torch brings its own copy
     of the runtime, which must be loaded BEFORE the library -- bench.py does that, a test process cannot)."""

@@ -9,7 +9,7 @@ import sys
 
 def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
-    want = ("primary_kernel", "order_kernel", "ao_kernel", "resolve_kernel", "resize_kernel")
+    want = ("primary_kernel", "ao_kernel", "finish_kernel", "resize_kernel")
     ks = [r for r in rows if any(w in r["Kernel_Name"] for w in want)]
     ks.sort(key=lambda r: int(r["Start_Timestamp"]))
     t0 = int(ks[0]["Start_Timestamp"])
