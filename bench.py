@@ -85,6 +85,15 @@ WORKLOADS = {
     "interior_1080p_ao": dict(
         mesh="interior", bvh="longest", width=1920, height=1080, ss=1, ao=3, golden="interior_1080p_s1_a3",
         label="interior stand-in for the missing sibenik.off, 1920x1080 -s 1 -a 3"),
+    # Generated height fields (tools/big_meshes.py; in memory, no golden frame: checked against the oracle at a small
+    # resolution before anything is timed).  The packed scenes -- 0.6 GB and 6 GB -- are far beyond the 32 MB of L2 and the
+    # 256 MB Infinity Cache: the workloads on which north_star's memory roofline means something.
+    "terrain_2m_1080p_ao": dict(
+        mesh="terrain:1000", bvh="longest", width=1920, height=1080, ss=1, ao=3, golden=None,
+        label="generated height field, 2.0 M triangles, 1920x1080 -s 1 -a 3"),
+    "terrain_20m_1080p_ao": dict(
+        mesh="terrain:3200:4", bvh="longest", width=1920, height=1080, ss=1, ao=3, golden=None,
+        label="generated height field, 20.5 M triangles (four times the size of the 2 M one: the reference's triangle test does not see triangles below ~5e-7 units of area), 1920x1080 -s 1 -a 3"),
 }
 DEFAULT_WORKLOAD = "bunny_1080p_ao"
 
@@ -98,6 +107,16 @@ def mesh_path(name: str) -> str:
     from tools.meshes import bunny_path, interior_path
 
     return bunny_path() if name == "bunny" else interior_path()
+
+
+def load_scene(rt, w):
+    """The workload's mesh as an rt.Scene (no BVH yet): an OFF file, or a mesh generated in memory ("terrain:<n>")."""
+    if w["mesh"].startswith("terrain:"):
+        from tools.big_meshes import terrain
+
+        parts = w["mesh"].split(":")  # terrain:<n>[:<scale about the camera>]
+        return rt.Scene.from_arrays(*terrain(int(parts[1]), scale=float(parts[2]) if len(parts) > 2 else 1.0))
+    return rt.Scene.load_off(mesh_path(w["mesh"]))
 
 
 def algorithmic_bytes(counters: dict, subpixels: int) -> dict:
@@ -296,7 +315,7 @@ def main():
         golden_md5, counters = g["pgm_md5"], g["counters"]
 
     e2e = None
-    if world == 1 and not args.no_end_to_end:
+    if world == 1 and not args.no_end_to_end and ":" not in w["mesh"]:  # (generated meshes are not files: no CLI run)
         e2e = end_to_end(w, golden_md5)  # (a child process, before this one opens the GPU)
 
     import numpy as np
@@ -325,7 +344,7 @@ def main():
 
     opt = workload_options(rt, w)
     t0 = time.perf_counter()
-    scene = rt.Scene.load_off(mesh_path(w["mesh"]))
+    scene = load_scene(rt, w)
     t_load = time.perf_counter() - t0
     scene.build_bvh(opt.bvh_method)
     t_scene = time.perf_counter() - t0
@@ -476,6 +495,8 @@ def main():
     else:
         total_rays, total_hits, total_occluded = my_rays, st["primary_hits"], st["ao_occluded"]
     images = {name: final_image(name) for name in rings}
+    scene_bytes, scene_copies, _ = rings["pipelined"].device_bytes()
+    calibration = rings["pipelined"].calibration()
 
     if rank == 0:
         md5 = {name: hashlib.md5(rt.pgm_bytes(img)).hexdigest() for name, img in images.items()}
@@ -504,6 +525,7 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32",
             "data": ("bunny.off (the reference's mesh asset)" if w["mesh"] == "bunny" else
+                     "synthetic height field generated in memory (tools/big_meshes.py)" if w["mesh"].startswith("terrain:") else
                      "synthetic interior scene, stand-in for the missing sibenik.off (tools/make_interior_mesh.py)")
                     + ", fixed camera, no randomness in this path",
             "config": {"workload": w["label"], "rays_per_frame": total_rays, "primary_hits": total_hits,
@@ -511,6 +533,12 @@ def main():
                        "frames_in_flight": in_flight, "frame_launch": "plain launches" if args.plain_launches else "hipGraph replay",
                        "pgm_md5": md5["pipelined"], "pgm_matches_golden": golden_md5 is not None,
                        "scene_load_s": round(t_load, 3), "scene_build_s": round(t_scene, 3),
+                       # one copy of the scene per GPU whatever the number of hosts; which form of the AO pass the ring's
+                       # calibration at upload chose for this scene (ms per ao_kernel without / with look-ahead loads)
+                       "scene_bytes_on_device": scene_bytes, "scene_copies_on_device": scene_copies,
+                       "triangles": scene.num_faces,
+                       "ao_pass_calibration": {"ms_without_lookahead": round(calibration[0], 4), "ms_with_lookahead": round(calibration[1], 4),
+                                               "lookahead_in_use": calibration[2]},
                        "device": torch.cuda.get_device_name(device)},
             # every block is exactly `steps` steps between barrier + synchronize; `value` / `ms_per_step` are the median block
             "blocks": dict(summary(pipe_ms), unit="ms per step", seconds_covered=round(sum(results["pipelined"]["seconds"]), 3),

@@ -180,6 +180,15 @@ int rt_ring_upload_scene(rt_ring *r, const rt_scene *s);
  * ring's hosts (ONE: the hosts share the arrays, like the single upload of src/opencl_host.cc:120-136) and the bytes
  * of everything requested, per-host frame buffers included.  Out pointers may be NULL. */
 int rt_ring_device_bytes(const rt_ring *r, uint64_t *scene_bytes, uint32_t *scene_copies, uint64_t *total_bytes);
+/* Run-time calibration (new; results never depend on it): the ambient-occlusion pass exists with and without
+ * look-ahead loads in its node loop, and which is faster depends on the scene.  rt_ring_upload* measure both on the
+ * uploaded scene (a few frames, ~15 ms) and keep the faster form for every host of the ring; rt_ring_set_calibration(r, 0)
+ * before the upload switches that off (the hosts keep the default form, or what rt_set_ao_prefetch set).
+ * rt_ring_calibration: ms per ao_kernel launch without / with the look-ahead as measured (0 = not measured) and the form
+ * in use (1 = with).  Out pointers may be NULL. */
+int rt_ring_set_calibration(rt_ring *r, int on);
+int rt_ring_calibration(const rt_ring *r, float *ms_without, float *ms_with, int *prefetch_in_use);
+int rt_set_ao_prefetch(rt_host *h, int on);
 uint32_t rt_ring_size(const rt_ring *r);        /* hosts */
 /* Band buffers: frame f is rendered by host f % size into buffer f % slots, slots = 2 * size, so that a frame's bands
  * (and, with a communicator, its assembled image) stay untouched while the next `size` frames are submitted. */

@@ -134,6 +134,9 @@ _SIGNATURES = {
                                  C.c_uint32, C.c_void_p]),
     "rt_ring_upload_scene": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rt_ring_device_bytes": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
+    "rt_ring_set_calibration": (C.c_int, [C.c_void_p, C.c_int]),
+    "rt_ring_calibration": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "rt_set_ao_prefetch": (C.c_int, [C.c_void_p, C.c_int]),
     "rt_ring_size": (C.c_uint32, [C.c_void_p]),
     "rt_ring_slots": (C.c_uint32, [C.c_void_p]),
     "rt_ring_local_rows": (C.c_uint32, [C.c_void_p]),
@@ -401,6 +404,10 @@ class Host:
         _check(load_library().rt_get_stream(self._h, C.byref(p)))
         return int(p.value or 0)
 
+    def set_ao_prefetch(self, on: bool) -> None:
+        """Which form of the AO pass's node loop this host launches (include/rt_hip.h, rt_set_ao_prefetch); same results."""
+        _check(load_library().rt_set_ao_prefetch(self._h, int(on)))
+
     def stats(self) -> dict:
         s = _Stats()
         _check(load_library().rt_get_stats(self._h, C.byref(s)))
@@ -465,6 +472,16 @@ class FrameRing:
 
     def upload_scene(self, scene: "Scene") -> None:
         _check(load_library().rt_ring_upload_scene(self._r, scene._h))
+
+    def set_calibration(self, on: bool) -> None:
+        """Before an upload: whether the upload measures which form of the AO pass suits the scene (default: yes)."""
+        _check(load_library().rt_ring_set_calibration(self._r, int(on)))
+
+    def calibration(self):
+        """(ms per ao_kernel without the look-ahead loads, with them -- 0.0: not measured --, whether they are in use)."""
+        a, b, c = C.c_float(), C.c_float(), C.c_int()
+        _check(load_library().rt_ring_calibration(self._r, C.byref(a), C.byref(b), C.byref(c)))
+        return float(a.value), float(b.value), bool(c.value)
 
     def device_bytes(self):
         """(bytes of the scene's arrays on the device, copies of them among the hosts -- one --, bytes of everything requested)."""

@@ -425,6 +425,31 @@ int rt_ring_device_bytes(const rt_ring *r, uint64_t *scene_bytes, uint32_t *scen
 	});
 }
 
+int rt_ring_set_calibration(rt_ring *r, int on) {
+	if (!r)
+		return fail(RT_E_INVALID, "null argument");
+	r->ring->setCalibration(on != 0);
+	return RT_OK;
+}
+
+int rt_ring_calibration(const rt_ring *r, float *ms_without, float *ms_with, int *prefetch_in_use) {
+	if (!r)
+		return fail(RT_E_INVALID, "null argument");
+	if (ms_without)
+		*ms_without = r->ring->calibrationMs()[0];
+	if (ms_with)
+		*ms_with = r->ring->calibrationMs()[1];
+	if (prefetch_in_use)
+		*prefetch_in_use = r->ring->aoPrefetch() ? 1 : 0;
+	return RT_OK;
+}
+
+int rt_set_ao_prefetch(rt_host *h, int on) {
+	if (!h)
+		return fail(RT_E_INVALID, "null argument");
+	return guarded([&] { h->dev->setAoPrefetch(on != 0); });
+}
+
 uint32_t rt_ring_size(const rt_ring *r) { return r ? r->ring->size() : 0; }
 uint32_t rt_ring_slots(const rt_ring *r) { return r ? r->ring->slots() : 0; }
 uint32_t rt_ring_local_rows(const rt_ring *r) { return r ? r->ring->localRows() : 0; }

@@ -1,5 +1,6 @@
 #include "device_renderer.h"
 
+#include <algorithm>
 #include <atomic>
 
 #include <hip/hip_runtime.h>
@@ -85,6 +86,7 @@ DeviceRenderer::DeviceRenderer(const RayTracer::Options &options, int device_, u
 	, scene_ready(false)
 	, frame_ready(false)
 	, graph_mode(true)
+	, ao_prefetch(true)
 	, scene_version(0)
 	, ao_blocks_override(0)
 	, epoch_event(nullptr)
@@ -333,11 +335,51 @@ void DeviceRenderer::launchFrame(void *device_u8, void *ao_start, void *ao_stop)
 #ifdef OCRT_STAMPS  // (instrumented build: the AO pass takes the minimum of its waves' start times into this slot)
 	OCRT_HIP(hipMemsetAsync((char *) d_counters + offsetof(FrameCounters, stamp) + 7 * sizeof(unsigned long long), 0xFF, sizeof(unsigned long long), s));
 #endif
-	launch_ao(scene, d_hits, d_occluded, d_order, d_counters, kp, ao_blocks_override ? ao_blocks_override : aoWorkgroups(), stream,
-	          ao_start, ao_stop);
+	launch_ao(scene, d_hits, d_occluded, d_order, d_counters, kp, ao_blocks_override ? ao_blocks_override : aoWorkgroups(), ao_prefetch,
+	          stream, ao_start, ao_stop);
 	OCRT_HIP(hipGetLastError());
 	launch_finish((float *) d_image, d_hits, d_occluded, d_counters, (unsigned char *) device_u8, kp, opts.width, grid, local_out_rows, stream);
 	OCRT_HIP(hipGetLastError());
+}
+
+void DeviceRenderer::setAoPrefetch(bool on) {
+	if (on == ao_prefetch)
+		return;
+	ao_prefetch = on;
+	++scene_version;  // (a captured frame bakes the kernel in: capture again)
+}
+
+bool DeviceRenderer::calibrateAoPrefetch(float *ms_without, float *ms_with) {
+	if (!scene_ready)
+		throw std::logic_error("calibration before upload");
+	const bool has_ao = kp.ao_mode == AO_UNIFORM && kp.ao_dirs > 0 && tile_count > 0 && kp.fast_walk && kp.walk_scale > 0.0f;
+	float median[2] = { 0.0f, 0.0f };
+	if (has_ao) {
+		const bool before = ao_prefetch;
+		std::vector<float> samples[2];
+		// interleaved, the first frame of each form not counted (code object pages, caches)
+		for (int round = 0; round < 6; ++round)
+			for (int form = 0; form < 2; ++form) {
+				ao_prefetch = form != 0;
+				enqueueRender();
+				synchronize();
+				if (round > 0)
+					samples[form].push_back(last_ao_ms);
+			}
+		for (int form = 0; form < 2; ++form) {
+			std::sort(samples[form].begin(), samples[form].end());
+			median[form] = samples[form][samples[form].size() / 2];
+		}
+		ao_prefetch = before;
+		setAoPrefetch(median[1] <= median[0]);
+		resetTimers();
+		frame_ready = false;
+	}
+	if (ms_without)
+		*ms_without = median[0];
+	if (ms_with)
+		*ms_with = median[1];
+	return ao_prefetch;
 }
 
 void DeviceRenderer::enqueueRender() {

@@ -127,6 +127,13 @@ class DeviceRenderer {
 			device_share = hosts < 1u ? 1u : hosts;
 			kp.shared_device = device_share > 1u ? 1 : 0;
 		}
+		// Which form of the ambient-occlusion pass's node loop is launched: with (default) or without the look-ahead loads
+		// of kernels.hip, OCRT_PF_SUCCESSORS -- same results, the faster one depends on the scene.  calibrateAoPrefetch()
+		// renders a few frames one at a time with each form (plain launches, HIP events around the ao_kernel), keeps the
+		// faster one and returns the two medians in ms (a frame ring does this once per uploaded scene).
+		void setAoPrefetch(bool on);
+		bool aoPrefetch() const { return ao_prefetch; }
+		bool calibrateAoPrefetch(float *ms_without = nullptr, float *ms_with = nullptr);
 		uint32_t aoWorkgroups() const { return device_share > 1u ? compute_units * 11u / 2u : compute_units * 8u; }
 		uint32_t globalRowOf(uint32_t local_row) const;  // output row of a local band row (may be >= height: padding)
 
@@ -195,6 +202,7 @@ class DeviceRenderer {
 		const FrameGraph *frameGraphFor(void *dst);
 		void dropFrameGraphs();
 		bool graph_mode;
+		bool ao_prefetch;
 		uint64_t scene_version;
 		uint32_t ao_blocks_override;  // (debug-knob builds: OCRT_AO_BLOCKS)
 		void *epoch_event;
@@ -210,7 +218,7 @@ void preload_kernels();
 void launch_primary(const SceneBuffers &scene, float *image, void *hits, void *occluded_of, void *tile_hits, void *order,
                     void *counters, const KernelParams &P, void *stream);
 void launch_ao(const SceneBuffers &scene, void *hits, void *occluded_of, void *order, void *counters, const KernelParams &P,
-               uint32_t workgroups, void *stream, void *event_before_ao, void *event_after_ao);
+               uint32_t workgroups, bool prefetch, void *stream, void *event_before_ao, void *event_after_ao);
 void launch_finish(float *image, const void *hits, const void *occluded_of, void *counters, unsigned char *out,
                    const KernelParams &P, uint32_t out_width, uint32_t n, uint32_t local_out_rows, void *stream);
 void launch_resize(const float *tmp, unsigned char *out, const KernelParams &P, uint32_t out_width, uint32_t n,

@@ -70,6 +70,14 @@ size_t FrameRing::upload(const PackedScene &scene) {
 	size_t bytes = on_device->bytes();
 	for (auto &h : hosts)
 		bytes += h->adopt(on_device);
+	// A stream of frames of this scene is coming: which form of the ambient-occlusion pass's node loop it takes is worth a
+	// few frames of measuring (DeviceRenderer::calibrateAoPrefetch: ~15 ms once per upload).  The first host measures on
+	// the idle device, all hosts follow.
+	if (calibrate_at_upload) {
+		const bool prefetch = hosts.front()->calibrateAoPrefetch(&calibration_ms[0], &calibration_ms[1]);
+		for (auto &h : hosts)
+			h->setAoPrefetch(prefetch);
+	}
 	// every host's two frames are captured now, not in the middle of the stream that follows
 	for (unsigned int slot = 0; slot < bound.size(); ++slot)
 		hosts[slot % hosts.size()]->prepareFrame(bufferOf(slot));

@@ -32,6 +32,11 @@ class FrameRing {
 
 		size_t upload(const PackedScene &scene);  // every renderer of the ring; returns the bytes requested on the device
 		size_t uploadedBytes() const { return uploaded_bytes; }  // what the last upload() returned
+		// upload() measures which form of the ambient-occlusion pass suits the scene (on by default); what it found:
+		// ms per ao_kernel without / with the look-ahead loads (0: not measured) and the form the hosts now launch.
+		void setCalibration(bool on) { calibrate_at_upload = on; }
+		const float *calibrationMs() const { return calibration_ms; }
+		bool aoPrefetch() const { return hosts.front()->aoPrefetch(); }
 		unsigned int size() const { return (unsigned int) hosts.size(); }
 		DeviceRenderer &host(unsigned int slot) { return *hosts.at(slot); }
 		void setGraphMode(bool on);
@@ -111,6 +116,8 @@ class FrameRing {
 		std::vector<bool> gather_pending; // per slot: a gather of this slot's bands was enqueued and not yet waited for
 		uint64_t next_frame;
 		size_t uploaded_bytes = 0;
+		bool calibrate_at_upload = true;
+		float calibration_ms[2] = { 0.0f, 0.0f };
 		Collected last;
 		bool have_last;
 		void *epoch;  // hipEvent_t

@@ -590,6 +590,24 @@ __device__ __forceinline__ u32x8 scalar_load_node(const float4 *nodes_ptr, uint3
 	"\tv_max3_f32 v59, v59, v60, v61\n"                  \
 	"\tv_min3_f32 v56, v56, v57, v58\n"                  \
 	"\tv_cmp_lt_f32 vcc, v59, v56\n"
+#ifdef OCRT_NO_CE  // (A/B builds: the select form of the mixed scaled test on the plane-form records, as until round 3)
+#define OCRT_TEST_MIXED_SCALED(LX, LY, LZ, HX, HY, HZ) \
+	"\tv_fma_f32 v56, " LX ", %[ix], %[oix]\n"         \
+	"\tv_fma_f32 v57, " HX ", %[ix], %[oix]\n"         \
+	"\tv_fma_f32 v58, " LY ", %[iy], %[oiy]\n"         \
+	"\tv_fma_f32 v59, " HY ", %[iy], %[oiy]\n"         \
+	"\tv_fma_f32 v60, " LZ ", %[iz], %[oiz] clamp\n"   \
+	"\tv_fma_f32 v61, " HZ ", %[iz], %[oiz] clamp\n"   \
+	"\tv_cndmask_b32 v62, v57, v56, %[px]\n"           \
+	"\tv_cndmask_b32 v56, v56, v57, %[px]\n"           \
+	"\tv_cndmask_b32 v57, v59, v58, %[py]\n"           \
+	"\tv_cndmask_b32 v58, v58, v59, %[py]\n"           \
+	"\tv_cndmask_b32 v59, v61, v60, %[pz]\n"           \
+	"\tv_cndmask_b32 v60, v60, v61, %[pz]\n"           \
+	"\tv_max3_f32 v62, v62, v57, v59\n"                \
+	"\tv_min3_f32 v56, v56, v58, v60\n"                \
+	"\tv_cmp_lt_f32 vcc, v62, v56\n"
+#endif
 // (LEAF: the s-register holding the node's leaf field; NEXT: where the walk goes on after an append)
 #define OCRT_WALK_LEAF(LEAF, NOW, NEXT)                 \
 	"\ts_cmp_eq_u32 " LEAF ", -2\n"                     \
@@ -611,26 +629,35 @@ __device__ __forceinline__ u32x8 scalar_load_node(const float4 *nodes_ptr, uint3
 	"\ts_cmp_ge_u32 %[waiting], 64\n"                   \
 	"\ts_cbranch_scc1 .Lw_full_%=\n"                    \
 	"\ts_branch " NEXT "\n"
-// (experiment, -DOCRT_PREFETCH=1|2|3: once a pair has arrived, touch the line the walk goes to if `a` is missed (1), the
-// line behind the pair (2), or both (3), with a one-dword scalar load nobody reads: the next turn's load then finds it
-// in the scalar cache or on its way)
-#if defined(OCRT_PREFETCH) && OCRT_PREFETCH == 1
-#define OCRT_WALK_PREFETCH "\ts_add_u32 s46, %[at], s51\n\ts_load_dword s47, %[base], s46\n"
-#elif defined(OCRT_PREFETCH) && OCRT_PREFETCH == 2
-#define OCRT_WALK_PREFETCH "\ts_add_u32 s46, %[at], 64\n\ts_load_dword s47, %[base], s46\n"
-#elif defined(OCRT_PREFETCH) && OCRT_PREFETCH == 3
-#define OCRT_WALK_PREFETCH "\ts_add_u32 s46, %[at], s51\n\ts_load_dword s47, %[base], s46\n\ts_add_u32 s46, %[at], 64\n\ts_load_dword s47, %[base], s46\n"
-#else
-#define OCRT_WALK_PREFETCH
-#endif
-#define OCRT_WALK_ASM(TEST_A, TEST_B)                       \
+// PF_B: what the loop does between the tests of a pair, once `a` is known to be hit.  OCRT_PF_SUCCESSORS touches -- with
+// one-dword scalar loads nobody reads -- both places the walk can go to after `b`: the line behind the pair and b's skip
+// target.  One of the two is the next load, which then finds its line in the scalar cache or on its way instead of
+// starting a round trip of its own: the walk is a chain of dependent loads, and this takes the test of `b` out of the
+// chain.  It pays where packets mostly descend (the bunny's model tiles: ambient-occlusion pass -2 %, frames in flight
+// -2.5 ... -3.7 %) and costs where they mostly miss (the interior scene: +1 ... 2 %; the useless one of the two loads is
+// waited for by the next s_waitcnt all the same) -- so a render host can be told which form to launch
+// (DeviceRenderer::setAoPrefetch; a frame ring measures both on its scene at upload).  Forms that touch the skip target of
+// `a` before its test, or the next line alone, measured worse on one side or the other (profiles/r04_notes.md).
+#define OCRT_PF_NONE ""
+// Only where `b` is an inner node: then every path from here leads to the loop's next load and its s_waitcnt lgkmcnt(0),
+// which also waits for these two.  Behind a leaf the loop may be LEFT (a leaf stop, a full list) -- with a load still on
+// its way to s47, a register the compiler is free to use again the moment the asm block ends: it would be overwritten
+// whenever the load lands.  (That was the first form of this; a 20 k-triangle height field showed it, the bunny did not.)
+#define OCRT_PF_SUCCESSORS                                    \
+	"\ts_cmp_lg_u32 s63, -1\n"                               \
+	"\ts_cbranch_scc1 .Lw_no_pf_%=\n"                        \
+	"\ts_add_u32 s46, %[at], 32\n"                           \
+	"\ts_load_dword s47, %[base], s46\n"                     \
+	"\ts_add_u32 s46, %[at], s59\n"                          \
+	"\ts_load_dword s47, %[base], s46\n"                     \
+	".Lw_no_pf_%=:\n"
+#define OCRT_WALK_ASM(TEST_A, TEST_B, PF_B)                 \
 	"\ts_branch .Lw_node_%=\n"                              \
 	".Lw_miss_a_%=:\n"                                      \
 	"\ts_add_u32 %[at], %[at], s51\n"                       \
 	".Lw_node_%=:\n"                                        \
 	"\ts_load_dwordx16 s[48:63], %[base], %[at]\n"          \
 	"\ts_waitcnt lgkmcnt(0)\n"                              \
-	OCRT_WALK_PREFETCH                                      \
 	TEST_A                                                  \
 	"\ts_and_b64 s[44:45], vcc, %[alive]\n"                 \
 	"\ts_cbranch_scc0 .Lw_miss_a_%=\n"                      \
@@ -638,6 +665,7 @@ __device__ __forceinline__ u32x8 scalar_load_node(const float4 *nodes_ptr, uint3
 	"\ts_cbranch_scc1 .Lw_leaf_a_%=\n"                      \
 	".Lw_next_b_%=:\n"                                      \
 	"\ts_add_u32 %[at], %[at], 32\n"                        \
+	PF_B                                                    \
 	TEST_B                                                  \
 	"\ts_and_b64 s[44:45], vcc, %[alive]\n"                 \
 	"\ts_cbranch_scc0 .Lw_miss_b_%=\n"                      \
@@ -677,13 +705,13 @@ __device__ __forceinline__ u32x8 scalar_load_node(const float4 *nodes_ptr, uint3
 #define OCRT_NEAR_N(LO, HI) HI
 #define OCRT_FAR_P(LO, HI) HI
 #define OCRT_FAR_N(LO, HI) LO
-#define OCRT_WALK_COHERENT(TEST, X, Y, Z)                                                                                 \
+#define OCRT_WALK_COHERENT(TEST, X, Y, Z, PF)                                                                               \
 	asm volatile(OCRT_WALK_ASM(TEST(OCRT_NEAR_##X("s48", "s52"), OCRT_NEAR_##Y("s49", "s53"),                              \
 	                                OCRT_NEAR_##Z("s50", "s54"), OCRT_FAR_##X("s48", "s52"),                               \
 	                                OCRT_FAR_##Y("s49", "s53"), OCRT_FAR_##Z("s50", "s54")),                               \
 	                           TEST(OCRT_NEAR_##X("s56", "s60"), OCRT_NEAR_##Y("s57", "s61"),                              \
 	                                OCRT_NEAR_##Z("s58", "s62"), OCRT_FAR_##X("s56", "s60"),                               \
-	                                OCRT_FAR_##Y("s57", "s61"), OCRT_FAR_##Z("s58", "s62")))                               \
+	                                OCRT_FAR_##Y("s57", "s61"), OCRT_FAR_##Z("s58", "s62")), PF)                           \
 	             : [at] "+s"(at), [waiting] "+s"(waiting), [stops] "+s"(leaf_stops), [hit] "=&s"(hit_mask),               \
 	               [leaf] "=&s"(leaf), [status] "=&s"(status)                                                            \
 	             : [base] "s"(walk_ptr), [alive] "s"(alive_mask), [below] "s"(below), [batch_below] "s"(batch_below),     \
@@ -691,8 +719,8 @@ __device__ __forceinline__ u32x8 scalar_load_node(const float4 *nodes_ptr, uint3
 	               [oix] "v"(ray.oix), [oiy] "v"(ray.oiy), [oiz] "v"(ray.oiz)                                             \
 	             : OCRT_WALK_CLOBBERS)
 
-#define OCRT_WALK_MIXED(TEST)                                                                                             \
-	asm volatile(OCRT_WALK_ASM(TEST("s48", "s49", "s50", "s52", "s53", "s54"), TEST("s56", "s57", "s58", "s60", "s61", "s62")) \
+#define OCRT_WALK_MIXED(TEST, PF)                                                                                         \
+	asm volatile(OCRT_WALK_ASM(TEST("s48", "s49", "s50", "s52", "s53", "s54"), TEST("s56", "s57", "s58", "s60", "s61", "s62"), PF) \
 	             : [at] "+s"(at), [waiting] "+s"(waiting), [stops] "+s"(leaf_stops), [hit] "=&s"(hit_mask),               \
 	               [leaf] "=&s"(leaf), [status] "=&s"(status)                                                            \
 	             : [base] "s"(walk_ptr), [alive] "s"(alive_mask), [below] "s"(below), [batch_below] "s"(batch_below),     \
@@ -700,8 +728,8 @@ __device__ __forceinline__ u32x8 scalar_load_node(const float4 *nodes_ptr, uint3
 	               [ix] "v"(ray.ix), [iy] "v"(ray.iy), [iz] "v"(ray.iz), [oix] "v"(ray.oix), [oiy] "v"(ray.oiy),          \
 	               [oiz] "v"(ray.oiz)                                                                                    \
 	             : OCRT_WALK_CLOBBERS)
-#define OCRT_WALK_MIXED_CE(TEST)                                                                                          \
-	asm volatile(OCRT_WALK_ASM(TEST("s48", "s49", "s50", "s52", "s53", "s54"), TEST("s56", "s57", "s58", "s60", "s61", "s62")) \
+#define OCRT_WALK_MIXED_CE(TEST, PF)                                                                                      \
+	asm volatile(OCRT_WALK_ASM(TEST("s48", "s49", "s50", "s52", "s53", "s54"), TEST("s56", "s57", "s58", "s60", "s61", "s62"), PF) \
 	             : [at] "+s"(at), [waiting] "+s"(waiting), [stops] "+s"(leaf_stops), [hit] "=&s"(hit_mask),               \
 	               [leaf] "=&s"(leaf), [status] "=&s"(status)                                                            \
 	             : [base] "s"(walk_ptr), [alive] "s"(alive_mask), [below] "s"(below), [batch_below] "s"(batch_below),     \
@@ -709,23 +737,23 @@ __device__ __forceinline__ u32x8 scalar_load_node(const float4 *nodes_ptr, uint3
 	               [ix] "v"(ray.ix), [iy] "v"(ray.iy), [iz] "v"(ray.iz), [oix] "v"(ray.oix), [oiy] "v"(ray.oiy),          \
 	               [oiz] "v"(ray.oiz)                                                                                    \
 	             : OCRT_WALK_CLOBBERS)
-#define OCRT_WALK_SWITCH(COHERENT_TEST, MIXED_TEST)                     \
+#define OCRT_WALK_SWITCH(COHERENT_TEST, MIXED_TEST, PF)                 \
 	switch (variant) {                                                  \
-	case 0u: OCRT_WALK_COHERENT(COHERENT_TEST, N, N, N); break;         \
-	case 1u: OCRT_WALK_COHERENT(COHERENT_TEST, P, N, N); break;         \
-	case 2u: OCRT_WALK_COHERENT(COHERENT_TEST, N, P, N); break;         \
-	case 3u: OCRT_WALK_COHERENT(COHERENT_TEST, P, P, N); break;         \
-	case 4u: OCRT_WALK_COHERENT(COHERENT_TEST, N, N, P); break;         \
-	case 5u: OCRT_WALK_COHERENT(COHERENT_TEST, P, N, P); break;         \
-	case 6u: OCRT_WALK_COHERENT(COHERENT_TEST, N, P, P); break;         \
-	case 7u: OCRT_WALK_COHERENT(COHERENT_TEST, P, P, P); break;         \
+	case 0u: OCRT_WALK_COHERENT(COHERENT_TEST, N, N, N, PF); break;     \
+	case 1u: OCRT_WALK_COHERENT(COHERENT_TEST, P, N, N, PF); break;     \
+	case 2u: OCRT_WALK_COHERENT(COHERENT_TEST, N, P, N, PF); break;     \
+	case 3u: OCRT_WALK_COHERENT(COHERENT_TEST, P, P, N, PF); break;     \
+	case 4u: OCRT_WALK_COHERENT(COHERENT_TEST, N, N, P, PF); break;     \
+	case 5u: OCRT_WALK_COHERENT(COHERENT_TEST, P, N, P, PF); break;     \
+	case 6u: OCRT_WALK_COHERENT(COHERENT_TEST, N, P, P, PF); break;     \
+	case 7u: OCRT_WALK_COHERENT(COHERENT_TEST, P, P, P, PF); break;     \
 	default: MIXED_TEST; break;                                         \
 	}
 
 // `variant`: 0..7 = sign octant of a coherent packet (bit 0: x reciprocals >= 0, bit 1: y, bit 2: z), 8 = mixed.
 // SCALED: `ray` was made with the frame's walk_scale and `below` is not looked at (the limit is 1.0).
 constexpr uint32_t WALK_MIXED = 8u;
-template <bool SCALED>
+template <bool SCALED, bool PREFETCH = false>
 __device__ __forceinline__ uint32_t walk_collect(uint32_t variant, const float4 *walk_ptr, uint32_t &at, const WalkRay &ray,
                                                  const SignMasks &sign, float below, unsigned long long alive_mask,
                                                  unsigned long long &hit_mask, uint32_t &leaf, uint32_t &waiting,
@@ -733,10 +761,18 @@ __device__ __forceinline__ uint32_t walk_collect(uint32_t variant, const float4 
                                                  uint32_t batch_below) {
 	uint32_t status;
 	if (SCALED) {
+#ifdef OCRT_NO_CE
+		OCRT_WALK_SWITCH(OCRT_TEST_COHERENT_SCALED, OCRT_WALK_MIXED(OCRT_TEST_MIXED_SCALED, OCRT_PF_NONE), OCRT_PF_NONE)
+#else
 		(void) sign;  // (mixed packets: the caller starts `at` in the centre / half-extent copy of the array)
-		OCRT_WALK_SWITCH(OCRT_TEST_COHERENT_SCALED, OCRT_WALK_MIXED_CE(OCRT_TEST_CE_SCALED))
+		if (PREFETCH) {
+			OCRT_WALK_SWITCH(OCRT_TEST_COHERENT_SCALED, OCRT_WALK_MIXED_CE(OCRT_TEST_CE_SCALED, OCRT_PF_SUCCESSORS), OCRT_PF_SUCCESSORS)
+		} else {
+			OCRT_WALK_SWITCH(OCRT_TEST_COHERENT_SCALED, OCRT_WALK_MIXED_CE(OCRT_TEST_CE_SCALED, OCRT_PF_NONE), OCRT_PF_NONE)
+		}
+#endif
 	} else {
-		OCRT_WALK_SWITCH(OCRT_TEST_COHERENT, OCRT_WALK_MIXED(OCRT_TEST_MIXED))
+		OCRT_WALK_SWITCH(OCRT_TEST_COHERENT, OCRT_WALK_MIXED(OCRT_TEST_MIXED, OCRT_PF_NONE), OCRT_PF_NONE)
 	}
 	return status;
 }
@@ -792,7 +828,7 @@ constexpr uint32_t INF_BITS = 0x7F800000u;
 // EXACT walks `nodes_ptr` (exact boxes); the fast form walks `walk_ptr` (padded boxes) and gates every candidate
 // leaf with its own box, the head of its leaf record (scalar loads for a leaf tested on the spot; in a batch each lane
 // loads its pair's record relative to the same scalar base: no buffer descriptor held across the walk).
-template <bool EXACT>
+template <bool EXACT, bool PREFETCH = false>
 __device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ nodes_ptr, const float4 *__restrict__ walk_ptr,
                                                     const float4 *__restrict__ tris_ptr,
                                                     uint32_t count, const Ray &ray_in, const float (&frame)[12][64], uint32_t h,
@@ -868,7 +904,11 @@ __device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ n
 		const uint32_t variant = walk_variant(sign, alive_mask);  // (lanes only leave: a coherent packet stays coherent)
 		// byte offset of the node; a mixed packet walks the centre / half-extent copy of the records, which lies behind
 		// the plane form's and its two END records (scene_pack.cc, make_walk_array: 2 * (count + 2) * 32 < 2^32)
+#ifdef OCRT_NO_CE
+		uint32_t at = 0u;
+#else
 		uint32_t at = variant == WALK_MIXED ? (count + 2u) * 32u : 0u;
+#endif
 		const uint32_t end = at + count * 32u;
 		const WalkRay walk_ray = tame ? make_walk_ray(with_origin(), walk_scale, true) : make_walk_ray(with_origin(), walk_scale);  // (wave-uniform)
 		const uint32_t lane_tag = fresh_lane() << 26;
@@ -878,7 +918,7 @@ __device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ n
 #ifdef OCRT_STAMPS
 			const unsigned long long tw0 = __builtin_amdgcn_s_memrealtime();
 #endif
-			const uint32_t status = walk_collect<true>(variant, walk_ptr, at, walk_ray, sign, below, alive_mask, hit_mask, leaf,
+			const uint32_t status = walk_collect<true, PREFETCH>(variant, walk_ptr, at, walk_ray, sign, below, alive_mask, hit_mask, leaf,
 			                                           waiting, leaf_stops, list_lds_address, lane_tag, batch_below);
 #ifdef OCRT_STAMPS
 			prof[0] += __builtin_amdgcn_s_memrealtime() - tw0;
@@ -1465,7 +1505,8 @@ struct AoArgs {
 #define OCRT_COLD_F32(FIELD) __uint_as_float(cold_u32<(uint32_t) offsetof(AoArgs, FIELD)>())
 #define OCRT_COLD_PTR(TYPE, FIELD) ((TYPE) cold_u64<(uint32_t) offsetof(AoArgs, FIELD)>())
 
-template <int MODE, bool SHARED>
+// PREFETCH: the node loop touches a pair's two successors ahead of time (OCRT_PF_SUCCESSORS): a launch-time choice.
+template <int MODE, bool SHARED, bool PREFETCH = false>
 __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void ao_kernel(AoArgs A) {
 	__shared__ TileShared shared_tiles[AO_WAVES];
 	__shared__ unsigned int wg_claim[4];  // the workgroup's current claim: first unit, units per wave, end (if dealt by cursor), cursor
@@ -1833,7 +1874,7 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 							                          OCRT_COLD_F32(P.ao_max_distance), A.P.ao_below, 0.0f, alive, false, &sh.occluded[h], sh.batch,
 							                          A.P.batch_below, walk_prof);
 						else
-							shared_walk_any_hit<false>(nullptr, walk_ptr, tris_ptr, count, ray, sh.frame, h,
+							shared_walk_any_hit<false, PREFETCH>(nullptr, walk_ptr, tris_ptr, count, ray, sh.frame, h,
 							                           0.0f, A.P.ao_below, OCRT_COLD_F32(P.walk_scale), alive, tame, &sh.occluded[h], sh.batch,
 							                           A.P.batch_below, walk_prof);
 					}
@@ -1996,7 +2037,7 @@ __global__ __launch_bounds__(256) void resize_kernel(const float *__restrict__ t
 void preload_kernels() {
 	hipFuncAttributes attr;
 	(void) hipFuncGetAttributes(&attr, (const void *) primary_kernel<true>);
-	(void) hipFuncGetAttributes(&attr, (const void *) ao_kernel<AO_UNIFORM, true>);
+	(void) hipFuncGetAttributes(&attr, (const void *) ao_kernel<AO_UNIFORM, true, true>);
 	(void) hipGetLastError();
 }
 
@@ -2043,7 +2084,8 @@ void launch_primary(const SceneBuffers &scene, float *image, void *hits, void *o
 }
 
 void launch_ao(const SceneBuffers &scene, void *hits, void *occluded_of, void *order, void *counters,
-               const KernelParams &params, uint32_t workgroups, void *stream, void *event_before_ao, void *event_after_ao) {
+               const KernelParams &params, uint32_t workgroups, bool prefetch, void *stream, void *event_before_ao,
+               void *event_after_ao) {
 	if (params.tiles_x * params.local_tile_rows == 0 || params.ao_mode == AO_NONE || params.ao_dirs == 0)
 		return;
 	hipStream_t s = (hipStream_t) stream;
@@ -2083,9 +2125,12 @@ void launch_ao(const SceneBuffers &scene, void *hits, void *occluded_of, void *o
 			launch(ao_kernel<AO_RANDOM, false>);
 	} else
 #endif
-	if (P.ao_mode == AO_UNIFORM)
-		launch(ao_kernel<AO_UNIFORM, true>);
-	else
+	if (P.ao_mode == AO_UNIFORM) {
+		if (prefetch)
+			launch(ao_kernel<AO_UNIFORM, true, true>);
+		else
+			launch(ao_kernel<AO_UNIFORM, true, false>);
+	} else
 		launch(ao_kernel<AO_RANDOM, true>);
 }
 

@@ -135,6 +135,43 @@ def test_ring_holds_one_copy_of_the_scene(rt, golden, scene_for):
     assert seen[3][1] == seen[3][0] + 3 * per_host and seen[6][1] == seen[6][0] + 6 * per_host
 
 
+def test_both_forms_of_the_ao_pass_render_the_same_frame(rt, golden, scene_for):
+    """The ambient-occlusion pass exists with and without look-ahead loads in its node loop (kernels.hip,
+    OCRT_PF_SUCCESSORS); a ring measures both at upload and keeps the faster.  Whatever it keeps, the frame is the golden
+    one -- here: each form forced on a host, then a ring with the calibration on and one with it off."""
+    case = golden["renders"][HEADLINE]
+    opt = options_for(rt, case)
+    scene = scene_for(case["mesh"], case["bvh"])[0]
+    images = []
+    for form in (False, True):
+        host = rt.Host(opt, 0)
+        host.set_ao_prefetch(form)
+        host.upload_scene(scene)
+        host.render()
+        images.append(host.download())
+        assert md5_of(rt, host.download_u8()) == case["pgm_md5"]
+        st = host.stats()
+        assert st["ao_occluded"] == case["counters"]["ao_occluded"] and st["primary_hits"] == case["counters"]["primary_hits"]
+        host.close()
+    assert np.array_equal(images[0].view(np.uint32), images[1].view(np.uint32))
+    ring = rt.FrameRing(opt, scene, hosts=3)
+    without, with_, in_use = ring.calibration()
+    assert 0.2 < without < 20.0 and 0.2 < with_ < 20.0  # measured, in ms, on this frame
+    assert in_use == (with_ <= without)
+    ring.run(7)
+    ring.drain()
+    assert md5_of(rt, ring.download_last()) == case["pgm_md5"]
+    ring.close()
+    ring = rt.FrameRing(opt, None, hosts=2)
+    ring.set_calibration(False)
+    ring.upload_scene(scene)
+    assert ring.calibration()[:2] == (0.0, 0.0)
+    ring.run(5)
+    ring.drain()
+    assert md5_of(rt, ring.download_last()) == case["pgm_md5"]
+    ring.close()
+
+
 def test_a_borrowed_host_cannot_outlive_its_ring(rt, golden, scene_for):
     """FrameRing.host() hands out views into the ring: a view keeps the ring alive, and once the ring is closed every
     call on it fails cleanly instead of touching freed memory."""

@@ -20,11 +20,11 @@ sys.path.insert(0, ROOT)
 
 def one(workload, frames):
     import opencl_raytracer_amd as rt
-    from bench import WORKLOADS, mesh_path, workload_options
+    from bench import WORKLOADS, load_scene, mesh_path, workload_options
 
     w = WORKLOADS[workload]
     opt = workload_options(rt, w)
-    scene = rt.Scene.load_off(mesh_path(w["mesh"])).build_bvh(opt.bvh_method)
+    scene = load_scene(rt, w).build_bvh(opt.bvh_method)
     ring = rt.FrameRing(opt, scene, hosts=1)
     ring.set_graph_mode(False)
     ring.run(10)

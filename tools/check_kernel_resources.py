@@ -111,7 +111,7 @@ def main():
                f"{k.get('SGPRs Spill', '?'):>10s} {k.get('VGPRs Spill', '?'):>10s} {k.get('LDS Size [bytes/block]', '?'):>7s}")
         lines.append(row)
         # hot: the default path = shared-walk instantiations of the primary pass and of the UNIFORM ambient-occlusion pass
-        hot = name.startswith("primary_kernel<true>") or name.startswith("ao_kernel<1, true>")
+        hot = name.startswith("primary_kernel<true>") or name.startswith("ao_kernel<1, true")
         walker = hot or name.startswith("ao_kernel<") or name.startswith("primary_kernel<")
         if walker and k.get("Occupancy [waves/SIMD]") != "8":
             errors.append(f"{name}: occupancy {k.get('Occupancy [waves/SIMD]')} waves/SIMD, the walk is scheduled for 8")
@@ -126,7 +126,7 @@ def main():
         for kname, p in places.items():
             short = kname.replace("ocrt::", "").replace("void ", "")
             lines.append(f"{short:44s} {p['total']:5d} {p['in_node_loop']:5d} {p['walk_turn']:5d} {p['per_packet']:5d}   {p['depths']}")
-            if not (short.startswith("primary_kernel<true>") or short.startswith("ao_kernel<1, true>")):
+            if not (short.startswith("primary_kernel<true>") or short.startswith("ao_kernel<1, true")):
                 continue
             if p["in_node_loop"]:
                 errors.append(f"{short}: {p['in_node_loop']} SGPR spill instructions inside the node loop")

@@ -10,11 +10,11 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import opencl_raytracer_amd as rt  # noqa: E402
-from bench import WORKLOADS, mesh_path, workload_options  # noqa: E402
+from bench import WORKLOADS, load_scene, mesh_path, workload_options  # noqa: E402
 
 w = WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "bunny_1080p_ao"]
 opt = workload_options(rt, w)
-scene = rt.Scene.load_off(mesh_path(w["mesh"])).build_bvh(opt.bvh_method)
+scene = load_scene(rt, w).build_bvh(opt.bvh_method)
 for n in ([int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else (1, 2, 4, 8)):
     worst, worst_ao = 0.0, 0.0
     for rank in range(n):

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 import opencl_raytracer_amd as rt  # noqa: E402
-from bench import WORKLOADS, mesh_path, workload_options  # noqa: E402
+from bench import WORKLOADS, load_scene, mesh_path, workload_options  # noqa: E402
 
 
 def main():
@@ -26,7 +26,7 @@ def main():
     if args.bvh:
         w["bvh"] = args.bvh
     opt = workload_options(rt, w)
-    scene = rt.Scene.load_off(mesh_path(w["mesh"])).build_bvh(opt.bvh_method)
+    scene = load_scene(rt, w).build_bvh(opt.bvh_method)
     host = rt.Host(opt, 0)
     host.upload_scene(scene)
     host.set_device_share(args.share)

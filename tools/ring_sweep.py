@@ -6,10 +6,10 @@ turn on the one GPU (rt.FrameRing) -- how many frames to keep in flight per GPU 
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import opencl_raytracer_amd as rt
-from bench import WORKLOADS, mesh_path, workload_options
+from bench import WORKLOADS, load_scene, mesh_path, workload_options
 w = WORKLOADS[sys.argv[1]]
 opt = workload_options(rt, w)
-scene = rt.Scene.load_off(mesh_path(w["mesh"])).build_bvh(opt.bvh_method)
+scene = load_scene(rt, w).build_bvh(opt.bvh_method)
 for n in (8, 4, 1):
     for hosts in (1, 2, 3, 4, 6):
         worst = 0.0

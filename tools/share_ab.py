@@ -6,11 +6,11 @@ frames in turn on the one GPU (rt.FrameRing); reads OCRT_* knobs from the enviro
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import opencl_raytracer_amd as rt
-from bench import WORKLOADS, mesh_path, workload_options
+from bench import WORKLOADS, load_scene, mesh_path, workload_options
 w = WORKLOADS[sys.argv[1]]
 n, hosts = int(sys.argv[2]), int(sys.argv[3])
 opt = workload_options(rt, w)
-scene = rt.Scene.load_off(mesh_path(w["mesh"])).build_bvh(opt.bvh_method)
+scene = load_scene(rt, w).build_bvh(opt.bvh_method)
 worst = 0.0
 for rank in range(min(n, 4)):
     ring = rt.FrameRing(opt, scene, 0, rank, n, hosts=hosts)

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 import opencl_raytracer_amd as rt  # noqa: E402
-from bench import WORKLOADS, mesh_path, workload_options  # noqa: E402
+from bench import WORKLOADS, load_scene, mesh_path, workload_options  # noqa: E402
 
 
 def main():
@@ -20,7 +20,7 @@ def main():
     frames = int(sys.argv[2]) if len(sys.argv) > 2 else 40
     w = WORKLOADS[name]
     opt = workload_options(rt, w)
-    scene = rt.Scene.load_off(mesh_path(w["mesh"])).build_bvh(opt.bvh_method)
+    scene = load_scene(rt, w).build_bvh(opt.bvh_method)
     hosts = [rt.Host(opt, 0) for _ in range(2)]
     for h in hosts:
         h.upload_scene(scene)
