@@ -495,6 +495,12 @@ def main():
     else:
         total_rays, total_hits, total_occluded = my_rays, st["primary_hits"], st["ao_occluded"]
     images = {name: final_image(name) for name in rings}
+    rccl_described = None
+    if rccl:
+        comm_ranks, version = rings["pipelined"].rccl_info()
+        rccl_described = {"comm_ranks": comm_ranks, "version_code": version, "world_size": world}
+        if comm_ranks not in (-1, world):
+            sys.exit(f"bench.py: the RCCL communicator has {comm_ranks} ranks, the job {world}")
     scene_bytes, scene_copies, _ = rings["pipelined"].device_bytes()
     calibration = rings["pipelined"].calibration()
 
@@ -530,7 +536,11 @@ def main():
                     + ", fixed camera, no randomness in this path",
             "config": {"workload": w["label"], "rays_per_frame": total_rays, "primary_hits": total_hits,
                        "parallelism": f"image bands x{world}" + (f", {gather}" if gather else ""),
-                       "frames_in_flight": in_flight, "frame_launch": "plain launches" if args.plain_launches else "hipGraph replay",
+                       "frames_in_flight": in_flight, "n_hosts_per_gpu": in_flight,
+                       # what the exchange step's communicator says about itself (ncclCommCount, ncclGetVersion): a scaling
+                       # record can check that RCCL really saw `n_gpus` ranks; null without RCCL (a single unlaunched process)
+                       "rccl": rccl_described,
+                       "frame_launch": "plain launches" if args.plain_launches else "hipGraph replay",
                        "pgm_md5": md5["pipelined"], "pgm_matches_golden": golden_md5 is not None,
                        "scene_load_s": round(t_load, 3), "scene_build_s": round(t_scene, 3),
                        # one copy of the scene per GPU whatever the number of hosts; which form of the AO pass the ring's

@@ -246,6 +246,12 @@ int rt_ring_cpu_times(const rt_ring *r, double *submit_s, double *wait_s, double
  * rt_rccl_unique_id (rank 0) fills 128 bytes that the caller hands to every rank (e.g. torch.distributed broadcast);
  * rt_ring_attach_rccl is collective (ncclCommInitRank with the ring's rank / nranks).  rt_rccl_available: 1 when
  * librccl.so.1 can be opened (it is opened at run time; the library loads without it). */
+/* A ring's exchange step waits at most `seconds` (default 30) for a frame's gather: a peer rank that died or posted a
+ * different number of frames makes rt_ring_run / rt_ring_drain / rt_ring_submit fail with RT_E_DEVICE instead of
+ * hanging.  rt_ring_rccl_info: what the attached communicator says about itself -- ranks (ncclCommCount), RCCL's
+ * version code (ncclGetVersion), -1 where unknown -- so that a run can state how many ranks RCCL really saw. */
+int rt_ring_set_gather_timeout(rt_ring *r, double seconds);
+int rt_ring_rccl_info(rt_ring *r, int *comm_ranks, int *rccl_version);
 int rt_rccl_available(void);
 int rt_rccl_unique_id(void *out128);
 int rt_ring_attach_rccl(rt_ring *r, const void *unique_id128);

@@ -134,6 +134,8 @@ _SIGNATURES = {
                                  C.c_uint32, C.c_void_p]),
     "rt_ring_upload_scene": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rt_ring_device_bytes": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
+    "rt_ring_set_gather_timeout": (C.c_int, [C.c_void_p, C.c_double]),
+    "rt_ring_rccl_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "rt_ring_set_calibration": (C.c_int, [C.c_void_p, C.c_int]),
     "rt_ring_calibration": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "rt_set_ao_prefetch": (C.c_int, [C.c_void_p, C.c_int]),
@@ -472,6 +474,16 @@ class FrameRing:
 
     def upload_scene(self, scene: "Scene") -> None:
         _check(load_library().rt_ring_upload_scene(self._r, scene._h))
+
+    def set_gather_timeout(self, seconds: float) -> None:
+        """The exchange step waits at most this long (default 30 s) for a frame's gather, then fails with RtError."""
+        _check(load_library().rt_ring_set_gather_timeout(self._r, float(seconds)))
+
+    def rccl_info(self):
+        """(ranks of the attached communicator by ncclCommCount, RCCL version code by ncclGetVersion); -1 = unknown."""
+        a, b = C.c_int(), C.c_int()
+        _check(load_library().rt_ring_rccl_info(self._r, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
 
     def set_calibration(self, on: bool) -> None:
         """Before an upload: whether the upload measures which form of the AO pass suits the scene (default: yes)."""

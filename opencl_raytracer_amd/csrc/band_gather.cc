@@ -4,8 +4,10 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>  // types only: the entry points are looked up at run time, the library is not linked
 
+#include <chrono>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <sstream>
 #include <string>
 
@@ -31,6 +33,9 @@ struct Rccl {
 	ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
 	ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
 	ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+	ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;             // optional
+	ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;  // optional
+	ncclResult_t (*GetVersion)(int *) = nullptr;                  // optional
 	ncclResult_t (*GroupStart)() = nullptr;
 	ncclResult_t (*GroupEnd)() = nullptr;
 	ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -68,6 +73,10 @@ const Rccl &rccl() {
 		api.Send = (decltype(api.Send)) sym("ncclSend");
 		api.Recv = (decltype(api.Recv)) sym("ncclRecv");
 		api.GetErrorString = (decltype(api.GetErrorString)) sym("ncclGetErrorString");
+		// (not every build has these: looked up without complaint)
+		api.CommAbort = (decltype(api.CommAbort)) dlsym(lib, "ncclCommAbort");
+		api.CommCount = (decltype(api.CommCount)) dlsym(lib, "ncclCommCount");
+		api.GetVersion = (decltype(api.GetVersion)) dlsym(lib, "ncclGetVersion");
 	});
 	return api;
 }
@@ -88,6 +97,30 @@ void nccl_check(ncclResult_t r, const char *what) {
 	}
 }
 #define OCRT_NCCL(call) nccl_check((call), #call)
+
+// Calls made between ncclGroupStart and ncclGroupEnd: the first failure is remembered, the group is ALWAYS closed (an
+// open group would swallow every later RCCL call of the process, torch.distributed's included), then it is thrown.
+struct NcclGroup {
+	const Rccl &api;
+	ncclResult_t first = ncclSuccess;
+	const char *where = nullptr;
+	explicit NcclGroup(const Rccl &a) : api(a) { nccl_check(api.GroupStart(), "ncclGroupStart"); }
+	void note(ncclResult_t r, const char *what) {
+		if (r != ncclSuccess && first == ncclSuccess) {
+			first = r;
+			where = what;
+		}
+	}
+	void end() {
+		const ncclResult_t closed = api.GroupEnd();
+		if (first != ncclSuccess)
+			nccl_check(first, where);
+		nccl_check(closed, "ncclGroupEnd");
+	}
+};
+#define OCRT_IN_GROUP(group, expression) (group).note((expression), #expression)
+
+double seconds_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // One workgroup per image row: the row's owner and its place in the owner's band buffer follow from the partition
 // arithmetic (band b = y / rows_per_band belongs to rank b % nranks; ocrt::Partition).
@@ -194,10 +227,14 @@ BandGather::~BandGather() { release(); }
 void BandGather::release() {
 	if (hipSetDevice(device) != hipSuccess)
 		return;
-	if (stream)
+	if (stream && !broken)
 		(void) hipStreamSynchronize((hipStream_t) stream);
-	if (comm && rccl().CommDestroy)
-		(void) rccl().CommDestroy((ncclComm_t) comm);
+	if (comm) {
+		if (broken && rccl().CommAbort)
+			(void) rccl().CommAbort((ncclComm_t) comm);  // (pending operations can never complete: do not wait for them)
+		else if (!broken && rccl().CommDestroy)
+			(void) rccl().CommDestroy((ncclComm_t) comm);
+	}
 	comm = nullptr;
 	for (void *e : done)
 		(void) hipEventDestroy((hipEvent_t) e);
@@ -222,16 +259,16 @@ void BandGather::enqueue(unsigned int slot, const void *device_bands) {
 	OCRT_HIP(hipSetDevice(device));
 	hipStream_t s = (hipStream_t) stream;
 	if (nranks > 1) {
-		OCRT_NCCL(api.GroupStart());
+		NcclGroup group(api);
 		if (rank == 0) {
 			for (unsigned int r = 1; r < nranks; ++r)
 				if (layout.bytesOf(r))
-					OCRT_NCCL(api.Recv((char *) stacked[slot] + (size_t) r * layout.stride(), layout.bytesOf(r), ncclUint8, (int) r,
-					                   (ncclComm_t) comm, s));
+					OCRT_IN_GROUP(group, api.Recv((char *) stacked[slot] + (size_t) r * layout.stride(), layout.bytesOf(r), ncclUint8,
+					                              (int) r, (ncclComm_t) comm, s));
 		} else if (layout.bytesOf(rank)) {
-			OCRT_NCCL(api.Send(device_bands, layout.bytesOf(rank), ncclUint8, 0, (ncclComm_t) comm, s));
+			OCRT_IN_GROUP(group, api.Send(device_bands, layout.bytesOf(rank), ncclUint8, 0, (ncclComm_t) comm, s));
 		}
-		OCRT_NCCL(api.GroupEnd());
+		group.end();
 	}
 	if (rank == 0)
 		launch_assemble_rows(layout, device_bands, stacked[slot], final_image[slot], stream);
@@ -243,12 +280,46 @@ void BandGather::wait(unsigned int slot) {
 		throw std::invalid_argument("band gather: bad slot");
 	OCRT_HIP(hipSetDevice(device));
 	// (mostly long done -- the slot comes round again a whole turn of the ring later --: ask before sleeping on it)
-	const hipError_t state = hipEventQuery((hipEvent_t) done[slot]);
-	if (state == hipSuccess)
-		return;
-	if (state != hipErrorNotReady)
-		OCRT_HIP(state);
-	OCRT_HIP(hipEventSynchronize((hipEvent_t) done[slot]));
+	// A BOUNDED wait: the gather completes only if every rank posts its half of it.  A rank that died, or that submitted
+	// a different number of frames, would leave the others asleep in here for ever -- inside rt_ring_run, where nobody can
+	// see why.  So the event is polled against a deadline, and missing it is an error (DeviceError -> RT_E_DEVICE: the rank
+	// ends with a message and a non-zero status instead of hanging the job); the communicator is then marked broken and
+	// aborted rather than destroyed (ncclCommDestroy would wait for the very operation that cannot finish).
+	if (broken)
+		throw DeviceError("band gather: the exchange step is broken (an earlier wait ran into its deadline)");
+	const double begin = seconds_now();
+	for (unsigned int polls = 0;; ++polls) {
+		const hipError_t state = hipEventQuery((hipEvent_t) done[slot]);
+		if (state == hipSuccess)
+			return;
+		if (state != hipErrorNotReady)
+			OCRT_HIP(state);
+		const double waited = seconds_now() - begin;
+		if (waited > timeout_s) {
+			broken = true;
+			std::ostringstream ss;
+			ss << "band gather: rank " << rank << " of " << nranks << " waited " << timeout_s << " s for the exchange step of slot " << slot
+			   << " -- a peer rank is gone or posted a different number of frames";
+			throw DeviceError(ss.str());
+		}
+		if (polls < 2000)
+			std::this_thread::yield();
+		else
+			std::this_thread::sleep_for(std::chrono::microseconds(waited < 0.01 ? 20 : 500));
+	}
+}
+
+void BandGather::describe(int *comm_ranks, int *rccl_version) const {
+	const Rccl &api = rccl();
+	int count = -1, version = -1;
+	if (comm && api.CommCount)
+		(void) api.CommCount((ncclComm_t) comm, &count);
+	if (api.GetVersion)
+		(void) api.GetVersion(&version);
+	if (comm_ranks)
+		*comm_ranks = count;
+	if (rccl_version)
+		*rccl_version = version;
 }
 
 const void *BandGather::image(unsigned int slot) const { return slot < final_image.size() ? final_image[slot] : nullptr; }
@@ -266,10 +337,10 @@ void BandGather::selfTest() {
 	try {
 		OCRT_HIP(hipMemcpy(a, pattern, 64, hipMemcpyHostToDevice));
 		OCRT_HIP(hipMemset(b, 0, 64));
-		OCRT_NCCL(api.GroupStart());
-		OCRT_NCCL(api.Send(a, 64, ncclUint8, (int) rank, (ncclComm_t) comm, s));
-		OCRT_NCCL(api.Recv(b, 64, ncclUint8, (int) rank, (ncclComm_t) comm, s));
-		OCRT_NCCL(api.GroupEnd());
+		NcclGroup group(api);
+		OCRT_IN_GROUP(group, api.Send(a, 64, ncclUint8, (int) rank, (ncclComm_t) comm, s));
+		OCRT_IN_GROUP(group, api.Recv(b, 64, ncclUint8, (int) rank, (ncclComm_t) comm, s));
+		group.end();
 		OCRT_HIP(hipStreamSynchronize(s));
 		OCRT_HIP(hipMemcpy(back, b, 64, hipMemcpyDeviceToHost));
 	} catch (...) {
@@ -292,9 +363,18 @@ GroupGather::GroupGather(const RayTracer::Options &options, const std::vector<in
 	OCRT_NCCL(api.CommInitAll(c.data(), (int) devices.size(), devices.data()));
 	for (ncclComm_t x : c)
 		comms.push_back(x);
-	OCRT_HIP(hipSetDevice(devices[0]));
-	OCRT_HIP(hipMalloc(&stacked, layout.stride() * layout.nranks));
-	OCRT_HIP(hipMalloc(&final_image, (size_t) layout.width * layout.height));
+	try {
+		OCRT_HIP(hipSetDevice(devices[0]));
+		OCRT_HIP(hipMalloc(&stacked, layout.stride() * layout.nranks));
+		OCRT_HIP(hipMalloc(&final_image, (size_t) layout.width * layout.height));
+	} catch (...) {  // (the destructor does not run for a constructor that throws)
+		for (size_t r = 0; r < comms.size(); ++r)
+			if (comms[r] && api.CommDestroy && hipSetDevice(devices[r]) == hipSuccess)
+				(void) api.CommDestroy((ncclComm_t) comms[r]);
+		if (stacked)
+			(void) hipFree(stacked);
+		throw;
+	}
 }
 
 GroupGather::~GroupGather() {
@@ -314,15 +394,15 @@ void GroupGather::enqueue(const std::vector<const void *> &bands, const std::vec
 		throw std::invalid_argument("group gather: one band buffer and one stream per device");
 	const Rccl &api = rccl_or_throw();
 	if (devices.size() > 1) {
-		OCRT_NCCL(api.GroupStart());
+		NcclGroup group(api);
 		for (unsigned int r = 1; r < devices.size(); ++r) {
 			if (!layout.bytesOf(r))
 				continue;
-			OCRT_NCCL(api.Send(bands[r], layout.bytesOf(r), ncclUint8, 0, (ncclComm_t) comms[r], (hipStream_t) streams[r]));
-			OCRT_NCCL(api.Recv((char *) stacked + (size_t) r * layout.stride(), layout.bytesOf(r), ncclUint8, (int) r,
-			                   (ncclComm_t) comms[0], (hipStream_t) streams[0]));
+			OCRT_IN_GROUP(group, api.Send(bands[r], layout.bytesOf(r), ncclUint8, 0, (ncclComm_t) comms[r], (hipStream_t) streams[r]));
+			OCRT_IN_GROUP(group, api.Recv((char *) stacked + (size_t) r * layout.stride(), layout.bytesOf(r), ncclUint8, (int) r,
+			                              (ncclComm_t) comms[0], (hipStream_t) streams[0]));
 		}
-		OCRT_NCCL(api.GroupEnd());
+		group.end();
 	}
 	OCRT_HIP(hipSetDevice(devices[0]));
 	launch_assemble_rows(layout, bands[0], stacked, final_image, streams[0]);

@@ -49,7 +49,14 @@ class BandGather {
 		// `device_bands` (localRows x width bytes, complete on the device) -> rank 0, asynchronously on the gather's
 		// own stream; on rank 0 followed by the assembly of slot `slot`'s final image.
 		void enqueue(unsigned int slot, const void *device_bands);
-		void wait(unsigned int slot);                  // CPU wait for that slot's last gather (and assembly)
+		// CPU wait for that slot's last gather (and assembly) -- bounded: DeviceError after timeout() seconds without it
+		// (a peer that died or posted fewer frames must not hang this rank), default 30 s.
+		void wait(unsigned int slot);
+		void setTimeout(double seconds) { timeout_s = seconds > 0.0 ? seconds : 30.0; }
+		double timeout() const { return timeout_s; }
+		// What the communicator says about itself: its number of ranks (ncclCommCount) and RCCL's version code
+		// (ncclGetVersion); -1 where the library lacks the entry point.
+		void describe(int *comm_ranks, int *rccl_version) const;
 		const void *image(unsigned int slot) const;    // rank 0: width x height bytes on the device; else nullptr
 		unsigned int slots() const { return (unsigned int) done.size(); }
 		const BandPlan &plan() const { return layout; }
@@ -63,6 +70,8 @@ class BandGather {
 		BandPlan layout;
 		unsigned int rank, nranks;
 		int device;
+		double timeout_s = 30.0;
+		bool broken = false;        // a wait timed out: the communicator is aborted, not destroyed
 		void *comm;                 // ncclComm_t
 		void *stream;               // hipStream_t: the gather's own
 		std::vector<void *> done;   // hipEvent_t per slot

@@ -627,6 +627,26 @@ int rt_ring_attach_rccl(rt_ring *r, const void *unique_id128) {
 	});
 }
 
+int rt_ring_set_gather_timeout(rt_ring *r, double seconds) {
+	if (!r)
+		return fail(RT_E_INVALID, "null ring");
+	return guarded([&] {
+		if (!r->ring->hasGather())
+			throw std::logic_error("no communicator attached (rt_ring_attach_rccl)");
+		r->ring->gatherOrNull()->setTimeout(seconds);
+	});
+}
+
+int rt_ring_rccl_info(rt_ring *r, int *comm_ranks, int *rccl_version) {
+	if (!r)
+		return fail(RT_E_INVALID, "null ring");
+	return guarded([&] {
+		if (!r->ring->hasGather())
+			throw std::logic_error("no communicator attached (rt_ring_attach_rccl)");
+		r->ring->gatherOrNull()->describe(comm_ranks, rccl_version);
+	});
+}
+
 int rt_ring_rccl_self_test(rt_ring *r) {
 	if (!r)
 		return fail(RT_E_INVALID, "null ring");

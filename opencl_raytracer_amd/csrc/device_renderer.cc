@@ -64,7 +64,7 @@ void warm_up_device(int device) {
 }
 
 DeviceRenderer::DeviceRenderer(const RayTracer::Options &options, int device_, unsigned int rank, unsigned int nranks,
-                               int ring_slot)
+                               int ring_slot, bool spare_top_class)
 	: opts(options)
 	, rt(options)
 	, device(device_)
@@ -133,7 +133,10 @@ DeviceRenderer::DeviceRenderer(const RayTracer::Options &options, int device_, u
 	// class: whatever else the process runs on the device (a collective's kernels) is not held up by it.
 	int least = 0, greatest = 0;
 	OCRT_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-	const int classes = least - greatest + 1;
+	// With an exchange step on the device (a multi-GPU job's ring) the HIGHEST class is the gather stream's alone
+	// (band_gather.cc): an RCCL receive waiting for a slower peer must not sit in a hardware queue ahead of a renderer's
+	// graph launches, nor the gather behind a whole frame; the renderers alternate over the classes below it.
+	const int classes = least - greatest + 1 - (spare_top_class && least - greatest + 1 > 2 ? 1 : 0);
 	const int priority = ring_slot < 0 || classes < 2 ? least : least - ring_slot % classes;
 	hipStream_t s;
 	OCRT_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority));

@@ -71,7 +71,10 @@ class DeviceRenderer {
 	public:
 		// `ring_slot`: this renderer's index among the renderers that take frames in turn on its GPU (FrameRing), -1 for
 		// a renderer on its own.  It picks the priority class of the renderer's stream, see the constructor.
-		DeviceRenderer(const RayTracer::Options &options, int device, unsigned int rank, unsigned int nranks, int ring_slot = -1);
+		// `spare_top_class`: leave the highest stream-priority class to somebody else (the ring's exchange step, whose
+		// stream must never queue behind a frame).
+		DeviceRenderer(const RayTracer::Options &options, int device, unsigned int rank, unsigned int nranks, int ring_slot = -1,
+		               bool spare_top_class = false);
 		~DeviceRenderer();
 		DeviceRenderer(const DeviceRenderer &) = delete;
 		DeviceRenderer &operator=(const DeviceRenderer &) = delete;

@@ -29,21 +29,32 @@ FrameRing::FrameRing(const RayTracer::Options &options, int device, unsigned int
 	if (count == 0 || count > 16)
 		throw std::invalid_argument("a frame ring holds 1 to 16 renderers");
 	for (unsigned int k = 0; k < count; ++k) {
-		hosts.emplace_back(new DeviceRenderer(options, device, rank, nranks, count > 1 ? (int) k : -1));
+		// (a ring of a multi-GPU job will get a gather: its stream takes the highest priority class for itself, the
+		// hosts are dealt over the others -- DeviceRenderer's constructor)
+		hosts.emplace_back(new DeviceRenderer(options, device, rank, nranks, count > 1 ? (int) k : -1, nranks > 1));
 		hosts.back()->setDeviceShare(count);
 	}
 	bound.assign(2 * count, nullptr);
 	gather_pending.assign(2 * count, false);
-	OCRT_HIP(hipSetDevice(hosts.front()->deviceIndex()));
 	extra.assign(count, nullptr);
-	for (unsigned int k = 0; k < count; ++k) {
-		const size_t bytes = (size_t) hosts[k]->localRows() * hosts[k]->width();
-		OCRT_HIP(hipMalloc(&extra[k], bytes ? bytes : 1));
+	try {
+		OCRT_HIP(hipSetDevice(hosts.front()->deviceIndex()));
+		for (unsigned int k = 0; k < count; ++k) {
+			const size_t bytes = (size_t) hosts[k]->localRows() * hosts[k]->width();
+			OCRT_HIP(hipMalloc(&extra[k], bytes ? bytes : 1));
+		}
+		hipEvent_t e;
+		OCRT_HIP(hipEventCreate(&e));
+		epoch = e;
+		resetClock();
+	} catch (...) {  // (no destructor runs for a constructor that throws: give back what was taken)
+		for (void *p : extra)
+			if (p)
+				(void) hipFree(p);
+		if (epoch)
+			(void) hipEventDestroy((hipEvent_t) epoch);
+		throw;
 	}
-	hipEvent_t e;
-	OCRT_HIP(hipEventCreate(&e));
-	epoch = e;
-	resetClock();
 }
 
 FrameRing::~FrameRing() {
@@ -96,6 +107,7 @@ void FrameRing::bindOutput(unsigned int slot, void *device_u8) {
 	for (const Collected &c : open)
 		if (c.slot == slot)
 			throw std::logic_error("frame ring: the slot has a frame in flight");
+	waitSlotFree(slot);  // (a gather of the slot's last frame may still be reading the buffer that is about to be replaced)
 	bound[slot] = device_u8;
 	DeviceRenderer &h = *hosts[slot % hosts.size()];
 	if (h.sceneReady())

@@ -61,6 +61,7 @@ class FrameRing {
 		void attachGather(std::unique_ptr<BandGather> gather);
 		bool hasGather() const { return gather != nullptr; }
 		void gatherSelfTest() { gather->selfTest(); }
+		BandGather *gatherOrNull() { return gather.get(); }
 
 		// Enqueues the next frame (all passes + device resize) on the next renderer and returns its number (0, 1, ...).
 		// Throws std::logic_error when every renderer already has a frame in flight.

@@ -1,6 +1,6 @@
 // fake_rccl.cc -- TEST INFRASTRUCTURE: a stand-in for librccl.so.1 that lets the product's RCCL exchange step
 // (ocrt::GroupGather / ocrt::BandGather, csrc/band_gather.cc) run with SEVERAL RANKS ON ONE GPU, which the real RCCL
-// refuses ("duplicate GPU").  It implements the nine entry points the product resolves at run time, for communicators
+// refuses ("duplicate GPU").  It implements the entry points the product resolves at run time, for communicators
 // whose ranks all live in ONE process (ncclCommInitAll, or ncclCommInitRank called once per rank with the same id): an
 // ncclSend / ncclRecv pair becomes a stream-ordered device-to-device copy -- the receive stream waits for an event
 // recorded on the send stream, then copies.  What it checks is the PRODUCT's side of the exchange: which buffers,
@@ -14,6 +14,7 @@
 #include <rccl/rccl.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -37,6 +38,17 @@ struct Op {
 	hipStream_t stream;
 	hipEvent_t ready;  // sends: recorded on the send stream when the send was posted
 };
+
+// FAKE_RCCL_HANG_ON_MISSING_SEND=1: a receive that finds no posted send does not fail -- it BLOCKS its stream, the way a
+// real receive waits for a peer that died or posted fewer frames (tests/test_fake_rccl.py: the product must notice and
+// give up).  The block is a one-thread kernel that sleeps until ncclCommAbort / ncclCommDestroy sets a flag in mapped
+// host memory, or a minute of the device clock has passed (every wave reaches its end whatever happens).
+__global__ void hang_kernel(const volatile int *released) {
+	const unsigned long long begin = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+	while (*released == 0 && __builtin_amdgcn_s_memrealtime() - begin < 6000000000ull)
+		__builtin_amdgcn_s_sleep(100);
+}
+int *release_flag = nullptr;  // hipHostMalloc'ed, mapped
 
 std::mutex mutex;
 int depth = 0, next_group = 1;
@@ -65,6 +77,20 @@ ncclResult_t run_batch() {
 				break;
 			}
 		if (match == sends.size() || sends[match].bytes != r.bytes) {
+			const char *hang = std::getenv("FAKE_RCCL_HANG_ON_MISSING_SEND");
+			if (hang && hang[0] == '1' && match == sends.size()) {
+				std::fprintf(stderr, "fake rccl: receive of %zu bytes on rank %d from %d finds no posted send: blocking its stream\n",
+				             r.bytes, r.comm->rank, r.peer);
+				if (!release_flag) {
+					if (hipHostMalloc((void **) &release_flag, sizeof(int), hipHostMallocMapped) != hipSuccess)
+						return ncclUnhandledCudaError;
+					*release_flag = 0;
+				}
+				if (hipSetDevice(r.comm->device) != hipSuccess)
+					return ncclUnhandledCudaError;
+				hipLaunchKernelGGL(hang_kernel, dim3(1), dim3(1), 0, r.stream, (const volatile int *) release_flag);
+				continue;
+			}
 			std::fprintf(stderr, "fake rccl: receive of %zu bytes on rank %d from %d finds no posted send of that size\n", r.bytes,
 			             r.comm->rank, r.peer);
 			return ncclInvalidUsage;
@@ -146,6 +172,23 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm) {
 		std::fprintf(stderr, "fake rccl: %llu send/receive pairs, %llu bytes so far\n", pairs_done, bytes_done);
 		pairs_done = 0;
 	}
+	return ncclSuccess;
+}
+
+ncclResult_t ncclCommAbort(ncclComm_t comm) {
+	if (release_flag)
+		*release_flag = 1;  // (whatever blocks a stream on this communicator's behalf lets go)
+	std::fprintf(stderr, "fake rccl: communicator of rank %d aborted\n", ((FakeComm *) comm)->rank);
+	return ncclCommDestroy(comm);
+}
+
+ncclResult_t ncclCommCount(const ncclComm_t comm, int *count) {
+	*count = ((const FakeComm *) comm)->nranks;
+	return ncclSuccess;
+}
+
+ncclResult_t ncclGetVersion(int *version) {
+	*version = 1;  // (no real RCCL reports this)
 	return ncclSuccess;
 }
 

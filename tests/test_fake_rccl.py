@@ -61,3 +61,19 @@ def test_ring_exchange_step_with_every_rank_in_one_process(golden, fake_dir, nam
     assert out["md5"] == [c["pgm_md5"]] * frames  # every frame, with the next ones already in flight behind it
     assert out["primary_hits"] == c["counters"]["primary_hits"] and out["ao_occluded"] == c["counters"]["ao_occluded"]
     assert out["last_image_elsewhere"] == 0  # the assembled image lives on rank 0 only
+
+
+def test_a_rank_that_posts_one_frame_fewer_does_not_hang_the_others(fake_dir):
+    """The exchange step's liveness guard (band_gather.cc, BandGather::wait): a peer that died or is a frame out of step
+    leaves rank 0's receive waiting for ever; the ring must fail with a device error within its deadline -- so that the
+    rank exits non-zero and the job ends -- and its close() must not wait for the operation that cannot finish."""
+    env = dict(os.environ, LD_LIBRARY_PATH=fake_dir + ":" + os.environ.get("LD_LIBRARY_PATH", ""), FAKE_RCCL_HANG_ON_MISSING_SEND="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fake_rccl", "ring_missing_frame_driver.py")], capture_output=True,
+                       text=True, env=env, timeout=120)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+    assert "finds no posted send: blocking its stream" in r.stderr
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["error"] and "waited 2 s for the exchange step" in out["error"] and "peer rank is gone" in out["error"]
+    assert 1.9 < out["waited_s"] < 30.0 and out["close_s"] < 30.0
+    assert "aborted" in r.stderr  # ncclCommAbort, not ncclCommDestroy
+    assert out["comm_ranks"] == 2  # what the communicator says about itself (rt_ring_rccl_info)
