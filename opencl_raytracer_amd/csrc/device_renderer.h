@@ -179,7 +179,9 @@ class DeviceRenderer {
 		uint32_t local_out_rows;
 		void *own_stream, *stream;
 		std::shared_ptr<const DeviceScene> scene_on_device;
-		void *d_image, *d_u8, *d_hits, *d_occluded, *d_tile_hits, *d_order, *d_counters;
+		void *d_image, *d_u8, *d_hits, *d_occluded, *d_tile_hits, *d_tile_base, *d_order, *d_counters;
+		size_t hit_slots;     // slots of the hit list: the scene's hit sub-pixels in this rank's bands (sizeHitList)
+		void sizeHitList();   // counts the hits per tile with one pass of the primary kernel and sizes the list by them
 		size_t image_bytes;  // float image of this rank's bands
 		size_t tile_count;
 		uint32_t compute_units;
@@ -219,11 +221,11 @@ class DeviceRenderer {
 // kernels.hip
 void preload_kernels();
 void launch_primary(const SceneBuffers &scene, float *image, void *hits, void *occluded_of, void *tile_hits, void *order,
-                    void *counters, const KernelParams &P, void *stream);
-void launch_ao(const SceneBuffers &scene, void *hits, void *occluded_of, void *order, void *counters, const KernelParams &P,
-               uint32_t workgroups, bool prefetch, void *stream, void *event_before_ao, void *event_after_ao);
-void launch_finish(float *image, const void *hits, const void *occluded_of, void *counters, unsigned char *out,
-                   const KernelParams &P, uint32_t out_width, uint32_t n, uint32_t local_out_rows, void *stream);
+                    const void *tile_base, void *counters, const KernelParams &P, void *stream);
+void launch_ao(const SceneBuffers &scene, void *hits, void *occluded_of, void *order, const void *tile_base, void *counters,
+               const KernelParams &P, uint32_t workgroups, bool prefetch, void *stream, void *event_before_ao, void *event_after_ao);
+void launch_finish(float *image, const void *hits, const void *occluded_of, const void *tile_base, void *counters,
+                   unsigned char *out, const KernelParams &P, uint32_t out_width, uint32_t n, uint32_t local_out_rows, void *stream);
 void launch_resize(const float *tmp, unsigned char *out, const KernelParams &P, uint32_t out_width, uint32_t n,
                    uint32_t local_out_rows, void *stream);
 

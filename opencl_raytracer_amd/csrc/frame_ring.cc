@@ -58,13 +58,16 @@ FrameRing::FrameRing(const RayTracer::Options &options, int device, unsigned int
 }
 
 FrameRing::~FrameRing() {
-	// renderers first (their destructors wait for their streams), then the gather, then the epoch event
+	// The gather first: it waits for its own stream (whose pending steps read the band buffers that go next) -- or, if a
+	// wait ran into its deadline, aborts the communicator, so that the operation that can never finish does not keep every
+	// later hipFree of this process waiting.  Then the renderers (their destructors wait for their streams), the buffers,
+	// the epoch event.
 	try {
 		drain();
 	} catch (...) {
 	}
-	hosts.clear();
 	gather.reset();
+	hosts.clear();
 	for (void *p : extra)
 		if (p)
 			(void) hipFree(p);

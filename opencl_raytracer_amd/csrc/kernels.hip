@@ -1017,6 +1017,7 @@ struct PrimaryArgs {
 	float *image;
 	HitRec *hits;
 	uint32_t *occluded_of, *tile_hits, *order;
+	const uint32_t *tile_base;  // first slot of each tile in the hit list (DeviceRenderer: a prefix sum of the tiles' hit counts)
 	FrameCounters *counters;
 	KernelParams P;
 };
@@ -1254,14 +1255,18 @@ __device__ __forceinline__ void primary_tile(const PrimaryArgs &A, ClosestBatch 
 		// kernel reads the word with a load of the same kind -- primary_kernel's tail)
 		__hip_atomic_store(&OCRT_PCOLD_PTR(uint32_t *, tile_hits)[tile], hit_count | ((want_ao && hit_count) ? cost << 8 : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	}
-	if (hit && want_ao) {
+	// The hit list holds a tile's hits at tile_base[tile] ..., in the order of the lanes.  (tile_base is the exclusive
+	// prefix sum of the tiles' hit counts -- a function of scene, options and the fixed camera, counted once per upload by
+	// a pass of this kernel that has no hit list yet: `hits` is null then and nothing is recorded.)
+	HitRec *const hit_list = OCRT_PCOLD_PTR(HitRec *, hits);
+	if (hit && want_ao && hit_list) {
 		HitRec rec;
 		rec.ox = best.px; rec.oy = best.py; rec.oz = best.pz;
 		rec.value = value;
 		rec.nx = nx; rec.ny = ny; rec.nz = nz;
 		rec.pixel = local_y * image_width + x;  // index into this rank's band image
-		const size_t slot = (size_t) tile * 64u + slot_in_tile;
-		OCRT_PCOLD_PTR(HitRec *, hits)[slot] = rec;
+		const size_t slot = (size_t) OCRT_PCOLD_PTR(const uint32_t *, tile_base)[tile] + slot_in_tile;
+		hit_list[slot] = rec;
 		OCRT_PCOLD_PTR(uint32_t *, occluded_of)[slot] = 0u;
 	}
 }
@@ -1498,6 +1503,7 @@ struct AoArgs {
 	const HitRec *hits;
 	uint32_t *occluded_of;
 	const uint32_t *order;
+	const uint32_t *tile_base;  // first slot of each tile in the hit list
 	FrameCounters *counters;
 	KernelParams P;
 };
@@ -1680,7 +1686,7 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 				{
 				const uint32_t lane = fresh_lane();  // (recomputed where it is needed: no register held across the walks)
 				if (lane < hit_count) {
-					const size_t slot = (size_t) tile * 64u + lane;
+					const size_t slot = (size_t) OCRT_COLD_PTR(const uint32_t *, tile_base)[tile] + lane;
 					const float4 *const hits = OCRT_COLD_PTR(const float4 *, hits);
 					const float4 q0 = hits[2 * slot];
 					const float4 q1 = hits[2 * slot + 1];
@@ -1779,7 +1785,7 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 						normalize3(rx, ry, rz);
 						if (along_normal) {
 							// the un-normalised shading normal itself (:263), kept in the hit record
-							const float4 q1 = ((const float4 *) A.hits)[2 * ((size_t) tile * 64u + h) + 1];
+							const float4 q1 = ((const float4 *) A.hits)[2 * ((size_t) A.tile_base[tile] + h) + 1];
 							rx = q1.x; ry = q1.y; rz = q1.z;
 						}
 					}
@@ -1898,7 +1904,7 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 					if (lane < hit_count) {
 						const uint32_t occluded = sh.occluded[lane];
 						if (occluded)
-							atomicAdd(&OCRT_COLD_PTR(uint32_t *, occluded_of)[(size_t) tile * 64u + lane], occluded);
+							atomicAdd(&OCRT_COLD_PTR(uint32_t *, occluded_of)[(size_t) OCRT_COLD_PTR(const uint32_t *, tile_base)[tile] + lane], occluded);
 					}
 				}
 				wave_lds_sync();
@@ -1958,6 +1964,7 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 // Band layout as in resize_kernel below.
 __global__ __launch_bounds__(256) void finish_kernel(float *__restrict__ image, const HitRec *__restrict__ hits,
                                                      const uint32_t *__restrict__ occluded_of,
+                                                     const uint32_t *__restrict__ tile_base,
                                                      FrameCounters *__restrict__ counters, unsigned char *__restrict__ out,
                                                      uint32_t width, uint32_t height, uint32_t total_width, uint32_t n,
                                                      uint32_t tiles_x, Partition part, uint32_t rows_per_band, uint32_t ao_divisor) {
@@ -1981,7 +1988,7 @@ __global__ __launch_bounds__(256) void finish_kernel(float *__restrict__ image, 
 				const uint32_t bits = __float_as_uint(v);
 				if (is_pending(bits)) {
 					const uint32_t column = x * n + sx;
-					const size_t slot = ((size_t) (row_index / TILE_H) * tiles_x + column / TILE_W) * 64u + (bits & 63u);
+					const size_t slot = (size_t) tile_base[(size_t) (row_index / TILE_H) * tiles_x + column / TILE_W] + (bits & 63u);
 					const uint32_t occluded = occluded_of[slot];
 					v = hits[slot].value * (1.0f - ((float) occluded / divisor));
 					row[sx] = v;
@@ -2052,7 +2059,7 @@ __global__ __launch_bounds__(256) void clear_stamps_kernel(FrameCounters *counte
 // The frame is three kernels (two without ambient occlusion): primary pass (+ ordering step in its tail), the
 // ambient-occlusion pass, the finishing kernel (AO factor + box filter + quantisation).
 void launch_primary(const SceneBuffers &scene, float *image, void *hits, void *occluded_of, void *tile_hits, void *order,
-                    void *counters, const KernelParams &P, void *stream) {
+                    const void *tile_base, void *counters, const KernelParams &P, void *stream) {
 	hipStream_t s = (hipStream_t) stream;
 #if defined(OCRT_STAMPS) || defined(OCRT_TAIL)
 	hipLaunchKernelGGL(clear_stamps_kernel, dim3(1), dim3(256), 0, s, (FrameCounters *) counters);
@@ -2072,6 +2079,7 @@ void launch_primary(const SceneBuffers &scene, float *image, void *hits, void *o
 		args.occluded_of = (uint32_t *) occluded_of;
 		args.tile_hits = (uint32_t *) tile_hits;
 		args.order = (uint32_t *) order;
+		args.tile_base = (const uint32_t *) tile_base;
 		args.counters = (FrameCounters *) counters;
 		args.P = P;
 		hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64 * PRIMARY_WAVES), 0, s, args);
@@ -2083,7 +2091,7 @@ void launch_primary(const SceneBuffers &scene, float *image, void *hits, void *o
 	launch(primary_kernel<true>);
 }
 
-void launch_ao(const SceneBuffers &scene, void *hits, void *occluded_of, void *order, void *counters,
+void launch_ao(const SceneBuffers &scene, void *hits, void *occluded_of, void *order, const void *tile_base, void *counters,
                const KernelParams &params, uint32_t workgroups, bool prefetch, void *stream, void *event_before_ao,
                void *event_after_ao) {
 	if (params.tiles_x * params.local_tile_rows == 0 || params.ao_mode == AO_NONE || params.ao_dirs == 0)
@@ -2111,6 +2119,7 @@ void launch_ao(const SceneBuffers &scene, void *hits, void *occluded_of, void *o
 		args.hits = (const HitRec *) hits;
 		args.occluded_of = (uint32_t *) occluded_of;
 		args.order = (const uint32_t *) order;
+		args.tile_base = (const uint32_t *) tile_base;
 		args.counters = (FrameCounters *) counters;
 		args.P = P;
 		hipLaunchKernelGGL(kernel, dim3(ao_blocks), dim3(64 * AO_WAVES), 0, s, args);
@@ -2135,7 +2144,7 @@ void launch_ao(const SceneBuffers &scene, void *hits, void *occluded_of, void *o
 }
 
 // `out`: this rank's 8-bit bands (local_out_rows x out_width), or null for a frame without the device resize.
-void launch_finish(float *image, const void *hits, const void *occluded_of, void *counters, unsigned char *out,
+void launch_finish(float *image, const void *hits, const void *occluded_of, const void *tile_base, void *counters, unsigned char *out,
                    const KernelParams &P, uint32_t out_width, uint32_t n, uint32_t local_out_rows, void *stream) {
 	if (local_out_rows == 0 || out_width == 0 || n == 0)
 		return;
@@ -2144,7 +2153,8 @@ void launch_finish(float *image, const void *hits, const void *occluded_of, void
 		return;  // (nothing pending, nothing to filter)
 	const uint32_t rows_per_band = P.part.band_tile_rows * TILE_H / n;
 	hipLaunchKernelGGL(finish_kernel, dim3((out_width + 255) / 256, local_out_rows), dim3(256), 0, (hipStream_t) stream, image,
-	                   (const HitRec *) hits, (const uint32_t *) occluded_of, (FrameCounters *) counters, out, out_width, P.height / n,
+	                   (const HitRec *) hits, (const uint32_t *) occluded_of, (const uint32_t *) tile_base, (FrameCounters *) counters, out,
+	                   out_width, P.height / n,
 	                   P.width, n, P.tiles_x, P.part, rows_per_band, P.ao_divisor ? P.ao_divisor : 1u);
 }
 

@@ -291,6 +291,8 @@ int main(int argc, const char **argv) {
 	// The HIP runtime, the device context and the kernels' code object cost 100-200 ms and do not depend on the scene:
 	// they come up on a second thread while this one reads the mesh and builds the BVH (reference order of the output
 	// kept: nothing is printed from that thread).
+	if (options.gpus == 0 || options.frames == 0 || options.in_flight > 16)  // (before anything is started)
+		usage_error(argv[0], "--gpus and --frames must be positive, --in-flight at most 16");
 	const RayTracer rt(options);
 	const bool plain_host = options.gpus == 1 && options.gather == "auto" && options.frames == 1 && options.in_flight <= 1;
 	std::thread warm_up;
@@ -305,10 +307,19 @@ int main(int argc, const char **argv) {
 	std::cout << Color::BLUE << "<- " << Info::Palette::SECTION << "BVH section" << Color::BLUE << " ->" << std::endl;
 	std::cout << Info::Palette::NORMAL << "Reading input mesh\xE2\x80\xA6" << std::endl;
 	Mesh mesh;
-	load_off_mesh(options.in, &mesh);
-	phase_clock.mark("load");
-	compute_vertex_normals(&mesh);
-	phase_clock.mark("normals");
+	try {
+		load_off_mesh(options.in, &mesh);
+		phase_clock.mark("load");
+		compute_vertex_normals(&mesh);
+		phase_clock.mark("normals");
+	} catch (...) {
+		// The loader throws like the reference's (src/mesh.cc:9,14,22,62: nobody catches, the process aborts with the
+		// message).  Same here -- but only once the warm-up thread is through: aborting while it is inside the HIP
+		// runtime's initialisation, with a joinable std::thread alive, would be a second failure on top of the first.
+		if (warm_up.joinable())
+			warm_up.join();
+		throw;
+	}
 	std::cout << Color::BLUE << "- " << Info::Palette::NORMAL << "Vertices: " << Info::Palette::HIGHLIGHT
 	          << mesh.vertices.size() << std::endl
 	          << Color::BLUE << "- " << Info::Palette::NORMAL << "Triangles: " << Info::Palette::HIGHLIGHT
@@ -331,10 +342,16 @@ int main(int argc, const char **argv) {
 		          << Color::RESET << std::endl;
 	}
 	BVH bvh(options.bvhMethod);
-	Info::measure("Building BVH", [&] {
-		bvh.buildBVH(mesh);
-		return true;
-	});
+	try {
+		Info::measure("Building BVH", [&] {
+			bvh.buildBVH(mesh);
+			return true;
+		});
+	} catch (...) {
+		if (warm_up.joinable())
+			warm_up.join();
+		throw;
+	}
 	phase_clock.mark("bvh");
 	// The CPU half of the upload -- faces into leaf order (reference src/render.cc:88-95), validation, device records,
 	// the walk tree -- needs no device: it runs here, beside the warm-up thread.  Malformed arrays end the run as they
@@ -361,8 +378,6 @@ int main(int argc, const char **argv) {
 	HipHost::printInfo();
 	phase_clock.mark("device table");
 	std::vector<unsigned char> image((size_t) options.width * options.height);
-	if (options.gpus == 0 || options.frames == 0 || options.in_flight > 16)
-		usage_error(argv[0], "--gpus and --frames must be positive, --in-flight at most 16");
 	const unsigned int in_flight = options.in_flight ? options.in_flight : options.frames > 1 ? 3u : 1u;
 	if (options.gpus > 1 || options.gather != "auto") {
 		HipHostGroup host(rt, options.gpus, options.device, options.gather.c_str());

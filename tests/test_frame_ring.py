@@ -133,6 +133,14 @@ def test_ring_holds_one_copy_of_the_scene(rt, golden, scene_for):
     assert seen[1][0] == seen[3][0] == seen[6][0]
     per_host = seen[1][1] - seen[1][0]
     assert seen[3][1] == seen[3][0] + 3 * per_host and seen[6][1] == seen[6][0] + 6 * per_host
+    # ... and a host's own buffers follow what is HIT: 36 bytes (hit record + occlusion counter) per hit sub-pixel, not
+    # 64 slots for every tile -- plus the float image, the 8-bit bands and three words per tile
+    sub = opt.total_width * opt.total_height
+    tiles = ((opt.total_width + 7) // 8) * ((opt.total_height + 7) // 8)
+    hits = case["counters"]["primary_hits"]
+    # (the image and the tile words cover whole bands of tile rows: a few rows more than the frame)
+    assert per_host <= 36 * hits + 1.15 * 4 * sub + 2 * opt.width * opt.height + 16 * tiles + 8192
+    assert per_host < 0.75 * (36 * 64 * tiles)  # (the old layout's hit list alone -- 64 slots per tile -- was larger than all of it)
 
 
 def test_both_forms_of_the_ao_pass_render_the_same_frame(rt, golden, scene_for):
