@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 
 #include <hip/hip_runtime.h>
 
@@ -9,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <sstream>
 
 namespace ocrt {
@@ -57,9 +59,13 @@ void warm_up_device(int device) {
 		return;
 	(void) hipFree(nullptr);  // (forces the context)
 	preload_kernels();
-	void *p = nullptr;        // the allocator's first call is slow too
-	if (hipMalloc(&p, 1 << 20) == hipSuccess)
+	void *p = nullptr;        // the allocator's first call is slow too, and so are the first copies in either direction
+	if (hipMalloc(&p, 1 << 20) == hipSuccess) {  // (the runtime sets up its staging buffers then: 5-10 ms that an upload would pay)
+		std::vector<unsigned char> staging(1 << 16, 0);
+		(void) hipMemcpy(p, staging.data(), staging.size(), hipMemcpyHostToDevice);
+		(void) hipMemcpy(staging.data(), p, staging.size(), hipMemcpyDeviceToHost);
 		(void) hipFree(p);
+	}
 	(void) hipGetLastError();
 }
 
@@ -210,7 +216,35 @@ std::string DeviceRenderer::deviceName() const {
 	return prop.name;
 }
 
+namespace {
+// the allocation made ahead of time by DeviceScene::reserve, waiting for the scene it was made for
+std::mutex reserved_mutex;
+void *reserved_arena = nullptr;
+size_t reserved_bytes = 0;
+int reserved_device = -1;
+
+size_t round_up(size_t bytes) { return (bytes + 255) & ~(size_t) 255; }
+
+// (A/B build: OCRT_UPLOAD_TIMINGS=1 prints where an upload's time goes)
+struct UploadClock {
+#ifdef OCRT_DEBUG_KNOBS
+	std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+	const bool on = std::getenv("OCRT_UPLOAD_TIMINGS") != nullptr;
+	void mark(const char *what) {
+		if (!on)
+			return;
+		const auto now = std::chrono::steady_clock::now();
+		std::fprintf(stderr, "upload: %s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
+		last = now;
+	}
+#else
+	void mark(const char *) {}
+#endif
+};
+}  // namespace
+
 std::shared_ptr<const DeviceScene> DeviceScene::create(int device, const PackedScene &scene, const RayTracer::Options &opts) {
+	UploadClock clock;
 	OCRT_HIP(hipSetDevice(device));
 	std::shared_ptr<DeviceScene> out(new DeviceScene());
 	out->device_index = device;
@@ -237,6 +271,7 @@ std::shared_ptr<const DeviceScene> DeviceScene::create(int device, const PackedS
 	const std::shared_ptr<const WalkArray> made = (scene.walk && scene.walk_max_distance == out->walk_distance)
 	                                                  ? scene.walk : std::make_shared<const WalkArray>(make_walk_array(scene, out->walk_distance));
 	const WalkArray &walk = *made;
+	clock.mark("direction table + walk array (made here unless prepared)");
 	out->scene_facts_ = scene_facts(scene, walk);
 	out->node_count = (uint32_t) scene.nodes.size();
 	out->tri_count = (uint32_t) scene.tris.size();
@@ -244,23 +279,50 @@ std::shared_ptr<const DeviceScene> DeviceScene::create(int device, const PackedS
 	const size_t tris_bytes = scene.tris.size() * sizeof(TriRec);
 	const size_t shade_bytes = scene.shade.size() * sizeof(ShadeRec);
 	const size_t ao_bytes = table.size() * sizeof(float);
-	// one node of zero padding: the shared walk fetches a node together with its successor
-	out->d_nodes = device_alloc(nodes_bytes + sizeof(NodeRec));
-	OCRT_HIP(hipMemset((char *) out->d_nodes + nodes_bytes, 0, sizeof(NodeRec)));
+	// One allocation for the five arrays (each starts on a 256-byte boundary) -- the one made ahead of time if there is
+	// one and it is large enough.  One node of zero padding behind the exact nodes: the shared walk fetches a node
+	// together with its successor.
 	const size_t walk_bytes = walk.nodes.size() * sizeof(NodeRec);
-	if (walk_bytes) {
-		out->d_walk = device_alloc(walk_bytes);
-		OCRT_HIP(hipMemcpy(out->d_walk, walk.nodes.data(), walk_bytes, hipMemcpyHostToDevice));
+	const size_t need = round_up(nodes_bytes + sizeof(NodeRec)) + round_up(walk_bytes) + round_up(tris_bytes) + round_up(shade_bytes) +
+	                    round_up(ao_bytes) + 256;
+	{
+		std::lock_guard<std::mutex> lock(reserved_mutex);
+		if (reserved_arena && reserved_device == device && reserved_bytes >= need) {
+			out->arena = reserved_arena;
+		} else if (reserved_arena && reserved_device == device) {
+			(void) hipFree(reserved_arena);  // (too small after all)
+		}
+		if (reserved_device == device) {
+			reserved_arena = nullptr;
+			reserved_bytes = 0;
+			reserved_device = -1;
+		}
 	}
-	out->d_tris = device_alloc(tris_bytes);
-	out->d_shade = device_alloc(shade_bytes);
-	out->d_ao = device_alloc(ao_bytes);
+	if (!out->arena)
+		out->arena = device_alloc(need);
+	char *at = (char *) out->arena;
+	auto take = [&](size_t bytes) {
+		void *p = at;
+		at += round_up(bytes);
+		return p;
+	};
+	out->d_nodes = take(nodes_bytes + sizeof(NodeRec));
+	out->d_walk = walk_bytes ? take(walk_bytes) : nullptr;
+	out->d_tris = take(tris_bytes);
+	out->d_shade = take(shade_bytes);
+	out->d_ao = take(ao_bytes ? ao_bytes : 1);
+	clock.mark("allocation");
+	const NodeRec zero{};
+	OCRT_HIP(hipMemcpy((char *) out->d_nodes + nodes_bytes, &zero, sizeof zero, hipMemcpyHostToDevice));
+	if (walk_bytes)
+		OCRT_HIP(hipMemcpy(out->d_walk, walk.nodes.data(), walk_bytes, hipMemcpyHostToDevice));
 	OCRT_HIP(hipMemcpy(out->d_nodes, scene.nodes.data(), nodes_bytes, hipMemcpyHostToDevice));
 	OCRT_HIP(hipMemcpy(out->d_tris, scene.tris.data(), tris_bytes, hipMemcpyHostToDevice));
 	OCRT_HIP(hipMemcpy(out->d_shade, scene.shade.data(), shade_bytes, hipMemcpyHostToDevice));
 	if (ao_bytes)
 		OCRT_HIP(hipMemcpy(out->d_ao, table.data(), ao_bytes, hipMemcpyHostToDevice));
 	OCRT_HIP(hipDeviceSynchronize());
+	clock.mark("copies of walk array, nodes, leaf records, normals, table");
 	out->device_bytes = nodes_bytes + walk_bytes + tris_bytes + shade_bytes + ao_bytes;
 	return out;
 }
@@ -268,11 +330,33 @@ std::shared_ptr<const DeviceScene> DeviceScene::create(int device, const PackedS
 DeviceScene::~DeviceScene() {
 	if (hipSetDevice(device_index) != hipSuccess)
 		return;
-	device_free(d_nodes);
-	device_free(d_walk);
-	device_free(d_tris);
-	device_free(d_shade);
-	device_free(d_ao);
+	device_free(arena);
+}
+
+void DeviceScene::reserve(int device, size_t bytes) {
+	if (bytes == 0 || hipSetDevice(device) != hipSuccess)
+		return;
+	void *p = nullptr;
+	if (hipMalloc(&p, bytes) != hipSuccess) {
+		(void) hipGetLastError();
+		return;  // (create() allocates for itself)
+	}
+	std::lock_guard<std::mutex> lock(reserved_mutex);
+	if (reserved_arena) {
+		(void) hipSetDevice(reserved_device);
+		(void) hipFree(reserved_arena);
+		(void) hipSetDevice(device);
+	}
+	reserved_arena = p;
+	reserved_bytes = bytes;
+	reserved_device = device;
+}
+
+size_t DeviceScene::bytesFor(size_t triangles, size_t ao_directions) {
+	const size_t nodes = triangles ? 2 * triangles - 1 : 0;
+	// exact nodes + padding, two copies of the walk records with their END records and slack, leaf records, normals, table
+	return round_up((nodes + 1) * sizeof(NodeRec)) + round_up((2 * (nodes + 2) + 2) * sizeof(NodeRec)) + round_up(triangles * sizeof(TriRec)) +
+	       round_up(triangles * sizeof(ShadeRec)) + round_up(ao_directions * 4 * sizeof(float) + 1) + 256;
 }
 
 bool DeviceScene::servesOptions(const RayTracer::Options &opts) const {
@@ -294,7 +378,7 @@ size_t DeviceRenderer::upload(const PackedScene &scene) {
 	return scene_bytes + adopt(std::move(made));
 }
 
-size_t DeviceRenderer::adopt(std::shared_ptr<const DeviceScene> scene) {
+size_t DeviceRenderer::adopt(std::shared_ptr<const DeviceScene> scene, const DeviceRenderer *layout_from) {
 	if (!scene || scene->device() != device)
 		throw std::invalid_argument("the scene lives on another device than the renderer");
 	if (!scene->servesOptions(opts))
@@ -307,7 +391,12 @@ size_t DeviceRenderer::adopt(std::shared_ptr<const DeviceScene> scene) {
 	scene_on_device = std::move(scene);
 	scene_ready = true;
 	++scene_version;  // (a captured frame bakes the scene's pointers and launch constants in)
-	sizeHitList();
+	if (layout_from && (layout_from == this || layout_from->scene_on_device != scene_on_device || layout_from->device != device ||
+	                    layout_from->tile_count != tile_count || layout_from->part.rank != part.rank ||
+	                    layout_from->part.nranks != part.nranks || layout_from->rt.totalWidth != rt.totalWidth ||
+	                    layout_from->rt.totalHeight != rt.totalHeight))
+		layout_from = nullptr;  // (not the same frame after all: count)
+	sizeHitList(layout_from);
 	return image_bytes + (size_t) local_out_rows * opts.width + hit_slots * (sizeof(HitRec) + sizeof(uint32_t)) +
 	       tile_count * 3 * sizeof(uint32_t) + sizeof(FrameCounters);
 }
@@ -318,7 +407,8 @@ size_t DeviceRenderer::adopt(std::shared_ptr<const DeviceScene> scene) {
 // exactly that many slots -- 36 bytes per hit sub-pixel instead of 36 x 64 per tile: 42 MB instead of 75 for the 1080p
 // bunny frame, 2.7 GB instead of 4.8 at 64 samples per pixel.  No allocation atomics between the passes: a tile's slots
 // are still at a fixed address.  Costs one primary pass (0.15 ms at 1080p) and two small copies per upload.
-void DeviceRenderer::sizeHitList() {
+void DeviceRenderer::sizeHitList(const DeviceRenderer *layout_from) {
+	UploadClock clock;
 	device_free(d_hits);
 	device_free(d_occluded);
 	hit_slots = 0;
@@ -330,11 +420,20 @@ void DeviceRenderer::sizeHitList() {
 		OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));
 		return;
 	}
+	if (layout_from) {  // (the same frame of the same scene: the same hits)
+		hit_slots = layout_from->hit_slots;
+		OCRT_HIP(hipMemcpy(d_tile_base, layout_from->d_tile_base, tile_count * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+		d_hits = device_alloc((hit_slots ? hit_slots : 1) * sizeof(HitRec));
+		d_occluded = device_alloc((hit_slots ? hit_slots : 1) * sizeof(uint32_t));
+		clock.mark("hit list laid out like the ring's first host");
+		return;
+	}
 	launch_primary(scene_on_device->buffers(), (float *) d_image, nullptr, nullptr, d_tile_hits, d_order, d_tile_base, d_counters, kp, stream);
 	OCRT_HIP(hipGetLastError());
 	std::vector<uint32_t> words(tile_count);
 	OCRT_HIP(hipMemcpyAsync(words.data(), d_tile_hits, tile_count * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t) stream));
 	OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));
+	clock.mark("counting pass + tile words to the host");
 	unsigned long long running = 0;
 	for (uint32_t &w : words) {
 		const uint32_t count = w & 0xFFu;
@@ -348,6 +447,7 @@ void DeviceRenderer::sizeHitList() {
 	OCRT_HIP(hipMemset(d_image, 0, image_bytes));  // (the counting pass left its pending tags there)
 	d_hits = device_alloc((hit_slots ? hit_slots : 1) * sizeof(HitRec));
 	d_occluded = device_alloc((hit_slots ? hit_slots : 1) * sizeof(uint32_t));
+	clock.mark("tile bases to the device, image cleared, hit list allocated");
 }
 
 DeviceRenderer::FrameEvents DeviceRenderer::takeEvents() {

@@ -39,6 +39,12 @@ class DeviceScene {
 		// (AO_MAX_DISTANCE, which sizes the walk array's margins) are baked in -- servesOptions() says whether another
 		// renderer's options agree.
 		static std::shared_ptr<const DeviceScene> create(int device, const PackedScene &scene, const RayTracer::Options &options);
+		// A scene's arrays live in ONE device allocation.  A front end that knows the size of what is coming before it has
+		// the arrays (the triangle count of a mesh file's header) can have that allocation made ahead of time -- on the
+		// thread that brings the device up -- and create() takes it over if it is large enough (else it is dropped).
+		// bytesFor: an upper bound of the allocation for a mesh of that many triangles.
+		static void reserve(int device, size_t bytes);
+		static size_t bytesFor(size_t triangles, size_t ao_directions);
 		~DeviceScene();
 		DeviceScene(const DeviceScene &) = delete;
 		DeviceScene &operator=(const DeviceScene &) = delete;
@@ -55,6 +61,7 @@ class DeviceScene {
 	private:
 		DeviceScene() = default;
 		int device_index = 0;
+		void *arena = nullptr;  // the one allocation the five arrays below point into
 		void *d_nodes = nullptr, *d_walk = nullptr, *d_tris = nullptr, *d_shade = nullptr, *d_ao = nullptr;
 		size_t device_bytes = 0;
 		uint32_t node_count = 0, tri_count = 0, ao_dirs = 0;
@@ -83,7 +90,9 @@ class DeviceRenderer {
 		size_t upload(const PackedScene &scene);
 		// Renders a scene that is on the device already (DeviceScene::create on this renderer's device, for options that
 		// agree with this renderer's: std::invalid_argument otherwise); returns the bytes of this renderer's own buffers.
-		size_t adopt(std::shared_ptr<const DeviceScene> scene);
+		// `layout_from`: a renderer of the SAME scene, options and partition that has adopted it already (a ring's first
+		// host): the hit list's layout is copied from it instead of being counted again.
+		size_t adopt(std::shared_ptr<const DeviceScene> scene, const DeviceRenderer *layout_from = nullptr);
 		const std::shared_ptr<const DeviceScene> &deviceScene() const { return scene_on_device; }
 
 		// Enqueues the ray-casting kernel for this rank's bands on the stream.
@@ -181,7 +190,7 @@ class DeviceRenderer {
 		std::shared_ptr<const DeviceScene> scene_on_device;
 		void *d_image, *d_u8, *d_hits, *d_occluded, *d_tile_hits, *d_tile_base, *d_order, *d_counters;
 		size_t hit_slots;     // slots of the hit list: the scene's hit sub-pixels in this rank's bands (sizeHitList)
-		void sizeHitList();   // counts the hits per tile with one pass of the primary kernel and sizes the list by them
+		void sizeHitList(const DeviceRenderer *layout_from);  // counts the hits per tile with one pass of the primary kernel (or copies another renderer's count) and sizes the list by them
 		size_t image_bytes;  // float image of this rank's bands
 		size_t tile_count;
 		uint32_t compute_units;

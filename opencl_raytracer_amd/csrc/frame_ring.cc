@@ -83,7 +83,7 @@ size_t FrameRing::upload(const PackedScene &scene) {
 	std::shared_ptr<const DeviceScene> on_device = DeviceScene::create(hosts.front()->deviceIndex(), scene, hosts.front()->rayTracer().options);
 	size_t bytes = on_device->bytes();
 	for (auto &h : hosts)
-		bytes += h->adopt(on_device);
+		bytes += h->adopt(on_device, h == hosts.front() ? nullptr : hosts.front().get());  // (the hit list's layout is counted once)
 	// A stream of frames of this scene is coming: which form of the ambient-occlusion pass's node loop it takes is worth a
 	// few frames of measuring (DeviceRenderer::calibrateAoPrefetch: ~15 ms once per upload).  The first host measures on
 	// the idle device, all hosts follow.

@@ -422,6 +422,19 @@ void HipHost::warmUp(const RayTracer &rt, int device) {
 	}
 }
 
+void HipHost::reserveScene(const RayTracer &rt, int device, size_t triangles) {
+	if (device < 0) {
+		const char *env = std::getenv("OCRT_DEVICE");
+		device = env ? std::atoi(env) : 0;
+	}
+	size_t directions = 0;
+	if (rt.options.enableAO && rt.options.aoNumSamples > 0)
+		directions = rt.options.aoMethod == RayTracer::AmbientOcclusionMethod::UNIFORM
+		                 ? ocrt::uniform_ao_table(rt.options.aoNumSamples, rt.options.aoAlphaMin, rt.options.aoAlphaMax).size() / 4
+		                 : rt.options.aoNumSamples + 2;
+	ocrt::DeviceScene::reserve(device, ocrt::DeviceScene::bytesFor(triangles, directions));
+}
+
 void HipHost::printInfo() {
 	Info info;
 	info.setTitle("Hardware information");

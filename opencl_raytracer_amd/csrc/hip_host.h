@@ -82,6 +82,9 @@ class HipHost {
 		// ... and also creates the render host's device state for `rt` (streams, image and hit-list buffers): the next
 		// HipHost(rt', device) whose options equal rt's adopts it instead of allocating its own.
 		static void warmUp(const RayTracer &rt, int device);
+		// ... and reserves the device allocation of a scene of `triangles` triangles (a mesh file's header says how many
+		// before the mesh is read): the upload that follows finds its memory waiting (DeviceScene::reserve).
+		static void reserveScene(const RayTracer &rt, int device, size_t triangles);
 
 		// Milliseconds the ray-casting kernel of the last operator()() took,
 		// measured with HIP events on the launch stream.

@@ -295,13 +295,25 @@ int main(int argc, const char **argv) {
 		usage_error(argv[0], "--gpus and --frames must be positive, --in-flight at most 16");
 	const RayTracer rt(options);
 	const bool plain_host = options.gpus == 1 && options.gather == "auto" && options.frames == 1 && options.in_flight <= 1;
+	// How many triangles are coming is in the file's header: the warm-up thread can then also make the scene's device
+	// allocation (a peek of a few bytes; whatever is wrong with the file is reported by the loader proper, below).
+	size_t triangles_announced = 0;
+	if (std::FILE *peek = std::fopen(options.in.c_str(), "rb")) {
+		char magic[8] = { 0 };
+		unsigned long v = 0, f = 0;
+		if (std::fscanf(peek, "%7s %lu %lu", magic, &v, &f) == 3 && std::string(magic) == "OFF" && f < (1ul << 25))
+			triangles_announced = f;
+		std::fclose(peek);
+	}
 	std::thread warm_up;
 	if (options.warm_up)
-		warm_up = std::thread([&options, &rt, plain_host] {
+		warm_up = std::thread([&options, &rt, plain_host, triangles_announced] {
 			if (plain_host)
 				HipHost::warmUp(rt, options.device);  // (... and the host's own buffers: main() adopts them below)
 			else
 				HipHost::warmUp(options.device);
+			if (triangles_announced && options.gpus == 1)
+				HipHost::reserveScene(rt, options.device, triangles_announced);
 		});
 	phase_clock.mark("options");
 	std::cout << Color::BLUE << "<- " << Info::Palette::SECTION << "BVH section" << Color::BLUE << " ->" << std::endl;

@@ -316,19 +316,39 @@ WalkArray make_walk_array(const PackedScene &scene, float ao_max_distance) {
 	out.ao_scale = walk_scale_for(ao_max_distance);
 	if (!walk_scale_usable(out.ao_scale, out.origin_limit))
 		out.ao_scale = 0.0f;
-	const float scaled_reach = out.ao_scale > 0.0f ? ao_max_distance * 1.001f : 0.0f;
 	const double camera[3] = { 0.0, 0.0, 2.0 };  // reference src/intersect_kernel.cl:284
-	out.nodes.resize(nodes.size() + 2);
-	for (size_t i = 0; i < nodes.size(); ++i) {
-		NodeRec w = nodes[i];
-		for (unsigned k = 0; k < 3; ++k) {
-			const double box = std::fmax(std::fabs((double) nodes[i].lo[k]), std::fabs((double) nodes[i].hi[k]));
-			const double origin = std::fmin((double) out.origin_limit, std::fmax(camera[k], box + reach));
-			w.lo[k] = padded_bound(nodes[i].lo[k], (float) origin, false, scaled_reach);
-			w.hi[k] = padded_bound(nodes[i].hi[k], (float) origin, true, scaled_reach);
+	// (both copies of the records are made in one sweep, the sweep cut into slices for a few threads: an upload's CPU
+	// time is the walk-tree rebuild and this)
+	const size_t records = nodes.size() + 2;
+	if (2 * records * sizeof(NodeRec) >= (size_t) 1 << 32)
+		out.ao_scale = 0.0f;  // (no room for the centre / half-extent copy below 2^32 bytes: the any-hit rays of such a scene take the exact form)
+	const bool with_ce = out.ao_scale > 0.0f;
+	const float scaled_reach_of = with_ce ? ao_max_distance * 1.001f : 0.0f;
+	out.nodes.resize(with_ce ? 2 * records : records);
+	auto pad_slice = [&](size_t from, size_t to) {
+		for (size_t i = from; i < to; ++i) {
+			NodeRec w = nodes[i];
+			double origin[3];
+			for (unsigned k = 0; k < 3; ++k) {
+				const double box = std::fmax(std::fabs((double) nodes[i].lo[k]), std::fabs((double) nodes[i].hi[k]));
+				origin[k] = std::fmin((double) out.origin_limit, std::fmax(camera[k], box + reach));
+				w.lo[k] = padded_bound(nodes[i].lo[k], (float) origin[k], false, scaled_reach_of);
+				w.hi[k] = padded_bound(nodes[i].hi[k], (float) origin[k], true, scaled_reach_of);
+			}
+			w.skip = nodes[i].skip * (uint32_t) sizeof(NodeRec);  // (node count < 2^27, checked at pack time)
+			out.nodes[i] = w;
+			if (with_ce)
+				out.nodes[records + i] = ce_record(w, origin);
 		}
-		w.skip = nodes[i].skip * (uint32_t) sizeof(NodeRec);  // (node count < 2^27, checked at pack time)
-		out.nodes[i] = w;
+	};
+	{
+		const size_t slices = nodes.size() > 16384 ? 4 : 1, per = (nodes.size() + slices - 1) / slices;
+		std::vector<std::future<void>> running;
+		for (size_t k = 1; k < slices; ++k)
+			running.push_back(std::async(std::launch::async, pad_slice, k * per, std::min(nodes.size(), (k + 1) * per)));
+		pad_slice(0, std::min(nodes.size(), per));
+		for (auto &r : running)
+			r.get();
 	}
 	// The record behind the last node ends the walk: every live ray "hits" its box (an infinite slab) and its
 	// leaf field says END.  One more, because a node is fetched together with its successor.
@@ -344,21 +364,9 @@ WalkArray make_walk_array(const PackedScene &scene, float ao_max_distance) {
 	// The same records once more in CENTRE / HALF-EXTENT form, behind the END records, for the packets whose rays do not
 	// agree on the sign of their direction (kernels.hip, OCRT_TEST_CE_SCALED): with t_c = fma(c, inv, oi) the two planes
 	// of an axis are fma(-e, |inv|, t_c) and fma(e, |inv|, t_c) whatever the sign of inv -- nine fmas and no selects.
-	// Only the scaled form (the any-hit rays) uses it.  Why it stays conservative: ce_record() below.
-	const size_t records = nodes.size() + 2;
-	if (2 * records * sizeof(NodeRec) >= (size_t) 1 << 32)
-		out.ao_scale = 0.0f;  // (no room for the copy below 2^32 bytes: the any-hit rays of such a scene take the exact form)
-	if (out.ao_scale > 0.0f) {
+	// Only the scaled form (the any-hit rays) uses it.  Why it stays conservative: ce_record() above.
+	if (with_ce) {
 		out.ce_offset = (uint32_t) (records * sizeof(NodeRec));
-		out.nodes.resize(2 * records);
-		for (size_t i = 0; i < nodes.size(); ++i) {
-			double origin[3];
-			for (unsigned k = 0; k < 3; ++k) {
-				const double box = std::fmax(std::fabs((double) nodes[i].lo[k]), std::fabs((double) nodes[i].hi[k]));
-				origin[k] = std::fmin((double) out.origin_limit, std::fmax(camera[k], box + reach));
-			}
-			out.nodes[records + i] = ce_record(out.nodes[i], origin);
-		}
 		NodeRec ce_end = end;  // centre 0, half-extent +inf: near = -inf, far = +inf for every finite ray
 		for (unsigned k = 0; k < 3; ++k) {
 			ce_end.lo[k] = 0.0f;

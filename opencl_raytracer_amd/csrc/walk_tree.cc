@@ -57,11 +57,12 @@ struct Builder {
 			out[at].leaf = l.index;
 			return box;
 		}
-		// (a run of lopsided splits must not exhaust the stack: halve by index from depth 48 on)
-		const size_t mid = depth < 48 ? split(begin, end) : begin + (end - begin) / 2;
+		// (a run of lopsided splits must not exhaust the stack: halve by index from depth 48 on; two leaves need no
+		// binning to be told apart -- half of all inner nodes are such pairs, and the 48 bin boxes cost more than they do)
+		const size_t mid = end - begin == 2 ? begin + 1 : depth < 48 ? split(begin, end) : begin + (end - begin) / 2;
 		const size_t left_at = at + 1, right_at = at + 1 + (2 * (mid - begin) - 1);
 		Box left, right;
-		if (depth < 4 && end - begin > 4096) {
+		if (depth < 6 && end - begin > 2048) {  // (up to 64 tasks: the top of the tree is where the long passes are)
 			std::future<Box> other = std::async(std::launch::async, [&] { return build(begin, mid, left_at, depth + 1); });
 			right = build(mid, end, right_at, depth + 1);
 			left = other.get();
