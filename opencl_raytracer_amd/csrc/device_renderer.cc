@@ -26,6 +26,9 @@ void hip_check(hipError_t err, const char *what) {
 }
 #define OCRT_HIP(call) hip_check((call), #call)
 
+constexpr uint32_t MAX_STRIP_TILES = 32u;
+constexpr size_t BIG_SCENE_BYTES = (size_t) 96 << 20;  // three times the L2s
+
 void *device_alloc(size_t bytes) {
 	void *p = nullptr;
 	OCRT_HIP(hipMalloc(&p, bytes ? bytes : 1));
@@ -155,7 +158,7 @@ DeviceRenderer::DeviceRenderer(const RayTracer::Options &options, int device_, u
 	d_image = device_alloc(image_bytes);
 	d_u8 = device_alloc((size_t) local_out_rows * opts.width);
 	// hit list: 64 slots per tile; ordered tile lists: one segment per XCD group
-	const size_t order_slots = (size_t) ((kp.tiles_x + 1) / 2) * 2 * kp.local_tile_rows;
+	const size_t order_slots = (size_t) ((kp.tiles_x + MAX_STRIP_TILES - 1) / MAX_STRIP_TILES) * MAX_STRIP_TILES * kp.local_tile_rows;  // (whole strips, whatever their width)
 	// (the hit list itself is sized once a scene is adopted: by what that scene's primary rays hit, sizeHitList)
 	d_tile_hits = device_alloc(tile_count * sizeof(uint32_t));
 	d_tile_base = device_alloc(tile_count * sizeof(uint32_t));
@@ -388,6 +391,23 @@ size_t DeviceRenderer::adopt(std::shared_ptr<const DeviceScene> scene, const Dev
 	freeScene();
 	kp = make_kernel_params(rt, scene->nodeCount(), scene->triCount(), scene->aoDirs(), part, &scene->facts());
 	kp.shared_device = device_share > 1u ? 1 : 0;
+	// How wide the strips are that the image is dealt to the eight XCD groups in (kernels.hip, "Tile <-> workgroup
+	// mapping").  Two tiles while the scene fits the caches -- the finest deal balances best.  A scene several times the
+	// 32 MB of L2 is fetched from HBM by every XCD whose rays reach it: an ambient-occlusion ray reaches AO_MAX_DISTANCE
+	// around its tile, twenty tiles of a 1080p frame on either side, so with 16-pixel strips all eight XCDs read the same
+	// nodes.  Strips of sixteen tiles keep most of an XCD's geometry its own (terrain, 2 M and 20 M triangles, 1080p:
+	// profiles/r04_notes.md) -- as long as the image is wide enough for every group to keep two strips.
+	kp.strip_tiles = 2u;
+	if (scene->bytes() > BIG_SCENE_BYTES)
+		while (kp.strip_tiles < MAX_STRIP_TILES && kp.tiles_x >= 2u * XCD_GROUPS * (kp.strip_tiles * 2u))
+			kp.strip_tiles *= 2u;
+#ifdef OCRT_DEBUG_KNOBS
+	if (const char *env = std::getenv("OCRT_STRIP_TILES")) {  // 2, 4, 8, 16 or 32
+		const uint32_t want = (uint32_t) std::atoi(env);
+		if (want >= 2u && want <= MAX_STRIP_TILES && (want & (want - 1u)) == 0u)
+			kp.strip_tiles = want;
+	}
+#endif
 	scene_on_device = std::move(scene);
 	scene_ready = true;
 	++scene_version;  // (a captured frame bakes the scene's pointers and launch constants in)

@@ -132,6 +132,9 @@ struct KernelParams {
 	uint32_t ao_claim_div;  // (set by launch_ao: the waves per XCD group)
 	uint32_t ao_guide;      // 0 (default): AO claims never shrink; n > 0 (debug knob OCRT_AO_GUIDE): a claim takes
 	                        // 1/ao_guide of the (tile, direction) units left in its queue, launch_ao multiplies n by the waves per XCD group
+	uint32_t strip_tiles;  // width, in tiles, of the vertical strips the image is dealt to the XCD groups in: a power of two,
+	                       // 2 by default (the finest deal: best balance, and a cache-resident scene does not care), wider for
+	                       // scenes far beyond the L2s, whose XCDs should not all fetch the same geometry (device_renderer.cc)
 	uint32_t tiles_x;      // tiles per image row
 	uint32_t local_tile_rows;  // tile rows this rank owns
 	Partition part;

@@ -987,10 +987,13 @@ __device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ n
 // Tile <-> workgroup mapping shared by the passes.  A workgroup of the primary
 // pass covers 2x2 tiles (16x16 sub-pixels).  Workgroups b and b+8 share an XCD
 // and its L2 (MI355X_MICROARCH.md, dispatch is round-robin over XCDs), so the
-// image is cut into vertical strips two tiles wide, strips are dealt round-robin
-// to the 8 XCD groups, and each group walks its strips top to bottom:
-// neighbouring workgroups of a group touch the same BVH region, while every
-// group still sees the whole image height.
+// image is cut into vertical strips KernelParams::strip_tiles wide (two by default),
+// strips are dealt round-robin to the 8 XCD groups, and each group walks its strips
+// top to bottom, row by row: neighbouring workgroups of a group touch the same BVH
+// region, while every group still sees the whole image height.  Strips of two tiles
+// balance best and are right while the scene lives in the caches; a scene far beyond
+// the L2s gets wider ones, so that an XCD's rays mostly meet geometry that only this
+// XCD needs (with 16-pixel strips all eight fetch the same nodes from HBM).
 
 // Kernel arguments that are READ AGAIN from the kernel-argument segment where they are used -- one scalar load each
 // (asm volatile: the compiler can neither hoist it out of a loop nor merge it with another) -- instead of being held in
@@ -1287,15 +1290,16 @@ struct OrderScratch {
 };
 __device__ __forceinline__ void order_group(const uint32_t *__restrict__ tile_hits, uint32_t *__restrict__ order,
                                             FrameCounters *__restrict__ counters, uint32_t tiles_x, uint32_t local_tile_rows,
-                                            bool no_sort, uint32_t cost_shift, uint32_t group, OrderScratch &scratch, uint32_t waves) {
+                                            uint32_t strip_tiles, bool no_sort, uint32_t cost_shift, uint32_t group,
+                                            OrderScratch &scratch, uint32_t waves) {
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-	const uint32_t strips = (tiles_x + 1u) >> 1;
+	const uint32_t strips = (tiles_x + strip_tiles - 1u) / strip_tiles;
 	const uint32_t strips_here = (strips + XCD_GROUPS - 1u - group) >> 3;
-	const uint32_t tiles_here = strips_here * 2u * local_tile_rows;  // incl. a possible column past the image
+	const uint32_t tiles_here = strips_here * strip_tiles * local_tile_rows;  // incl. possible columns past the image
 	// this group's segment of `order` starts where the previous groups' capacity ends
 	uint32_t segment = 0u;
 	for (uint32_t g = 0; g < group; ++g)
-		segment += ((strips + XCD_GROUPS - 1u - g) >> 3) * 2u * local_tile_rows;
+		segment += ((strips + XCD_GROUPS - 1u - g) >> 3) * strip_tiles * local_tile_rows;
 	if (threadIdx.x < 65u)
 		scratch.bucket[threadIdx.x] = 0u;
 	if (threadIdx.x == 0u) {
@@ -1303,20 +1307,20 @@ __device__ __forceinline__ void order_group(const uint32_t *__restrict__ tile_hi
 		scratch.hit_total = 0u;
 	}
 	__syncthreads();
-	// tile e of the group: strip (e / (2 * rows)), then row-major 2-wide; returns its word (0: nothing there)
+	// tile e of the group: strip (e / (strip_tiles * rows)), then row-major across the strip; returns its word (0: nothing there)
 	auto word_of = [&](uint32_t e, uint32_t &tile) -> uint32_t {
 		if (e >= tiles_here)
 			return 0u;
-		const uint32_t per_strip = 2u * local_tile_rows;
+		const uint32_t per_strip = strip_tiles * local_tile_rows;
 		const uint32_t strip_index = e / per_strip, within = e - strip_index * per_strip;
-		const uint32_t tile_x = 2u * (group + XCD_GROUPS * strip_index) + (within & 1u);
-		const uint32_t local_row = within >> 1;
+		const uint32_t local_row = within / strip_tiles;
+		const uint32_t tile_x = strip_tiles * (group + XCD_GROUPS * strip_index) + (within - local_row * strip_tiles);
 		tile = local_row * tiles_x + tile_x;
 		if (tile_x >= tiles_x)
 			return 0u;
 		return __hip_atomic_load(&tile_hits[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	};
-	// One wave per block of 64 spatially consecutive tiles (2 wide, 32 high).  key: the block's cost, 1..64.
+	// One wave per block of 64 spatially consecutive tiles (a strip wide, 64 / strip_tiles high).  key: the block's cost, 1..64.
 	const uint32_t n_blocks = (tiles_here + 63u) >> 6;
 	auto block_key = [&](uint32_t block, uint32_t &tile, uint32_t &word, unsigned long long &work_mask, uint32_t &cost) -> uint32_t {
 		word = word_of(block * 64u + lane, tile);
@@ -1414,14 +1418,17 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) __attribute__((amdgpu_waves_per
 	}
 	const uint32_t group = blockIdx.x & (XCD_GROUPS - 1u), seq = blockIdx.x >> 3;
 	{
-		const uint32_t strips = (A.P.tiles_x + 1u) >> 1;
+		const uint32_t strip_tiles = A.P.strip_tiles, columns = strip_tiles >> 1;  // (a workgroup is two tiles wide)
+		const uint32_t strips = (A.P.tiles_x + strip_tiles - 1u) / strip_tiles;
 		const uint32_t row_blocks = (A.P.local_tile_rows + PRIMARY_ROWS - 1u) / PRIMARY_ROWS;
 		const uint32_t strips_here = (strips + XCD_GROUPS - 1u - group) >> 3;
-		const uint32_t strip_index = seq / row_blocks;
-		const uint32_t row_block = seq - strip_index * row_blocks;
-		const uint32_t tile_x = 2u * (group + XCD_GROUPS * strip_index) + (wave & 1u);
+		const uint32_t per_strip = row_blocks * columns;
+		const uint32_t strip_index = seq / per_strip;
+		const uint32_t rest = seq - strip_index * per_strip;
+		const uint32_t row_block = rest / columns;
+		const uint32_t tile_x = strip_tiles * (group + XCD_GROUPS * strip_index) + 2u * (rest - row_block * columns) + (wave & 1u);
 		const uint32_t local_row = PRIMARY_ROWS * row_block + (wave >> 1);
-		if (seq < strips_here * row_blocks && tile_x < A.P.tiles_x && local_row < A.P.local_tile_rows)
+		if (seq < strips_here * per_strip && tile_x < A.P.tiles_x && local_row < A.P.local_tile_rows)
 			primary_tile<SHARED>(A, closest_batches, tile_x, local_row);
 	}
 	// ---- the tail: is this the group's last workgroup? ----
@@ -1437,8 +1444,8 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) __attribute__((amdgpu_waves_per
 		return;
 	FrameCounters *const counters = OCRT_PCOLD_PTR(FrameCounters *, counters);
 	order_group(OCRT_PCOLD_PTR(const uint32_t *, tile_hits), OCRT_PCOLD_PTR(uint32_t *, order), counters, OCRT_PCOLD_U32(P.tiles_x),
-	            OCRT_PCOLD_U32(P.local_tile_rows), OCRT_PCOLD_U32(P.debug_no_sort) != 0u, OCRT_PCOLD_U32(P.cost_shift), group, scratch,
-	            PRIMARY_WAVES);
+	            OCRT_PCOLD_U32(P.local_tile_rows), OCRT_PCOLD_U32(P.strip_tiles), OCRT_PCOLD_U32(P.debug_no_sort) != 0u,
+	            OCRT_PCOLD_U32(P.cost_shift), group, scratch, PRIMARY_WAVES);
 	if (threadIdx.x == 0u)
 		__hip_atomic_store(&counters->queue[group].done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -1541,9 +1548,10 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 		const uint32_t group = (home + turn) & (XCD_GROUPS - 1u);
 		uint32_t segment = 0u;
 		{
-			const uint32_t strips = (OCRT_COLD_U32(P.tiles_x) + 1u) >> 1, rows = OCRT_COLD_U32(P.local_tile_rows);
+			const uint32_t strip_tiles = OCRT_COLD_U32(P.strip_tiles);
+			const uint32_t strips = (OCRT_COLD_U32(P.tiles_x) + strip_tiles - 1u) / strip_tiles, rows = OCRT_COLD_U32(P.local_tile_rows);
 			for (uint32_t g = 0; g < group; ++g)
-				segment += ((strips + XCD_GROUPS - 1u - g) >> 3) * 2u * rows;
+				segment += ((strips + XCD_GROUPS - 1u - g) >> 3) * strip_tiles * rows;
 		}
 		// the group's work in units of (tile, table direction), tile-major
 		uint32_t units, claim_max;
@@ -2066,8 +2074,8 @@ void launch_primary(const SceneBuffers &scene, float *image, void *hits, void *o
 #endif
 	if (P.tiles_x * P.local_tile_rows == 0)
 		return;
-	const uint32_t strips = (P.tiles_x + 1u) >> 1, row_blocks = (P.local_tile_rows + PRIMARY_ROWS - 1u) / PRIMARY_ROWS;
-	const uint32_t blocks = XCD_GROUPS * ((strips + XCD_GROUPS - 1u) >> 3) * row_blocks;
+	const uint32_t strips = (P.tiles_x + P.strip_tiles - 1u) / P.strip_tiles, row_blocks = (P.local_tile_rows + PRIMARY_ROWS - 1u) / PRIMARY_ROWS;
+	const uint32_t blocks = XCD_GROUPS * ((strips + XCD_GROUPS - 1u) >> 3) * row_blocks * (P.strip_tiles >> 1);
 	auto launch = [&](auto kernel) {
 		PrimaryArgs args;
 		args.walk_ptr = (const float4 *) scene.walk;

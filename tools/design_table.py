@@ -9,13 +9,15 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROWS = [  # workload, label, (round 2, round 1) one-frame-at-a-time Mrays/s
-    ("bunny_1080p_ao", "**bunny 1080p `-s 1 -a 3`** (headline)", "21 890 / 15 533"),
-    ("bunny_1080p_primary", "bunny 1080p primary only", "6 730 / 7 900"),
-    ("bunny_600_defaults", "bunny 600² CLI defaults", "20 177 / 13 500"),
-    ("bunny_1080p_s64", "bunny 1080p `-s 64` (2.2 G rays)", "41 392 / 36 900"),
-    ("interior_1080p_ao", "interior stand-in 1080p", "34 774 / 22 900"),
-    ("interior_4k_ao", "interior stand-in 4K", "41 351 / 34 200"),
+ROWS = [  # workload, label, (round 3, round 2, round 1) one-frame-at-a-time Mrays/s
+    ("bunny_1080p_ao", "**bunny 1080p `-s 1 -a 3`** (headline)", "23 911 / 21 890 / 15 533"),
+    ("bunny_1080p_primary", "bunny 1080p primary only", "7 526 / 6 730 / 7 900"),
+    ("bunny_600_defaults", "bunny 600² CLI defaults", "23 720 / 20 177 / 13 500"),
+    ("bunny_1080p_s64", "bunny 1080p `-s 64` (2.2 G rays)", "42 896 / 41 392 / 36 900"),
+    ("interior_1080p_ao", "interior stand-in 1080p", "37 112 / 34 774 / 22 900"),
+    ("interior_4k_ao", "interior stand-in 4K", "43 093 / 41 351 / 34 200"),
+    ("terrain_2m_1080p_ao", "height field, 2.0 M triangles, 1080p (0.58 GB of scene)", "new"),
+    ("terrain_20m_1080p_ao", "height field, 20.5 M triangles, 1080p (6.0 GB of scene)", "new"),
 ]
 
 
@@ -24,11 +26,13 @@ def thousands(x):
 
 
 def main():
-    prefix = sys.argv[1] if len(sys.argv) > 1 else "r03"
+    prefix = sys.argv[1] if len(sys.argv) > 1 else "r04"
     lines = json.load(open(os.path.join(ROOT, "profiles", f"{prefix}_bench_lines.json")))
     for key, label, earlier in ROWS:
+        if key not in lines:
+            continue
         b = lines[key]
-        r, p = b["roofline"], b["roofline"]["frame_pipelined"]
+        r, p = b["roofline"], b["roofline"].get("frame_pipelined") or {"achieved": float("nan"), "frac": float("nan"), "frac_of_measured_ceiling": float("nan")}
         blocks = b.get("blocks", {})
         spread = f" ({thousands(blocks['mrays_per_s_min'])}–{thousands(blocks['mrays_per_s_max'])})" if blocks.get("n", 0) > 1 else ""
         value = f"**{thousands(b['value'])}**" if key == "bunny_1080p_ao" else thousands(b["value"])

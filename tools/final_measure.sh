@@ -6,7 +6,7 @@
 OUT=$1
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/$OUT
-WORKLOADS="bunny_1080p_ao bunny_1080p_primary bunny_600_defaults bunny_1080p_s64 interior_1080p_ao interior_4k_ao"
+WORKLOADS="bunny_1080p_ao bunny_1080p_primary bunny_600_defaults bunny_1080p_s64 interior_1080p_ao interior_4k_ao terrain_2m_1080p_ao terrain_20m_1080p_ao"
 $R/tools/pmc_collect.sh $OUT/pmc $WORKLOADS > $R/$OUT/pmc.log 2>&1
 cp $R/$OUT/pmc/pmc.json $R/profiles/pmc.json
 cd /tmp && export TMPDIR=/tmp

@@ -20,9 +20,12 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 KNOBS = [{}, {}, {}, {"OCRT_BATCH_BELOW": "0"}, {"OCRT_BATCH_BELOW": "65"}, {"OCRT_AO_CLAIM_MAX": "1"}, {"OCRT_AO_CLAIM_MAX": "28"},
          {"OCRT_KEEP_TREE": "1"}, {"OCRT_FORCE_EXACT_WALK": "1"}, {"OCRT_AO_BLOCKS": "2"}, {"OCRT_NO_SHARED_WALK": "1"},
-         {"OCRT_CONTRACT": "0.3"}, {"OCRT_CONTRACT": "2.0"}, {"OCRT_AO_GUIDE": "3"}, {"OCRT_NO_SCALED_WALK": "1"}]
+         {"OCRT_CONTRACT": "0.3"}, {"OCRT_CONTRACT": "2.0"}, {"OCRT_AO_GUIDE": "3"}, {"OCRT_NO_SCALED_WALK": "1"},
+         {"OCRT_STRIP_TILES": "4"}, {"OCRT_STRIP_TILES": "16"}, {"OCRT_STRIP_TILES": "32"}]
 SMALL_MESHES = [(name, bvh) for name in ("blob", "ties", "single") for bvh in (0, 1)]
-MESHES = SMALL_MESHES + [("bunny", 0), ("interior", 0)]  # (the big scenes: longest-axis trees only)
+# (the big scenes: longest-axis trees only; "terrain:<n>": a height field generated in memory, tools/big_meshes.py -- full
+# tiles whose ambient-occlusion packets descend into dense geometry: what showed round 4's look-ahead race)
+MESHES = SMALL_MESHES + [("bunny", 0), ("interior", 0), ("terrain:60", 0), ("terrain:150", 0), ("slivers", 0)]
 
 
 def mesh_path(name):
@@ -46,7 +49,8 @@ def draw_case(rng):
         focal=rng.choice([0.7, 1.0, 1.0, 1.6]), shading=rng.choice([1, 1, 0]), amin=rng.choice([4, 4, 10, 0]),
         amax=rng.choice([90, 90, 60]),
         share=rng.choice([1, 1, 3, 6]),  # (a host that is told it shares its GPU launches a smaller AO grid and keeps its claim size)
-        ring=rng.choice([0, 0, 0, 2]))   # (0: one blocking host; n: a ring of n hosts, graph replay, three frames)
+        ring=rng.choice([0, 0, 0, 2]),   # (0: one blocking host; n: a ring of n hosts, graph replay, three frames)
+        lookahead=rng.choice([0, 1, 2]))  # (the form of the AO pass: without / with look-ahead loads / as calibrated or by default)
 
 
 def run_case(rt, orc, oracle, scenes, case):
@@ -54,7 +58,13 @@ def run_case(rt, orc, oracle, scenes, case):
     `scenes`: cache {(mesh, bvh): (Scene, SceneArrays)} owned by the caller (per binding)."""
     key = (case["mesh"], case["bvh"])
     if key not in scenes:
-        scene = rt.Scene.load_off(mesh_path(case["mesh"])).build_bvh(case["bvh"])
+        if case["mesh"].startswith("terrain:") or case["mesh"] == "slivers":
+            from tools import big_meshes
+
+            arrays = big_meshes.slivers() if case["mesh"] == "slivers" else big_meshes.terrain(int(case["mesh"].split(":")[1]))
+            scene = rt.Scene.from_arrays(*arrays).build_bvh(case["bvh"])
+        else:
+            scene = rt.Scene.load_off(mesh_path(case["mesh"])).build_bvh(case["bvh"])
         scenes[key] = (scene, orc.SceneArrays.from_scene(scene))
     scene, arrays = scenes[key]
     for k in [k for k in os.environ if k.startswith("OCRT_") and k not in ("OCRT_LIB_DIR", "OCRT_DEVICE")]:
@@ -66,7 +76,12 @@ def run_case(rt, orc, oracle, scenes, case):
                                   enable_shading=case["shading"])
         opt.ao_alpha_min, opt.ao_alpha_max = case["amin"], case["amax"]
         if case["ring"]:
-            ring = rt.FrameRing(opt, scene, hosts=case["ring"])
+            ring = rt.FrameRing(opt, None, hosts=case["ring"])
+            if case["lookahead"] < 2 and hasattr(ring, "set_calibration"):
+                ring.set_calibration(False)
+                for slot in range(case["ring"]):
+                    ring.host(slot).set_ao_prefetch(bool(case["lookahead"]))
+            ring.upload_scene(scene)
             ring.run(3)
             ring.drain()
             host = ring.host(2 % case["ring"])
@@ -74,6 +89,8 @@ def run_case(rt, orc, oracle, scenes, case):
             ring.close()
         else:
             host = rt.Host(opt, 0)
+            if case["lookahead"] < 2 and hasattr(host, "set_ao_prefetch"):
+                host.set_ao_prefetch(bool(case["lookahead"]))
             host.upload_scene(scene)
             host.set_device_share(case["share"])
             host.render()

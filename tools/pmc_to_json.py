@@ -32,7 +32,7 @@ def main():
     out_dir, workloads = sys.argv[1], sys.argv[2:]
     result = {
         "kernel_source_sha256": kernel_source_sha(),
-        "source": "profiles/r03_pmc_<workload>.txt (rocprofv3 --pmc, one pass per counter group, tools/pmc_collect.sh)",
+        "source": "profiles/r04_pmc_<workload>.txt (rocprofv3 --pmc, one pass per counter group, tools/pmc_collect.sh)",
         "units": "per launch of the dominant kernel; SQ_*_CYCLES and SQ_WAIT_* count quad-cycles",
         "workloads": {},
     }
@@ -47,7 +47,7 @@ def main():
         entry = {
             "kernel": names[0],
             "valu_insts": c.get("SQ_INSTS_VALU"), "salu_insts": c.get("SQ_INSTS_SALU"), "smem_insts": c.get("SQ_INSTS_SMEM"),
-            # every kernel of a frame together (primary, order, ao, resolve; the resize is not part of prof_run's frames)
+            # every kernel of a frame together (primary pass with the ordering step, ambient-occlusion pass, finishing kernel)
             "frame_valu_insts": sum(k.get("SQ_INSTS_VALU", 0.0) for name, k in kernels.items() if "ocrt::" in name),
             "vmem_rd_insts": c.get("SQ_INSTS_VMEM_RD"), "lds_insts": c.get("SQ_INSTS_LDS"), "branch_insts": c.get("SQ_INSTS_BRANCH"),
             "waves": c.get("SQ_WAVES"), "wave_quad_cycles": c.get("SQ_WAVE_CYCLES"), "busy_cycles": c.get("SQ_BUSY_CYCLES"),
