@@ -496,13 +496,13 @@ __device__ __forceinline__ u32x8 scalar_load_node(const float4 *nodes_ptr, uint3
 // reciprocal (WalkRay); should a NaN still arise, v_max3 / v_min3 drop it (IEEE maxNum / minNum, the kernel runs
 // with IEEE mode on) -- one constraint fewer, conservative.
 //
-// Most packets are sign-coherent -- every live lane's reciprocal direction has the same sign on each axis (all
-// primary tiles off the image's centre lines, most ambient-occlusion packets) --: the near and far plane of each
-// axis are then known when the loop is entered and the test is 6 v_fma + max + min + max3 + min3 + cmp = 11 vector
-// instructions; the loop exists once per sign octant (OCRT_WALK_COHERENT).  Mixed packets select per lane with
-// v_cndmask on the sign masks: 17 (the first generation of this loop computed (b - o) * inv exactly: 23).  The
-// any-hit rays of the ambient-occlusion pass, whose max_distance is one number per frame, take the SCALED form of
-// the test: 9 and 15 (OCRT_TEST_COHERENT_SCALED below).  What an instruction costs here (tools/microbench/
+// Primary packets are sign-coherent -- every live lane's reciprocal direction has the same sign on each axis -- but on
+// the image's centre lines: the near and far plane of each axis are then known when the loop is entered and the test is
+// 6 v_fma + max + min + max3 + min3 + cmp = 11 vector instructions; the loop exists once per sign octant
+// (OCRT_WALK_COHERENT).  Mixed packets select per lane with v_cndmask on the sign masks: 17 (the first generation of
+// this loop computed (b - o) * inv exactly: 23).  The any-hit rays of the ambient-occlusion pass, whose max_distance is
+// one number per frame, take the SCALED form of the test on centre / half-extent records: 12, one loop for every packet
+// (OCRT_TEST_CE_SCALED below).  What an instruction costs here (tools/microbench/
 // valu_rate_probe.hip, 8 waves per SIMD): ~2.3 cycles per SIMD for v_fma / v_mul / v_add / v_mov on registers, ~4.2
 // for everything else (min / max / max3 / cmp / cndmask, v_pk_fma_f32, and alone also an fma with a scalar operand):
 // the 11-instruction test runs at 35.7 cycles, the 9-instruction one at 28.3, a v_pk_fma_f32 version with 8 at 35.9.
@@ -557,26 +557,18 @@ __device__ __forceinline__ u32x8 scalar_load_node(const float4 *nodes_ptr, uint3
 	"\tv_cmp_le_f32 vcc, v62, v56\n"
 // The SCALED form (any-hit rays, whose max_distance is one number per frame): the reciprocals carry a factor
 // ~ 1 / max_distance, so "t < max_distance" reads "t' <= 1" and both limits fit the CLAMP modifier of the z-axis fmas
-// (clamp to [0, 1]): near = max3(x, y, clamp(z)), far = min3(x, y, clamp(z)), hit iff near < far -- 9 vector
-// instructions, 15 for mixed packets (clamping both z values before the select equals clamping the selected one).
-// The comparison is strict so that a box behind the origin on z (far clamped to 0, near >= 0) fails; why no pair the
-// reference accepts is lost to that: scene_pack.cc, padded_bound ("The scaled form").
-#define OCRT_TEST_COHERENT_SCALED(NX, NY, NZ, FX, FY, FZ) \
-	"\tv_fma_f32 v56, " NX ", %[ix], %[oix]\n"            \
-	"\tv_fma_f32 v57, " NY ", %[iy], %[oiy]\n"            \
-	"\tv_fma_f32 v58, " NZ ", %[iz], %[oiz] clamp\n"      \
-	"\tv_fma_f32 v59, " FX ", %[ix], %[oix]\n"            \
-	"\tv_fma_f32 v60, " FY ", %[iy], %[oiy]\n"            \
-	"\tv_fma_f32 v61, " FZ ", %[iz], %[oiz] clamp\n"      \
-	"\tv_max3_f32 v56, v56, v57, v58\n"                   \
-	"\tv_min3_f32 v59, v59, v60, v61\n"                   \
-	"\tv_cmp_lt_f32 vcc, v56, v59\n"
-// Mixed packets of the SCALED form read the CENTRE / HALF-EXTENT copy of the walk array (scene_pack.cc, ce_record:
-// c in the lo fields, e in the hi fields; the copy lies behind the plane form's records and their END records):
-// t_c = fma(c, inv, oi), near = fma(-e, |inv|, t_c), far = fma(e, |inv|, t_c) -- right for either sign of inv, so no
-// selects: 9 v_fma + max3 + min3 + cmp = 12 vector instructions, nine of them of the fast class (the select form
-// took 15, nine of them of the slow class: tools/microbench/valu_rate_probe.hip).  Conservative like the plane form
-// (the half-extent carries the rounding of t_c: proof at ce_record).
+// (clamp to [0, 1]): near = max3(x, y, clamp(z)), far = min3(x, y, clamp(z)), hit iff near < far.  The comparison is
+// strict so that a box behind the origin on z (far clamped to 0, near >= 0) fails; why no pair the reference accepts is
+// lost to that: scene_pack.cc, padded_bound ("The scaled form").
+// It reads the CENTRE / HALF-EXTENT copy of the walk array (scene_pack.cc, ce_record: c in the lo fields, e in the hi
+// fields; the copy lies behind the plane form's records and their END records):
+// t_c = fma(c, inv, oi), near = fma(-e, |inv|, t_c), far = fma(e, |inv|, t_c) -- right for either sign of inv, so ONE loop
+// serves every any-hit packet: 9 v_fma + max3 + min3 + cmp = 12 vector instructions, nine of them of the fast class.
+// (Rounds 2-3 walked the plane-form records here too: a loop per sign octant, 6 fma + max3 + min3 + cmp = 9 per node, and
+// a select form of 15 -- nine of them of the slow class -- for packets whose rays disagree on a sign, a third of the
+// bunny's model packets.  The one loop measures 1.3 ... 4.4 % faster per frame on every workload, although coherent
+// packets execute three instructions more per node: fast-class fmas, one array in the caches, a ninth of the code.)
+// Conservative like the plane form (the half-extent carries the rounding of t_c: proof at ce_record).
 #define OCRT_TEST_CE_SCALED(CX, CY, CZ, EX, EY, EZ)       \
 	"\tv_fma_f32 v56, " CX ", %[ix], %[oix]\n"           \
 	"\tv_fma_f32 v57, " CY ", %[iy], %[oiy]\n"           \
@@ -590,24 +582,6 @@ __device__ __forceinline__ u32x8 scalar_load_node(const float4 *nodes_ptr, uint3
 	"\tv_max3_f32 v59, v59, v60, v61\n"                  \
 	"\tv_min3_f32 v56, v56, v57, v58\n"                  \
 	"\tv_cmp_lt_f32 vcc, v59, v56\n"
-#ifdef OCRT_NO_CE  // (A/B builds: the select form of the mixed scaled test on the plane-form records, as until round 3)
-#define OCRT_TEST_MIXED_SCALED(LX, LY, LZ, HX, HY, HZ) \
-	"\tv_fma_f32 v56, " LX ", %[ix], %[oix]\n"         \
-	"\tv_fma_f32 v57, " HX ", %[ix], %[oix]\n"         \
-	"\tv_fma_f32 v58, " LY ", %[iy], %[oiy]\n"         \
-	"\tv_fma_f32 v59, " HY ", %[iy], %[oiy]\n"         \
-	"\tv_fma_f32 v60, " LZ ", %[iz], %[oiz] clamp\n"   \
-	"\tv_fma_f32 v61, " HZ ", %[iz], %[oiz] clamp\n"   \
-	"\tv_cndmask_b32 v62, v57, v56, %[px]\n"           \
-	"\tv_cndmask_b32 v56, v56, v57, %[px]\n"           \
-	"\tv_cndmask_b32 v57, v59, v58, %[py]\n"           \
-	"\tv_cndmask_b32 v58, v58, v59, %[py]\n"           \
-	"\tv_cndmask_b32 v59, v61, v60, %[pz]\n"           \
-	"\tv_cndmask_b32 v60, v60, v61, %[pz]\n"           \
-	"\tv_max3_f32 v62, v62, v57, v59\n"                \
-	"\tv_min3_f32 v56, v56, v58, v60\n"                \
-	"\tv_cmp_lt_f32 vcc, v62, v56\n"
-#endif
 // (LEAF: the s-register holding the node's leaf field; NEXT: where the walk goes on after an append)
 #define OCRT_WALK_LEAF(LEAF, NOW, NEXT)                 \
 	"\ts_cmp_eq_u32 " LEAF ", -2\n"                     \
@@ -761,17 +735,18 @@ __device__ __forceinline__ uint32_t walk_collect(uint32_t variant, const float4 
                                                  uint32_t batch_below) {
 	uint32_t status;
 	if (SCALED) {
-#ifdef OCRT_NO_CE
-		OCRT_WALK_SWITCH(OCRT_TEST_COHERENT_SCALED, OCRT_WALK_MIXED(OCRT_TEST_MIXED_SCALED, OCRT_PF_NONE), OCRT_PF_NONE)
-#else
-		(void) sign;  // (mixed packets: the caller starts `at` in the centre / half-extent copy of the array)
+		// one loop for every any-hit packet, whatever its rays' signs (the caller starts `at` in the centre / half-extent
+		// copy of the array)
+		(void) sign;
+		(void) variant;
 		if (PREFETCH) {
-			OCRT_WALK_SWITCH(OCRT_TEST_COHERENT_SCALED, OCRT_WALK_MIXED_CE(OCRT_TEST_CE_SCALED, OCRT_PF_SUCCESSORS), OCRT_PF_SUCCESSORS)
+			OCRT_WALK_MIXED_CE(OCRT_TEST_CE_SCALED, OCRT_PF_SUCCESSORS);
 		} else {
-			OCRT_WALK_SWITCH(OCRT_TEST_COHERENT_SCALED, OCRT_WALK_MIXED_CE(OCRT_TEST_CE_SCALED, OCRT_PF_NONE), OCRT_PF_NONE)
+			OCRT_WALK_MIXED_CE(OCRT_TEST_CE_SCALED, OCRT_PF_NONE);
 		}
-#endif
 	} else {
+		// (the primary pass keeps the plane form and its loop per sign octant: its packets are coherent but for the
+		// image's centre lines, and 11 instructions beat 14: 1-5 % of the pass)
 		OCRT_WALK_SWITCH(OCRT_TEST_COHERENT, OCRT_WALK_MIXED(OCRT_TEST_MIXED, OCRT_PF_NONE), OCRT_PF_NONE)
 	}
 	return status;
@@ -900,15 +875,11 @@ __device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ n
 #endif
 		};
 		const uint32_t list_lds_address = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (uintptr_t) &batch.entry[0]);  // (low half of the flat address; scalar)
-		const SignMasks sign = sign_masks(ray_in);
-		const uint32_t variant = walk_variant(sign, alive_mask);  // (lanes only leave: a coherent packet stays coherent)
-		// byte offset of the node; a mixed packet walks the centre / half-extent copy of the records, which lies behind
-		// the plane form's and its two END records (scene_pack.cc, make_walk_array: 2 * (count + 2) * 32 < 2^32)
-#ifdef OCRT_NO_CE
-		uint32_t at = 0u;
-#else
-		uint32_t at = variant == WALK_MIXED ? (count + 2u) * 32u : 0u;
-#endif
+		const SignMasks sign{ 0ull, 0ull, 0ull };  // (not looked at by the any-hit loop)
+		const uint32_t variant = WALK_MIXED;
+		// byte offset of the node: the walk reads the centre / half-extent copy of the records, which lies behind the plane
+		// form's and its two END records (scene_pack.cc, make_walk_array: 2 * (count + 2) * 32 < 2^32)
+		uint32_t at = (count + 2u) * 32u;
 		const uint32_t end = at + count * 32u;
 		const WalkRay walk_ray = tame ? make_walk_ray(with_origin(), walk_scale, true) : make_walk_ray(with_origin(), walk_scale);  // (wave-uniform)
 		const uint32_t lane_tag = fresh_lane() << 26;
@@ -1120,10 +1091,11 @@ __device__ __forceinline__ void primary_tile(const PrimaryArgs &A, ClosestBatch 
 			const unsigned long long alive_mask = wave_ballot(active);
 			const SignMasks sign = sign_masks(ray);
 			const uint32_t variant = walk_variant(sign, alive_mask);
+			const uint32_t first = 0u;  // (the plane-form records)
 			const WalkRay walk_ray = make_walk_ray(ray, 1.0f);
 			const uint32_t list_lds_address = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (uintptr_t) &cb.entry[0]);  // (low half of the flat address; scalar)
-			const uint32_t end = count * 32u;
-			uint32_t at = 0u;  // byte offset
+			const uint32_t end = first + count * 32u;
+			uint32_t at = first;  // byte offset
 			while (alive_mask != 0ull && at < end) {
 				uint32_t leaf = 0u;
 				unsigned long long hit_mask = 0ull;

@@ -323,7 +323,7 @@ WalkArray make_walk_array(const PackedScene &scene, float ao_max_distance) {
 	if (2 * records * sizeof(NodeRec) >= (size_t) 1 << 32)
 		out.ao_scale = 0.0f;  // (no room for the centre / half-extent copy below 2^32 bytes: the any-hit rays of such a scene take the exact form)
 	const bool with_ce = out.ao_scale > 0.0f;
-	const float scaled_reach_of = with_ce ? ao_max_distance * 1.001f : 0.0f;
+	const float scaled_reach_of = out.ao_scale > 0.0f ? ao_max_distance * 1.001f : 0.0f;
 	out.nodes.resize(with_ce ? 2 * records : records);
 	auto pad_slice = [&](size_t from, size_t to) {
 		for (size_t i = from; i < to; ++i) {

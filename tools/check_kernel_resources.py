@@ -76,12 +76,20 @@ def lane_ops_by_place(isa_text: str):
                     begin = None
             if regions:
                 # loop depth of a line = the depth noted at the last basic-block label before it
+                # ("in Loop: Header=... Depth=N" on the label's own line or on a "; %bb.N:" comment; a loop header lists
+                # its parents first, over several comment lines, and says "This Inner Loop Header: Depth=N" /
+                # "This Loop Header: Depth=N" last: that one counts)
                 depth, depths = 0, []
-                for text in body:
-                    m = re.match(r"^\.LBB\d+_\d+:(.*)", text)
+                for j, text in enumerate(body):
+                    m = re.match(r"^(\.LBB\d+_\d+:|; %bb\.\d+:)(.*)", text)
                     if m:
-                        d = re.search(r"Depth=(\d+)", m.group(1))
-                        depth = int(d.group(1)) if d else 0
+                        note, k = m.group(2), j + 1
+                        while k < len(body) and re.match(r"^\s+;", body[k]):  # the comment's continuation lines
+                            note += body[k]
+                            k += 1
+                        own = re.search(r"This (?:Inner )?Loop Header: Depth=(\d+)", note)
+                        inside = re.search(r"in Loop: Header=\S+ Depth=(\d+)", note)
+                        depth = int(own.group(1)) if own else int(inside.group(1)) if inside else 0
                     depths.append(depth)
                 lane = [j for j, text in enumerate(body) if "v_writelane" in text or "v_readlane" in text]
                 walk_depth = max(depths[a] for a, _ in regions)  # the loop that holds the asm blocks
