@@ -139,6 +139,7 @@ _SIGNATURES = {
     "rt_ring_set_calibration": (C.c_int, [C.c_void_p, C.c_int]),
     "rt_ring_calibration": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "rt_set_ao_prefetch": (C.c_int, [C.c_void_p, C.c_int]),
+    "rt_walk_entries": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_double)]),
     "rt_ring_size": (C.c_uint32, [C.c_void_p]),
     "rt_ring_slots": (C.c_uint32, [C.c_void_p]),
     "rt_ring_local_rows": (C.c_uint32, [C.c_void_p]),
@@ -409,6 +410,12 @@ class Host:
     def set_ao_prefetch(self, on: bool) -> None:
         """Which form of the AO pass's node loop this host launches (include/rt_hip.h, rt_set_ao_prefetch); same results."""
         _check(load_library().rt_set_ao_prefetch(self._h, int(on)))
+
+    def walk_entries(self) -> dict:
+        """Where the tiles' any-hit walks enter the tree (include/rt_hip.h, rt_walk_entries)."""
+        hit, narrowed, share = C.c_uint32(), C.c_uint32(), C.c_double()
+        _check(load_library().rt_walk_entries(self._h, C.byref(hit), C.byref(narrowed), C.byref(share)))
+        return {"tiles_hit": hit.value, "tiles_narrowed": narrowed.value, "mean_share": share.value}
 
     def stats(self) -> dict:
         s = _Stats()

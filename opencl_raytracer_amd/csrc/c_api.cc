@@ -444,6 +444,20 @@ int rt_ring_calibration(const rt_ring *r, float *ms_without, float *ms_with, int
 	return RT_OK;
 }
 
+int rt_walk_entries(rt_host *h, uint32_t *tiles_hit, uint32_t *tiles_narrowed, double *mean_share) {
+	if (!h)
+		return fail(RT_E_INVALID, "null argument");
+	return guarded([&] {
+		const ocrt::DeviceRenderer::WalkEntries e = h->dev->walkEntries();
+		if (tiles_hit)
+			*tiles_hit = e.tiles_hit;
+		if (tiles_narrowed)
+			*tiles_narrowed = e.tiles_narrowed;
+		if (mean_share)
+			*mean_share = e.mean_share;
+	});
+}
+
 int rt_set_ao_prefetch(rt_host *h, int on) {
 	if (!h)
 		return fail(RT_E_INVALID, "null argument");

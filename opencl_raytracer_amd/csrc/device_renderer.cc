@@ -87,6 +87,7 @@ DeviceRenderer::DeviceRenderer(const RayTracer::Options &options, int device_, u
 	, d_occluded(nullptr)
 	, d_tile_hits(nullptr)
 	, d_tile_base(nullptr)
+	, d_tile_entry(nullptr)
 	, d_order(nullptr)
 	, d_counters(nullptr)
 	, hit_slots(0)
@@ -162,6 +163,7 @@ DeviceRenderer::DeviceRenderer(const RayTracer::Options &options, int device_, u
 	// (the hit list itself is sized once a scene is adopted: by what that scene's primary rays hit, sizeHitList)
 	d_tile_hits = device_alloc(tile_count * sizeof(uint32_t));
 	d_tile_base = device_alloc(tile_count * sizeof(uint32_t));
+	d_tile_entry = device_alloc(tile_count * 2 * sizeof(uint32_t));
 	d_order = device_alloc(order_slots * sizeof(uint32_t));
 	d_counters = device_alloc(sizeof(FrameCounters));
 	OCRT_HIP(hipMemsetAsync(d_counters, 0, sizeof(FrameCounters), (hipStream_t) stream));  // (once: the kernels keep it clean, device_types.h)
@@ -199,6 +201,7 @@ DeviceRenderer::~DeviceRenderer() {
 	device_free(d_occluded);
 	device_free(d_tile_hits);
 	device_free(d_tile_base);
+	device_free(d_tile_entry);
 	device_free(d_order);
 	device_free(d_counters);
 	if (own_stream)
@@ -418,7 +421,7 @@ size_t DeviceRenderer::adopt(std::shared_ptr<const DeviceScene> scene, const Dev
 		layout_from = nullptr;  // (not the same frame after all: count)
 	sizeHitList(layout_from);
 	return image_bytes + (size_t) local_out_rows * opts.width + hit_slots * (sizeof(HitRec) + sizeof(uint32_t)) +
-	       tile_count * 3 * sizeof(uint32_t) + sizeof(FrameCounters);
+	       tile_count * 5 * sizeof(uint32_t) + sizeof(FrameCounters);
 }
 
 // The hit list is sized by what is hit.  Camera, scene and options are fixed for this renderer, so the number of hit
@@ -437,12 +440,17 @@ void DeviceRenderer::sizeHitList(const DeviceRenderer *layout_from) {
 		d_hits = device_alloc(sizeof(HitRec));  // (never read: no sub-pixel is left pending)
 		d_occluded = device_alloc(sizeof(uint32_t));
 		OCRT_HIP(hipMemsetAsync(d_tile_base, 0, tile_count * sizeof(uint32_t), (hipStream_t) stream));
+		OCRT_HIP(hipMemsetAsync(d_tile_entry, 0, tile_count * 2 * sizeof(uint32_t), (hipStream_t) stream));
 		OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));
 		return;
 	}
 	if (layout_from) {  // (the same frame of the same scene: the same hits)
 		hit_slots = layout_from->hit_slots;
-		OCRT_HIP(hipMemcpy(d_tile_base, layout_from->d_tile_base, tile_count * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+		// (on this renderer's stream, and waited for: the stream is a non-blocking one, which work on the null stream is not
+		// ordered against, and a copy or fill between device buffers need not have finished when its call returns)
+		OCRT_HIP(hipMemcpyAsync(d_tile_base, layout_from->d_tile_base, tile_count * sizeof(uint32_t), hipMemcpyDeviceToDevice, (hipStream_t) stream));
+		OCRT_HIP(hipMemcpyAsync(d_tile_entry, layout_from->d_tile_entry, tile_count * 2 * sizeof(uint32_t), hipMemcpyDeviceToDevice, (hipStream_t) stream));
+		OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));
 		d_hits = device_alloc((hit_slots ? hit_slots : 1) * sizeof(HitRec));
 		d_occluded = device_alloc((hit_slots ? hit_slots : 1) * sizeof(uint32_t));
 		clock.mark("hit list laid out like the ring's first host");
@@ -463,11 +471,33 @@ void DeviceRenderer::sizeHitList(const DeviceRenderer *layout_from) {
 	if (running >= (1ull << 32))
 		throw std::invalid_argument("more than 2^32 hit sub-pixels in one rank's bands");
 	hit_slots = (size_t) running;
-	OCRT_HIP(hipMemcpy(d_tile_base, words.data(), tile_count * sizeof(uint32_t), hipMemcpyHostToDevice));
-	OCRT_HIP(hipMemset(d_image, 0, image_bytes));  // (the counting pass left its pending tags there)
+	OCRT_HIP(hipMemcpyAsync(d_tile_base, words.data(), tile_count * sizeof(uint32_t), hipMemcpyHostToDevice, (hipStream_t) stream));
+	OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));  // (`words` is pageable memory of this function)
 	d_hits = device_alloc((hit_slots ? hit_slots : 1) * sizeof(HitRec));
 	d_occluded = device_alloc((hit_slots ? hit_slots : 1) * sizeof(uint32_t));
 	clock.mark("tile bases to the device, image cleared, hit list allocated");
+	// ... and, now that there is a hit list, where each tile's any-hit rays enter the walk tree: a second pass of the
+	// primary kernel fills the list, entry_kernel reads the tiles' hit points (kernels.hip; the whole array where the
+	// fast walk is not used).  Like the bases: once per upload.
+	if (kp.fast_walk && scene_on_device->buffers().walk) {
+		launch_primary(scene_on_device->buffers(), (float *) d_image, d_hits, d_occluded, d_tile_hits, d_order, d_tile_base, d_counters, kp, stream);
+		launch_entries(scene_on_device->buffers(), d_hits, d_tile_hits, d_tile_base, d_tile_entry, kp, stream);
+		OCRT_HIP(hipGetLastError());
+	} else {
+		std::vector<uint32_t> all(2 * (size_t) tile_count);
+		for (size_t t = 0; t < tile_count; ++t) {
+			all[2 * t] = 0u;
+			all[2 * t + 1] = 0xFFFFFFFFu;
+		}
+		OCRT_HIP(hipMemcpyAsync(d_tile_entry, all.data(), all.size() * sizeof(uint32_t), hipMemcpyHostToDevice, (hipStream_t) stream));
+		OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));
+	}
+	// (the passes above left their pending tags in the image.  On the renderer's own stream: it is a non-blocking one, a
+	// fill on the null stream would not be ordered against the frames that follow -- and was not, until round 4: a 530 MB
+	// image at 64 samples per pixel takes long enough to clear for the first frame's primary pass to be overtaken by it.)
+	OCRT_HIP(hipMemsetAsync(d_image, 0, image_bytes, (hipStream_t) stream));
+	OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));
+	clock.mark("entries of the tiles' any-hit walks");
 }
 
 DeviceRenderer::FrameEvents DeviceRenderer::takeEvents() {
@@ -500,11 +530,38 @@ void DeviceRenderer::launchFrame(void *device_u8, void *ao_start, void *ao_stop)
 #ifdef OCRT_STAMPS  // (instrumented build: the AO pass takes the minimum of its waves' start times into this slot)
 	OCRT_HIP(hipMemsetAsync((char *) d_counters + offsetof(FrameCounters, stamp) + 7 * sizeof(unsigned long long), 0xFF, sizeof(unsigned long long), s));
 #endif
-	launch_ao(scene, d_hits, d_occluded, d_order, d_tile_base, d_counters, kp, ao_blocks_override ? ao_blocks_override : aoWorkgroups(), ao_prefetch,
+	launch_ao(scene, d_hits, d_occluded, d_order, d_tile_base, d_tile_entry, d_counters, kp, ao_blocks_override ? ao_blocks_override : aoWorkgroups(), ao_prefetch,
 	          stream, ao_start, ao_stop);
 	OCRT_HIP(hipGetLastError());
 	launch_finish((float *) d_image, d_hits, d_occluded, d_tile_base, d_counters, (unsigned char *) device_u8, kp, opts.width, grid, local_out_rows, stream);
 	OCRT_HIP(hipGetLastError());
+}
+
+DeviceRenderer::WalkEntries DeviceRenderer::walkEntries() const {
+	if (!scene_ready)
+		throw std::logic_error("walkEntries: no scene on the device");
+	useDevice();
+	WalkEntries out{ 0, 0, 1.0 };
+	const bool has_ao = kp.ao_mode != AO_NONE && kp.ao_dirs > 0;
+	if (tile_count == 0 || !has_ao || kp.node_count == 0)
+		return out;
+	std::vector<uint32_t> words(tile_count), ranges(2 * (size_t) tile_count);
+	OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));
+	OCRT_HIP(hipMemcpyAsync(words.data(), d_tile_hits, tile_count * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t) stream));
+	OCRT_HIP(hipMemcpyAsync(ranges.data(), d_tile_entry, ranges.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t) stream));
+	OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));
+	const double whole = (double) kp.node_count * sizeof(NodeRec);
+	double sum = 0.0;
+	for (size_t t = 0; t < tile_count; ++t) {
+		if ((words[t] & 0xFFu) == 0u)
+			continue;
+		++out.tiles_hit;
+		const double bytes = std::min(whole, (double) ranges[2 * t + 1]) - (double) ranges[2 * t];
+		out.tiles_narrowed += ranges[2 * t] != 0u || bytes < whole;
+		sum += bytes / whole;
+	}
+	out.mean_share = out.tiles_hit ? sum / out.tiles_hit : 1.0;
+	return out;
 }
 
 void DeviceRenderer::setAoPrefetch(bool on) {

@@ -144,6 +144,13 @@ class DeviceRenderer {
 		// renders a few frames one at a time with each form (plain launches, HIP events around the ao_kernel), keeps the
 		// faster one and returns the two medians in ms (a frame ring does this once per uploaded scene).
 		void setAoPrefetch(bool on);
+		// Where the tiles' any-hit walks enter the tree (sizeHitList, entry_kernel): of the tiles with hits, how many walk
+		// less than the whole tree, and the mean share of the node records a tile's rays are confined to.
+		struct WalkEntries {
+			uint32_t tiles_hit, tiles_narrowed;
+			double mean_share;
+		};
+		WalkEntries walkEntries() const;
 		bool aoPrefetch() const { return ao_prefetch; }
 		bool calibrateAoPrefetch(float *ms_without = nullptr, float *ms_with = nullptr);
 		uint32_t aoWorkgroups() const { return device_share > 1u ? compute_units * 11u / 2u : compute_units * 8u; }
@@ -188,7 +195,7 @@ class DeviceRenderer {
 		uint32_t local_out_rows;
 		void *own_stream, *stream;
 		std::shared_ptr<const DeviceScene> scene_on_device;
-		void *d_image, *d_u8, *d_hits, *d_occluded, *d_tile_hits, *d_tile_base, *d_order, *d_counters;
+		void *d_image, *d_u8, *d_hits, *d_occluded, *d_tile_hits, *d_tile_base, *d_tile_entry, *d_order, *d_counters;
 		size_t hit_slots;     // slots of the hit list: the scene's hit sub-pixels in this rank's bands (sizeHitList)
 		void sizeHitList(const DeviceRenderer *layout_from);  // counts the hits per tile with one pass of the primary kernel (or copies another renderer's count) and sizes the list by them
 		size_t image_bytes;  // float image of this rank's bands
@@ -231,8 +238,11 @@ class DeviceRenderer {
 void preload_kernels();
 void launch_primary(const SceneBuffers &scene, float *image, void *hits, void *occluded_of, void *tile_hits, void *order,
                     const void *tile_base, void *counters, const KernelParams &P, void *stream);
-void launch_ao(const SceneBuffers &scene, void *hits, void *occluded_of, void *order, const void *tile_base, void *counters,
-               const KernelParams &P, uint32_t workgroups, bool prefetch, void *stream, void *event_before_ao, void *event_after_ao);
+void launch_entries(const SceneBuffers &scene, const void *hits, const void *tile_hits, const void *tile_base, void *tile_entry,
+                    const KernelParams &P, void *stream);
+void launch_ao(const SceneBuffers &scene, void *hits, void *occluded_of, void *order, const void *tile_base, const void *tile_entry,
+               void *counters, const KernelParams &P, uint32_t workgroups, bool prefetch, void *stream, void *event_before_ao,
+               void *event_after_ao);
 void launch_finish(float *image, const void *hits, const void *occluded_of, const void *tile_base, void *counters,
                    unsigned char *out, const KernelParams &P, uint32_t out_width, uint32_t n, uint32_t local_out_rows, void *stream);
 void launch_resize(const float *tmp, unsigned char *out, const KernelParams &P, uint32_t out_width, uint32_t n,

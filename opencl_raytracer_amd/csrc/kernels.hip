@@ -625,12 +625,19 @@ __device__ __forceinline__ u32x8 scalar_load_node(const float4 *nodes_ptr, uint3
 	"\ts_add_u32 s46, %[at], s59\n"                          \
 	"\ts_load_dword s47, %[base], s46\n"                     \
 	".Lw_no_pf_%=:\n"
-#define OCRT_WALK_ASM(TEST_A, TEST_B, PF_B)                 \
+// HEAD: what is checked while a pair is being fetched.  OCRT_HEAD_END: the walk is over once `at` has left the range it
+// was given (the any-hit walks of a tile run through ONE subtree, its entry: ao_kernel) -- two scalar instructions per
+// pair, in the shadow of the load (which is waited for on the way out too: its sixteen registers are the compiler's again
+// once the block ends; the records behind any range are there to be read, END records at the latest).
+#define OCRT_HEAD_NONE ""
+#define OCRT_HEAD_END "\ts_cmp_ge_u32 %[at], %[end]\n\ts_cbranch_scc1 .Lw_over_wait_%=\n"
+#define OCRT_WALK_ASM(HEAD, TEST_A, TEST_B, PF_B)           \
 	"\ts_branch .Lw_node_%=\n"                              \
 	".Lw_miss_a_%=:\n"                                      \
 	"\ts_add_u32 %[at], %[at], s51\n"                       \
 	".Lw_node_%=:\n"                                        \
 	"\ts_load_dwordx16 s[48:63], %[base], %[at]\n"          \
+	HEAD                                                    \
 	"\ts_waitcnt lgkmcnt(0)\n"                              \
 	TEST_A                                                  \
 	"\ts_and_b64 s[44:45], vcc, %[alive]\n"                 \
@@ -667,6 +674,8 @@ __device__ __forceinline__ u32x8 scalar_load_node(const float4 *nodes_ptr, uint3
 	".Lw_full_%=:\n"                                        \
 	"\ts_mov_b32 %[status], 2\n"                            \
 	"\ts_branch .Lw_out_%=\n"                               \
+	".Lw_over_wait_%=:\n"                                   \
+	"\ts_waitcnt lgkmcnt(0)\n"                              \
 	".Lw_over_%=:\n"                                        \
 	"\ts_mov_b32 %[status], 0\n"                            \
 	".Lw_out_%=:\n"
@@ -680,7 +689,7 @@ __device__ __forceinline__ u32x8 scalar_load_node(const float4 *nodes_ptr, uint3
 #define OCRT_FAR_P(LO, HI) HI
 #define OCRT_FAR_N(LO, HI) LO
 #define OCRT_WALK_COHERENT(TEST, X, Y, Z, PF)                                                                               \
-	asm volatile(OCRT_WALK_ASM(TEST(OCRT_NEAR_##X("s48", "s52"), OCRT_NEAR_##Y("s49", "s53"),                              \
+	asm volatile(OCRT_WALK_ASM(OCRT_HEAD_NONE, TEST(OCRT_NEAR_##X("s48", "s52"), OCRT_NEAR_##Y("s49", "s53"),              \
 	                                OCRT_NEAR_##Z("s50", "s54"), OCRT_FAR_##X("s48", "s52"),                               \
 	                                OCRT_FAR_##Y("s49", "s53"), OCRT_FAR_##Z("s50", "s54")),                               \
 	                           TEST(OCRT_NEAR_##X("s56", "s60"), OCRT_NEAR_##Y("s57", "s61"),                              \
@@ -694,7 +703,7 @@ __device__ __forceinline__ u32x8 scalar_load_node(const float4 *nodes_ptr, uint3
 	             : OCRT_WALK_CLOBBERS)
 
 #define OCRT_WALK_MIXED(TEST, PF)                                                                                         \
-	asm volatile(OCRT_WALK_ASM(TEST("s48", "s49", "s50", "s52", "s53", "s54"), TEST("s56", "s57", "s58", "s60", "s61", "s62"), PF) \
+	asm volatile(OCRT_WALK_ASM(OCRT_HEAD_NONE, TEST("s48", "s49", "s50", "s52", "s53", "s54"), TEST("s56", "s57", "s58", "s60", "s61", "s62"), PF) \
 	             : [at] "+s"(at), [waiting] "+s"(waiting), [stops] "+s"(leaf_stops), [hit] "=&s"(hit_mask),               \
 	               [leaf] "=&s"(leaf), [status] "=&s"(status)                                                            \
 	             : [base] "s"(walk_ptr), [alive] "s"(alive_mask), [below] "s"(below), [batch_below] "s"(batch_below),     \
@@ -703,10 +712,10 @@ __device__ __forceinline__ u32x8 scalar_load_node(const float4 *nodes_ptr, uint3
 	               [oiz] "v"(ray.oiz)                                                                                    \
 	             : OCRT_WALK_CLOBBERS)
 #define OCRT_WALK_MIXED_CE(TEST, PF)                                                                                      \
-	asm volatile(OCRT_WALK_ASM(TEST("s48", "s49", "s50", "s52", "s53", "s54"), TEST("s56", "s57", "s58", "s60", "s61", "s62"), PF) \
+	asm volatile(OCRT_WALK_ASM(OCRT_HEAD_END, TEST("s48", "s49", "s50", "s52", "s53", "s54"), TEST("s56", "s57", "s58", "s60", "s61", "s62"), PF) \
 	             : [at] "+s"(at), [waiting] "+s"(waiting), [stops] "+s"(leaf_stops), [hit] "=&s"(hit_mask),               \
 	               [leaf] "=&s"(leaf), [status] "=&s"(status)                                                            \
-	             : [base] "s"(walk_ptr), [alive] "s"(alive_mask), [below] "s"(below), [batch_below] "s"(batch_below),     \
+	             : [base] "s"(walk_ptr), [alive] "s"(alive_mask), [end] "s"(walk_end), [batch_below] "s"(batch_below),    \
 	               [list] "s"(list_lds_address), [tag] "v"(lane_tag),                                                      \
 	               [ix] "v"(ray.ix), [iy] "v"(ray.iy), [iz] "v"(ray.iz), [oix] "v"(ray.oix), [oiy] "v"(ray.oiy),          \
 	               [oiz] "v"(ray.oiz)                                                                                    \
@@ -732,7 +741,8 @@ __device__ __forceinline__ uint32_t walk_collect(uint32_t variant, const float4 
                                                  const SignMasks &sign, float below, unsigned long long alive_mask,
                                                  unsigned long long &hit_mask, uint32_t &leaf, uint32_t &waiting,
                                                  uint32_t &leaf_stops, uint32_t list_lds_address, uint32_t lane_tag,
-                                                 uint32_t batch_below) {
+                                                 uint32_t batch_below, uint32_t walk_end = 0xFFFFFFFFu) {
+	(void) walk_end;  // (the any-hit loop's: byte offset behind the subtree it walks)
 	uint32_t status;
 	if (SCALED) {
 		// one loop for every any-hit packet, whatever its rays' signs (the caller starts `at` in the centre / half-extent
@@ -809,7 +819,7 @@ __device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ n
                                                     uint32_t count, const Ray &ray_in, const float (&frame)[12][64], uint32_t h,
                                                     float max_distance, float below, float walk_scale, bool alive, bool tame,
                                                     unsigned int *occluded, LeafBatch &batch, uint32_t batch_below,
-                                                    unsigned long long *prof) {
+                                                    unsigned long long *prof, uint32_t entry_begin = 0u, uint32_t entry_end = 0xFFFFFFFFu) {
 	(void) prof;  // (-DOCRT_STAMPS builds: time in the node loop / in batches, loop entries, batches, leaf stops)
 	// the live lanes as a scalar mask: the node steps then need no per-lane bookkeeping at all
 	unsigned long long alive_mask = wave_ballot(alive);
@@ -878,9 +888,13 @@ __device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ n
 		const SignMasks sign{ 0ull, 0ull, 0ull };  // (not looked at by the any-hit loop)
 		const uint32_t variant = WALK_MIXED;
 		// byte offset of the node: the walk reads the centre / half-extent copy of the records, which lies behind the plane
-		// form's and its two END records (scene_pack.cc, make_walk_array: 2 * (count + 2) * 32 < 2^32)
-		uint32_t at = (count + 2u) * 32u;
-		const uint32_t end = at + count * 32u;
+		// form's and its two END records (scene_pack.cc, make_walk_array: 2 * (count + 2) * 32 < 2^32) -- and of that copy
+		// only the tile's ENTRY subtree [entry_begin, entry_end): the deepest node under which every leaf lies that a ray
+		// of this tile can reach (entry_kernel)
+		const uint32_t copy = (count + 2u) * 32u;
+		uint32_t at = copy + entry_begin;
+		const uint32_t whole = count * 32u;
+		const uint32_t end = copy + (entry_end < whole ? entry_end : whole);
 		const WalkRay walk_ray = tame ? make_walk_ray(with_origin(), walk_scale, true) : make_walk_ray(with_origin(), walk_scale);  // (wave-uniform)
 		const uint32_t lane_tag = fresh_lane() << 26;
 		while (alive_mask != 0ull && at < end) {
@@ -890,7 +904,7 @@ __device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ n
 			const unsigned long long tw0 = __builtin_amdgcn_s_memrealtime();
 #endif
 			const uint32_t status = walk_collect<true, PREFETCH>(variant, walk_ptr, at, walk_ray, sign, below, alive_mask, hit_mask, leaf,
-			                                           waiting, leaf_stops, list_lds_address, lane_tag, batch_below);
+			                                           waiting, leaf_stops, list_lds_address, lane_tag, batch_below, end);
 #ifdef OCRT_STAMPS
 			prof[0] += __builtin_amdgcn_s_memrealtime() - tw0;
 			prof[2] += 1;
@@ -1483,6 +1497,7 @@ struct AoArgs {
 	uint32_t *occluded_of;
 	const uint32_t *order;
 	const uint32_t *tile_base;  // first slot of each tile in the hit list
+	const uint2 *tile_entry;    // per tile: the byte range of the walk records its any-hit rays have to walk (entry_kernel)
 	FrameCounters *counters;
 	KernelParams P;
 };
@@ -1632,6 +1647,13 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 				const uint32_t entry = (uint32_t) __builtin_amdgcn_readfirstlane((int) OCRT_COLD_PTR(const uint32_t *, order)[segment + tile_index]);
 				const uint32_t tile = entry & 0x03FFFFFFu;
 				const uint32_t hit_count = (entry >> 26) + 1u;
+				// the subtree this tile's rays walk (two words, made scalar by hand like every load through a re-read pointer)
+				uint32_t entry_begin, entry_end;
+				{
+					const uint2 range = OCRT_COLD_PTR(const uint2 *, tile_entry)[tile];
+					entry_begin = (uint32_t) __builtin_amdgcn_readfirstlane((int) range.x);
+					entry_end = (uint32_t) __builtin_amdgcn_readfirstlane((int) range.y);
+				}
 				uint32_t total = hit_count * n_dirs;  // the rays of this piece of the job: directions dir0 ...
 				// A claim dealt by the cursor: the next piece of the tile's directions -- enough to fill a packet, twice that
 				// at most (64 >> floor(log2(hit_count)) directions) -- or nothing, if the siblings have taken them all.
@@ -1862,7 +1884,7 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 						else
 							shared_walk_any_hit<false, PREFETCH>(nullptr, walk_ptr, tris_ptr, count, ray, sh.frame, h,
 							                           0.0f, A.P.ao_below, OCRT_COLD_F32(P.walk_scale), alive, tame, &sh.occluded[h], sh.batch,
-							                           A.P.batch_below, walk_prof);
+							                           A.P.batch_below, walk_prof, entry_begin, entry_end);
 					}
 					take_from_cursor();  // (fixed shares: the cursor holds nothing)
 					} while (total != 0u);
@@ -1931,6 +1953,73 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 		atomicAdd(&A.counters->stamp[10 + (end_bucket > 31 ? 31 : end_bucket)], 1ull);
 	}
 #endif
+}
+
+// ---------------------------------------------------------------------------
+// Once per upload (camera, scene and options are fixed, so a tile's hit points are the same in every frame): for every
+// tile the ENTRY of its ambient-occlusion walks -- the deepest node of the walk tree under which every leaf lies that a
+// ray of the tile can reach.  Such a ray starts at one of the tile's hit points (+ normal * 1e-5) and is at most
+// AO_MAX_DISTANCE long, and the reference's slab test (src/intersect_kernel.cl:21-61: t_near < max_distance, t_far > 0)
+// only passes for a box the ray's origin is within max_distance of on every axis; so a leaf whose box stays clear of the
+// box of the tile's origins grown by max_distance (and a margin for roundings: 1 % of it + 2^-20 of the coordinates) is
+// tested by none of the tile's rays, in any tree.  From the root down: while exactly ONE child's (padded) box meets that
+// region, go there.  One wave per tile, every lane doing the same -- speed is nobody's concern here.  A frame's packets
+// then walk [begin, end) of the records instead of the whole array: nothing on the bunny's plane, -2 % node tests on its
+// model (AO_MAX_DISTANCE is a fifth of it), -23 % on the interior scene (tools/analysis/ao_packets.cc, ENTRY rows).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void entry_kernel(const NodeRec *__restrict__ walk, const HitRec *__restrict__ hits,
+                                                    const uint32_t *__restrict__ tile_hits, const uint32_t *__restrict__ tile_base,
+                                                    uint2 *__restrict__ tile_entry, uint32_t tiles, uint32_t node_count,
+                                                    float max_distance) {
+	const uint32_t tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+	if (tile >= tiles)
+		return;
+	const uint32_t hit_count = tile_hits[tile] & 0xFFu;
+	const float inf = __builtin_inff();
+	float lo[3] = { inf, inf, inf }, hi[3] = { -inf, -inf, -inf };
+	bool odd = false;  // an origin that is not a number: nothing can be said, the whole tree it is
+	if (lane < hit_count) {
+		const HitRec rec = hits[(size_t) tile_base[tile] + lane];
+		const float o[3] = { rec.ox + rec.nx * (1.0f / 100000.0f), rec.oy + rec.ny * (1.0f / 100000.0f), rec.oz + rec.nz * (1.0f / 100000.0f) };
+		for (int k = 0; k < 3; ++k) {
+			const float margin = max_distance * 1.01f + fabsf(o[k]) * 0x1.0p-20f + 1.0e-30f;
+			lo[k] = o[k] - margin;
+			hi[k] = o[k] + margin;
+			odd = odd || !(fabsf(o[k]) < inf);
+		}
+	}
+	for (int k = 0; k < 3; ++k)
+		for (int offset = 32; offset >= 1; offset >>= 1) {
+			lo[k] = fminf(lo[k], __shfl_xor(lo[k], offset));
+			hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], offset));
+		}
+	uint32_t at = 0u;  // node index
+	if (hit_count != 0u && wave_ballot(odd) == 0ull && max_distance > 0.0f)
+		for (;;) {
+			const uint32_t skip = walk[at].skip / (uint32_t) sizeof(NodeRec);  // (the walk array keeps byte offsets)
+			if (skip <= 1u)
+				break;
+			uint32_t chosen = 0u, meeting = 0u;
+			for (uint32_t c = at + 1u; c < at + skip && meeting < 2u;) {
+				const NodeRec child = walk[c];
+				const bool clear = child.lo[0] > hi[0] || child.hi[0] < lo[0] || child.lo[1] > hi[1] || child.hi[1] < lo[1] ||
+				                   child.lo[2] > hi[2] || child.hi[2] < lo[2];
+				if (!clear) {
+					++meeting;
+					chosen = c;
+				}
+				const uint32_t child_skip = child.skip / (uint32_t) sizeof(NodeRec);
+				c += child_skip ? child_skip : 1u;
+			}
+			if (meeting != 1u)
+				break;
+			at = chosen;
+		}
+	if (lane == 0u) {
+		const uint32_t skip = hit_count ? walk[at].skip : 0u;
+		tile_entry[tile] = make_uint2(at * (uint32_t) sizeof(NodeRec), at * (uint32_t) sizeof(NodeRec) + (skip ? skip : (uint32_t) sizeof(NodeRec)));
+		(void) node_count;
+	}
 }
 
 // Pass 3, the frame's last kernel: value *= 1 - hits / n (reference :256 and :305-307) for the sub-pixels that wait
@@ -2071,8 +2160,19 @@ void launch_primary(const SceneBuffers &scene, float *image, void *hits, void *o
 	launch(primary_kernel<true>);
 }
 
-void launch_ao(const SceneBuffers &scene, void *hits, void *occluded_of, void *order, const void *tile_base, void *counters,
-               const KernelParams &params, uint32_t workgroups, bool prefetch, void *stream, void *event_before_ao,
+// Fills `tile_entry` (two words per tile) for the frame whose hit list is in `hits`: once per upload (entry_kernel).
+void launch_entries(const SceneBuffers &scene, const void *hits, const void *tile_hits, const void *tile_base, void *tile_entry,
+                    const KernelParams &P, void *stream) {
+	const uint32_t tiles = P.tiles_x * P.local_tile_rows;
+	if (tiles == 0)
+		return;
+	hipLaunchKernelGGL(entry_kernel, dim3((tiles + 3u) / 4u), dim3(256), 0, (hipStream_t) stream, (const NodeRec *) scene.walk,
+	                   (const HitRec *) hits, (const uint32_t *) tile_hits, (const uint32_t *) tile_base, (uint2 *) tile_entry, tiles,
+	                   P.node_count, P.ao_max_distance);
+}
+
+void launch_ao(const SceneBuffers &scene, void *hits, void *occluded_of, void *order, const void *tile_base, const void *tile_entry,
+               void *counters, const KernelParams &params, uint32_t workgroups, bool prefetch, void *stream, void *event_before_ao,
                void *event_after_ao) {
 	if (params.tiles_x * params.local_tile_rows == 0 || params.ao_mode == AO_NONE || params.ao_dirs == 0)
 		return;
@@ -2100,6 +2200,7 @@ void launch_ao(const SceneBuffers &scene, void *hits, void *occluded_of, void *o
 		args.occluded_of = (uint32_t *) occluded_of;
 		args.order = (const uint32_t *) order;
 		args.tile_base = (const uint32_t *) tile_base;
+		args.tile_entry = (const uint2 *) tile_entry;
 		args.counters = (FrameCounters *) counters;
 		args.P = P;
 		hipLaunchKernelGGL(kernel, dim3(ao_blocks), dim3(64 * AO_WAVES), 0, s, args);

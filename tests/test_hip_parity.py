@@ -215,6 +215,31 @@ def test_interior_standin_matches_oracle(rt, oracle):
         host.close()
 
 
+@pytest.mark.parametrize("mesh", ["interior", "bunny"])
+def test_entry_subtrees_confine_the_walks_and_change_nothing(rt, oracle, scene_for, mesh):
+    """An upload finds, per tile, the subtree its any-hit rays can reach within AO_MAX_DISTANCE (entry_kernel), and the
+    tile's packets walk that alone.  Whatever the distance -- a hundredth of the scene, the reference's default, more than
+    the scene -- the image is the oracle's; and the narrowing is there when the distance is short and gone when it is not."""
+    import orc
+
+    scene, arrays = scene_for(mesh, "longest")
+    shares = []
+    for distance in (0.02, 0.2, 0.9, 50.0):
+        opt = rt.Options.defaults(width=128, height=72, n_super_samples=4, ao_num_samples=2, ao_max_distance=distance)
+        host = render_hip(rt, scene, opt)
+        ref_img, counters, _ = oracle.render(orc.params_from_options(opt), arrays)
+        assert np.array_equal(bits(host.download()), bits(ref_img)), distance
+        assert host.stats()["ao_occluded"] == counters["ao_occluded"]
+        e = host.walk_entries()
+        assert e["tiles_hit"] > 0 and 0.0 < e["mean_share"] <= 1.0
+        shares.append(e["mean_share"])
+        if distance == 50.0:
+            assert e["tiles_narrowed"] == 0 and e["mean_share"] == 1.0
+        host.close()
+    assert shares[0] < shares[1] <= shares[2] <= shares[3]
+    assert shares[0] < 0.5  # (a tile and a fiftieth of the scene around it: half the tree at most, on average)
+
+
 def test_render_cli_writes_the_golden_pgm(rt, golden, tmp_path):
     """End to end through the `render` binary: same flags as the reference CLI (src/render.cc:19-43), the
     reference's phase lines and ray notice (:63-128), PGM file byte-identical to the golden one -- on one device,

@@ -106,7 +106,7 @@ struct Tree {
 };
 
 // One packet through the shared walk.  fat_k = 0: the kernel as it is.
-static void walk_packet(const Tree &T, const R *rays, int n, float D, int batch_below, int fat_k, Events &ev) {
+static void walk_packet(const Tree &T, const R *rays, int n, float D, int batch_below, int fat_k, Events &ev, size_t from = 0, size_t to = (size_t) -1) {
 	const std::vector<NodeRec> &N = *T.nodes;
 	bool alive[64];
 	int live = n;
@@ -158,7 +158,8 @@ static void walk_packet(const Tree &T, const R *rays, int n, float D, int batch_
 		}
 		fat_waiting.erase(fat_waiting.begin(), fat_waiting.begin() + count);
 	};
-	for (size_t i = 0; i < N.size() && live;) {
+	if (to > N.size()) to = N.size();
+	for (size_t i = from; i < to && live;) {
 		bool hit[64];
 		int hits = 0;
 		for (int l = 0; l < n; ++l) {
@@ -280,6 +281,7 @@ int main(int argc, char **argv) {
 	// variants: [packets: current, dense, octant] x [fat: 0, 2, 4, 8, 16]
 	const int NP = 3;
 	static Events ev[3][NP][NF];
+	static Events entry_ev[3];
 	static unsigned long long tiles_in[3], jobs_in[3][NP], hits_in[3], partial_tiles[3];
 	// the ground plane: the two largest triangles
 	float plane_y = -0.48f;
@@ -293,6 +295,7 @@ int main(int argc, char **argv) {
 #pragma omp parallel
 	{
 		static thread_local Events lev[3][NP][NF];
+		static thread_local Events lentry[3];
 		unsigned long long ltiles[3] = { 0 }, ljobs[3][NP] = { { 0 } }, lhits[3] = { 0 }, lpartial[3] = { 0 };
 #pragma omp for schedule(dynamic, 1)
 		for (int ty = 0; ty < (H + 7) / 8; ty += stride)
@@ -388,6 +391,33 @@ int main(int argc, char **argv) {
 					}
 				}
 				for (const R &r : all) lev[cls][0][0].own_nodes += own_walk(trees[0], r, D);
+				{
+					// ENTRY: the deepest node whose subtree holds every leaf a ray of this tile can reach (the box of the
+					// tile's ray origins grown by D): descend from the root while exactly one child's box meets that region
+					float qlo[3] = { INFINITY, INFINITY, INFINITY }, qhi[3] = { -INFINITY, -INFINITY, -INFINITY };
+					for (int l = 0; l < nh; ++l) for (int k = 0; k < 3; ++k) { qlo[k] = fminf(qlo[k], hp[l][k] - D * 1.002f - 1e-4f); qhi[k] = fmaxf(qhi[k], hp[l][k] + D * 1.002f + 1e-4f); }
+					const std::vector<NodeRec> &N0 = *trees[0].nodes;
+					size_t at = 0;
+					for (;;) {
+						if (N0[at].skip == 1) break;
+						size_t chosen = 0; int count = 0;
+						for (size_t c = at + 1; c < at + N0[at].skip; c += N0[c].skip) {
+							bool over = true;
+							for (int k = 0; k < 3; ++k) over = over && !(N0[c].lo[k] > qhi[k] || N0[c].hi[k] < qlo[k]);
+							if (over) { ++count; chosen = c; }
+						}
+						if (count != 1) break;
+						at = chosen;
+					}
+					int lg = 0;
+					while ((2 << lg) <= nh) ++lg;
+					const int chunk = 64 >> lg;
+					for (int q0 = 0; q0 < ND; q0 += chunk) {
+						const int dirs = std::min(chunk, ND - q0), total = dirs * nh;
+						for (int base = 0; base < total; base += 64)
+							walk_packet(trees[0], &all[(size_t) q0 * nh + base], std::min(64, total - base), D, batch_below, 0, lentry[cls], at, at + N0[at].skip);
+					}
+				}
 			}
 #pragma omp critical
 		{
@@ -399,6 +429,7 @@ int main(int argc, char **argv) {
 					jobs_in[c][p] += ljobs[c][p];
 					for (int f = 0; f < NF; ++f) ev[c][p][f].add(lev[c][p][f]);
 				}
+				entry_ev[c].add(lentry[c]);
 			}
 		}
 	}
@@ -414,6 +445,13 @@ int main(int argc, char **argv) {
 		       partial_tiles[c] * (unsigned long long) scale, hits_in[c] * (unsigned long long) scale, hits_in[c] * scale * ND / 1e6,
 		       (double) ev[c][0][0].own_nodes / (double) (hits_in[c] * ND ? hits_in[c] * ND : 1));
 		printf("%-8s %-4s %9s %6s %6s %7s %7s %6s %7s %7s %7s %7s %7s %8s %8s\n", "packets", "fat", "packets", "rays/p", "coh%", "nodes/p", "lanes%", "spot/p", "app/p", "pairs/p", "bat/p", "fatp/p", "fatb/p", "VALU/p", "M VALU");
+		if (entry_ev[c].packets) {
+			const Events &e = entry_ev[c];
+			const double pk = (double) e.packets, cost = M.cost(e, tiles_in[c] * 4);
+			printf("%-8s %-4d %9.0f %6.1f %6.1f %7.1f %7.1f %6.2f %7.1f %7.1f %7.2f %7.1f %7.2f %8.0f %8.1f\n", "ENTRY", 0, pk * scale, e.rays / pk,
+			       100.0 * e.coherent_packets / pk, (e.nodes_coherent + e.nodes_mixed) / pk, 100.0 * e.lane_hits / (double) (e.lane_alive ? e.lane_alive : 1), e.spot_leaves / pk,
+			       e.appends / pk, e.pairs / pk, e.batches / pk, 0.0, 0.0, cost / pk, cost * scale / 1e6);
+		}
 		for (int p = 0; p < NP; ++p)
 			for (int f = 0; f < NF; ++f) {
 				const Events &e = ev[c][p][f];
