@@ -189,13 +189,15 @@ int rt_ring_device_bytes(const rt_ring *r, uint64_t *scene_bytes, uint32_t *scen
 int rt_ring_set_calibration(rt_ring *r, int on);
 int rt_ring_calibration(const rt_ring *r, float *ms_without, float *ms_with, int *prefetch_in_use);
 int rt_set_ao_prefetch(rt_host *h, int on);
-/* Entry subtrees (new; results never depend on them): an upload finds, for every 8x8 tile of the host's band, the deepest
- * node of the walk tree under which every leaf lies that an ambient-occlusion ray of the tile can reach (AO_MAX_DISTANCE,
- * src/intersect_kernel.cl:217 and the slab test of :21-61), and the tile's any-hit rays walk that subtree alone.  This
- * reports, over the tiles with hits: their number, how many walk less than the whole tree, and the mean share of the node
- * records a tile's rays are confined to (1.0 = no narrowing: AO_MAX_DISTANCE of the scene's size).  Out pointers may be
- * NULL.  RT_E_STATE without a scene. */
-int rt_walk_entries(rt_host *h, uint32_t *tiles_hit, uint32_t *tiles_narrowed, double *mean_share);
+/* Walk intervals (new; results never depend on them): an upload finds, for every 8x8 tile of the host's band, the part of
+ * the tree's node records -- an interval of the pre-order array -- outside which no leaf lies that an ambient-occlusion ray
+ * of the tile can reach (AO_MAX_DISTANCE, src/intersect_kernel.cl:217, and the slab test of :21-61), once for any ray
+ * from the tile and once for each table direction of a full tile (the 64 rays of one packet); the any-hit packets walk
+ * their interval alone.  This reports, over the tiles with hits: their number, how many have a tile interval short of the
+ * whole array, the mean share of the records inside the tile intervals, and the mean share inside the intervals the
+ * packets actually use (1.0 = no narrowing: AO_MAX_DISTANCE of the scene's size).  Out pointers may be NULL.
+ * RT_E_STATE without a scene. */
+int rt_walk_entries(rt_host *h, uint32_t *tiles_hit, uint32_t *tiles_narrowed, double *mean_share, double *mean_packet_share);
 uint32_t rt_ring_size(const rt_ring *r);        /* hosts */
 /* Band buffers: frame f is rendered by host f % size into buffer f % slots, slots = 2 * size, so that a frame's bands
  * (and, with a communicator, its assembled image) stay untouched while the next `size` frames are submitted. */

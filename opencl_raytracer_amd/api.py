@@ -139,7 +139,8 @@ _SIGNATURES = {
     "rt_ring_set_calibration": (C.c_int, [C.c_void_p, C.c_int]),
     "rt_ring_calibration": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "rt_set_ao_prefetch": (C.c_int, [C.c_void_p, C.c_int]),
-    "rt_walk_entries": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_double)]),
+    "rt_walk_entries": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_double),
+                        C.POINTER(C.c_double)]),
     "rt_ring_size": (C.c_uint32, [C.c_void_p]),
     "rt_ring_slots": (C.c_uint32, [C.c_void_p]),
     "rt_ring_local_rows": (C.c_uint32, [C.c_void_p]),
@@ -412,10 +413,11 @@ class Host:
         _check(load_library().rt_set_ao_prefetch(self._h, int(on)))
 
     def walk_entries(self) -> dict:
-        """Where the tiles' any-hit walks enter the tree (include/rt_hip.h, rt_walk_entries)."""
-        hit, narrowed, share = C.c_uint32(), C.c_uint32(), C.c_double()
-        _check(load_library().rt_walk_entries(self._h, C.byref(hit), C.byref(narrowed), C.byref(share)))
-        return {"tiles_hit": hit.value, "tiles_narrowed": narrowed.value, "mean_share": share.value}
+        """The intervals of the node array the tiles' any-hit packets walk (include/rt_hip.h, rt_walk_entries)."""
+        hit, narrowed, share, packet_share = C.c_uint32(), C.c_uint32(), C.c_double(), C.c_double()
+        _check(load_library().rt_walk_entries(self._h, C.byref(hit), C.byref(narrowed), C.byref(share), C.byref(packet_share)))
+        return {"tiles_hit": hit.value, "tiles_narrowed": narrowed.value, "mean_share": share.value,
+                "mean_packet_share": packet_share.value}
 
     def stats(self) -> dict:
         s = _Stats()

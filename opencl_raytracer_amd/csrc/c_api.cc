@@ -444,7 +444,7 @@ int rt_ring_calibration(const rt_ring *r, float *ms_without, float *ms_with, int
 	return RT_OK;
 }
 
-int rt_walk_entries(rt_host *h, uint32_t *tiles_hit, uint32_t *tiles_narrowed, double *mean_share) {
+int rt_walk_entries(rt_host *h, uint32_t *tiles_hit, uint32_t *tiles_narrowed, double *mean_share, double *mean_packet_share) {
 	if (!h)
 		return fail(RT_E_INVALID, "null argument");
 	return guarded([&] {
@@ -455,6 +455,8 @@ int rt_walk_entries(rt_host *h, uint32_t *tiles_hit, uint32_t *tiles_narrowed, d
 			*tiles_narrowed = e.tiles_narrowed;
 		if (mean_share)
 			*mean_share = e.mean_share;
+		if (mean_packet_share)
+			*mean_packet_share = e.mean_packet_share;
 	});
 }
 

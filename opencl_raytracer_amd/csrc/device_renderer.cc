@@ -163,7 +163,6 @@ DeviceRenderer::DeviceRenderer(const RayTracer::Options &options, int device_, u
 	// (the hit list itself is sized once a scene is adopted: by what that scene's primary rays hit, sizeHitList)
 	d_tile_hits = device_alloc(tile_count * sizeof(uint32_t));
 	d_tile_base = device_alloc(tile_count * sizeof(uint32_t));
-	d_tile_entry = device_alloc(tile_count * 2 * sizeof(uint32_t));
 	d_order = device_alloc(order_slots * sizeof(uint32_t));
 	d_counters = device_alloc(sizeof(FrameCounters));
 	OCRT_HIP(hipMemsetAsync(d_counters, 0, sizeof(FrameCounters), (hipStream_t) stream));  // (once: the kernels keep it clean, device_types.h)
@@ -201,7 +200,6 @@ DeviceRenderer::~DeviceRenderer() {
 	device_free(d_occluded);
 	device_free(d_tile_hits);
 	device_free(d_tile_base);
-	device_free(d_tile_entry);
 	device_free(d_order);
 	device_free(d_counters);
 	if (own_stream)
@@ -421,7 +419,16 @@ size_t DeviceRenderer::adopt(std::shared_ptr<const DeviceScene> scene, const Dev
 		layout_from = nullptr;  // (not the same frame after all: count)
 	sizeHitList(layout_from);
 	return image_bytes + (size_t) local_out_rows * opts.width + hit_slots * (sizeof(HitRec) + sizeof(uint32_t)) +
-	       tile_count * 5 * sizeof(uint32_t) + sizeof(FrameCounters);
+	       tile_count * 3 * sizeof(uint32_t) + (tile_entry_owner.use_count() == 1 ? entryBytes() : 0) + sizeof(FrameCounters);
+}
+
+void DeviceRenderer::allocEntries(size_t bytes) {
+	const int on_device = device;
+	tile_entry_owner = std::shared_ptr<void>(device_alloc(bytes), [on_device](void *p) {
+		if (p && hipSetDevice(on_device) == hipSuccess)
+			(void) hipFree(p);
+	});
+	d_tile_entry = tile_entry_owner.get();
 }
 
 // The hit list is sized by what is hit.  Camera, scene and options are fixed for this renderer, so the number of hit
@@ -434,22 +441,26 @@ void DeviceRenderer::sizeHitList(const DeviceRenderer *layout_from) {
 	UploadClock clock;
 	device_free(d_hits);
 	device_free(d_occluded);
+	tile_entry_owner.reset();  // (the table goes when the last renderer that walks by it lets go)
+	d_hits = d_occluded = d_tile_entry = nullptr;
 	hit_slots = 0;
 	const bool has_ao = kp.ao_mode != AO_NONE && kp.ao_dirs > 0;
 	if (tile_count == 0 || !has_ao) {
 		d_hits = device_alloc(sizeof(HitRec));  // (never read: no sub-pixel is left pending)
 		d_occluded = device_alloc(sizeof(uint32_t));
+		allocEntries(sizeof(uint32_t) * 2);
 		OCRT_HIP(hipMemsetAsync(d_tile_base, 0, tile_count * sizeof(uint32_t), (hipStream_t) stream));
-		OCRT_HIP(hipMemsetAsync(d_tile_entry, 0, tile_count * 2 * sizeof(uint32_t), (hipStream_t) stream));
 		OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));
 		return;
 	}
 	if (layout_from) {  // (the same frame of the same scene: the same hits)
 		hit_slots = layout_from->hit_slots;
+		// the walk intervals are read-only between uploads: the ring's hosts share ONE table (like the scene's arrays)
+		tile_entry_owner = layout_from->tile_entry_owner;
+		d_tile_entry = tile_entry_owner.get();
 		// (on this renderer's stream, and waited for: the stream is a non-blocking one, which work on the null stream is not
 		// ordered against, and a copy or fill between device buffers need not have finished when its call returns)
 		OCRT_HIP(hipMemcpyAsync(d_tile_base, layout_from->d_tile_base, tile_count * sizeof(uint32_t), hipMemcpyDeviceToDevice, (hipStream_t) stream));
-		OCRT_HIP(hipMemcpyAsync(d_tile_entry, layout_from->d_tile_entry, tile_count * 2 * sizeof(uint32_t), hipMemcpyDeviceToDevice, (hipStream_t) stream));
 		OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));
 		d_hits = device_alloc((hit_slots ? hit_slots : 1) * sizeof(HitRec));
 		d_occluded = device_alloc((hit_slots ? hit_slots : 1) * sizeof(uint32_t));
@@ -475,6 +486,7 @@ void DeviceRenderer::sizeHitList(const DeviceRenderer *layout_from) {
 	OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));  // (`words` is pageable memory of this function)
 	d_hits = device_alloc((hit_slots ? hit_slots : 1) * sizeof(HitRec));
 	d_occluded = device_alloc((hit_slots ? hit_slots : 1) * sizeof(uint32_t));
+	allocEntries(entryBytes());
 	clock.mark("tile bases to the device, image cleared, hit list allocated");
 	// ... and, now that there is a hit list, where each tile's any-hit rays enter the walk tree: a second pass of the
 	// primary kernel fills the list, entry_kernel reads the tiles' hit points (kernels.hip; the whole array where the
@@ -484,8 +496,8 @@ void DeviceRenderer::sizeHitList(const DeviceRenderer *layout_from) {
 		launch_entries(scene_on_device->buffers(), d_hits, d_tile_hits, d_tile_base, d_tile_entry, kp, stream);
 		OCRT_HIP(hipGetLastError());
 	} else {
-		std::vector<uint32_t> all(2 * (size_t) tile_count);
-		for (size_t t = 0; t < tile_count; ++t) {
+		std::vector<uint32_t> all(entryBytes() / sizeof(uint32_t));
+		for (size_t t = 0; t < all.size() / 2; ++t) {
 			all[2 * t] = 0u;
 			all[2 * t + 1] = 0xFFFFFFFFu;
 		}
@@ -541,26 +553,37 @@ DeviceRenderer::WalkEntries DeviceRenderer::walkEntries() const {
 	if (!scene_ready)
 		throw std::logic_error("walkEntries: no scene on the device");
 	useDevice();
-	WalkEntries out{ 0, 0, 1.0 };
+	WalkEntries out{ 0, 0, 1.0, 1.0 };
 	const bool has_ao = kp.ao_mode != AO_NONE && kp.ao_dirs > 0;
 	if (tile_count == 0 || !has_ao || kp.node_count == 0)
 		return out;
-	std::vector<uint32_t> words(tile_count), ranges(2 * (size_t) tile_count);
+	const size_t stride = (size_t) kp.ao_dirs + 1;  // (intervals per tile: entry_kernel)
+	std::vector<uint32_t> words(tile_count), ranges(entryBytes() / sizeof(uint32_t));
 	OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));
 	OCRT_HIP(hipMemcpyAsync(words.data(), d_tile_hits, tile_count * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t) stream));
 	OCRT_HIP(hipMemcpyAsync(ranges.data(), d_tile_entry, ranges.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t) stream));
 	OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));
 	const double whole = (double) kp.node_count * sizeof(NodeRec);
-	double sum = 0.0;
+	double sum = 0.0, sum_packets = 0.0;
+	unsigned long long packets = 0;
 	for (size_t t = 0; t < tile_count; ++t) {
 		if ((words[t] & 0xFFu) == 0u)
 			continue;
 		++out.tiles_hit;
-		const double bytes = std::min(whole, (double) ranges[2 * t + 1]) - (double) ranges[2 * t];
-		out.tiles_narrowed += ranges[2 * t] != 0u || bytes < whole;
+		const uint32_t *const of_tile = &ranges[2 * stride * t];
+		const double bytes = std::min(whole, (double) of_tile[1]) - (double) of_tile[0];
+		out.tiles_narrowed += of_tile[0] != 0u || bytes < whole;
 		sum += bytes / whole;
+		// what the tile's packets walk: a full tile's, one table direction each, have intervals of their own
+		const bool per_direction = (words[t] & 0xFFu) == 64u && kp.ao_mode == AO_UNIFORM;
+		for (size_t k = 1; k < stride; ++k) {
+			const uint32_t *const r = per_direction ? of_tile + 2 * k : of_tile;
+			sum_packets += (std::min(whole, (double) r[1]) - (double) r[0]) / whole;
+			++packets;
+		}
 	}
 	out.mean_share = out.tiles_hit ? sum / out.tiles_hit : 1.0;
+	out.mean_packet_share = packets ? sum_packets / (double) packets : 1.0;
 	return out;
 }
 

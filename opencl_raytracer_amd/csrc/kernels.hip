@@ -1497,7 +1497,7 @@ struct AoArgs {
 	uint32_t *occluded_of;
 	const uint32_t *order;
 	const uint32_t *tile_base;  // first slot of each tile in the hit list
-	const uint2 *tile_entry;    // per tile: the byte range of the walk records its any-hit rays have to walk (entry_kernel)
+	const uint2 *tile_entry;    // per tile, 1 + ao_dirs byte ranges of the walk records: what its any-hit rays have to walk (entry_kernel)
 	FrameCounters *counters;
 	KernelParams P;
 };
@@ -1647,13 +1647,6 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 				const uint32_t entry = (uint32_t) __builtin_amdgcn_readfirstlane((int) OCRT_COLD_PTR(const uint32_t *, order)[segment + tile_index]);
 				const uint32_t tile = entry & 0x03FFFFFFu;
 				const uint32_t hit_count = (entry >> 26) + 1u;
-				// the subtree this tile's rays walk (two words, made scalar by hand like every load through a re-read pointer)
-				uint32_t entry_begin, entry_end;
-				{
-					const uint2 range = OCRT_COLD_PTR(const uint2 *, tile_entry)[tile];
-					entry_begin = (uint32_t) __builtin_amdgcn_readfirstlane((int) range.x);
-					entry_end = (uint32_t) __builtin_amdgcn_readfirstlane((int) range.y);
-				}
 				uint32_t total = hit_count * n_dirs;  // the rays of this piece of the job: directions dir0 ...
 				// A claim dealt by the cursor: the next piece of the tile's directions -- enough to fill a packet, twice that
 				// at most (64 >> floor(log2(hit_count)) directions) -- or nothing, if the siblings have taken them all.
@@ -1871,6 +1864,15 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 						float4 shared_dir = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 						if (whole && MODE == AO_UNIFORM)
 							shared_dir = OCRT_COLD_PTR(const float4 *, ao_table)[dir0 + (base >> 6)];
+						// the interval of the walk array this packet has to walk (entry_kernel): the one of its table direction,
+						// or the tile's.  Two words, made scalar by hand like every load through a re-read pointer.
+						uint32_t entry_begin, entry_end;
+						{
+							const uint32_t which = (whole && MODE == AO_UNIFORM) ? 1u + dir0 + (base >> 6) : 0u;
+							const uint2 range = OCRT_COLD_PTR(const uint2 *, tile_entry)[(size_t) tile * (OCRT_COLD_U32(P.ao_dirs) + 1u) + which];
+							entry_begin = (uint32_t) __builtin_amdgcn_readfirstlane((int) range.x);
+							entry_end = (uint32_t) __builtin_amdgcn_readfirstlane((int) range.y);
+						}
 						if (alive)
 							setup_ray(base + lane, whole, shared_dir);
 						const bool exact = !scene_fast || (!tame && wave_ballot(alive && !ray_is_selectable(ray, OCRT_COLD_F32(P.origin_limit))) != 0ull);
@@ -1957,68 +1959,141 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 
 // ---------------------------------------------------------------------------
 // Once per upload (camera, scene and options are fixed, so a tile's hit points are the same in every frame): for every
-// tile the ENTRY of its ambient-occlusion walks -- the deepest node of the walk tree under which every leaf lies that a
-// ray of the tile can reach.  Such a ray starts at one of the tile's hit points (+ normal * 1e-5) and is at most
-// AO_MAX_DISTANCE long, and the reference's slab test (src/intersect_kernel.cl:21-61: t_near < max_distance, t_far > 0)
-// only passes for a box the ray's origin is within max_distance of on every axis; so a leaf whose box stays clear of the
-// box of the tile's origins grown by max_distance (and a margin for roundings: 1 % of it + 2^-20 of the coordinates) is
-// tested by none of the tile's rays, in any tree.  From the root down: while exactly ONE child's (padded) box meets that
-// region, go there.  One wave per tile, every lane doing the same -- speed is nobody's concern here.  A frame's packets
-// then walk [begin, end) of the records instead of the whole array: nothing on the bunny's plane, -2 % node tests on its
-// model (AO_MAX_DISTANCE is a fifth of it), -23 % on the interior scene (tools/analysis/ao_packets.cc, ENTRY rows).
+// tile, WHERE in the walk array its ambient-occlusion packets have to walk.  An any-hit ray starts at one of the tile's hit
+// points (+ normal * 1e-5) and is at most AO_MAX_DISTANCE long: the reference's slab test (src/intersect_kernel.cl:21-61:
+// t_near < max_distance, t_far > 0, t_near <= t_far) only passes for a box that holds a point o + t d with 0 <= t <=
+// max_distance, a point of the SEGMENT the ray covers.  So a leaf whose box stays clear of the box around the segments of
+// a set of rays (grown by a margin for the roundings: 1 % of the distance + 2^-20 of the coordinates) is tested by none of
+// them, in any tree.  The walk array is the tree in pre-order with skip offsets, so a walk can start at ANY record and
+// stop at any other: it visits what lies between in the usual way.  An interval [begin, end) for a region: from the root
+// down, `begin` moves to the first child that meets the region whenever that child follows clear ones or is the only one
+// that meets it (its parent's test and the clear subtrees are skipped), `end` moves to the end of the last child that
+// meets it.  Where exactly one child meets the region at every level this is the deepest subtree that holds everything
+// reachable; below that it trims both flanks.
+// Per tile, 1 + ao_dirs intervals: [0] for the tile's hit points grown by the distance on every side -- any ray from the
+// tile: packets of tiles that are not full (several table directions in one packet) and the RANDOM mode --, [1 + k] for
+// the 64 rays of table direction k, a full tile's packet: the box around 64 segments, a third of the other's volume or
+// less.  One wave per tile: lanes = hits while the origins and tangent frames (reference :225-236) go to LDS, then lanes
+// = intervals, each going down the tree on its own; speed is nobody's concern here.
+// Node tests per packet against walking the whole array (tools/analysis/ao_packets.cc, rows TRIM and PDIR): the bunny's
+// plane 7.4 -> 5.8, its model tiles 104.8 -> 91.2 (AO_MAX_DISTANCE is a fifth of the model), the interior scene 38.2 -> 21.2.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void entry_kernel(const NodeRec *__restrict__ walk, const HitRec *__restrict__ hits,
-                                                    const uint32_t *__restrict__ tile_hits, const uint32_t *__restrict__ tile_base,
-                                                    uint2 *__restrict__ tile_entry, uint32_t tiles, uint32_t node_count,
-                                                    float max_distance) {
-	const uint32_t tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+constexpr uint32_t ENTRY_WAVES = 4;
+__global__ __launch_bounds__(64 * ENTRY_WAVES) void entry_kernel(const NodeRec *__restrict__ walk, const HitRec *__restrict__ hits,
+                                                                 const uint32_t *__restrict__ tile_hits, const uint32_t *__restrict__ tile_base,
+                                                                 const float4 *__restrict__ ao_table, uint2 *__restrict__ tile_entry,
+                                                                 uint32_t tiles, uint32_t ao_dirs, int32_t uniform_table,
+                                                                 float max_distance) {
+	__shared__ float origin[ENTRY_WAVES][3][64];
+	__shared__ float frame[ENTRY_WAVES][9][64];  // basis_x, basis_y (the normal), basis_z
+	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+	const uint32_t tile = blockIdx.x * ENTRY_WAVES + wave;
 	if (tile >= tiles)
-		return;
+		return;  // (a whole wave: the waves of a workgroup never meet at a barrier)
 	const uint32_t hit_count = tile_hits[tile] & 0xFFu;
-	const float inf = __builtin_inff();
-	float lo[3] = { inf, inf, inf }, hi[3] = { -inf, -inf, -inf };
-	bool odd = false;  // an origin that is not a number: nothing can be said, the whole tree it is
+	const uint32_t stride = 1u + ao_dirs;
+	uint2 *const out = tile_entry + (size_t) tile * stride;
+	const uint32_t whole = walk[0].skip / (uint32_t) sizeof(NodeRec);
 	if (lane < hit_count) {
 		const HitRec rec = hits[(size_t) tile_base[tile] + lane];
-		const float o[3] = { rec.ox + rec.nx * (1.0f / 100000.0f), rec.oy + rec.ny * (1.0f / 100000.0f), rec.oz + rec.nz * (1.0f / 100000.0f) };
-		for (int k = 0; k < 3; ++k) {
-			const float margin = max_distance * 1.01f + fabsf(o[k]) * 0x1.0p-20f + 1.0e-30f;
-			lo[k] = o[k] - margin;
-			hi[k] = o[k] + margin;
-			odd = odd || !(fabsf(o[k]) < inf);
-		}
+		const float nx = rec.nx, ny = rec.ny, nz = rec.nz;
+		const float eps = 1.0f / 100000.0f;
+		origin[wave][0][lane] = rec.ox + nx * eps;
+		origin[wave][1][lane] = rec.oy + ny * eps;
+		origin[wave][2][lane] = rec.oz + nz * eps;
+		float hx = nx, hy = ny, hz = nz;
+		const float ax = fabsf(nx), ay = fabsf(ny), az = fabsf(nz);
+		if (ax <= ay && ax <= az)
+			hx = 1.0f;
+		else if (ay <= ax && ay <= az)
+			hy = 1.0f;
+		else if (az <= ax && az <= ay)
+			hz = 1.0f;
+		float bxx = hy * nz - hz * ny, bxy = hz * nx - hx * nz, bxz = hx * ny - hy * nx;
+		normalize3(bxx, bxy, bxz);
+		float bzx = bxy * nz - bxz * ny, bzy = bxz * nx - bxx * nz, bzz = bxx * ny - bxy * nx;
+		normalize3(bzx, bzy, bzz);
+		frame[wave][0][lane] = bxx; frame[wave][1][lane] = bxy; frame[wave][2][lane] = bxz;
+		frame[wave][3][lane] = nx;  frame[wave][4][lane] = ny;  frame[wave][5][lane] = nz;
+		frame[wave][6][lane] = bzx; frame[wave][7][lane] = bzy; frame[wave][8][lane] = bzz;
 	}
-	for (int k = 0; k < 3; ++k)
-		for (int offset = 32; offset >= 1; offset >>= 1) {
-			lo[k] = fminf(lo[k], __shfl_xor(lo[k], offset));
-			hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], offset));
-		}
-	uint32_t at = 0u;  // node index
-	if (hit_count != 0u && wave_ballot(odd) == 0ull && max_distance > 0.0f)
-		for (;;) {
-			const uint32_t skip = walk[at].skip / (uint32_t) sizeof(NodeRec);  // (the walk array keeps byte offsets)
-			if (skip <= 1u)
-				break;
-			uint32_t chosen = 0u, meeting = 0u;
-			for (uint32_t c = at + 1u; c < at + skip && meeting < 2u;) {
-				const NodeRec child = walk[c];
-				const bool clear = child.lo[0] > hi[0] || child.hi[0] < lo[0] || child.lo[1] > hi[1] || child.hi[1] < lo[1] ||
-				                   child.lo[2] > hi[2] || child.hi[2] < lo[2];
-				if (!clear) {
-					++meeting;
-					chosen = c;
+	wave_lds_sync();
+	const float inf = __builtin_inff();
+	for (uint32_t j = lane; j < stride; j += 64u) {
+		// ---- the region of interval j ----
+		float lo[3] = { inf, inf, inf }, hi[3] = { -inf, -inf, -inf };
+		bool odd = !(max_distance > 0.0f) || hit_count == 0u;  // nothing can be said: the whole array it is
+		const bool one_direction = j != 0u && uniform_table != 0 && hit_count == 64u;
+		float4 table = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+		if (one_direction)
+			table = ao_table[j - 1u];
+		for (uint32_t h = 0u; h < hit_count; ++h) {
+			const float o[3] = { origin[wave][0][h], origin[wave][1][h], origin[wave][2][h] };
+			for (int k = 0; k < 3; ++k) {
+				float a = o[k], b = o[k];
+				float margin = fabsf(o[k]) * 0x1.0p-20f + 1.0e-30f;
+				if (one_direction) {
+					// ray_dir = basis_x * xs + basis_y * ys + basis_z * zs (reference :246), its length 1 up to roundings
+					const float d = (frame[wave][k][h] * table.x + frame[wave][3 + k][h] * table.y) + frame[wave][6 + k][h] * table.z;
+					b = o[k] + d * (max_distance * 1.01f);
+					margin += max_distance * 0.01f;
+				} else {
+					a = o[k] - max_distance * 1.01f;
+					b = o[k] + max_distance * 1.01f;
 				}
-				const uint32_t child_skip = child.skip / (uint32_t) sizeof(NodeRec);
-				c += child_skip ? child_skip : 1u;
+				odd = odd || !(fabsf(a) < inf) || !(fabsf(b) < inf);
+				lo[k] = fminf(lo[k], fminf(a, b) - margin);
+				hi[k] = fmaxf(hi[k], fmaxf(a, b) + margin);
 			}
-			if (meeting != 1u)
-				break;
-			at = chosen;
 		}
-	if (lane == 0u) {
-		const uint32_t skip = hit_count ? walk[at].skip : 0u;
-		tile_entry[tile] = make_uint2(at * (uint32_t) sizeof(NodeRec), at * (uint32_t) sizeof(NodeRec) + (skip ? skip : (uint32_t) sizeof(NodeRec)));
-		(void) node_count;
+		// ---- its interval (node indices; the walk array keeps byte offsets) ----
+		const auto skip_of = [&](uint32_t n) { return walk[n].skip / (uint32_t) sizeof(NodeRec); };
+		const auto meets = [&](uint32_t n) {
+			const NodeRec box = walk[n];
+			return !(box.lo[0] > hi[0] || box.hi[0] < lo[0] || box.lo[1] > hi[1] || box.hi[1] < lo[1] || box.lo[2] > hi[2] || box.hi[2] < lo[2]);
+		};
+		uint32_t begin = 0u, end = whole ? whole : 1u;
+		if (!odd && (j == 0u || one_direction)) {
+			uint32_t n = 0u;
+			while (skip_of(n) > 1u) {  // left
+				uint32_t first = 0u, index = 0u, others = 0u;
+				for (uint32_t c = n + 1u; c < n + skip_of(n); c += skip_of(c)) {
+					if (first)
+						others += meets(c) ? 1u : 0u;
+					else {
+						++index;
+						if (meets(c))
+							first = c;
+					}
+				}
+				if (first == 0u) {  // (no child meets it: nothing under this node can be reached)
+					n += skip_of(n);
+					break;
+				}
+				if (index == 1u && others != 0u)
+					break;
+				n = first;
+			}
+			begin = n;
+			n = 0u;
+			while (skip_of(n) > 1u) {  // right
+				uint32_t last = 0u;
+				for (uint32_t c = n + 1u; c < n + skip_of(n); c += skip_of(c))
+					if (meets(c))
+						last = c;
+				if (last == 0u) {
+					end = n;
+					break;
+				}
+				end = last + skip_of(last);
+				n = last;
+			}
+			if (begin > end)
+				begin = end;
+		}
+		// (a tile that is not full never looks at its per-direction intervals: they are filled with interval 0's rule
+		// all the same -- the whole array here, harmless -- so that every word of the table is defined)
+		out[j] = make_uint2(begin * (uint32_t) sizeof(NodeRec), end * (uint32_t) sizeof(NodeRec));
 	}
 }
 
@@ -2160,15 +2235,17 @@ void launch_primary(const SceneBuffers &scene, float *image, void *hits, void *o
 	launch(primary_kernel<true>);
 }
 
-// Fills `tile_entry` (two words per tile) for the frame whose hit list is in `hits`: once per upload (entry_kernel).
+// Fills `tile_entry` (1 + ao_dirs intervals of two words per tile) for the frame whose hit list is in `hits`: once per
+// upload (entry_kernel).
 void launch_entries(const SceneBuffers &scene, const void *hits, const void *tile_hits, const void *tile_base, void *tile_entry,
                     const KernelParams &P, void *stream) {
 	const uint32_t tiles = P.tiles_x * P.local_tile_rows;
 	if (tiles == 0)
 		return;
-	hipLaunchKernelGGL(entry_kernel, dim3((tiles + 3u) / 4u), dim3(256), 0, (hipStream_t) stream, (const NodeRec *) scene.walk,
-	                   (const HitRec *) hits, (const uint32_t *) tile_hits, (const uint32_t *) tile_base, (uint2 *) tile_entry, tiles,
-	                   P.node_count, P.ao_max_distance);
+	hipLaunchKernelGGL(entry_kernel, dim3((tiles + ENTRY_WAVES - 1u) / ENTRY_WAVES), dim3(64 * ENTRY_WAVES), 0, (hipStream_t) stream,
+	                   (const NodeRec *) scene.walk, (const HitRec *) hits, (const uint32_t *) tile_hits, (const uint32_t *) tile_base,
+	                   (const float4 *) scene.ao_table, (uint2 *) tile_entry, tiles, P.ao_dirs, P.ao_mode == AO_UNIFORM && scene.ao_table ? 1 : 0,
+	                   P.ao_max_distance);
 }
 
 void launch_ao(const SceneBuffers &scene, void *hits, void *occluded_of, void *order, const void *tile_base, const void *tile_entry,

@@ -131,14 +131,20 @@ def test_ring_holds_one_copy_of_the_scene(rt, golden, scene_for):
         assert md5_of(rt, ring.download_last()) == case["pgm_md5"]
         ring.close()
     assert seen[1][0] == seen[3][0] == seen[6][0]
-    per_host = seen[1][1] - seen[1][0]
-    assert seen[3][1] == seen[3][0] + 3 * per_host and seen[6][1] == seen[6][0] + 6 * per_host
-    # ... and a host's own buffers follow what is HIT: 36 bytes (hit record + occlusion counter) per hit sub-pixel, not
-    # 64 slots for every tile -- plus the float image, the 8-bit bands and three words per tile
+    # total = scene + (what the hosts share besides) + hosts x (a host's own buffers)
+    per_host = (seen[6][1] - seen[3][1]) // 3
+    shared = seen[3][1] - seen[3][0] - 3 * per_host
+    assert seen[6][1] == seen[6][0] + shared + 6 * per_host and seen[1][1] == seen[1][0] + shared + per_host
+    # ... shared: the table of walk intervals, 1 + ao_dirs of two words per tile (rt_walk_entries); a host's own buffers
+    # follow what is HIT: 36 bytes (hit record + occlusion counter) per hit sub-pixel, not 64 slots for every tile -- plus
+    # the float image, the 8-bit bands and three words per tile
     sub = opt.total_width * opt.total_height
     tiles = ((opt.total_width + 7) // 8) * ((opt.total_height + 7) // 8)
     hits = case["counters"]["primary_hits"]
-    # (the image and the tile words cover whole bands of tile rows: a few rows more than the frame)
+    dirs = case["counters"]["ao_rays"] // hits
+    assert dirs * hits == case["counters"]["ao_rays"]
+    # (the image and the words per tile cover whole bands of tile rows: a few rows more than the frame)
+    assert 8 * (dirs + 1) * tiles <= shared <= 1.15 * 8 * (dirs + 1) * tiles + 64
     assert per_host <= 36 * hits + 1.15 * 4 * sub + 2 * opt.width * opt.height + 16 * tiles + 8192
     assert per_host < 0.75 * (36 * 64 * tiles)  # (the old layout's hit list alone -- 64 slots per tile -- was larger than all of it)
 

@@ -216,10 +216,11 @@ def test_interior_standin_matches_oracle(rt, oracle):
 
 
 @pytest.mark.parametrize("mesh", ["interior", "bunny"])
-def test_entry_subtrees_confine_the_walks_and_change_nothing(rt, oracle, scene_for, mesh):
-    """An upload finds, per tile, the subtree its any-hit rays can reach within AO_MAX_DISTANCE (entry_kernel), and the
-    tile's packets walk that alone.  Whatever the distance -- a hundredth of the scene, the reference's default, more than
-    the scene -- the image is the oracle's; and the narrowing is there when the distance is short and gone when it is not."""
+def test_walk_intervals_confine_the_walks_and_change_nothing(rt, oracle, scene_for, mesh):
+    """An upload finds, per tile and per table direction of a full tile, the interval of the node array its any-hit rays
+    can reach within AO_MAX_DISTANCE (entry_kernel), and the packets walk that alone.  Whatever the distance -- a hundredth
+    of the scene, the reference's default, more than the scene -- the image is the oracle's; and the narrowing is there
+    when the distance is short and gone when it is not."""
     import orc
 
     scene, arrays = scene_for(mesh, "longest")
@@ -231,7 +232,7 @@ def test_entry_subtrees_confine_the_walks_and_change_nothing(rt, oracle, scene_f
         assert np.array_equal(bits(host.download()), bits(ref_img)), distance
         assert host.stats()["ao_occluded"] == counters["ao_occluded"]
         e = host.walk_entries()
-        assert e["tiles_hit"] > 0 and 0.0 < e["mean_share"] <= 1.0
+        assert e["tiles_hit"] > 0 and 0.0 < e["mean_packet_share"] <= e["mean_share"] <= 1.0
         shares.append(e["mean_share"])
         if distance == 50.0:
             assert e["tiles_narrowed"] == 0 and e["mean_share"] == 1.0

@@ -281,7 +281,7 @@ int main(int argc, char **argv) {
 	// variants: [packets: current, dense, octant] x [fat: 0, 2, 4, 8, 16]
 	const int NP = 3;
 	static Events ev[3][NP][NF];
-	static Events entry_ev[3];
+	static Events entry_ev[3], trim_ev[3], pdir_ev[3];
 	static unsigned long long tiles_in[3], jobs_in[3][NP], hits_in[3], partial_tiles[3];
 	// the ground plane: the two largest triangles
 	float plane_y = -0.48f;
@@ -295,7 +295,7 @@ int main(int argc, char **argv) {
 #pragma omp parallel
 	{
 		static thread_local Events lev[3][NP][NF];
-		static thread_local Events lentry[3];
+		static thread_local Events lentry[3], ltrim[3], lpdir[3];
 		unsigned long long ltiles[3] = { 0 }, ljobs[3][NP] = { { 0 } }, lhits[3] = { 0 }, lpartial[3] = { 0 };
 #pragma omp for schedule(dynamic, 1)
 		for (int ty = 0; ty < (H + 7) / 8; ty += stride)
@@ -417,6 +417,91 @@ int main(int argc, char **argv) {
 						for (int base = 0; base < total; base += 64)
 							walk_packet(trees[0], &all[(size_t) q0 * nh + base], std::min(64, total - base), D, batch_below, 0, lentry[cls], at, at + N0[at].skip);
 					}
+					// TRIM: the walk goes through a pre-order INTERVAL, which need not be a subtree: from the entry on, drop a node
+					// (and the ancestors' tests) while its first child is clear of the region, cut the tail while the last child is
+					auto meets = [&](size_t c) {
+						bool over = true;
+						for (int k = 0; k < 3; ++k) over = over && !(N0[c].lo[k] > qhi[k] || N0[c].hi[k] < qlo[k]);
+						return over;
+					};
+					size_t begin = at, end = at + N0[at].skip;
+					if (N0[at].skip > 1) {
+						size_t n = at;
+						for (;;) {  // left
+							if (N0[n].skip == 1) break;
+							size_t first = 0, index = 0, others = 0;
+							for (size_t c = n + 1; c < n + N0[n].skip; c += N0[c].skip) {
+								if (first) others += meets(c);
+								else { ++index; if (meets(c)) first = c; }
+							}
+							if (!first) { n = n + N0[n].skip; break; }
+							if (index == 1 && others) break;
+							n = first;
+						}
+						begin = n;
+						n = at;
+						for (;;) {  // right
+							if (N0[n].skip == 1) break;
+							size_t last = 0;
+							for (size_t c = n + 1; c < n + N0[n].skip; c += N0[c].skip)
+								if (meets(c)) last = c;
+							if (!last) { end = n; break; }
+							end = last + N0[last].skip;
+							n = last;
+						}
+						if (begin > end) begin = end;
+					}
+					for (int q0 = 0; q0 < ND; q0 += chunk) {
+						const int dirs = std::min(chunk, ND - q0), total = dirs * nh;
+						for (int base = 0; base < total && begin < end; base += 64)
+							walk_packet(trees[0], &all[(size_t) q0 * nh + base], std::min(64, total - base), D, batch_below, 0, ltrim[cls], begin, end);
+					}
+					// PDIR: the same interval, found per PACKET for the box of its rays' segments o ... o + D d (a table of
+					// tiles x direction chunks made at upload)
+					for (int q0 = 0; q0 < ND; q0 += chunk) {
+						const int dirs = std::min(chunk, ND - q0), total = dirs * nh;
+						for (int base = 0; base < total; base += 64) {
+							const R *rays = &all[(size_t) q0 * nh + base];
+							const int nr = std::min(64, total - base);
+							float plo[3] = { INFINITY, INFINITY, INFINITY }, phi[3] = { -INFINITY, -INFINITY, -INFINITY };
+							for (int l = 0; l < nr; ++l)
+								for (int k = 0; k < 3; ++k) {
+									const float a = rays[l].o[k], b = rays[l].o[k] + rays[l].d[k] * D * 1.002f, m = D * 0.002f + 1e-4f;
+									plo[k] = fminf(plo[k], fminf(a, b) - m);
+									phi[k] = fmaxf(phi[k], fmaxf(a, b) + m);
+								}
+							auto pmeets = [&](size_t c) {
+								bool over = true;
+								for (int k = 0; k < 3; ++k) over = over && !(N0[c].lo[k] > phi[k] || N0[c].hi[k] < plo[k]);
+								return over;
+							};
+							size_t pb = 0, pe = N0[0].skip, n = 0;
+							for (;;) {
+								if (N0[n].skip == 1) break;
+								size_t first = 0, index = 0, others = 0;
+								for (size_t c = n + 1; c < n + N0[n].skip; c += N0[c].skip) {
+									if (first) others += pmeets(c);
+									else { ++index; if (pmeets(c)) first = c; }
+								}
+								if (!first) { n = n + N0[n].skip; break; }
+								if (index == 1 && others) break;
+								n = first;
+							}
+							pb = n;
+							n = 0;
+							for (;;) {
+								if (N0[n].skip == 1) break;
+								size_t last = 0;
+								for (size_t c = n + 1; c < n + N0[n].skip; c += N0[c].skip)
+									if (pmeets(c)) last = c;
+								if (!last) { pe = n; break; }
+								pe = last + N0[last].skip;
+								n = last;
+							}
+							if (pb < pe) walk_packet(trees[0], rays, nr, D, batch_below, 0, lpdir[cls], pb, pe);
+							else { ++lpdir[cls].packets; lpdir[cls].rays += nr; }
+						}
+					}
 				}
 			}
 #pragma omp critical
@@ -430,6 +515,8 @@ int main(int argc, char **argv) {
 					for (int f = 0; f < NF; ++f) ev[c][p][f].add(lev[c][p][f]);
 				}
 				entry_ev[c].add(lentry[c]);
+				trim_ev[c].add(ltrim[c]);
+				pdir_ev[c].add(lpdir[c]);
 			}
 		}
 	}
@@ -449,6 +536,20 @@ int main(int argc, char **argv) {
 			const Events &e = entry_ev[c];
 			const double pk = (double) e.packets, cost = M.cost(e, tiles_in[c] * 4);
 			printf("%-8s %-4d %9.0f %6.1f %6.1f %7.1f %7.1f %6.2f %7.1f %7.1f %7.2f %7.1f %7.2f %8.0f %8.1f\n", "ENTRY", 0, pk * scale, e.rays / pk,
+			       100.0 * e.coherent_packets / pk, (e.nodes_coherent + e.nodes_mixed) / pk, 100.0 * e.lane_hits / (double) (e.lane_alive ? e.lane_alive : 1), e.spot_leaves / pk,
+			       e.appends / pk, e.pairs / pk, e.batches / pk, 0.0, 0.0, cost / pk, cost * scale / 1e6);
+		}
+		if (trim_ev[c].packets) {
+			const Events &e = trim_ev[c];
+			const double pk = (double) e.packets, cost = M.cost(e, tiles_in[c] * 4);
+			printf("%-8s %-4d %9.0f %6.1f %6.1f %7.1f %7.1f %6.2f %7.1f %7.1f %7.2f %7.1f %7.2f %8.0f %8.1f\n", "TRIM", 0, pk * scale, e.rays / pk,
+			       100.0 * e.coherent_packets / pk, (e.nodes_coherent + e.nodes_mixed) / pk, 100.0 * e.lane_hits / (double) (e.lane_alive ? e.lane_alive : 1), e.spot_leaves / pk,
+			       e.appends / pk, e.pairs / pk, e.batches / pk, 0.0, 0.0, cost / pk, cost * scale / 1e6);
+		}
+		if (pdir_ev[c].packets) {
+			const Events &e = pdir_ev[c];
+			const double pk = (double) e.packets, cost = M.cost(e, tiles_in[c] * 4);
+			printf("%-8s %-4d %9.0f %6.1f %6.1f %7.1f %7.1f %6.2f %7.1f %7.1f %7.2f %7.1f %7.2f %8.0f %8.1f\n", "PDIR", 0, pk * scale, e.rays / pk,
 			       100.0 * e.coherent_packets / pk, (e.nodes_coherent + e.nodes_mixed) / pk, 100.0 * e.lane_hits / (double) (e.lane_alive ? e.lane_alive : 1), e.spot_leaves / pk,
 			       e.appends / pk, e.pairs / pk, e.batches / pk, 0.0, 0.0, cost / pk, cost * scale / 1e6);
 		}
