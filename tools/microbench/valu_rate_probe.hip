@@ -76,6 +76,11 @@ KERNEL(node_test_8, "v_pk_fma_f32 v[40:41], s[20:21], v[50:51], v[52:53]", "v_pk
 // ... and with the two clamps folded into the z-axis fmas (t scaled so that the far limit is 1.0)
 KERNEL(node_test_9, "v_fma_f32 v40, s20, v48, v49\n v_fma_f32 v41, s21, v48, v49\n v_fma_f32 v42, s22, v48, v49 clamp", "v_fma_f32 v43, s23, v48, v49\n v_fma_f32 v44, s20, v48, v49\n v_fma_f32 v45, s21, v48, v49 clamp",
        "v_max3_f32 v40, v40, v41, v42", "v_min3_f32 v43, v43, v44, v45", "v_cmp_le_f32 vcc, v40, v43", "s_and_b64 s[24:25], vcc, exec", "", "")
+// ... and round 4's centre / half-extent test, the one loop of every any-hit packet: 9 v_fma + max3 + min3 + cmp
+KERNEL(node_test_12, "v_fma_f32 v40, s20, v48, v49\n v_fma_f32 v41, s21, v48, v49\n v_fma_f32 v42, s22, v48, v49",
+       "v_fma_f32 v43, -s23, |v48|, v40\n v_fma_f32 v40, s23, |v48|, v40", "v_fma_f32 v44, -s20, |v48|, v41\n v_fma_f32 v41, s20, |v48|, v41",
+       "v_fma_f32 v45, -s21, |v48|, v42 clamp\n v_fma_f32 v42, s21, |v48|, v42 clamp", "v_max3_f32 v43, v43, v44, v45", "v_min3_f32 v40, v40, v41, v42",
+       "v_cmp_lt_f32 vcc, v43, v40", "s_and_b64 s[24:25], vcc, exec")
 KERNEL1(fma_svv_clamp, "v_fma_f32", "s20, v49, v50 clamp")
 KERNEL(fma_svv_4regs, "v_fma_f32 v40, s20, v48, v49", "v_fma_f32 v41, s21, v48, v49", "v_fma_f32 v42, s22, v48, v49", "v_fma_f32 v43, s23, v48, v49",
        "v_fma_f32 v44, s20, v48, v49", "v_fma_f32 v45, s21, v48, v49", "v_fma_f32 v46, s22, v48, v49", "v_fma_f32 v47, s23, v48, v49")
@@ -88,7 +93,8 @@ int main() {
 	const Kind kinds[] = {K(fma_vvv), K(fma_self), K(fma_svv), K(fma_vsv), K(fma_vvs), K(mul_vv), K(mul_sv), K(add_vv), K(sub_sv), K(max_vv), K(max_sv), K(max_cv),
 	                      K(max3_vvv), K(min3_svv), K(med3_vvv), K(mov_v), K(mov_s), K(cndmask_vcc), K(cndmask_s), K(and_vv), K(add_u32), K(lshl_add), K(cmp_vcc), K(cmp_sgpr),
 	                      K(pk_fma_vvv), K(pk_fma_svv), K(pk_fma_svv_sel), K(pk_mul_vv), {"node_test_11 (4 tests per turn)", node_test_11, 44.0}, {"node_test_8 (4 tests per turn)", node_test_8, 32.0},
-	                      {"node_test_9 (4 tests per turn)", node_test_9, 36.0}, K(fma_svv_clamp), K(fma_svv_4regs)};
+	                      {"node_test_9 (4 tests per turn)", node_test_9, 36.0}, {"node_test_12 (4 tests per turn)", node_test_12, 48.0}, K(fma_svv_clamp),
+	                      K(fma_svv_4regs)};
 	const int iters = 10000;
 	for (const Kind &kind : kinds) {
 		double best = 1e30, ghz = 0;

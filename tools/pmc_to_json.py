@@ -28,6 +28,11 @@ def parse(path):
     return kernels
 
 
+def in_frame(name):
+    """A kernel of every frame -- not the one an upload runs once (entry_kernel: the tiles' walk intervals)."""
+    return "ocrt::" in name and "entry_kernel" not in name
+
+
 def main():
     out_dir, workloads = sys.argv[1], sys.argv[2:]
     result = {
@@ -48,7 +53,7 @@ def main():
             "kernel": names[0],
             "valu_insts": c.get("SQ_INSTS_VALU"), "salu_insts": c.get("SQ_INSTS_SALU"), "smem_insts": c.get("SQ_INSTS_SMEM"),
             # every kernel of a frame together (primary pass with the ordering step, ambient-occlusion pass, finishing kernel)
-            "frame_valu_insts": sum(k.get("SQ_INSTS_VALU", 0.0) for name, k in kernels.items() if "ocrt::" in name),
+            "frame_valu_insts": sum(k.get("SQ_INSTS_VALU", 0.0) for name, k in kernels.items() if in_frame(name)),
             "vmem_rd_insts": c.get("SQ_INSTS_VMEM_RD"), "lds_insts": c.get("SQ_INSTS_LDS"), "branch_insts": c.get("SQ_INSTS_BRANCH"),
             "waves": c.get("SQ_WAVES"), "wave_quad_cycles": c.get("SQ_WAVE_CYCLES"), "busy_cycles": c.get("SQ_BUSY_CYCLES"),
             "wait_any_quad_cycles": c.get("SQ_WAIT_ANY"), "wait_inst_any_quad_cycles": c.get("SQ_WAIT_INST_ANY"),
@@ -65,10 +70,12 @@ def main():
                 "hbm_bytes": (2.0 * fetch_kb + write_kb) * 1024.0,
             },
             # What one SIMD sustains on the node test's own instruction mix with 8 waves resident
-            # (tools/microbench/valu_rate_probe.hip, profiles/r02_valu_rate_probe.txt): 3.15 cycles per instruction for the
-            # 9-instruction test of the ambient-occlusion pass, 3.24 for the 11-instruction one of the primary pass; only
-            # v_fma / v_mul / v_add / v_mov on registers reach the guide's 2 cycles (2.3 measured).
-            "valu_ceiling_measured": round(1.0 / 3.15, 3) if WORKLOADS[w]["ao"] else round(1.0 / 3.24, 3),
+            # (tools/microbench/valu_rate_probe.hip, profiles/r04_valu_rate_probe.txt): 3.38 cycles per instruction for the
+            # 12-instruction centre / half-extent test of the ambient-occlusion pass (rounds 2-3: the 9-instruction plane
+            # form, 3.15), 3.24 for the 11-instruction one of the primary pass; only v_fma / v_mul / v_add / v_mov on
+            # REGISTERS reach the guide's 2 cycles (2.3 measured) -- an fma with an SGPR operand, as every fma of a node
+            # test is, issues at 3-4.2.
+            "valu_ceiling_measured": round(1.0 / 3.38, 3) if WORKLOADS[w]["ao"] else round(1.0 / 3.24, 3),
         }
         shared_path = os.path.join(out_dir, f"pmc_{w}__shared.txt")
         if os.path.exists(shared_path):  # the same frame with the grid of a host that shares its GPU
@@ -77,7 +84,7 @@ def main():
             if names:
                 entry["shared_valu_insts"] = shared[names[0]].get("SQ_INSTS_VALU")
                 entry["shared_waves"] = shared[names[0]].get("SQ_WAVES")
-                entry["shared_frame_valu_insts"] = sum(k.get("SQ_INSTS_VALU", 0.0) for name, k in shared.items() if "ocrt::" in name)
+                entry["shared_frame_valu_insts"] = sum(k.get("SQ_INSTS_VALU", 0.0) for name, k in shared.items() if in_frame(name))
         result["workloads"][w] = entry
     json.dump(result, sys.stdout, indent=1)
     print()
