@@ -26,6 +26,7 @@ void hip_check(hipError_t err, const char *what) {
 }
 #define OCRT_HIP(call) hip_check((call), #call)
 
+constexpr size_t MAX_ENTRY_TABLE_BYTES = (size_t) 2 << 30;
 constexpr uint32_t MAX_STRIP_TILES = 32u;
 constexpr size_t BIG_SCENE_BYTES = (size_t) 96 << 20;  // three times the L2s
 
@@ -398,6 +399,14 @@ size_t DeviceRenderer::adopt(std::shared_ptr<const DeviceScene> scene, const Dev
 	// around its tile, twenty tiles of a 1080p frame on either side, so with 16-pixel strips all eight XCDs read the same
 	// nodes.  Strips of sixteen tiles keep most of an XCD's geometry its own (terrain, 2 M and 20 M triangles, 1080p:
 	// profiles/r04_notes.md) -- as long as the image is wide enough for every group to keep two strips.
+	// The walk intervals (kernels.hip, entry_kernel): one per tile and table direction -- unless that table would be out of
+	// proportion (many samples per pixel AND many directions: 64 x 301 at 1080p would be 5 GB), then the tiles' own only.
+	if (kp.ao_mode != AO_UNIFORM || (size_t) tile_count * (1 + (size_t) kp.ao_dirs) * 2 * sizeof(uint32_t) > MAX_ENTRY_TABLE_BYTES)
+		kp.entry_stride = 1u;
+#ifdef OCRT_DEBUG_KNOBS
+	if (std::getenv("OCRT_ENTRY_PER_TILE"))  // the tiles' own intervals only (what a frame with too large a table gets)
+		kp.entry_stride = 1u;
+#endif
 	kp.strip_tiles = 2u;
 	if (scene->bytes() > BIG_SCENE_BYTES)
 		while (kp.strip_tiles < MAX_STRIP_TILES && kp.tiles_x >= 2u * XCD_GROUPS * (kp.strip_tiles * 2u))
@@ -557,7 +566,7 @@ DeviceRenderer::WalkEntries DeviceRenderer::walkEntries() const {
 	const bool has_ao = kp.ao_mode != AO_NONE && kp.ao_dirs > 0;
 	if (tile_count == 0 || !has_ao || kp.node_count == 0)
 		return out;
-	const size_t stride = (size_t) kp.ao_dirs + 1;  // (intervals per tile: entry_kernel)
+	const size_t stride = kp.entry_stride;  // (intervals per tile: entry_kernel)
 	std::vector<uint32_t> words(tile_count), ranges(entryBytes() / sizeof(uint32_t));
 	OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));
 	OCRT_HIP(hipMemcpyAsync(words.data(), d_tile_hits, tile_count * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t) stream));
@@ -575,8 +584,8 @@ DeviceRenderer::WalkEntries DeviceRenderer::walkEntries() const {
 		out.tiles_narrowed += of_tile[0] != 0u || bytes < whole;
 		sum += bytes / whole;
 		// what the tile's packets walk: a full tile's, one table direction each, have intervals of their own
-		const bool per_direction = (words[t] & 0xFFu) == 64u && kp.ao_mode == AO_UNIFORM;
-		for (size_t k = 1; k < stride; ++k) {
+		const bool per_direction = (words[t] & 0xFFu) == 64u && kp.ao_mode == AO_UNIFORM && stride > 1;
+		for (size_t k = 1; k <= kp.ao_dirs; ++k) {
 			const uint32_t *const r = per_direction ? of_tile + 2 * k : of_tile;
 			sum_packets += (std::min(whole, (double) r[1]) - (double) r[0]) / whole;
 			++packets;

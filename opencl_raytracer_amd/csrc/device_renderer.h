@@ -198,7 +198,7 @@ class DeviceRenderer {
 		std::shared_ptr<const DeviceScene> scene_on_device;
 		void *d_image, *d_u8, *d_hits, *d_occluded, *d_tile_hits, *d_tile_base, *d_tile_entry, *d_order, *d_counters;
 		size_t hit_slots;     // slots of the hit list: the scene's hit sub-pixels in this rank's bands (sizeHitList)
-		size_t entryBytes() const { return (size_t) tile_count * ((size_t) kp.ao_dirs + 1) * 2 * sizeof(uint32_t); }  // the tiles' walk intervals (entry_kernel)
+		size_t entryBytes() const { return (size_t) tile_count * kp.entry_stride * 2 * sizeof(uint32_t); }  // the tiles' walk intervals (entry_kernel)
 		std::shared_ptr<void> tile_entry_owner;  // d_tile_entry: one table for the hosts of a ring (sizeHitList)
 		void allocEntries(size_t bytes);
 		void sizeHitList(const DeviceRenderer *layout_from);  // counts the hits per tile with one pass of the primary kernel (or copies another renderer's count) and sizes the list by them

@@ -135,6 +135,7 @@ struct KernelParams {
 	uint32_t strip_tiles;  // width, in tiles, of the vertical strips the image is dealt to the XCD groups in: a power of two,
 	                       // 2 by default (the finest deal: best balance, and a cache-resident scene does not care), wider for
 	                       // scenes far beyond the L2s, whose XCDs should not all fetch the same geometry (device_renderer.cc)
+	uint32_t entry_stride; // walk intervals per tile (kernels.hip, entry_kernel): 1 + ao_dirs, or 1 where that table would be too large
 	uint32_t tiles_x;      // tiles per image row
 	uint32_t local_tile_rows;  // tile rows this rank owns
 	Partition part;

@@ -1868,8 +1868,9 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 						// or the tile's.  Two words, made scalar by hand like every load through a re-read pointer.
 						uint32_t entry_begin, entry_end;
 						{
-							const uint32_t which = (whole && MODE == AO_UNIFORM) ? 1u + dir0 + (base >> 6) : 0u;
-							const uint2 range = OCRT_COLD_PTR(const uint2 *, tile_entry)[(size_t) tile * (OCRT_COLD_U32(P.ao_dirs) + 1u) + which];
+							const uint32_t stride = OCRT_COLD_U32(P.entry_stride);  // (1: this frame keeps the tiles' own intervals only)
+							const uint32_t which = (whole && MODE == AO_UNIFORM && stride > 1u) ? 1u + dir0 + (base >> 6) : 0u;
+							const uint2 range = OCRT_COLD_PTR(const uint2 *, tile_entry)[(size_t) tile * stride + which];
 							entry_begin = (uint32_t) __builtin_amdgcn_readfirstlane((int) range.x);
 							entry_end = (uint32_t) __builtin_amdgcn_readfirstlane((int) range.y);
 						}
@@ -1982,7 +1983,7 @@ constexpr uint32_t ENTRY_WAVES = 4;
 __global__ __launch_bounds__(64 * ENTRY_WAVES) void entry_kernel(const NodeRec *__restrict__ walk, const HitRec *__restrict__ hits,
                                                                  const uint32_t *__restrict__ tile_hits, const uint32_t *__restrict__ tile_base,
                                                                  const float4 *__restrict__ ao_table, uint2 *__restrict__ tile_entry,
-                                                                 uint32_t tiles, uint32_t ao_dirs, int32_t uniform_table,
+                                                                 uint32_t tiles, uint32_t stride, int32_t uniform_table,
                                                                  float max_distance) {
 	__shared__ float origin[ENTRY_WAVES][3][64];
 	__shared__ float frame[ENTRY_WAVES][9][64];  // basis_x, basis_y (the normal), basis_z
@@ -1991,7 +1992,6 @@ __global__ __launch_bounds__(64 * ENTRY_WAVES) void entry_kernel(const NodeRec *
 	if (tile >= tiles)
 		return;  // (a whole wave: the waves of a workgroup never meet at a barrier)
 	const uint32_t hit_count = tile_hits[tile] & 0xFFu;
-	const uint32_t stride = 1u + ao_dirs;
 	uint2 *const out = tile_entry + (size_t) tile * stride;
 	const uint32_t whole = walk[0].skip / (uint32_t) sizeof(NodeRec);
 	if (lane < hit_count) {
@@ -2244,7 +2244,7 @@ void launch_entries(const SceneBuffers &scene, const void *hits, const void *til
 		return;
 	hipLaunchKernelGGL(entry_kernel, dim3((tiles + ENTRY_WAVES - 1u) / ENTRY_WAVES), dim3(64 * ENTRY_WAVES), 0, (hipStream_t) stream,
 	                   (const NodeRec *) scene.walk, (const HitRec *) hits, (const uint32_t *) tile_hits, (const uint32_t *) tile_base,
-	                   (const float4 *) scene.ao_table, (uint2 *) tile_entry, tiles, P.ao_dirs, P.ao_mode == AO_UNIFORM && scene.ao_table ? 1 : 0,
+	                   (const float4 *) scene.ao_table, (uint2 *) tile_entry, tiles, P.entry_stride, P.ao_mode == AO_UNIFORM && scene.ao_table ? 1 : 0,
 	                   P.ao_max_distance);
 }
 

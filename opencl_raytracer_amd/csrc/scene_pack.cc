@@ -508,6 +508,7 @@ KernelParams make_kernel_params(const RayTracer &rt, uint32_t node_count, uint32
 	p.ao_below = std::nextafterf(p.ao_max_distance, -std::numeric_limits<float>::infinity());
 	p.tiles_x = (p.width + TILE_W - 1) / TILE_W;
 	p.strip_tiles = 2u;  // (DeviceRenderer::adopt widens the strips for scenes far beyond the L2s)
+	p.entry_stride = 1u + ao_dirs;  // (... and keeps the tiles' own walk intervals only where the table per direction would be too large)
 	p.part = part;
 	p.local_tile_rows = local_tile_rows_for(p.height, part);
 	return p;

@@ -411,6 +411,8 @@ def test_lane_by_lane_walk_still_matches(rt_knobs, golden, scene_for_knobs, name
     {"OCRT_AO_BLOCKS": "3"},            # three workgroups do the whole AO pass
     {"OCRT_KEEP_TREE": "1"},            # walk the uploaded tree instead of the rebuilt one
     {"OCRT_KEEP_TREE": "1", "OCRT_NO_SHARED_WALK": "1"},
+    {"OCRT_ENTRY_PER_TILE": "1"},       # the tiles' own walk intervals only (what a frame with too large a table gets)
+    {"OCRT_ENTRY_PER_TILE": "1", "OCRT_KEEP_TREE": "1"},
 ])
 def test_scheduling_knobs_do_not_change_the_image(rt_knobs, golden, scene_for_knobs, knobs, monkeypatch):
     """Claim sizes, tile order, batching thresholds and the form of the walk only change who does what when.  (The

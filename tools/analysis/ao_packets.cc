@@ -89,7 +89,7 @@ struct Model {
 	Model() {
 		const char *m = getenv("MODEL");
 		if (m && std::string(m) == "r4") {
-			setup = 100; mixed = 12; spot = 86; batch = 116;
+			setup = 100; coherent = 12; mixed = 12; spot = 86; batch = 116;  // (one loop for every packet: 12 either way)
 		}
 	}
 	double cost(const Events &e, unsigned long long jobs) const {
@@ -470,10 +470,25 @@ int main(int argc, char **argv) {
 									plo[k] = fminf(plo[k], fminf(a, b) - m);
 									phi[k] = fmaxf(phi[k], fmaxf(a, b) + m);
 								}
+							static const int pray = getenv("PRAY") ? atoi(getenv("PRAY")) : 0;  // experiment: boxes around groups of 64 / PRAY rays instead of one
 							auto pmeets = [&](size_t c) {
 								bool over = true;
 								for (int k = 0; k < 3; ++k) over = over && !(N0[c].lo[k] > phi[k] || N0[c].hi[k] < plo[k]);
-								return over;
+								if (!over || !pray) return over;
+								const int group = 64 / pray;
+								for (int g0 = 0; g0 < nr; g0 += group) {
+									float glo[3] = { INFINITY, INFINITY, INFINITY }, ghi[3] = { -INFINITY, -INFINITY, -INFINITY };
+									for (int l = g0; l < std::min(nr, g0 + group); ++l)
+										for (int k = 0; k < 3; ++k) {
+											const float a = rays[l].o[k], b = rays[l].o[k] + rays[l].d[k] * D * 1.002f, m = D * 0.002f + 1e-4f;
+											glo[k] = fminf(glo[k], fminf(a, b) - m);
+											ghi[k] = fmaxf(ghi[k], fmaxf(a, b) + m);
+										}
+									bool g = true;
+									for (int k = 0; k < 3; ++k) g = g && !(N0[c].lo[k] > ghi[k] || N0[c].hi[k] < glo[k]);
+									if (g) return true;
+								}
+								return false;
 							};
 							size_t pb = 0, pe = N0[0].skip, n = 0;
 							for (;;) {

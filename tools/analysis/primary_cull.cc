@@ -55,8 +55,8 @@ int main(int argc, char **argv) {
 	const int W = argc > 2 ? atoi(argv[2]) : 1920, H = argc > 3 ? atoi(argv[3]) : 1080;
 	const int stride = argc > 4 ? atoi(argv[4]) : 3;
 	const float a = 1.0f * (W > H ? W : H);
-	unsigned long long packets = 0, plain = 0, culled = 0, batched = 0, plain_pairs = 0, culled_pairs = 0, batched_pairs = 0;
-#pragma omp parallel for schedule(dynamic, 1) reduction(+ : packets, plain, culled, batched, plain_pairs, culled_pairs, batched_pairs)
+	unsigned long long packets = 0, plain = 0, culled = 0, batched = 0, plain_pairs = 0, culled_pairs = 0, batched_pairs = 0, interval_visits = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : interval_visits, packets, plain, culled, batched, plain_pairs, culled_pairs, batched_pairs)
 	for (int ty = 0; ty < H / 8; ty += stride) for (int tx = 0; tx < W / 8; tx += stride) {
 		R rays[64];
 		for (int l = 0; l < 64; ++l) {
@@ -67,6 +67,53 @@ int main(int argc, char **argv) {
 			for (int k = 0; k < 3; ++k) { r.d[k] = d[k] / len; r.inv[k] = 1.0f / r.d[k]; }
 		}
 		++packets;
+		{
+			// the tile's interval: segments from where a ray enters the root box to where it leaves it
+			float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+			bool any = false;
+			for (int l = 0; l < 64; ++l) {
+				float tn = 0.0f, tf = 100000.0f;
+				for (int k = 0; k < 3; ++k) {
+					float a = (P.nodes[0].lo[k] - rays[l].o[k]) * rays[l].inv[k], b = (P.nodes[0].hi[k] - rays[l].o[k]) * rays[l].inv[k];
+					tn = fmaxf(tn, fminf(a, b)); tf = fminf(tf, fmaxf(a, b));
+				}
+				if (!(tn <= tf)) continue;
+				any = true;
+				for (int k = 0; k < 3; ++k) {
+					const float a = rays[l].o[k] + rays[l].d[k] * tn * 0.999f, b = rays[l].o[k] + rays[l].d[k] * tf * 1.001f;
+					lo[k] = fminf(lo[k], fminf(a, b) - 1e-4f); hi[k] = fmaxf(hi[k], fmaxf(a, b) + 1e-4f);
+				}
+			}
+			auto meets = [&](size_t c) {
+				bool over = true;
+				for (int k = 0; k < 3; ++k) over = over && !(P.nodes[c].lo[k] > hi[k] || P.nodes[c].hi[k] < lo[k]);
+				return over;
+			};
+			size_t begin = 0, end = any ? P.nodes[0].skip : 0, n = 0;
+			while (any && P.nodes[n].skip > 1) {
+				size_t first = 0, index = 0, others = 0;
+				for (size_t c = n + 1; c < n + P.nodes[n].skip; c += P.nodes[c].skip) {
+					if (first) others += meets(c);
+					else { ++index; if (meets(c)) first = c; }
+				}
+				if (!first) { n += P.nodes[n].skip; break; }
+				if (index == 1 && others) break;
+				n = first;
+			}
+			begin = n; n = 0;
+			while (any && P.nodes[n].skip > 1) {
+				size_t last = 0;
+				for (size_t c = n + 1; c < n + P.nodes[n].skip; c += P.nodes[c].skip) if (meets(c)) last = c;
+				if (!last) { end = n; break; }
+				end = last + P.nodes[last].skip; n = last;
+			}
+			for (size_t i = begin; i < end;) {
+				++interval_visits;
+				int hits = 0;
+				for (int l = 0; l < 64; ++l) hits += slab(P.nodes[i], rays[l], 100000.0f);
+				if (hits) ++i; else i += P.nodes[i].skip;
+			}
+		}
 		for (int mode = 0; mode < 3; ++mode) {
 			float best[64], limit[64];
 			for (int l = 0; l < 64; ++l) { best[l] = INFINITY; limit[l] = 100000.0f; }
@@ -89,6 +136,7 @@ int main(int argc, char **argv) {
 			if (mode == 0) { plain += visits; plain_pairs += pairs; } else if (mode == 1) { culled += visits; culled_pairs += pairs; } else { batched += visits; batched_pairs += pairs; }
 		}
 	}
+	printf("with a walk interval per tile (box around the rays' segments inside the root box): %.1f node tests per packet\n", (double) interval_visits / packets);
 	printf("%llu primary packets: %.1f node tests and %.1f (lane, leaf) pairs per packet as it is; limit = best hit at once: %.1f and %.1f; after every 64 pairs: %.1f and %.1f\n",
 	       packets, (double) plain / packets, (double) plain_pairs / packets, (double) culled / packets, (double) culled_pairs / packets, (double) batched / packets, (double) batched_pairs / packets);
 }

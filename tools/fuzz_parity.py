@@ -21,7 +21,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 KNOBS = [{}, {}, {}, {"OCRT_BATCH_BELOW": "0"}, {"OCRT_BATCH_BELOW": "65"}, {"OCRT_AO_CLAIM_MAX": "1"}, {"OCRT_AO_CLAIM_MAX": "28"},
          {"OCRT_KEEP_TREE": "1"}, {"OCRT_FORCE_EXACT_WALK": "1"}, {"OCRT_AO_BLOCKS": "2"}, {"OCRT_NO_SHARED_WALK": "1"},
          {"OCRT_CONTRACT": "0.3"}, {"OCRT_CONTRACT": "2.0"}, {"OCRT_AO_GUIDE": "3"}, {"OCRT_NO_SCALED_WALK": "1"},
-         {"OCRT_STRIP_TILES": "4"}, {"OCRT_STRIP_TILES": "16"}, {"OCRT_STRIP_TILES": "32"}]
+         {"OCRT_STRIP_TILES": "4"}, {"OCRT_STRIP_TILES": "16"}, {"OCRT_STRIP_TILES": "32"}, {"OCRT_ENTRY_PER_TILE": "1"}]
 SMALL_MESHES = [(name, bvh) for name in ("blob", "ties", "single") for bvh in (0, 1)]
 # (the big scenes: longest-axis trees only; "terrain:<n>": a height field generated in memory, tools/big_meshes.py -- full
 # tiles whose ambient-occlusion packets descend into dense geometry: what showed round 4's look-ahead race)
