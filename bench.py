@@ -503,6 +503,8 @@ def main():
             sys.exit(f"bench.py: the RCCL communicator has {comm_ranks} ranks, the job {world}")
     scene_bytes, scene_copies, _ = rings["pipelined"].device_bytes()
     calibration = rings["pipelined"].calibration()
+    # how far the walk intervals found at upload confine the any-hit packets (rt_walk_entries; this rank's bands)
+    intervals = rings["pipelined"].host(0).walk_entries()
 
     if rank == 0:
         md5 = {name: hashlib.md5(rt.pgm_bytes(img)).hexdigest() for name, img in images.items()}
@@ -549,6 +551,9 @@ def main():
                        "triangles": scene.num_faces,
                        "ao_pass_calibration": {"ms_without_lookahead": round(calibration[0], 4), "ms_with_lookahead": round(calibration[1], 4),
                                                "lookahead_in_use": calibration[2]},
+                       "walk_intervals": {"tiles_hit": intervals["tiles_hit"],
+                                          "share_of_node_records_per_tile": round(intervals["mean_share"], 4),
+                                          "share_of_node_records_per_packet": round(intervals["mean_packet_share"], 4)},
                        "device": torch.cuda.get_device_name(device)},
             # every block is exactly `steps` steps between barrier + synchronize; `value` / `ms_per_step` are the median block
             "blocks": dict(summary(pipe_ms), unit="ms per step", seconds_covered=round(sum(results["pipelined"]["seconds"]), 3),
