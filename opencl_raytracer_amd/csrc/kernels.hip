@@ -2153,6 +2153,71 @@ __global__ __launch_bounds__(256) void finish_kernel(float *__restrict__ image, 
 		atomicAdd(&counters->occluded, (unsigned long long) block_total);
 }
 
+// The same pass for supersampled frames (n >= 2).  With one thread per output pixel a wave's 64 lanes read 64 places
+// 4 n bytes apart -- and, through the tags, 64 tiles' parts of the hit list -- with every load: at `-s 64` (n = 8: a pixel is a
+// whole tile) that is 64 cache lines per instruction and the pass runs at the L1's line rate, 3.85 ms for 3.8 GB
+// (profiles/r04_notes.md, section 13).  Here a workgroup takes `pixels_per_block` neighbouring output pixels of one row:
+// its threads sweep the n sub-pixel rows ALONG the rows (a wave reads 256 contiguous bytes of the image and the slots of
+// eight neighbouring tiles), replace the tags as above, write back, and leave the values in LDS; then one thread per
+// output pixel adds its n x n values up in the reference's order (ssY-major, ssX-minor: src/ray_tracer.cc:7-13) -- the
+// same additions in the same order as finish_kernel's, so the same bits.  The cells of a pixel are n * n | 1 floats
+// apart (odd: the adding threads do not meet in a bank).
+constexpr uint32_t FINISH_CELL_FLOATS = 4160u;  // 64 pixels of 8 x 8 sub-pixels and their padding
+__global__ __launch_bounds__(256) void finish_wide_kernel(float *__restrict__ image, const HitRec *__restrict__ hits,
+                                                          const uint32_t *__restrict__ occluded_of,
+                                                          const uint32_t *__restrict__ tile_base,
+                                                          FrameCounters *__restrict__ counters, unsigned char *__restrict__ out,
+                                                          uint32_t width, uint32_t height, uint32_t total_width, uint32_t n,
+                                                          uint32_t tiles_x, Partition part, uint32_t rows_per_band, uint32_t ao_divisor,
+                                                          uint32_t pixels_per_block) {
+	__shared__ float cell[FINISH_CELL_FLOATS];
+	__shared__ unsigned int block_total;
+	if (threadIdx.x == 0)
+		block_total = 0u;
+	const uint32_t x0 = blockIdx.x * pixels_per_block;
+	const uint32_t pixels = width - x0 < pixels_per_block ? width - x0 : pixels_per_block;
+	const uint32_t columns = pixels * n;
+	const uint32_t stride = (n * n) | 1u;
+	const uint32_t j = blockIdx.y;
+	const uint32_t band_local = j / rows_per_band;
+	const uint32_t y = (band_local * part.nranks + part.rank) * rows_per_band + (j - band_local * rows_per_band);
+	const float divisor = (float) ao_divisor;
+	uint32_t mine = 0u;
+	for (uint32_t sy = 0; sy < n; ++sy) {
+		const uint32_t row_index = j * n + sy;
+		float *row = image + (size_t) row_index * total_width + (size_t) x0 * n;
+		const uint32_t *bases = tile_base + (size_t) (row_index / TILE_H) * tiles_x;
+		for (uint32_t c = threadIdx.x; c < columns; c += 256u) {
+			float v = row[c];
+			const uint32_t bits = __float_as_uint(v);
+			if (is_pending(bits)) {
+				const size_t slot = (size_t) bases[(x0 * n + c) / TILE_W] + (bits & 63u);
+				const uint32_t occluded = occluded_of[slot];
+				v = hits[slot].value * (1.0f - ((float) occluded / divisor));
+				row[c] = v;
+				mine += occluded;
+			}
+			const uint32_t p = c / n;
+			cell[p * stride + sy * n + (c - p * n)] = v;
+		}
+	}
+	for (int offset = 32; offset > 0; offset >>= 1)
+		mine += (uint32_t) __shfl_down((int) mine, offset);
+	__syncthreads();
+	if ((threadIdx.x & 63u) == 0u && mine)
+		atomicAdd(&block_total, mine);
+	if (out && threadIdx.x < pixels) {
+		const float *cells = cell + threadIdx.x * stride;
+		float total = 0.0f;
+		for (uint32_t i = 0; i < n * n; ++i)
+			total += cells[i];
+		out[(size_t) j * width + x0 + threadIdx.x] = y < height ? (unsigned char) ((total / (float) (n * n)) * 255.0f) : (unsigned char) 0;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0 && block_total)
+		atomicAdd(&counters->occluded, (unsigned long long) block_total);
+}
+
 // Supersample box filter + 8-bit quantisation on the device: one thread per
 // output pixel, ssY-major / ssX-minor float summation and truncating store,
 // exactly reference src/ray_tracer.cc:3-16.  Works on this rank's bands only: both the
@@ -2310,6 +2375,17 @@ void launch_finish(float *image, const void *hits, const void *occluded_of, cons
 	if (!has_ao && !out)
 		return;  // (nothing pending, nothing to filter)
 	const uint32_t rows_per_band = P.part.band_tile_rows * TILE_H / n;
+	const uint32_t cells_per_pixel = (n * n) | 1u;
+	if (n >= 2u && cells_per_pixel <= FINISH_CELL_FLOATS) {
+		// supersampled: a workgroup per run of output pixels, swept along the sub-pixel rows (finish_wide_kernel)
+		uint32_t pixels_per_block = FINISH_CELL_FLOATS / cells_per_pixel;
+		pixels_per_block = pixels_per_block > 256u ? 256u : pixels_per_block > 16u ? pixels_per_block & ~15u : pixels_per_block;
+		hipLaunchKernelGGL(finish_wide_kernel, dim3((out_width + pixels_per_block - 1u) / pixels_per_block, local_out_rows), dim3(256), 0,
+		                   (hipStream_t) stream, image, (const HitRec *) hits, (const uint32_t *) occluded_of, (const uint32_t *) tile_base,
+		                   (FrameCounters *) counters, out, out_width, P.height / n, P.width, n, P.tiles_x, P.part, rows_per_band,
+		                   P.ao_divisor ? P.ao_divisor : 1u, pixels_per_block);
+		return;
+	}
 	hipLaunchKernelGGL(finish_kernel, dim3((out_width + 255) / 256, local_out_rows), dim3(256), 0, (hipStream_t) stream, image,
 	                   (const HitRec *) hits, (const uint32_t *) occluded_of, (const uint32_t *) tile_base, (FrameCounters *) counters, out,
 	                   out_width, P.height / n,
