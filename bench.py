@@ -285,7 +285,7 @@ def main():
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--in-flight", type=int, default=0, choices=list(range(17)),
                     help="render hosts per GPU taking the frames in turn (1: one frame at a time; 0 = by the number of "
-                         "ranks: 3 up to four GPUs, 12 at eight)")
+                         "ranks: 3 on one GPU, 6 on two to seven, 8 from eight on)")
     ap.add_argument("--min-seconds", type=float, default=0.5, help="repeat each block of --steps steps until this much time is covered")
     ap.add_argument("--plain-launches", action="store_true", help="launch the kernels one by one instead of replaying the captured graph")
     ap.add_argument("--pacing", type=float, default=-1.0, help="the ring's pacing factor (rt_ring_set_pacing); default: the library's")
@@ -354,12 +354,17 @@ def main():
     # frames in turn: while frame i's ambient-occlusion pass runs out (its last quarter runs at falling occupancy: the
     # queues are drained, the workgroups end one by one) the next frames' passes fill the wave slots it frees, and the
     # latency-bound primary pass runs beside a vector-issue-bound one.  The smaller a rank's share of the frame, the
-    # more of it is start and end of passes, hence more hosts at eight ranks -- an eighth of the headline frame on one
-    # GPU takes 0.426 / 0.197 / 0.168 / 0.180 / 0.157 / 0.166 ms per frame with 1 / 3 / 6 / 8 / 12 / 16 hosts, a quarter
-    # 0.613 / 0.296 / 0.314 / 0.289 / 0.289 / 0.283 with 1 / 3 / 4 / 6 / 8 / 12, a half 0.523 / 0.530 / 0.516 / 0.519 with 3 / 4 / 6 / 8
-    # (tools/ring_sweep.py, tools/analysis/queues_sweep.py on round 4's final kernels; the 4K and 64-samples frames do
-    # not care: 0.460 / 0.462 / 0.463 and 4.78 / 4.80 / 4.69 ms with 3 / 6 / 12).
-    in_flight = args.in_flight if args.in_flight > 0 else 3 if world <= 4 else 12
+    # more of it is start and end of passes, hence more hosts where the frame is split -- ms per frame on one GPU
+    # (tools/analysis/queues_sweep.py, round 4's final kernels and grids, 600-frame runs, repeatable to 1 %):
+    #   whole frame   2 / 3 / 4 / 6 hosts           1.042 / 0.977 / 0.996 / 1.007
+    #   a half        3 / 4 / 6                     0.540 / 0.523 / 0.505
+    #   a quarter     3 / 4 / 6 / 8 / 12            0.303 / 0.292 / 0.270 / 0.293 / 0.273
+    #   an eighth     6 / 8 / 12 / 16               0.153 / 0.142 / 0.161 / 0.143
+    # (a multi-GPU ring deals its hosts over two stream priority classes -- the third is the gather's --; that 8 and 16
+    # hosts beat 12 points at the runtime's hardware queues, GPU_MAX_HW_QUEUES = 4 by default, dividing evenly or not:
+    # with 16 queues the eighth reads 0.161 / 0.154 / 0.151 for 8 / 12 / 16.  The 4K and 64-samples frames do not care:
+    # 0.460 / 0.462 / 0.463 and 4.78 / 4.80 / 4.69 ms for an eighth with 3 / 6 / 12.)
+    in_flight = args.in_flight if args.in_flight > 0 else 3 if world == 1 else 6 if world < 8 else 8
     rings = {"pipelined": rt.FrameRing(opt, scene, device_index, rank, world, hosts=in_flight),
              "blocking": rt.FrameRing(opt, scene, device_index, rank, world, hosts=1)}
     for ring in rings.values():

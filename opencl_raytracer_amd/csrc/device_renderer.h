@@ -133,8 +133,11 @@ class DeviceRenderer {
 		const void *deviceBands() const { return d_u8; }
 		void *streamHandle() const { return stream; }
 		// How many hosts take frames in turn on this GPU.  Alone, the persistent ambient-occlusion pass fills the chip
-		// (8 workgroups per CU); in company it leaves room -- 5.5 per CU -- so that the other frames' passes run beside
-		// it all the time and not only while it runs out (measured per workload: profiles/r02_notes.md).
+		// (8 workgroups per CU); in company it leaves room -- 4.5 per CU with up to five hosts, 3 from six on (the small
+		// shares of a frame split over many GPUs) -- so that the other frames' passes run beside it all the time and not
+		// only while it runs out (rounds 2-3 measured 5.5 per CU; re-swept on round 4's kernels, profiles/r04_notes.md
+		// section 14: three hosts, whole frame, 5.5 -> 4.5 per CU: headline -1.5 %, interior -3.5 %, 600^2 +-0; an eighth
+		// of the headline frame with twelve hosts 0.162 -> 0.153 ms, a quarter with six 0.289 -> 0.272).
 		void setDeviceShare(unsigned hosts) {
 			device_share = hosts < 1u ? 1u : hosts;
 			kp.shared_device = device_share > 1u ? 1 : 0;
@@ -154,7 +157,9 @@ class DeviceRenderer {
 		WalkEntries walkEntries() const;
 		bool aoPrefetch() const { return ao_prefetch; }
 		bool calibrateAoPrefetch(float *ms_without = nullptr, float *ms_with = nullptr);
-		uint32_t aoWorkgroups() const { return device_share > 1u ? compute_units * 11u / 2u : compute_units * 8u; }
+		uint32_t aoWorkgroups() const {
+			return device_share >= 6u ? compute_units * 3u : device_share > 1u ? compute_units * 9u / 2u : compute_units * 8u;
+		}
 		uint32_t globalRowOf(uint32_t local_row) const;  // output row of a local band row (may be >= height: padding)
 
 		void downloadFloat(float *host_image);          // full totalWidth x totalHeight (rows of other ranks' bands: 0)

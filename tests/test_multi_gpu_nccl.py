@@ -81,11 +81,11 @@ def test_bare_gpus_flag_starts_its_own_ranks(golden):
 def test_four_gloo_ranks_rehearse_the_eight_gpu_run(golden):
     """The shape of the driver's 8-GPU run on the one GPU of the box, as far as its process limit allows (six processes
     may hold the GPU: this test runner, the torchrun agent and four ranks; gloo, because RCCL refuses two ranks on one
-    device): each rank with the twelve render hosts per GPU that bench.py uses at eight ranks and a blocking ring beside
+    device): each rank with the eight render hosts per GPU that bench.py uses at eight ranks and a blocking ring beside
     them, bands of 4 rows dealt round-robin, the gather, barriers and all-reduces of the timing contract.  The assembled
     PGM is the golden one in both modes."""
-    out = _run_bench(4, extra_env={"OCRT_BENCH_BACKEND": "gloo"}, bare=True, extra_args=["--in-flight", "12"])
-    assert out["n_gpus"] == 4 and out["config"]["frames_in_flight"] == 12
+    out = _run_bench(4, extra_env={"OCRT_BENCH_BACKEND": "gloo"}, bare=True, extra_args=["--in-flight", "8"])
+    assert out["n_gpus"] == 4 and out["config"]["frames_in_flight"] == 8
     assert out["config"]["pgm_md5"] == golden["renders"]["bunny_600_defaults"]["pgm_md5"]
     assert out["blocking"]["pgm_md5"] == golden["renders"]["bunny_600_defaults"]["pgm_md5"]
     assert out["config"]["rays_per_frame"] == 1440000 + 28 * golden["renders"]["bunny_600_defaults"]["counters"]["primary_hits"]

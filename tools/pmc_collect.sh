@@ -19,7 +19,7 @@ for W in "$@"; do
     timeout -k 10 180 rocprofv3 --pmc $C --output-format csv -d $R/$OUT/$W/p$i -- python3 $R/tools/prof_run.py --frames 2 --workload $W > $R/$OUT/$W.p$i.log 2>&1 || echo "$W pass $i failed"
   done
   python3 $R/tools/pmc_summary.py $R/$OUT/$W > $R/$OUT/pmc_$W.txt
-  # the instruction counts once more for the grid a host launches when it SHARES its GPU (a ring of three: 5.5 workgroups
+  # the instruction counts once more for the grid a host launches when it SHARES its GPU (a ring of three: 4.5 workgroups
   # per CU instead of 8 -- other claim counts, hence other instruction counts)
   timeout -k 10 180 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d $R/$OUT/${W}__shared/p1 -- python3 $R/tools/prof_run.py --frames 2 --share 3 --workload $W > $R/$OUT/$W.shared.log 2>&1 || echo "$W shared pass failed"
   python3 $R/tools/pmc_summary.py $R/$OUT/${W}__shared > $R/$OUT/pmc_${W}__shared.txt
