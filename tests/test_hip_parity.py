@@ -111,6 +111,39 @@ def test_zero_normals_on_a_rebuilt_tree(rt, oracle, scene_for, monkeypatch):
     host.close()
 
 
+@pytest.mark.parametrize("samples,width,height", [(4, 37, 11), (9, 37, 11), (16, 261, 5), (25, 19, 7), (49, 23, 9), (64, 70, 3),
+                                                  (81, 13, 6), (256, 21, 5), (1024, 9, 4), (4225, 3, 2)])
+def test_supersampled_frames_finish_like_the_oracle(rt, oracle, scene_for, samples, width, height):
+    """The frame's last kernel at every grid size: n x n sub-pixels per pixel with n = 2 ... 32 through the kernel that
+    sweeps along the sub-pixel rows (one, several and a fraction of a workgroup's run of pixels per row; widths that are no
+    multiple of anything), n = 65 through the one-thread-per-pixel form it falls back to beyond its LDS cells -- floats
+    (the ambient-occlusion factor written back) and bytes (box filter in the reference's order, src/ray_tracer.cc:7-13)
+    against the oracle's, whole and cut into the bands of three ranks."""
+    import orc
+
+    scene, arrays = scene_for("blob", "longest")
+    opt = rt.Options.defaults(width=width, height=height, n_super_samples=samples, ao_num_samples=2)
+    ref_img, counters, _ = oracle.render(orc.params_from_options(opt), arrays)
+    ref_u8 = oracle.resize(ref_img, opt.width, opt.height, opt.n_super_samples)
+    host = render_hip(rt, scene, opt)
+    assert np.count_nonzero(bits(host.download()) != bits(ref_img)) == 0
+    assert np.array_equal(host.download_u8(), ref_u8)
+    assert host.stats()["ao_occluded"] == counters["ao_occluded"]
+    host.close()
+    occluded = 0
+    rows_seen = np.zeros(height, dtype=bool)
+    for rank in range(3):
+        part = render_hip(rt, scene, opt, rank, 3)
+        rows = part.local_to_global_rows()
+        local = part.download_u8_local()
+        keep = rows < height
+        assert np.array_equal(local[keep], ref_u8[rows[keep]]), rank
+        rows_seen[rows[keep]] = True
+        occluded += part.stats()["ao_occluded"]
+        part.close()
+    assert rows_seen.all() and occluded == counters["ao_occluded"]
+
+
 def test_tree_independence_1080p(rt, golden, scene_for):
     """the PGM does not depend on the BVH strategy (bunny has no
     equal-distance ties between different leaves at these pixels)."""
