@@ -408,7 +408,8 @@ size_t DeviceRenderer::adopt(std::shared_ptr<const DeviceScene> scene, const Dev
 		kp.entry_stride = 1u;
 #endif
 	kp.strip_tiles = 2u;
-	if (scene->bytes() > BIG_SCENE_BYTES)
+	scene_beyond_caches = scene->bytes() > BIG_SCENE_BYTES;
+	if (scene_beyond_caches)
 		while (kp.strip_tiles < MAX_STRIP_TILES && kp.tiles_x >= 2u * XCD_GROUPS * (kp.strip_tiles * 2u))
 			kp.strip_tiles *= 2u;
 #ifdef OCRT_DEBUG_KNOBS

@@ -111,18 +111,20 @@ def test_zero_normals_on_a_rebuilt_tree(rt, oracle, scene_for, monkeypatch):
     host.close()
 
 
-@pytest.mark.parametrize("samples,width,height", [(4, 37, 11), (9, 37, 11), (16, 261, 5), (25, 19, 7), (49, 23, 9), (64, 70, 3),
-                                                  (81, 13, 6), (256, 21, 5), (1024, 9, 4), (4225, 3, 2)])
-def test_supersampled_frames_finish_like_the_oracle(rt, oracle, scene_for, samples, width, height):
+@pytest.mark.parametrize("samples,width,height,ao", [(4, 37, 11, 2), (9, 37, 11, 2), (16, 261, 5, 2), (25, 19, 7, 2), (49, 23, 9, 2),
+                                                     (64, 70, 3, 2), (81, 13, 6, 2), (256, 21, 5, 2), (1024, 9, 4, 2), (4225, 3, 2, 2),
+                                                     (16, 29, 6, 0), (64, 300, 2, 0)])
+def test_supersampled_frames_finish_like_the_oracle(rt, oracle, scene_for, samples, width, height, ao):
     """The frame's last kernel at every grid size: n x n sub-pixels per pixel with n = 2 ... 32 through the kernel that
     sweeps along the sub-pixel rows (one, several and a fraction of a workgroup's run of pixels per row; widths that are no
     multiple of anything), n = 65 through the one-thread-per-pixel form it falls back to beyond its LDS cells -- floats
     (the ambient-occlusion factor written back) and bytes (box filter in the reference's order, src/ray_tracer.cc:7-13)
-    against the oracle's, whole and cut into the bands of three ranks."""
+    against the oracle's, whole and cut into the bands of three ranks; also without ambient occlusion (no tags: the box
+    filter alone)."""
     import orc
 
     scene, arrays = scene_for("blob", "longest")
-    opt = rt.Options.defaults(width=width, height=height, n_super_samples=samples, ao_num_samples=2)
+    opt = rt.Options.defaults(width=width, height=height, n_super_samples=samples, ao_num_samples=ao, enable_ao=int(ao != 0))
     ref_img, counters, _ = oracle.render(orc.params_from_options(opt), arrays)
     ref_u8 = oracle.resize(ref_img, opt.width, opt.height, opt.n_super_samples)
     host = render_hip(rt, scene, opt)

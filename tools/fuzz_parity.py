@@ -1,6 +1,6 @@
 """Randomised parity sweep (GPU box): renders random small configurations -- image size, supersampling,
 AO rings / distance / angles, focal length, mesh, BVH strategy, hosts that share their GPU, scheduling knobs -- with the
-HIP path and with the oracle and compares float images and statistics bit for bit.
+HIP path and with the oracle and compares float images, 8-bit images and statistics bit for bit.
 
     python tools/fuzz_parity.py [n_cases] [seed]
 
@@ -43,7 +43,7 @@ def draw_case(rng):
     name, bvh = rng.choice(MESHES)
     return dict(
         mesh=name, bvh=bvh, knobs=rng.choice(KNOBS),
-        width=rng.randint(1, 150), height=rng.randint(1, 110), ss=rng.choice([1, 1, 2, 4, 5, 9, 16]),
+        width=rng.randint(1, 150), height=rng.randint(1, 110), ss=rng.choice([1, 1, 2, 4, 5, 9, 16, 25, 36, 64]),
         ao=rng.choice([0, 1, 2, 3, 3, 4, 6]),
         aod=rng.choice([0.05, 0.2, 0.2, 0.5, 3.0, 0.25, 1.0, 0.0371, 7.3e-7, 2.5e6, 17.0]),
         focal=rng.choice([0.7, 1.0, 1.0, 1.6]), shading=rng.choice([1, 1, 0]), amin=rng.choice([4, 4, 10, 0]),
@@ -85,7 +85,7 @@ def run_case(rt, orc, oracle, scenes, case):
             ring.run(3)
             ring.drain()
             host = ring.host(2 % case["ring"])
-            got, st = host.download(), host.stats()
+            got, got_u8, st = host.download(), ring.download_last(), host.stats()  # (the ring's frames are filtered into ITS band buffers)
             ring.close()
         else:
             host = rt.Host(opt, 0)
@@ -94,13 +94,15 @@ def run_case(rt, orc, oracle, scenes, case):
             host.upload_scene(scene)
             host.set_device_share(case["share"])
             host.render()
-            got, st = host.download(), host.stats()
+            got, got_u8, st = host.download(), host.download_u8(), host.stats()
             host.close()
     finally:
         for k in case["knobs"]:
             os.environ.pop(k, None)
     ref, counters, _ = oracle.render(orc.params_from_options(opt), arrays)
-    same = np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    # floats (incl. the ambient-occlusion factors the frame's last kernel wrote back) and the 8-bit image it box-filtered
+    same = np.array_equal(got.view(np.uint32), ref.view(np.uint32)) and \
+        np.array_equal(got_u8, oracle.resize(ref, opt.width, opt.height, opt.n_super_samples))
     stats_ok = all(st[k] == counters[k] for k in ("primary_rays", "primary_hits", "ao_rays", "ao_occluded"))
     return same, stats_ok
 
