@@ -555,7 +555,7 @@ void DeviceRenderer::launchFrame(void *device_u8, void *ao_start, void *ao_stop)
 	launch_ao(scene, d_hits, d_occluded, d_order, d_tile_base, d_tile_entry, d_counters, kp, ao_blocks_override ? ao_blocks_override : aoWorkgroups(), ao_prefetch,
 	          stream, ao_start, ao_stop);
 	OCRT_HIP(hipGetLastError());
-	launch_finish((float *) d_image, d_hits, d_occluded, d_tile_base, d_counters, (unsigned char *) device_u8, kp, opts.width, grid, local_out_rows, stream);
+	launch_finish((float *) d_image, d_hits, d_occluded, d_tile_base, (unsigned char *) device_u8, kp, opts.width, grid, local_out_rows, stream);
 	OCRT_HIP(hipGetLastError());
 }
 
@@ -874,11 +874,19 @@ RenderStats DeviceRenderer::stats() {
 	if (!frame_ready)
 		return out;
 	synchronize();
+	const bool has_ao = kp.ao_mode != AO_NONE && kp.ao_dirs > 0;
+	if (has_ao) {
+		// The frame's occlusion total is summed when it is asked for (kernels.hip, occluded_sum_kernel): the counts are in
+		// the hit list until this host's next frame clears them.
+		launch_occluded_sum(d_occluded, hit_slots, d_counters, stream);
+		OCRT_HIP(hipGetLastError());
+		OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));
+	}
 	FrameCounters c{};
 	OCRT_HIP(hipMemcpy(&c, d_counters, sizeof c, hipMemcpyDeviceToHost));
 	for (const GroupQueue &q : c.queue)
 		out.primary_hits += q.hits;
-	out.ao_occluded = kp.ao_mode != AO_NONE && kp.ao_dirs > 0 ? c.occluded : 0;
+	out.ao_occluded = has_ao ? c.occluded : 0;
 #ifdef OCRT_TAIL
 	std::fprintf(stderr, "AO pass: last wave ended %.3f ms after the ordering step; waves by the time they ended at (0.05 ms buckets):", (c.stamp[8] - c.stamp[7]) * 1e-5);
 	for (int k = 0; k < 32; ++k)

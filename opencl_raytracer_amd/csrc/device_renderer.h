@@ -258,8 +258,9 @@ void launch_entries(const SceneBuffers &scene, const void *hits, const void *til
 void launch_ao(const SceneBuffers &scene, void *hits, void *occluded_of, void *order, const void *tile_base, const void *tile_entry,
                void *counters, const KernelParams &P, uint32_t workgroups, bool prefetch, void *stream, void *event_before_ao,
                void *event_after_ao);
-void launch_finish(float *image, const void *hits, const void *occluded_of, const void *tile_base, void *counters,
+void launch_finish(float *image, const void *hits, const void *occluded_of, const void *tile_base,
                    unsigned char *out, const KernelParams &P, uint32_t out_width, uint32_t n, uint32_t local_out_rows, void *stream);
+void launch_occluded_sum(const void *occluded_of, size_t slots, void *counters, void *stream);
 void launch_resize(const float *tmp, unsigned char *out, const KernelParams &P, uint32_t out_width, uint32_t n,
                    uint32_t local_out_rows, void *stream);
 

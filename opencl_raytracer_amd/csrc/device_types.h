@@ -76,7 +76,7 @@ struct alignas(128) GroupQueue {
 static_assert(sizeof(GroupQueue) == 128, "one line per queue");
 struct FrameCounters {
 	GroupQueue queue[XCD_GROUPS];
-	unsigned long long occluded;  // occluded AO rays (summed by the finishing kernel)
+	unsigned long long occluded;  // occluded AO rays: summed from the hit list's counts when the statistic is asked for (occluded_sum_kernel)
 	// The device's own 100 MHz clock (s_memrealtime) read by the kernels: when the primary pass began (its first
 	// workgroup), when the last workgroup of the ambient-occlusion pass ended; the ordering steps' ends are in the
 	// queues.  A frame replayed from a captured hipGraph has no HIP events inside it that could be timed

@@ -2103,54 +2103,41 @@ __global__ __launch_bounds__(64 * ENTRY_WAVES) void entry_kernel(const NodeRec *
 // reference's order (ssY-major, ssX-minor), replaces every pending tag (primary_tile) by
 // value * (1 - occluded / n_dirs) -- value and count from the tile's slot of the hit list --, WRITES THAT BACK (the float
 // image is what `download` hands out, reference src/opencl_host.cc:150-153) and sums.  `out` may be null (a frame
-// without the device resize).  The frame's occlusion count is summed per lane, per wave by cross-lane adds, per
-// workgroup in LDS, and reaches the counter with one atomic per workgroup.
+// without the device resize).  (The frame's occlusion TOTAL is no business of the frame: until round 4 this kernel summed
+// it -- per lane, wave, workgroup, then one atomic per workgroup on ONE address: 8 640 of them at 1080p, which took
+// longer than the rest of the kernel, 48 us -> 12 us without, 0.29 -> 0.07 ms at 4K.  The counts stay in the hit list
+// until the host's next frame, and whoever asks for the statistic has them summed then: occluded_sum_kernel.)
 // Band layout as in resize_kernel below.
 __global__ __launch_bounds__(256) void finish_kernel(float *__restrict__ image, const HitRec *__restrict__ hits,
                                                      const uint32_t *__restrict__ occluded_of,
-                                                     const uint32_t *__restrict__ tile_base,
-                                                     FrameCounters *__restrict__ counters, unsigned char *__restrict__ out,
+                                                     const uint32_t *__restrict__ tile_base, unsigned char *__restrict__ out,
                                                      uint32_t width, uint32_t height, uint32_t total_width, uint32_t n,
                                                      uint32_t tiles_x, Partition part, uint32_t rows_per_band, uint32_t ao_divisor) {
-	__shared__ unsigned int block_total;
-	if (threadIdx.x == 0)
-		block_total = 0u;
-	__syncthreads();
 	const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t j = blockIdx.y;
 	const uint32_t band_local = j / rows_per_band;
 	const uint32_t y = (band_local * part.nranks + part.rank) * rows_per_band + (j - band_local * rows_per_band);
-	uint32_t mine = 0u;
-	if (x < width) {
-		const float divisor = (float) ao_divisor;
-		float total = 0.0f;
-		for (uint32_t sy = 0; sy < n; ++sy) {
-			const uint32_t row_index = j * n + sy;
-			float *row = image + (size_t) row_index * total_width + (size_t) x * n;
-			for (uint32_t sx = 0; sx < n; ++sx) {
-				float v = row[sx];
-				const uint32_t bits = __float_as_uint(v);
-				if (is_pending(bits)) {
-					const uint32_t column = x * n + sx;
-					const size_t slot = (size_t) tile_base[(size_t) (row_index / TILE_H) * tiles_x + column / TILE_W] + (bits & 63u);
-					const uint32_t occluded = occluded_of[slot];
-					v = hits[slot].value * (1.0f - ((float) occluded / divisor));
-					row[sx] = v;
-					mine += occluded;
-				}
-				total += v;
+	if (x >= width)
+		return;
+	const float divisor = (float) ao_divisor;
+	float total = 0.0f;
+	for (uint32_t sy = 0; sy < n; ++sy) {
+		const uint32_t row_index = j * n + sy;
+		float *row = image + (size_t) row_index * total_width + (size_t) x * n;
+		for (uint32_t sx = 0; sx < n; ++sx) {
+			float v = row[sx];
+			const uint32_t bits = __float_as_uint(v);
+			if (is_pending(bits)) {
+				const uint32_t column = x * n + sx;
+				const size_t slot = (size_t) tile_base[(size_t) (row_index / TILE_H) * tiles_x + column / TILE_W] + (bits & 63u);
+				v = hits[slot].value * (1.0f - ((float) occluded_of[slot] / divisor));
+				row[sx] = v;
 			}
+			total += v;
 		}
-		if (out)
-			out[(size_t) j * width + x] = y < height ? (unsigned char) ((total / (float) (n * n)) * 255.0f) : (unsigned char) 0;
 	}
-	for (int offset = 32; offset > 0; offset >>= 1)
-		mine += (uint32_t) __shfl_down((int) mine, offset);
-	if ((threadIdx.x & 63u) == 0u && mine)
-		atomicAdd(&block_total, mine);
-	__syncthreads();
-	if (threadIdx.x == 0 && block_total)
-		atomicAdd(&counters->occluded, (unsigned long long) block_total);
+	if (out)
+		out[(size_t) j * width + x] = y < height ? (unsigned char) ((total / (float) (n * n)) * 255.0f) : (unsigned char) 0;
 }
 
 // The same pass for supersampled frames (n >= 2).  With one thread per output pixel a wave's 64 lanes read 64 places
@@ -2165,15 +2152,11 @@ __global__ __launch_bounds__(256) void finish_kernel(float *__restrict__ image, 
 constexpr uint32_t FINISH_CELL_FLOATS = 4160u;  // 64 pixels of 8 x 8 sub-pixels and their padding
 __global__ __launch_bounds__(256) void finish_wide_kernel(float *__restrict__ image, const HitRec *__restrict__ hits,
                                                           const uint32_t *__restrict__ occluded_of,
-                                                          const uint32_t *__restrict__ tile_base,
-                                                          FrameCounters *__restrict__ counters, unsigned char *__restrict__ out,
+                                                          const uint32_t *__restrict__ tile_base, unsigned char *__restrict__ out,
                                                           uint32_t width, uint32_t height, uint32_t total_width, uint32_t n,
                                                           uint32_t tiles_x, Partition part, uint32_t rows_per_band, uint32_t ao_divisor,
                                                           uint32_t pixels_per_block) {
 	__shared__ float cell[FINISH_CELL_FLOATS];
-	__shared__ unsigned int block_total;
-	if (threadIdx.x == 0)
-		block_total = 0u;
 	const uint32_t x0 = blockIdx.x * pixels_per_block;
 	const uint32_t pixels = width - x0 < pixels_per_block ? width - x0 : pixels_per_block;
 	const uint32_t columns = pixels * n;
@@ -2182,7 +2165,6 @@ __global__ __launch_bounds__(256) void finish_wide_kernel(float *__restrict__ im
 	const uint32_t band_local = j / rows_per_band;
 	const uint32_t y = (band_local * part.nranks + part.rank) * rows_per_band + (j - band_local * rows_per_band);
 	const float divisor = (float) ao_divisor;
-	uint32_t mine = 0u;
 	for (uint32_t sy = 0; sy < n; ++sy) {
 		const uint32_t row_index = j * n + sy;
 		float *row = image + (size_t) row_index * total_width + (size_t) x0 * n;
@@ -2192,20 +2174,14 @@ __global__ __launch_bounds__(256) void finish_wide_kernel(float *__restrict__ im
 			const uint32_t bits = __float_as_uint(v);
 			if (is_pending(bits)) {
 				const size_t slot = (size_t) bases[(x0 * n + c) / TILE_W] + (bits & 63u);
-				const uint32_t occluded = occluded_of[slot];
-				v = hits[slot].value * (1.0f - ((float) occluded / divisor));
+				v = hits[slot].value * (1.0f - ((float) occluded_of[slot] / divisor));
 				row[c] = v;
-				mine += occluded;
 			}
 			const uint32_t p = c / n;
 			cell[p * stride + sy * n + (c - p * n)] = v;
 		}
 	}
-	for (int offset = 32; offset > 0; offset >>= 1)
-		mine += (uint32_t) __shfl_down((int) mine, offset);
 	__syncthreads();
-	if ((threadIdx.x & 63u) == 0u && mine)
-		atomicAdd(&block_total, mine);
 	if (out && threadIdx.x < pixels) {
 		const float *cells = cell + threadIdx.x * stride;
 		float total = 0.0f;
@@ -2213,9 +2189,27 @@ __global__ __launch_bounds__(256) void finish_wide_kernel(float *__restrict__ im
 			total += cells[i];
 		out[(size_t) j * width + x0 + threadIdx.x] = y < height ? (unsigned char) ((total / (float) (n * n)) * 255.0f) : (unsigned char) 0;
 	}
+}
+
+// The occlusion counts of a frame, summed: RenderStats::ao_occluded, on demand (DeviceRenderer::stats) -- the counts are
+// in the hit list from the end of the ambient-occlusion pass until the host's next primary pass clears them slot by slot.
+// Grid-stride, per lane / wave / workgroup, one atomic per workgroup (at most 256) onto a total the launcher has zeroed.
+__global__ __launch_bounds__(256) void occluded_sum_kernel(const uint32_t *__restrict__ occluded_of, size_t slots,
+                                                           FrameCounters *__restrict__ counters) {
+	__shared__ unsigned long long block_total;
+	if (threadIdx.x == 0)
+		block_total = 0ull;
+	__syncthreads();
+	unsigned long long mine = 0ull;
+	for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (size_t) gridDim.x * blockDim.x)
+		mine += occluded_of[i];
+	for (int offset = 32; offset > 0; offset >>= 1)
+		mine += (unsigned long long) __shfl_down((long long) mine, offset);
+	if ((threadIdx.x & 63u) == 0u && mine)
+		atomicAdd(&block_total, mine);
 	__syncthreads();
 	if (threadIdx.x == 0 && block_total)
-		atomicAdd(&counters->occluded, (unsigned long long) block_total);
+		atomicAdd(&counters->occluded, block_total);
 }
 
 // Supersample box filter + 8-bit quantisation on the device: one thread per
@@ -2367,7 +2361,7 @@ void launch_ao(const SceneBuffers &scene, void *hits, void *occluded_of, void *o
 }
 
 // `out`: this rank's 8-bit bands (local_out_rows x out_width), or null for a frame without the device resize.
-void launch_finish(float *image, const void *hits, const void *occluded_of, const void *tile_base, void *counters, unsigned char *out,
+void launch_finish(float *image, const void *hits, const void *occluded_of, const void *tile_base, unsigned char *out,
                    const KernelParams &P, uint32_t out_width, uint32_t n, uint32_t local_out_rows, void *stream) {
 	if (local_out_rows == 0 || out_width == 0 || n == 0)
 		return;
@@ -2382,14 +2376,25 @@ void launch_finish(float *image, const void *hits, const void *occluded_of, cons
 		pixels_per_block = pixels_per_block > 256u ? 256u : pixels_per_block > 16u ? pixels_per_block & ~15u : pixels_per_block;
 		hipLaunchKernelGGL(finish_wide_kernel, dim3((out_width + pixels_per_block - 1u) / pixels_per_block, local_out_rows), dim3(256), 0,
 		                   (hipStream_t) stream, image, (const HitRec *) hits, (const uint32_t *) occluded_of, (const uint32_t *) tile_base,
-		                   (FrameCounters *) counters, out, out_width, P.height / n, P.width, n, P.tiles_x, P.part, rows_per_band,
+		                   out, out_width, P.height / n, P.width, n, P.tiles_x, P.part, rows_per_band,
 		                   P.ao_divisor ? P.ao_divisor : 1u, pixels_per_block);
 		return;
 	}
 	hipLaunchKernelGGL(finish_kernel, dim3((out_width + 255) / 256, local_out_rows), dim3(256), 0, (hipStream_t) stream, image,
-	                   (const HitRec *) hits, (const uint32_t *) occluded_of, (const uint32_t *) tile_base, (FrameCounters *) counters, out,
+	                   (const HitRec *) hits, (const uint32_t *) occluded_of, (const uint32_t *) tile_base, out,
 	                   out_width, P.height / n,
 	                   P.width, n, P.tiles_x, P.part, rows_per_band, P.ao_divisor ? P.ao_divisor : 1u);
+}
+
+// counters->occluded = the sum of the hit list's `slots` occlusion counts (stream-ordered: after the frames enqueued so far).
+void launch_occluded_sum(const void *occluded_of, size_t slots, void *counters, void *stream) {
+	FrameCounters *const c = (FrameCounters *) counters;
+	(void) hipMemsetAsync(&c->occluded, 0, sizeof c->occluded, (hipStream_t) stream);
+	if (slots == 0)
+		return;
+	const size_t blocks = (slots + 4095) / 4096;  // (16 counts per thread at least)
+	hipLaunchKernelGGL(occluded_sum_kernel, dim3((unsigned) (blocks < 256 ? blocks : 256)), dim3(256), 0, (hipStream_t) stream,
+	                   (const uint32_t *) occluded_of, slots, c);
 }
 
 void launch_resize(const float *tmp, unsigned char *out, const KernelParams &P, uint32_t out_width, uint32_t n,
