@@ -152,7 +152,9 @@ int rt_set_device_share(rt_host *h, unsigned int hosts);
 /* Ray counts of the last frame and HIP-event timing of the ray-casting passes
  * on the launch stream (last frame, running total in ms and number of frames
  * since the reset): *_kernel_ms covers every pass of a frame, *_ao_ms the
- * launch of the ambient-occlusion kernel alone (0 for frames without AO). */
+ * launch of the ambient-occlusion kernel alone (0 for frames without AO).
+ * Waits for the host's stream; the count of occluded rays is summed on the device when this is called (the frames do not
+ * sum it), so it describes the LAST frame the host has been given -- ask before submitting the next one. */
 int rt_get_stats(rt_host *h, rt_stats *out);
 float rt_last_kernel_ms(const rt_host *h);
 double rt_total_kernel_ms(const rt_host *h);
