@@ -8,23 +8,28 @@
 // layout, traversal order, where a value is computed) is free and is chosen
 // for the CDNA4 wave64 machine.
 //
-// Work decomposition: one 64-lane wavefront per 8x8 tile of sub-pixels, in two
-// passes with a tiny ordering step between them and a resolve step after.
+// Work decomposition: one 64-lane wavefront per 8x8 tile of sub-pixels, in two ray passes and a finishing sweep --
+// three kernels per frame (round 3: six), captured once per host as a hipGraph and replayed.
 //   primary_kernel  every lane casts its primary ray (closest hit) and computes
 //                   the smooth normal and head-light term.  Sub-pixels that need
-//                   no ambient occlusion are final; the tile's other hits are
-//                   ballot-compacted into the tile's 64 slots of the hit list.
-//   order_kernel    counting sort of the non-empty tiles by AO cost class, the costly
-//                   ones first, per XCD group.
+//                   no ambient occlusion are final; the tile's other hits leave a TAG in the image and
+//                   are ballot-compacted into the tile's slots of the hit list (tile_base: sized by what is hit).
+//                   Its TAIL is the ordering step: the last workgroup of each XCD group to finish sorts the
+//                   group's non-empty tiles by AO cost class (counting sort, the costly blocks first).
 //   ao_kernel       persistent workgroups claim runs of (tile, table direction) units in
 //                   that order -- a tile at a time, whose directions the four waves take
 //                   from a cursor in LDS.  A wave rebuilds the tile's tangent frames in its
 //                   LDS slice and casts one packet of 64 any-hit rays per
 //                   direction -- one table direction from the tile's neighbouring
-//                   surface points -- that stop at the first accepted triangle;
+//                   surface points -- that stop at the first accepted triangle and walk only
+//                   the interval of the node array their segments can reach (entry_kernel, once per upload);
 //                   occlusion counts are LDS atomics, flushed to a per-hit counter
 //                   when the claim is done.
-//   resolve_kernel  a thread per hit-list slot, grid-stride: value * (1 - occluded / n) -> image.
+//   finish_kernel / finish_wide_kernel
+//                   value * (1 - occluded / n) into the tagged sub-pixels and the supersample box filter +
+//                   quantisation of the same sweep (n = 1: a thread per pixel; n >= 2: along the sub-pixel rows).
+//   (on demand)     entry_kernel: the walk intervals, once per upload; occluded_sum_kernel: the frame's occlusion
+//                   total when the statistics are asked for; resize_kernel: a box filter on its own.
 // Why not one fused launch (it was, see profiles/r01_notes.md): cost per tile
 // varies 30x (background vs model, 29 rays per hit sub-pixel), so the frame used
 // to end on a long tail of half-empty CUs.  With the tiles' costs known after the
@@ -37,9 +42,9 @@
 // wave scheduler, is only compiled into the A/B build (-DOCRT_DEBUG_KNOBS, where
 // OCRT_NO_SHARED_WALK=1 selects it); the product library does not contain it.
 //
-// What bounds it: the scene (12 MB) is cache-resident, HBM traffic is negligible;
-// the walk is bound by vector-instruction issue (9 to 17 per node and packet) and the
-// latency of the one scalar load per pair of nodes -- see DESIGN.md section 5 and
+// What bounds it: the scene (19 MB) is cache-resident, HBM traffic is negligible;
+// the walk is bound by vector-instruction issue (11 to 17 per node and primary packet, 12 per any-hit packet) and the
+// latency of the one scalar load per pair of nodes (scenes beyond the caches: by that latency alone) -- see DESIGN.md section 5 and
 // profiles/r0*_notes.md for the counters and the microbenchmarks.
 #include <hip/hip_runtime.h>
 
@@ -1580,7 +1585,7 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 			// claim_max units, to the end of the queue; how the waves divide it is decided below.  (Guided self-scheduling -- the share
 			// shrinking to 1/ao_guide of what is left per wave of the group -- is kept behind OCRT_AO_GUIDE: the
 			// single directions it hands out at the end cost a claim each, two barriers and a tile set-up, and
-			// lengthened the pass by 3-5 %; the costly tiles are claimed first anyway, order_kernel.)
+			// lengthened the pass by 3-5 %; the costly tiles are claimed first anyway: order_group.)
 			uint32_t per_wave = 0u, first = units;  // (wave 0's, scalar; in registers until the siblings are done with the last claim)
 			if (wave == 0u) {
 				FrameCounters *const counters = OCRT_COLD_PTR(FrameCounters *, counters);
@@ -2149,7 +2154,9 @@ __global__ __launch_bounds__(256) void finish_kernel(float *__restrict__ image, 
 // output pixel adds its n x n values up in the reference's order (ssY-major, ssX-minor: src/ray_tracer.cc:7-13) -- the
 // same additions in the same order as finish_kernel's, so the same bits.  The cells of a pixel are n * n | 1 floats
 // apart (odd: the adding threads do not meet in a bank).
+// RESOLVE = false: the box filter alone, of an image that holds no tags any more (a resize on its own: launch_resize).
 constexpr uint32_t FINISH_CELL_FLOATS = 4160u;  // 64 pixels of 8 x 8 sub-pixels and their padding
+template <bool RESOLVE>
 __global__ __launch_bounds__(256) void finish_wide_kernel(float *__restrict__ image, const HitRec *__restrict__ hits,
                                                           const uint32_t *__restrict__ occluded_of,
                                                           const uint32_t *__restrict__ tile_base, unsigned char *__restrict__ out,
@@ -2172,7 +2179,7 @@ __global__ __launch_bounds__(256) void finish_wide_kernel(float *__restrict__ im
 		for (uint32_t c = threadIdx.x; c < columns; c += 256u) {
 			float v = row[c];
 			const uint32_t bits = __float_as_uint(v);
-			if (is_pending(bits)) {
+			if (RESOLVE && is_pending(bits)) {
 				const size_t slot = (size_t) bases[(x0 * n + c) / TILE_W] + (bits & 63u);
 				v = hits[slot].value * (1.0f - ((float) occluded_of[slot] / divisor));
 				row[c] = v;
@@ -2374,7 +2381,7 @@ void launch_finish(float *image, const void *hits, const void *occluded_of, cons
 		// supersampled: a workgroup per run of output pixels, swept along the sub-pixel rows (finish_wide_kernel)
 		uint32_t pixels_per_block = FINISH_CELL_FLOATS / cells_per_pixel;
 		pixels_per_block = pixels_per_block > 256u ? 256u : pixels_per_block > 16u ? pixels_per_block & ~15u : pixels_per_block;
-		hipLaunchKernelGGL(finish_wide_kernel, dim3((out_width + pixels_per_block - 1u) / pixels_per_block, local_out_rows), dim3(256), 0,
+		hipLaunchKernelGGL(finish_wide_kernel<true>, dim3((out_width + pixels_per_block - 1u) / pixels_per_block, local_out_rows), dim3(256), 0,
 		                   (hipStream_t) stream, image, (const HitRec *) hits, (const uint32_t *) occluded_of, (const uint32_t *) tile_base,
 		                   out, out_width, P.height / n, P.width, n, P.tiles_x, P.part, rows_per_band,
 		                   P.ao_divisor ? P.ao_divisor : 1u, pixels_per_block);
@@ -2402,6 +2409,17 @@ void launch_resize(const float *tmp, unsigned char *out, const KernelParams &P, 
 	if (local_out_rows == 0 || out_width == 0 || n == 0)
 		return;
 	const uint32_t rows_per_band = P.part.band_tile_rows * TILE_H / n;
+	const uint32_t cells_per_pixel = (n * n) | 1u;
+	if (n >= 2u && cells_per_pixel <= FINISH_CELL_FLOATS) {
+		// supersampled: along the sub-pixel rows, like the frame's own finishing sweep (no tags to resolve, nothing written back)
+		uint32_t pixels_per_block = FINISH_CELL_FLOATS / cells_per_pixel;
+		pixels_per_block = pixels_per_block > 256u ? 256u : pixels_per_block > 16u ? pixels_per_block & ~15u : pixels_per_block;
+		hipLaunchKernelGGL(finish_wide_kernel<false>, dim3((out_width + pixels_per_block - 1u) / pixels_per_block, local_out_rows), dim3(256), 0,
+		                   (hipStream_t) stream, const_cast<float *>(tmp), (const HitRec *) nullptr, (const uint32_t *) nullptr,
+		                   (const uint32_t *) nullptr, out, out_width, P.height / n, P.width, n, P.tiles_x, P.part, rows_per_band, 1u,
+		                   pixels_per_block);
+		return;
+	}
 	hipLaunchKernelGGL(resize_kernel, dim3((out_width + 255) / 256, local_out_rows), dim3(256), 0,
 	                   (hipStream_t) stream, tmp, out, out_width, P.height / n, P.width, n, P.part, rows_per_band);
 }
