@@ -365,37 +365,85 @@ def main():
     # with 16 queues the eighth reads 0.161 / 0.154 / 0.151 for 8 / 12 / 16.  The 4K and 64-samples frames do not care:
     # 0.460 / 0.462 / 0.463 and 4.78 / 4.80 / 4.69 ms for an eighth with 3 / 6 / 12.)
     in_flight = args.in_flight if args.in_flight > 0 else 3 if world == 1 else 6 if world < 8 else 8
-    rings = {"pipelined": rt.FrameRing(opt, scene, device_index, rank, world, hosts=in_flight),
-             "blocking": rt.FrameRing(opt, scene, device_index, rank, world, hosts=1)}
-    for ring in rings.values():
-        ring.set_graph_mode(not args.plain_launches)
-        if args.pacing >= 0.0:
-            ring.set_pacing(args.pacing)
+    def make_rings():
+        made = {"pipelined": rt.FrameRing(opt, scene, device_index, rank, world, hosts=in_flight),
+                "blocking": rt.FrameRing(opt, scene, device_index, rank, world, hosts=1)}
+        for ring in made.values():
+            ring.set_graph_mode(not args.plain_launches)
+            if args.pacing >= 0.0:
+                ring.set_pacing(args.pacing)
+        return made
+
+    rings = make_rings()
 
     # The exchange step of a multi-GPU frame: the ring's own RCCL gather (one process per GPU; the unique id is made on
     # rank 0 and handed round by torch.distributed).  The gloo rehearsal on a one-GPU box cannot use RCCL (it refuses
-    # two ranks on one device): there the ring writes into torch tensors and the gather is torch's, staged through host memory.
+    # two ranks on one device): there the ring writes into torch tensors and the gather is torch's, staged through host
+    # memory.  Should the library's own gather fail to come up on a real multi-GPU job (RCCL not loadable, a communicator
+    # that cannot be made), the job does not die without a number: every rank learns of it (an all-reduce after each step
+    # of the set-up), the rings are made afresh without a gather, and torch.distributed gathers the same band buffers on
+    # the device -- slower (Python takes part in every frame) and said so in the line (`config.parallelism`, `config.rccl`).
     from opencl_raytracer_amd.multi_gpu import BandGatherer, BandLayout
 
     layout = BandLayout(opt, world)
     assert layout.local_rows(rank) == rings["pipelined"].local_rows
     rccl = launched and backend == "nccl"
-    staged = launched and not rccl
-    bands, gatherers = {}, {}
-    if launched:
+    rccl_failure = None
+
+    def bind_bands():
         for name, ring in rings.items():
-            bands[name] = [torch.zeros((layout.max_rows, opt.width), dtype=torch.uint8, device=device) for _ in range(ring.slots)]
+            if name not in bands:
+                bands[name] = [torch.zeros((layout.max_rows, opt.width), dtype=torch.uint8, device=device) for _ in range(ring.slots)]
             for k, b in enumerate(bands[name]):
                 ring.bind_output(k, b.data_ptr())
-            gatherers[name] = BandGatherer(layout, rank, "cpu" if staged else device)
+
+    def any_rank_failed(error: str) -> bool:
+        flag = torch.tensor([1 if error else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        return bool(int(flag[0]))
+
+    bands, gatherers = {}, {}
+    if launched:
+        bind_bands()
     if rccl:
+        error = ""
+        try:  # (loads RCCL and makes an id: what can fail on one rank alone, before any rank waits for another)
+            if os.environ.get("OCRT_BENCH_FAIL_RCCL"):  # rehearsal knob: take the fallback
+                raise RuntimeError("OCRT_BENCH_FAIL_RCCL is set")
+            rt.rccl_unique_id()
+        except Exception as exc:  # noqa: BLE001
+            error = f"{type(exc).__name__}: {exc}"
+        failed = any_rank_failed(error)
         for name, ring in rings.items():
-            uid = torch.zeros(128, dtype=torch.uint8, device=device)
-            if rank == 0:
-                uid = torch.frombuffer(bytearray(rt.rccl_unique_id()), dtype=torch.uint8).to(device)
-            dist.broadcast(uid, 0)
-            ring.attach_rccl(bytes(uid.cpu().numpy().tobytes()))
-            ring.rccl_self_test()
+            if failed:
+                break
+            try:
+                uid = torch.zeros(128, dtype=torch.uint8, device=device)
+                if rank == 0:
+                    uid = torch.frombuffer(bytearray(rt.rccl_unique_id()), dtype=torch.uint8).to(device)
+                dist.broadcast(uid, 0)
+                ring.attach_rccl(bytes(uid.cpu().numpy().tobytes()))
+                ring.rccl_self_test()
+            except Exception as exc:  # noqa: BLE001
+                error = f"{type(exc).__name__}: {exc}"
+            failed = any_rank_failed(error)
+        if failed:
+            rccl_failure = error or "the set-up failed on another rank"
+            rccl = False
+            for ring in rings.values():
+                ring.close()
+            rings = make_rings()
+            bind_bands()
+    staged = launched and not rccl
+    host_staged = staged and backend != "nccl"  # (gloo: through host memory; the RCCL fallback gathers on the device)
+    if launched:
+        for name in rings:
+            gatherers[name] = BandGatherer(layout, rank, "cpu" if host_staged else device)
+
+    def gathered(name, slot):
+        band = bands[name][slot]
+        return gatherers[name](band.cpu() if host_staged else band)
+
     last_image = {}
 
     def run_steps(name, steps):
@@ -409,13 +457,13 @@ def main():
             ring.submit()
             while ring.in_flight > max(1, hosts - 1) or (hosts == 1 and ring.in_flight):
                 _, slot, _ = ring.collect_info()
-                last_image[name] = gatherers[name](bands[name][slot].cpu())
+                last_image[name] = gathered(name, slot)
 
     def fence(name):
         ring = rings[name]
         while staged and ring.in_flight:
             _, slot, _ = ring.collect_info()
-            last_image[name] = gatherers[name](bands[name][slot].cpu())
+            last_image[name] = gathered(name, slot)
         ring.drain()
         torch.cuda.synchronize(device)
         if launched:
@@ -425,7 +473,7 @@ def main():
     def final_image(name):
         """The last frame's assembled image on rank 0 (numpy), None elsewhere."""
         if staged:
-            return last_image[name].numpy() if rank == 0 else None
+            return last_image[name].cpu().numpy() if rank == 0 else None
         if rccl and rank != 0:
             return None
         return rings[name].download_last()
@@ -502,7 +550,7 @@ def main():
     else:
         total_rays, total_hits, total_occluded = my_rays, st["primary_hits"], st["ao_occluded"]
     images = {name: final_image(name) for name in rings}
-    rccl_described = None
+    rccl_described = {"failed": rccl_failure, "world_size": world} if rccl_failure else None
     if rccl:
         comm_ranks, version = rings["pipelined"].rccl_info()
         rccl_described = {"comm_ranks": comm_ranks, "version_code": version, "world_size": world}
@@ -531,7 +579,9 @@ def main():
         pipe_ms, block_ms = per_step_ms("pipelined"), per_step_ms("blocking")
         ms_per_step = statistics.median(pipe_ms)
         value = total_rays / (ms_per_step * 1e-3) / 1e6
-        gather = "the ring's RCCL gather to rank 0" if rccl else f"{backend} gather to rank 0 (rehearsal, staged through the host)" if launched else None
+        gather = ("the ring's RCCL gather to rank 0" if rccl else
+                  f"torch.distributed ({backend}) gather to rank 0 on the device -- the library's RCCL gather could not be set up: {rccl_failure}"
+                  if rccl_failure else f"{backend} gather to rank 0 (rehearsal, staged through the host)" if launched else None)
         out = {
             # BASELINE.json's metric, verbatim, for the 1920x1080 workloads it is quoted on
             "metric": "Mrays/s at 1920×1080 (bunny.off, sibenik.off); PGM bit-exact vs CPU" if "1080p" in args.workload

@@ -54,6 +54,17 @@ def test_rccl_world_of_one_runs_the_gather(golden):
     assert out["config"]["pgm_matches_golden"] is True and out["value"] > 0
 
 
+def test_the_job_survives_a_gather_that_cannot_be_set_up(golden):
+    """Should the library's own RCCL gather fail to come up (here: the rehearsal knob refuses it on every rank), the ranks
+    agree on it, make their rings afresh without a gather, and torch.distributed gathers the same band buffers on the
+    device: the line still comes, with the golden image, and says which exchange step it was measured with."""
+    out = _run_bench(1, extra_env={"OCRT_BENCH_FAIL_RCCL": "1"})
+    assert out["n_gpus"] == 1 and "could not be set up" in out["config"]["parallelism"]
+    assert out["config"]["rccl"]["failed"] and "OCRT_BENCH_FAIL_RCCL" in out["config"]["rccl"]["failed"]
+    assert out["config"]["pgm_md5"] == golden["renders"]["bunny_600_defaults"]["pgm_md5"]
+    assert out["blocking"]["pgm_md5"] == golden["renders"]["bunny_600_defaults"]["pgm_md5"] and out["value"] > 0
+
+
 def test_rccl_two_ranks_assemble_the_golden_frame(golden):
     import torch
 
