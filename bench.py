@@ -276,6 +276,11 @@ def summary(values):
 
 
 def main():
+    # The hosts' driver shares device memory between processes by dmabuf only: RCCL's peer-to-peer set-up (and torch's
+    # sharing of device tensors) fails with `hipIpcGetMemHandle: invalid argument` under the legacy IPC mode.  The variable
+    # is exported on the boxes this runs on; set here too, before the HIP runtime starts, for a shell that lacks it (the
+    # ranks a bare `--gpus N` starts inherit it).
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)  # (a quarter of a second of frames per block)
