@@ -288,6 +288,10 @@ void download_floats(HipHostGroup &, float *) {
 
 int main(int argc, const char **argv) {
 	CliOptions options(argc, argv);
+	// (--gpus N: RCCL's peer-to-peer set-up shares device memory between its devices by dmabuf; the hosts' driver refuses
+	// the legacy IPC mode with `hipIpcGetMemHandle: invalid argument`.  Set before the HIP runtime starts, not overriding a caller's choice.)
+	if (options.gpus > 1)
+		setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
 	// The HIP runtime, the device context and the kernels' code object cost 100-200 ms and do not depend on the scene:
 	// they come up on a second thread while this one reads the mesh and builds the BVH (reference order of the output
 	// kept: nothing is printed from that thread).
