@@ -47,12 +47,14 @@ def test_group_gather_with_many_ranks_on_one_gpu(golden, tmp_path, fake_dir, nam
     assert hashlib.md5(out.read_bytes()).hexdigest() == c["pgm_md5"]
 
 
-@pytest.mark.parametrize("name,ranks,hosts", [("bunny_600_defaults", 8, 3), ("bunny_101x77_s9_a2", 3, 2), ("blob_128x96_s4_a3", 2, 1),
-                                              ("bunny_1080p_s1_a3", 4, 3)])
-def test_ring_exchange_step_with_every_rank_in_one_process(golden, fake_dir, name, ranks, hosts):
+# (ranks, hosts per rank, frames: bench.py takes 6 hosts per GPU at 2 - 7 ranks and 8 from eight on; more frames than the
+# 2 x hosts band buffers of a ring, so that every slot is bound, gathered from and reused)
+@pytest.mark.parametrize("name,ranks,hosts,frames", [("bunny_600_defaults", 8, 8, 20), ("bunny_101x77_s9_a2", 3, 2, 7),
+                                                     ("blob_128x96_s4_a3", 2, 6, 15), ("blob_128x96_s4_a3", 2, 1, 7),
+                                                     ("bunny_1080p_s1_a3", 4, 3, 7)])
+def test_ring_exchange_step_with_every_rank_in_one_process(golden, fake_dir, name, ranks, hosts, frames):
     c = golden["renders"][name]
     env = dict(os.environ, LD_LIBRARY_PATH=fake_dir + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
-    frames = 7
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fake_rccl", "ring_ranks_driver.py"), name, str(ranks), str(hosts),
                         str(frames)], capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
