@@ -8,6 +8,10 @@
 //   packets   current  : the kernel's pieces (64 >> floor(log2(hits)) directions per piece, 64 rays per packet)
 //             dense    : the tile's rays direction-major, 64 at a time across direction boundaries
 //             octant   : the tile's rays sorted by the sign octant of their direction, then direction-major
+//   PCULL     a LOWER BOUND for any table made per packet at upload: nodes clear of the box around the packet's segments are
+//             skipped, inner nodes that hold that box whole are entered, both at no cost
+//   PCUT K    at most K intervals per packet: the largest subtree of the list is replaced by its children that meet the box
+//             around the packet's segments, neighbours merging, while the list stays within K (what a K-entry table could hold)
 //   fat K     subtrees of at most K leaves are "fat leaves": a packet that reaches one with fewer than `batch_below`
 //             lanes appends (lane, fat leaf) pairs and skips it; the pairs are expanded 64 at a time, every lane
 //             testing the K leaf boxes of ITS pair (dense work instead of wave-wide tests for a few lanes)
@@ -106,7 +110,9 @@ struct Tree {
 };
 
 // One packet through the shared walk.  fat_k = 0: the kernel as it is.
-static void walk_packet(const Tree &T, const R *rays, int n, float D, int batch_below, int fat_k, Events &ev, size_t from = 0, size_t to = (size_t) -1) {
+static void walk_packet(const Tree &T, const R *rays, int n, float D, int batch_below, int fat_k, Events &ev, size_t from = 0, size_t to = (size_t) -1,
+                        const float *region_lo = nullptr, const float *region_hi = nullptr,
+                        const std::vector<std::pair<size_t, size_t>> *ranges = nullptr) {
 	const std::vector<NodeRec> &N = *T.nodes;
 	bool alive[64];
 	int live = n;
@@ -159,7 +165,21 @@ static void walk_packet(const Tree &T, const R *rays, int n, float D, int batch_
 		fat_waiting.erase(fat_waiting.begin(), fat_waiting.begin() + count);
 	};
 	if (to > N.size()) to = N.size();
+	const size_t n_ranges = ranges ? ranges->size() : 1;
+	for (size_t range = 0; range < n_ranges && live; ++range) {
+	if (ranges) { from = (*ranges)[range].first; to = (*ranges)[range].second; }
 	for (size_t i = from; i < to && live;) {
+		if (region_lo) {
+			// PCULL, a lower bound for ANY table made per packet at upload: a node clear of the box around the packet's
+			// segments is skipped at no cost, an inner node that holds that box whole is entered at no cost
+			bool meets = true, holds = true;
+			for (int k = 0; k < 3; ++k) {
+				meets = meets && !(N[i].lo[k] > region_hi[k] || N[i].hi[k] < region_lo[k]);
+				holds = holds && N[i].lo[k] <= region_lo[k] && N[i].hi[k] >= region_hi[k];
+			}
+			if (!meets) { i += N[i].skip; continue; }
+			if (holds && N[i].skip > 1) { ++i; continue; }
+		}
 		bool hit[64];
 		int hits = 0;
 		for (int l = 0; l < n; ++l) {
@@ -194,6 +214,7 @@ static void walk_packet(const Tree &T, const R *rays, int n, float D, int batch_
 			continue;
 		}
 		++i;
+	}
 	}
 	if (live) {
 		if (!fat_waiting.empty()) run_fat_batch(fat_waiting.size());
@@ -281,7 +302,7 @@ int main(int argc, char **argv) {
 	// variants: [packets: current, dense, octant] x [fat: 0, 2, 4, 8, 16]
 	const int NP = 3;
 	static Events ev[3][NP][NF];
-	static Events entry_ev[3], trim_ev[3], pdir_ev[3];
+	static Events entry_ev[3], trim_ev[3], pdir_ev[3], pcull_ev[3], pcut_ev[3][3];
 	static unsigned long long tiles_in[3], jobs_in[3][NP], hits_in[3], partial_tiles[3];
 	// the ground plane: the two largest triangles
 	float plane_y = -0.48f;
@@ -295,7 +316,7 @@ int main(int argc, char **argv) {
 #pragma omp parallel
 	{
 		static thread_local Events lev[3][NP][NF];
-		static thread_local Events lentry[3], ltrim[3], lpdir[3];
+		static thread_local Events lentry[3], ltrim[3], lpdir[3], lpcull[3], lpcut[3][3];
 		unsigned long long ltiles[3] = { 0 }, ljobs[3][NP] = { { 0 } }, lhits[3] = { 0 }, lpartial[3] = { 0 };
 #pragma omp for schedule(dynamic, 1)
 		for (int ty = 0; ty < (H + 7) / 8; ty += stride)
@@ -515,6 +536,38 @@ int main(int argc, char **argv) {
 							}
 							if (pb < pe) walk_packet(trees[0], rays, nr, D, batch_below, 0, lpdir[cls], pb, pe);
 							else { ++lpdir[cls].packets; lpdir[cls].rays += nr; }
+							walk_packet(trees[0], rays, nr, D, batch_below, 0, lpcull[cls], 0, (size_t) -1, plo, phi);
+							// PCUT K: at most K intervals per packet -- from [whole array] on, the largest subtree of the list is replaced by
+							// its children that meet the box (neighbours in the array merge into one interval) while the list stays within K
+							for (int kk = 0; kk < 3; ++kk) {
+								const size_t K = (size_t) (2 << kk);
+								std::vector<size_t> cut = { 0 };  // subtree roots, in array order
+								auto intervals_of = [&](const std::vector<size_t> &c) {
+									std::vector<std::pair<size_t, size_t>> out;
+									for (size_t node : c) {
+										if (!out.empty() && out.back().second == node) out.back().second = node + N0[node].skip;
+										else out.push_back({ node, node + N0[node].skip });
+									}
+									return out;
+								};
+								for (;;) {
+									size_t pick = cut.size(), size = 1;
+									for (size_t j = 0; j < cut.size(); ++j)
+										if (N0[cut[j]].skip > size) { size = N0[cut[j]].skip; pick = j; }
+									if (pick == cut.size()) break;
+									std::vector<size_t> next(cut.begin(), cut.begin() + (long) pick);
+									const size_t node = cut[pick];
+									for (size_t c = node + 1; c < node + N0[node].skip; c += N0[c].skip)
+										if (pmeets(c)) next.push_back(c);
+									next.insert(next.end(), cut.begin() + (long) pick + 1, cut.end());
+									if (intervals_of(next).size() > K) break;
+									cut.swap(next);
+									if (cut.empty()) break;
+								}
+								const auto ranges = intervals_of(cut);
+								if (!ranges.empty()) walk_packet(trees[0], rays, nr, D, batch_below, 0, lpcut[cls][kk], 0, (size_t) -1, nullptr, nullptr, &ranges);
+								else { ++lpcut[cls][kk].packets; lpcut[cls][kk].rays += nr; }
+							}
 						}
 					}
 				}
@@ -532,6 +585,8 @@ int main(int argc, char **argv) {
 				entry_ev[c].add(lentry[c]);
 				trim_ev[c].add(ltrim[c]);
 				pdir_ev[c].add(lpdir[c]);
+				pcull_ev[c].add(lpcull[c]);
+				for (int kk = 0; kk < 3; ++kk) pcut_ev[c][kk].add(lpcut[c][kk]);
 			}
 		}
 	}
@@ -568,6 +623,21 @@ int main(int argc, char **argv) {
 			       100.0 * e.coherent_packets / pk, (e.nodes_coherent + e.nodes_mixed) / pk, 100.0 * e.lane_hits / (double) (e.lane_alive ? e.lane_alive : 1), e.spot_leaves / pk,
 			       e.appends / pk, e.pairs / pk, e.batches / pk, 0.0, 0.0, cost / pk, cost * scale / 1e6);
 		}
+		if (pcull_ev[c].packets) {
+			const Events &e = pcull_ev[c];
+			const double pk = (double) e.packets, cost = M.cost(e, tiles_in[c] * 4);
+			printf("%-8s %-4d %9.0f %6.1f %6.1f %7.1f %7.1f %6.2f %7.1f %7.1f %7.2f %7.1f %7.2f %8.0f %8.1f\n", "PCULL", 0, pk * scale, e.rays / pk,
+			       100.0 * e.coherent_packets / pk, (e.nodes_coherent + e.nodes_mixed) / pk, 100.0 * e.lane_hits / (double) (e.lane_alive ? e.lane_alive : 1), e.spot_leaves / pk,
+			       e.appends / pk, e.pairs / pk, e.batches / pk, 0.0, 0.0, cost / pk, cost * scale / 1e6);
+		}
+		for (int kk = 0; kk < 3; ++kk)
+			if (pcut_ev[c][kk].packets) {
+				const Events &e = pcut_ev[c][kk];
+				const double pk = (double) e.packets, cost = M.cost(e, tiles_in[c] * 4);
+				printf("%-8s %-4d %9.0f %6.1f %6.1f %7.1f %7.1f %6.2f %7.1f %7.1f %7.2f %7.1f %7.2f %8.0f %8.1f\n", kk == 0 ? "PCUT2" : kk == 1 ? "PCUT4" : "PCUT8", 0, pk * scale, e.rays / pk,
+				       100.0 * e.coherent_packets / pk, (e.nodes_coherent + e.nodes_mixed) / pk, 100.0 * e.lane_hits / (double) (e.lane_alive ? e.lane_alive : 1), e.spot_leaves / pk,
+				       e.appends / pk, e.pairs / pk, e.batches / pk, 0.0, 0.0, cost / pk, cost * scale / 1e6);
+			}
 		for (int p = 0; p < NP; ++p)
 			for (int f = 0; f < NF; ++f) {
 				const Events &e = ev[c][p][f];
