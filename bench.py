@@ -136,8 +136,10 @@ def kernel_source_sha() -> str:
     """Identifies the kernels the PMC counters under profiles/ were collected for: sha256 over the sources that
     decide what a launch executes (kernels, record layouts, scene packing, the walk tree)."""
     h = hashlib.sha256()
-    for name in ("kernels.hip", "device_types.h", "tri_predicate.h", "exact_reciprocal.h", "scene_pack.cc", "walk_tree.cc"):
-        with open(os.path.join(ROOT, "opencl_raytracer_amd", "csrc", name), "rb") as f:
+    csrc = os.path.join(ROOT, "opencl_raytracer_amd", "csrc")
+    parts = sorted(os.path.join("kernels", n) for n in os.listdir(os.path.join(csrc, "kernels")) if n.endswith(".h"))
+    for name in ["kernels.hip"] + parts + ["device_types.h", "tri_predicate.h", "exact_reciprocal.h", "scene_pack.cc", "walk_tree.cc"]:
+        with open(os.path.join(csrc, name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()
 

@@ -1,0 +1,475 @@
+// kernels/primary.hip.h -- pass 1: primary rays (closest hit, smooth normal, head-light term) and the ordering step in its tail
+// (part of the one translation unit kernels.hip; see its head for the passes and the arithmetic contract)
+#pragma once
+#include "walk.hip.h"
+
+namespace ocrt {
+
+// Tile <-> workgroup mapping shared by the passes.  A workgroup of the primary
+// pass covers 2x2 tiles (16x16 sub-pixels).  Workgroups b and b+8 share an XCD
+// and its L2 (MI355X_MICROARCH.md, dispatch is round-robin over XCDs), so the
+// image is cut into vertical strips KernelParams::strip_tiles wide (two by default),
+// strips are dealt round-robin to the 8 XCD groups, and each group walks its strips
+// top to bottom, row by row: neighbouring workgroups of a group touch the same BVH
+// region, while every group still sees the whole image height.  Strips of two tiles
+// balance best and are right while the scene lives in the caches; a scene far beyond
+// the L2s gets wider ones, so that an XCD's rays mostly meet geometry that only this
+// XCD needs (with 16-pixel strips all eight fetch the same nodes from HBM).
+
+// Kernel arguments that are READ AGAIN from the kernel-argument segment where they are used -- one scalar load each
+// (asm volatile: the compiler can neither hoist it out of a loop nor merge it with another) -- instead of being held in
+// scalar registers, and spilled from them to VGPR lanes, across the walks (see AoArgs).
+template <uint32_t OFFSET>
+__device__ __forceinline__ uint32_t cold_u32() {
+	uint32_t v;
+	asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "i"(OFFSET));
+	return v;
+}
+template <uint32_t OFFSET>
+__device__ __forceinline__ unsigned long long cold_u64() {
+	unsigned long long v;
+	asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "i"(OFFSET));
+	return v;
+}
+
+// The primary pass's arguments as one block (see AoArgs for why): the walk holds the two pointers at the head,
+// node_count, primary_below and batch_below in registers; what the tile's epilogue and the kernel's tail need is read
+// again there.
+struct PrimaryArgs {
+	const float4 *walk_ptr, *tris_ptr;
+	const float4 *nodes_ptr, *shade;
+	float *image;
+	HitRec *hits;
+	uint32_t *occluded_of, *tile_hits, *order;
+	const uint32_t *tile_base;  // first slot of each tile in the hit list (DeviceRenderer: a prefix sum of the tiles' hit counts)
+	FrameCounters *counters;
+	KernelParams P;
+};
+#define OCRT_PCOLD_U32(FIELD) cold_u32<(uint32_t) offsetof(PrimaryArgs, FIELD)>()
+#define OCRT_PCOLD_PTR(TYPE, FIELD) ((TYPE) cold_u64<(uint32_t) offsetof(PrimaryArgs, FIELD)>())
+
+// A hit sub-pixel that still waits for its ambient-occlusion factor holds, in the float image, a TAG instead of a value:
+// a negative quiet NaN whose low six bits are the sub-pixel's slot in its tile's part of the hit list (no value the
+// path computes is a NaN: the head-light term is clamped to [0, 1]).  The finishing kernel puts the value there.
+constexpr uint32_t PENDING_TAG = 0xFFC00000u;
+__device__ __forceinline__ bool is_pending(uint32_t bits) { return (bits & 0xFFFFFFC0u) == PENDING_TAG; }
+
+// SHARED: the shared walk.  (The A/B build also instantiates the first generation, SHARED = false; two instantiations,
+// so that its per-lane state stays out of the default path's register budget.)
+// One tile of the primary pass, one wave.
+template <bool SHARED>
+__device__ __forceinline__ void primary_tile(const PrimaryArgs &A, ClosestBatch *closest_batches, uint32_t tile_x, uint32_t local_row) {
+	const KernelParams &P = A.P;  // (fields used BEFORE or IN the walk only; the epilogue reads its own again)
+	const float4 *__restrict__ const walk_ptr = A.walk_ptr, *__restrict__ const tris_ptr = A.tris_ptr;
+	const float4 *__restrict__ const nodes_ptr = A.nodes_ptr;  // (exact form and first-generation walk only)
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t wave = threadIdx.x >> 6;
+	const SceneViews scene = make_views(nodes_ptr, tris_ptr, P);
+	const uint32_t tile = local_row * P.tiles_x + tile_x;
+	const uint32_t tile_y = global_tile_row(P.part, local_row);
+	const uint32_t x = tile_x * TILE_W + (lane & 7u);
+	const uint32_t y = tile_y * TILE_H + (lane >> 3);
+	const bool active = x < P.width && y < P.height;
+	// the float image holds this rank's bands only, one after the other: row `local_y` of it is image row `y`
+	const uint32_t local_y = local_row * TILE_H + (lane >> 3);
+	const uint32_t count = P.node_count;
+
+	// reference src/intersect_kernel.cl:279-295
+	float dx = ((float) x + 0.5f) / P.a - P.half_w;
+	float dy = -(((float) y + 0.5f) / P.a - P.half_h);
+	float dz = -1.0f;
+	normalize3(dx, dy, dz);
+	const Ray ray = make_ray(0.0f, 0.0f, 2.0f, dx, dy, dz);
+	Hit best;
+	best.distance = __builtin_inff();
+	best.leaf = 0;
+	best.s = best.t = 0.0f;
+	best.px = best.py = best.pz = 0.0f;
+	bool hit = false;
+	uint32_t leaf_stops = 0u;  // leaves the tile's shared walk stopped at: how dense the geometry is along these rays
+	if (SHARED) {
+		const bool exact = !P.fast_walk || wave_ballot(active && !ray_is_selectable(ray, P.origin_limit)) != 0ull;
+		// closest hit = minimum of (distance, reference leaf), see nearer(); reference :106-112
+		auto leaf_test = [&](uint32_t leaf, bool box) {
+			const float4 *tri = tris_ptr + LEAF_F4 * leaf + LEAF_TRI_F4;
+			const float4 q0 = tri[0], q1 = tri[1], q2 = tri[2], q3 = tri[3];
+			if (box) {
+				const TriResult tr = tri_eval<true>(q0, q1, q2, q3, ray);
+				if (tr.accepted) {
+					hit = true;
+					if (nearer(tr.distance, leaf, best)) {
+						best.distance = tr.distance;
+						best.leaf = leaf;
+						best.s = tr.s;
+						best.t = tr.t;
+						best.px = tr.px; best.py = tr.py; best.pz = tr.pz;
+					}
+				}
+			}
+		};
+		if (!exact) {
+			// Leaves hit by few lanes are collected and tested 64 pairs at a time (see ClosestBatch).
+			ClosestBatch &cb = closest_batches[wave];
+			cb.best_key[lane] = KEY_NONE;
+			if (lane < 2u)
+				cb.hit_bits[lane] = 0u;
+			unsigned long long my_key = KEY_NONE;  // from the leaves tested on the spot
+			uint32_t waiting = 0u;
+			auto key_of = [](float distance, uint32_t leaf) {
+				return ((unsigned long long) __float_as_uint(distance) << 32) | leaf;
+			};
+			auto run_batch = [&](uint32_t n) {
+				wave_lds_sync();
+				const uint32_t pair = cb.entry[lane < n ? lane : 0u];
+				const int owner = (int) (pair >> 26);
+				Ray theirs = ray;  // (all primary rays start at the eye)
+				theirs.dx = __shfl(ray.dx, owner); theirs.dy = __shfl(ray.dy, owner); theirs.dz = __shfl(ray.dz, owner);
+				theirs.ix = __shfl(ray.ix, owner); theirs.iy = __shfl(ray.iy, owner); theirs.iz = __shfl(ray.iz, owner);
+				if (lane < n) {
+					// a candidate of the padded walk: the leaf's own box decides whether the reference tests it (:189)
+					const uint32_t leaf = pair & 0x03FFFFFFu;
+					const float4 lo = load_f4(scene.tris, leaf * LEAF_BYTES), hi = load_f4(scene.tris, leaf * LEAF_BYTES + 16u);
+					if (exact_leaf_gate(lo, hi, theirs, P.primary_below)) {
+						const TriResult tr = tri_test<true>(scene.tris, leaf, theirs);
+						if (tr.accepted) {
+							atomicMin(&cb.best_key[owner], key_of(tr.distance, leaf));
+							atomicOr(&cb.hit_bits[owner >> 5], 1u << (owner & 31));
+						}
+					}
+				}
+			};
+			const unsigned long long alive_mask = wave_ballot(active);
+			const SignMasks sign = sign_masks(ray);
+			const uint32_t variant = walk_variant(sign, alive_mask);
+			const uint32_t first = 0u;  // (the plane-form records)
+			const WalkRay walk_ray = make_walk_ray(ray, 1.0f);
+			const uint32_t list_lds_address = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (uintptr_t) &cb.entry[0]);  // (low half of the flat address; scalar)
+			const uint32_t end = first + count * 32u;
+			uint32_t at = first;  // byte offset
+			while (alive_mask != 0ull && at < end) {
+				uint32_t leaf = 0u;
+				unsigned long long hit_mask = 0ull;
+				const uint32_t status = walk_collect<false>(variant, walk_ptr, at, walk_ray, sign, P.primary_below, alive_mask, hit_mask,
+				                                            leaf, waiting, leaf_stops, list_lds_address, lane << 26, P.batch_below);
+				if (status == 0u)
+					break;
+				if (status == 1u) {
+					const float4 *rec = tris_ptr + LEAF_F4 * leaf;
+					const float4 lo = rec[0], hi = rec[1], q0 = rec[2], q1 = rec[3], q2 = rec[4], q3 = rec[5];
+					if (((hit_mask >> lane) & 1ull) && exact_leaf_gate(lo, hi, ray, P.primary_below)) {
+						const TriResult tr = tri_eval<true>(q0, q1, q2, q3, ray);
+						if (tr.accepted) {
+							hit = true;
+							const unsigned long long key = key_of(tr.distance, leaf);
+							my_key = key < my_key ? key : my_key;
+						}
+					}
+				} else {
+					run_batch(64u);
+					waiting -= 64u;
+					if (lane < waiting)  // the pairs beyond the batch move to the front
+						cb.entry[lane] = cb.entry[64u + lane];
+				}
+				at += 32u;
+			}
+			if (waiting != 0u)
+				run_batch(waiting);
+			wave_lds_sync();
+			const unsigned long long batched = cb.best_key[lane];
+			const unsigned long long key = batched < my_key ? batched : my_key;
+			hit = hit || ((cb.hit_bits[lane >> 5] >> (lane & 31u)) & 1u);
+			// the nearest hit's barycentrics and position: the same test once more, on the ray's own lane.  (A
+			// distance of +inf or NaN never satisfies the reference's `best.distance > distance`: `best` stays as it is.)
+			if (hit && (uint32_t) (key >> 32) < INF_BITS) {
+				const uint32_t leaf = (uint32_t) key;
+				const TriResult tr = tri_test<true>(scene.tris, leaf, ray);
+				best.distance = tr.distance;
+				best.leaf = leaf;
+				best.s = tr.s;
+				best.t = tr.t;
+				best.px = tr.px; best.py = tr.py; best.pz = tr.pz;
+			}
+		} else {
+			uint32_t mine = 0u;
+			uint32_t at = 0u;
+			while (at < count) {
+				const u32x8 node = scalar_load_node(nodes_ptr, at);
+				const float4 lo = make_float4(__uint_as_float(node[0]), __uint_as_float(node[1]), __uint_as_float(node[2]), 0.0f);
+				const float4 hi = make_float4(__uint_as_float(node[4]), __uint_as_float(node[5]), __uint_as_float(node[6]), 0.0f);
+				const uint32_t skip = node[3], leaf = node[7];
+				const bool box = exact_box(lo, hi, ray, 100000.0f, active, at, skip, mine);
+				const bool any = wave_ballot(box) != 0ull;
+				if (any && leaf != NONE) {
+					leaf_test(leaf, box);
+					++leaf_stops;
+				}
+				at = (uint32_t) __builtin_amdgcn_readfirstlane((int) (at + (any ? 1u : skip)));
+			}
+		}
+	}
+#ifdef OCRT_DEBUG_KNOBS
+	if (!SHARED) {
+		const bool regular = P.scene_regular && ray_is_regular(ray);
+		uint32_t i = active ? 0u : count;
+		Pending pending = { NONE, NONE };
+		for (;;) {
+			const unsigned long long walking = wave_ballot(can_walk(pending, i, count));
+			const unsigned long long leaves = wave_ballot(pending.first != NONE);
+			if (leaves != 0ull && ((uint32_t) __popcll(leaves) >= P.leaf_min || walking == 0ull)) {
+				if (pending.first != NONE) {
+					const TriResult tr = tri_test<true>(scene.tris, pending.first, ray);
+					// closest hit = minimum of (distance, reference leaf), see nearer(); reference :106-112
+					if (tr.accepted) {
+						hit = true;
+						if (nearer(tr.distance, pending.first, best)) {
+							best.distance = tr.distance;
+							best.leaf = pending.first;
+							best.s = tr.s;
+							best.t = tr.t;
+							best.px = tr.px; best.py = tr.py; best.pz = tr.pz;
+						}
+					}
+					pending.first = pending.second;
+					pending.second = NONE;
+				}
+				continue;
+			}
+			if (walking == 0ull)
+				break;
+			advance_walkers(scene, ray, regular, 100000.0f, P.primary_below, count, i, pending);
+			if ((uint32_t) __popcll(wave_ballot(pending.first != NONE)) < P.leaf_min)
+				advance_walkers(scene, ray, regular, 100000.0f, P.primary_below, count, i, pending);
+		}
+	}
+#endif
+
+	// smooth normal and head-light term, reference :296-304
+	float value = 0.0f;
+	float nx = 0.0f, ny = 0.0f, nz = 0.0f;
+	if (hit) {
+		const float4 *const shade = OCRT_PCOLD_PTR(const float4 *, shade);
+		const float4 n0 = shade[3 * (size_t) best.leaf + 0];
+		const float4 n1 = shade[3 * (size_t) best.leaf + 1];
+		const float4 n2 = shade[3 * (size_t) best.leaf + 2];
+		const float b0 = 1.0f - best.s - best.t, b1 = best.s, b2 = best.t;
+		nx = (n0.x * b0 + n1.x * b1) + n2.x * b2;
+		ny = (n0.y * b0 + n1.y * b1) + n2.y * b2;
+		nz = (n0.z * b0 + n1.z * b1) + n2.z * b2;
+		normalize3(nx, ny, nz);
+		value = 1.0f;
+		if (OCRT_PCOLD_U32(P.shading))
+			value = fminf(fmaxf(-dot3(nx, ny, nz, dx, dy, dz), 0.0f), 1.0f);
+	}
+	const bool want_ao = OCRT_PCOLD_U32(P.ao_mode) != (uint32_t) AO_NONE && OCRT_PCOLD_U32(P.ao_dirs) > 0u;
+	const uint32_t image_width = OCRT_PCOLD_U32(P.width);
+	// the tile's hits go into the tile's own 64 slots of the hit list, compacted
+	const unsigned long long hit_mask = wave_ballot(hit);
+	const uint32_t hit_count = (uint32_t) __popcll(hit_mask);
+	const uint32_t slot_in_tile = rank_in(hit_mask);
+	if (active)  // final already, or the tag that says which slot will bring the ambient-occlusion factor
+		OCRT_PCOLD_PTR(float *, image)[(size_t) local_y * image_width + x] = (hit && want_ao) ? __uint_as_float(PENDING_TAG | slot_in_tile) : value;
+	if (lane == 0u) {
+		// hit count, and above it the tile's AO cost class 1..64 for the ordering step: its 28 AO packets
+		// walk about as far as the primary packet did (correlation 0.8-0.9, tools/analysis/packet_union.cc).
+		// The hit count does not predict the cost at all: a sparse tile's packets mix several directions
+		// and walk as many nodes as a full tile's.
+		uint32_t cost = SHARED ? leaf_stops : hit_count;
+		cost = cost < 1u ? 1u : cost;
+		cost = cost > 64u ? 64u : cost;
+		// (a store that is coherent across the device: the workgroup that orders the group's tiles at the end of this very
+		// kernel reads the word with a load of the same kind -- primary_kernel's tail)
+		__hip_atomic_store(&OCRT_PCOLD_PTR(uint32_t *, tile_hits)[tile], hit_count | ((want_ao && hit_count) ? cost << 8 : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+	// The hit list holds a tile's hits at tile_base[tile] ..., in the order of the lanes.  (tile_base is the exclusive
+	// prefix sum of the tiles' hit counts -- a function of scene, options and the fixed camera, counted once per upload by
+	// a pass of this kernel that has no hit list yet: `hits` is null then and nothing is recorded.)
+	HitRec *const hit_list = OCRT_PCOLD_PTR(HitRec *, hits);
+	if (hit && want_ao && hit_list) {
+		HitRec rec;
+		rec.ox = best.px; rec.oy = best.py; rec.oz = best.pz;
+		rec.value = value;
+		rec.nx = nx; rec.ny = ny; rec.nz = nz;
+		rec.pixel = local_y * image_width + x;  // index into this rank's band image
+		const size_t slot = (size_t) OCRT_PCOLD_PTR(const uint32_t *, tile_base)[tile] + slot_in_tile;
+		hit_list[slot] = rec;
+		OCRT_PCOLD_PTR(uint32_t *, occluded_of)[slot] = 0u;
+	}
+}
+
+// ---------------------------------------------------------------------------
+// Ordering step of one XCD group, run by the LAST workgroup of the primary pass that finishes in the group (below):
+// blocks of 64 neighbouring tiles sorted by their AO cost (sum of the tiles' cost classes >> KernelParams::cost_shift,
+// capped: the costly blocks share the top key and keep their spatial order, the cheap ones follow by cost --
+// scene_pack.cc says why); the tiles of a block stay together and in spatial order (counting sort, one wave per
+// block).  Also sums the group's hit sub-pixels.  Every tile word is read with a device-coherent load: the words were
+// written by other workgroups of this kernel.
+// ---------------------------------------------------------------------------
+struct OrderScratch {
+	unsigned int bucket[65];  // non-empty tiles per key, then the keys' write cursors
+	unsigned int cost_total;  // sum of the group's tiles' cost classes
+	unsigned int hit_total;   // hit sub-pixels of the group
+	unsigned int last;        // (primary_kernel's tail: this workgroup is the group's last)
+};
+__device__ __forceinline__ void order_group(const uint32_t *__restrict__ tile_hits, uint32_t *__restrict__ order,
+                                            FrameCounters *__restrict__ counters, uint32_t tiles_x, uint32_t local_tile_rows,
+                                            uint32_t strip_tiles, bool no_sort, uint32_t cost_shift, uint32_t group,
+                                            OrderScratch &scratch, uint32_t waves) {
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	const uint32_t strips = (tiles_x + strip_tiles - 1u) / strip_tiles;
+	const uint32_t strips_here = (strips + XCD_GROUPS - 1u - group) >> 3;
+	const uint32_t tiles_here = strips_here * strip_tiles * local_tile_rows;  // incl. possible columns past the image
+	// this group's segment of `order` starts where the previous groups' capacity ends
+	uint32_t segment = 0u;
+	for (uint32_t g = 0; g < group; ++g)
+		segment += ((strips + XCD_GROUPS - 1u - g) >> 3) * strip_tiles * local_tile_rows;
+	if (threadIdx.x < 65u)
+		scratch.bucket[threadIdx.x] = 0u;
+	if (threadIdx.x == 0u) {
+		scratch.cost_total = 0u;
+		scratch.hit_total = 0u;
+	}
+	__syncthreads();
+	// tile e of the group: strip (e / (strip_tiles * rows)), then row-major across the strip; returns its word (0: nothing there)
+	auto word_of = [&](uint32_t e, uint32_t &tile) -> uint32_t {
+		if (e >= tiles_here)
+			return 0u;
+		const uint32_t per_strip = strip_tiles * local_tile_rows;
+		const uint32_t strip_index = e / per_strip, within = e - strip_index * per_strip;
+		const uint32_t local_row = within / strip_tiles;
+		const uint32_t tile_x = strip_tiles * (group + XCD_GROUPS * strip_index) + (within - local_row * strip_tiles);
+		tile = local_row * tiles_x + tile_x;
+		if (tile_x >= tiles_x)
+			return 0u;
+		return __hip_atomic_load(&tile_hits[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	};
+	// One wave per block of 64 spatially consecutive tiles (a strip wide, 64 / strip_tiles high).  key: the block's cost, 1..64.
+	const uint32_t n_blocks = (tiles_here + 63u) >> 6;
+	auto block_key = [&](uint32_t block, uint32_t &tile, uint32_t &word, unsigned long long &work_mask, uint32_t &cost) -> uint32_t {
+		word = word_of(block * 64u + lane, tile);
+		const uint32_t cls = word >> 8;
+		work_mask = wave_ballot(cls != 0u);
+		cost = cls;
+		for (int offset = 32; offset >= 1; offset >>= 1)
+			cost += (uint32_t) __shfl_xor((int) cost, offset);
+		const uint32_t key = no_sort ? 1u : 1u + (cost >> cost_shift);
+		return key > 64u ? 64u : key;
+	};
+	for (uint32_t block = wave; block < n_blocks; block += waves) {
+		uint32_t tile = 0u, word, cost;
+		unsigned long long work_mask;
+		const uint32_t key = block_key(block, tile, word, work_mask, cost);
+		uint32_t hit_sum = word & 0xFFu;
+		for (int offset = 32; offset >= 1; offset >>= 1)
+			hit_sum += (uint32_t) __shfl_xor((int) hit_sum, offset);
+		if (lane == 0u) {
+			if (work_mask != 0ull) {
+				atomicAdd(&scratch.bucket[key], (uint32_t) __popcll(work_mask));
+				atomicAdd(&scratch.cost_total, cost);
+			}
+			if (hit_sum)
+				atomicAdd(&scratch.hit_total, hit_sum);
+		}
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		// exclusive prefix over descending keys: costly regions first, so that the frame ends on short claims
+		uint32_t running = 0u;
+		for (int k = 64; k >= 1; --k) {
+			const uint32_t n = scratch.bucket[k];
+			scratch.bucket[k] = running;
+			running += n;
+		}
+		counters->queue[group].work_tiles = running;
+		counters->queue[group].cost_sum = scratch.cost_total;
+		counters->queue[group].hits = scratch.hit_total;
+		counters->queue[group].head = 0u;
+	}
+	__syncthreads();
+	for (uint32_t block = wave; block < n_blocks; block += waves) {
+		uint32_t tile = 0u, word, cost;
+		unsigned long long work_mask;
+		const uint32_t key = block_key(block, tile, word, work_mask, cost);
+		if (work_mask == 0ull)
+			continue;
+		uint32_t base = 0u;
+		if (lane == 0u)
+			base = atomicAdd(&scratch.bucket[key], (uint32_t) __popcll(work_mask));
+		base = (uint32_t) __builtin_amdgcn_readfirstlane((int) base);
+		// entry = tile (26 bits: at most 2^32 sub-pixels per frame) | hit count - 1 (6 bits); inside a block
+		// the tiles keep their spatial order
+		if (word >> 8)
+			order[segment + base + rank_in(work_mask)] = tile | (((word & 0xFFu) - 1u) << 26);
+	}
+	if (threadIdx.x == 0) {
+		counters->queue[group].tick_ordered = (unsigned long long) __builtin_amdgcn_s_memrealtime();
+#ifdef OCRT_TAIL  // (the AO pass starts right after this kernel: its waves' end times are counted from here)
+		atomicMax(&counters->stamp[7], __builtin_amdgcn_s_memrealtime());
+#endif
+	}
+}
+
+// ---------------------------------------------------------------------------
+// Pass 1: primary rays, then -- the last workgroup of each XCD group -- the group's ordering step.  Four waves per
+// workgroup, one tile each; they meet once, at the end.
+//
+// Why the ordering step lives here and not in a kernel of its own: it is 8 workgroups of work, and as a kernel it cost
+// a frame that shares its GPU ~0.2 ms of waiting (a launch boundary on either side, and workgroups of 1024 threads that
+// need 16 free wave slots on one CU while other frames' persistent passes hold them).  The hand-over inside the kernel:
+// every wave's tile word is a device-coherent store (primary_tile), drained (s_waitcnt vmcnt(0)) before the workgroup's
+// barrier; then ONE returning atomic per workgroup on the group's `done` counter -- whoever takes it to the number of
+// the group's workgroups is the last, reads the words with device-coherent loads and puts the counter back to 0 for the
+// next frame.  (MI355X_MICROARCH.md, inter-workgroup visibility: sc1 stores drained before the counter, sc1 loads after it.)
+// ---------------------------------------------------------------------------
+#ifndef OCRT_PRIMARY_WAVES
+#define OCRT_PRIMARY_WAVES 4
+#endif
+constexpr uint32_t PRIMARY_WAVES = OCRT_PRIMARY_WAVES;  // 4, 8 or 16: a workgroup covers a block of tiles 2 wide and PRIMARY_WAVES / 2 high
+constexpr uint32_t PRIMARY_ROWS = PRIMARY_WAVES / 2u;
+
+template <bool SHARED>
+__global__ __launch_bounds__(64 * PRIMARY_WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void primary_kernel(PrimaryArgs A) {
+	__shared__ ClosestBatch closest_batches[PRIMARY_WAVES];
+	__shared__ OrderScratch scratch;
+	const uint32_t wave = threadIdx.x >> 6;
+	if (blockIdx.x == 0u && threadIdx.x == 0u) {
+		FrameCounters *const counters = A.counters;
+		counters->tick_begin = __builtin_amdgcn_s_memrealtime();
+		// the sums the LATER kernels of this frame add to (nobody touches them before this kernel has ended)
+		counters->occluded = 0ull;
+		counters->tick_ao_end = 0ull;
+	}
+	const uint32_t group = blockIdx.x & (XCD_GROUPS - 1u), seq = blockIdx.x >> 3;
+	{
+		const uint32_t strip_tiles = A.P.strip_tiles, columns = strip_tiles >> 1;  // (a workgroup is two tiles wide)
+		const uint32_t strips = (A.P.tiles_x + strip_tiles - 1u) / strip_tiles;
+		const uint32_t row_blocks = (A.P.local_tile_rows + PRIMARY_ROWS - 1u) / PRIMARY_ROWS;
+		const uint32_t strips_here = (strips + XCD_GROUPS - 1u - group) >> 3;
+		const uint32_t per_strip = row_blocks * columns;
+		const uint32_t strip_index = seq / per_strip;
+		const uint32_t rest = seq - strip_index * per_strip;
+		const uint32_t row_block = rest / columns;
+		const uint32_t tile_x = strip_tiles * (group + XCD_GROUPS * strip_index) + 2u * (rest - row_block * columns) + (wave & 1u);
+		const uint32_t local_row = PRIMARY_ROWS * row_block + (wave >> 1);
+		if (seq < strips_here * per_strip && tile_x < A.P.tiles_x && local_row < A.P.local_tile_rows)
+			primary_tile<SHARED>(A, closest_batches, tile_x, local_row);
+	}
+	// ---- the tail: is this the group's last workgroup? ----
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (this wave's tile word has left)
+	__syncthreads();
+	if (threadIdx.x == 0u) {
+		FrameCounters *const counters = OCRT_PCOLD_PTR(FrameCounters *, counters);
+		const uint32_t before = __hip_atomic_fetch_add(&counters->queue[group].done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		scratch.last = before + 1u == gridDim.x / XCD_GROUPS ? 1u : 0u;
+	}
+	__syncthreads();
+	if (scratch.last == 0u)
+		return;
+	FrameCounters *const counters = OCRT_PCOLD_PTR(FrameCounters *, counters);
+	order_group(OCRT_PCOLD_PTR(const uint32_t *, tile_hits), OCRT_PCOLD_PTR(uint32_t *, order), counters, OCRT_PCOLD_U32(P.tiles_x),
+	            OCRT_PCOLD_U32(P.local_tile_rows), OCRT_PCOLD_U32(P.strip_tiles), OCRT_PCOLD_U32(P.debug_no_sort) != 0u,
+	            OCRT_PCOLD_U32(P.cost_shift), group, scratch, PRIMARY_WAVES);
+	if (threadIdx.x == 0u)
+		__hip_atomic_store(&counters->queue[group].done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+}  // namespace ocrt
