@@ -1,6 +1,7 @@
 #include "device_renderer.h"
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 
@@ -471,18 +472,30 @@ void DeviceRenderer::sizeHitList(const DeviceRenderer *layout_from) {
 		// (on this renderer's stream, and waited for: the stream is a non-blocking one, which work on the null stream is not
 		// ordered against, and a copy or fill between device buffers need not have finished when its call returns)
 		OCRT_HIP(hipMemcpyAsync(d_tile_base, layout_from->d_tile_base, tile_count * sizeof(uint32_t), hipMemcpyDeviceToDevice, (hipStream_t) stream));
+		// (the tile words too: hit count | cost class per tile, what walkEntries() and the statistics read before this
+		// renderer's own first frame has written them)
+		OCRT_HIP(hipMemcpyAsync(d_tile_hits, layout_from->d_tile_hits, tile_count * sizeof(uint32_t), hipMemcpyDeviceToDevice, (hipStream_t) stream));
 		OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));
+		// ... and the order its tiles are claimed in by the ambient-occlusion pass
+		tile_cost = layout_from->tile_cost;
+		installOrder(layout_from->order_host, layout_from->queue_static);
 		d_hits = device_alloc((hit_slots ? hit_slots : 1) * sizeof(HitRec));
 		d_occluded = device_alloc((hit_slots ? hit_slots : 1) * sizeof(uint32_t));
 		clock.mark("hit list laid out like the ring's first host");
 		return;
 	}
-	launch_primary(scene_on_device->buffers(), (float *) d_image, nullptr, nullptr, d_tile_hits, d_order, d_tile_base, d_counters, kp, stream);
+	launch_primary(scene_on_device->buffers(), (float *) d_image, nullptr, nullptr, d_tile_hits, d_tile_base, d_counters, kp, stream);
 	OCRT_HIP(hipGetLastError());
 	std::vector<uint32_t> words(tile_count);
 	OCRT_HIP(hipMemcpyAsync(words.data(), d_tile_hits, tile_count * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t) stream));
 	OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));
 	clock.mark("counting pass + tile words to the host");
+	// the order the ambient-occlusion pass claims the tiles in: by the cost class the counting pass found (the leaves each
+	// tile's primary packet stopped at) until somebody has measured what the tiles' any-hit rays really cost
+	tile_words = words;
+	tile_cost.clear();
+	orderTiles();
+	clock.mark("tiles ordered for the ambient-occlusion pass");
 	unsigned long long running = 0;
 	for (uint32_t &w : words) {
 		const uint32_t count = w & 0xFFu;
@@ -502,7 +515,7 @@ void DeviceRenderer::sizeHitList(const DeviceRenderer *layout_from) {
 	// primary kernel fills the list, entry_kernel reads the tiles' hit points (kernels.hip; the whole array where the
 	// fast walk is not used).  Like the bases: once per upload.
 	if (kp.fast_walk && scene_on_device->buffers().walk) {
-		launch_primary(scene_on_device->buffers(), (float *) d_image, d_hits, d_occluded, d_tile_hits, d_order, d_tile_base, d_counters, kp, stream);
+		launch_primary(scene_on_device->buffers(), (float *) d_image, d_hits, d_occluded, d_tile_hits, d_tile_base, d_counters, kp, stream);
 		launch_entries(scene_on_device->buffers(), d_hits, d_tile_hits, d_tile_base, d_tile_entry, kp, stream);
 		OCRT_HIP(hipGetLastError());
 	} else {
@@ -520,6 +533,161 @@ void DeviceRenderer::sizeHitList(const DeviceRenderer *layout_from) {
 	OCRT_HIP(hipMemsetAsync(d_image, 0, image_bytes, (hipStream_t) stream));
 	OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));
 	clock.mark("entries of the tiles' any-hit walks");
+}
+
+// The order in which the ambient-occlusion pass claims the tiles (kernels/ao.hip.h): per XCD group -- the image's strips
+// are dealt round-robin to eight groups, kernels/primary.hip.h -- a list of the group's non-empty tiles, entry = tile |
+// (hit count - 1) << 26, costly tiles first so that the pass ends on short claims.  Camera, scene and options are fixed
+// per upload, so the list is too: it is made here, once, on the host (until round 4 the last workgroup of every frame's
+// primary pass sorted its group's tiles again).
+// The rule (`tile_cost` empty): blocks of 64 neighbouring tiles -- a strip wide, 64 / strip_tiles high -- by the sum of
+// their tiles' cost classes >> cost_shift, capped: every block of the model shares the top key and those blocks keep
+// their spatial order (neighbouring claims walk the same part of the tree: scalar cache and L2 see it again; a finer
+// key cost 3-10 % per frame, scene_pack.cc), the cheap blocks follow by cost; inside a block the tiles stay in spatial
+// order.  With measured costs per tile (`tile_cost`, DeviceRenderer::measureTileCosts): see orderByMeasuredCost.
+void DeviceRenderer::orderTiles() {
+	const uint32_t strip_tiles = kp.strip_tiles, rows = kp.local_tile_rows, tiles_x = kp.tiles_x;
+	const uint32_t strips = (tiles_x + strip_tiles - 1u) / strip_tiles;
+	const size_t order_slots = (size_t) ((tiles_x + MAX_STRIP_TILES - 1) / MAX_STRIP_TILES) * MAX_STRIP_TILES * rows;
+	std::vector<uint32_t> order(order_slots ? order_slots : 1, 0u);
+	std::array<std::array<uint32_t, 3>, XCD_GROUPS> constants{};
+	const bool measured = tile_cost.size() == tile_count;
+	size_t segment = 0;
+	for (uint32_t group = 0; group < XCD_GROUPS; ++group) {
+		const uint32_t strips_here = (strips + XCD_GROUPS - 1u - group) >> 3;
+		const uint32_t per_strip = strip_tiles * rows;
+		const uint32_t tiles_here = strips_here * per_strip;  // incl. possible columns past the image
+		// element e of the group: strip e / per_strip, then row-major across the strip
+		struct Element {
+			uint32_t tile, word;
+		};
+		std::vector<Element> elements;
+		elements.reserve(tiles_here);
+		for (uint32_t e = 0; e < tiles_here; ++e) {
+			const uint32_t strip_index = e / per_strip, within = e - strip_index * per_strip;
+			const uint32_t local_row = within / strip_tiles;
+			const uint32_t tile_x = strip_tiles * (group + XCD_GROUPS * strip_index) + (within - local_row * strip_tiles);
+			const uint32_t tile = local_row * tiles_x + tile_x;
+			elements.push_back(Element{ tile, tile_x < tiles_x ? tile_words[tile] : 0u });
+		}
+		uint32_t work = 0, cost_total = 0, hit_total = 0;
+		for (const Element &el : elements) {
+			hit_total += el.word & 0xFFu;
+			if (el.word >> 8) {
+				++work;
+				cost_total += el.word >> 8;
+			}
+		}
+		std::vector<uint32_t> listed;  // indices into `elements`, in claim order
+		listed.reserve(work);
+		if (measured) {
+			std::vector<uint32_t> candidates;
+			for (uint32_t e = 0; e < tiles_here; ++e)
+				if (elements[e].word >> 8)
+					candidates.push_back(e);
+			std::vector<float> cost(candidates.size());
+			for (size_t i = 0; i < candidates.size(); ++i)
+				cost[i] = tile_cost[elements[candidates[i]].tile];
+			for (uint32_t at : orderByMeasuredCost(cost))
+				listed.push_back(candidates[at]);
+		} else {
+			const uint32_t n_blocks = (tiles_here + 63u) >> 6;
+			std::vector<std::pair<uint32_t, uint32_t>> blocks;  // (key, block), stable by block
+			for (uint32_t block = 0; block < n_blocks; ++block) {
+				uint32_t cost = 0;
+				for (uint32_t e = block * 64u; e < tiles_here && e < block * 64u + 64u; ++e)
+					cost += elements[e].word >> 8;
+				uint32_t key = kp.debug_no_sort ? 1u : 1u + (cost >> kp.cost_shift);
+				blocks.push_back({ key > 64u ? 64u : key, block });
+			}
+			std::stable_sort(blocks.begin(), blocks.end(), [](const auto &a, const auto &b) { return a.first > b.first; });
+			for (const auto &b : blocks)
+				for (uint32_t e = b.second * 64u; e < tiles_here && e < b.second * 64u + 64u; ++e)
+					if (elements[e].word >> 8)
+						listed.push_back(e);
+		}
+		for (size_t i = 0; i < listed.size(); ++i) {
+			const Element &el = elements[listed[i]];
+			order[segment + i] = el.tile | (((el.word & 0xFFu) - 1u) << 26);  // (tile: 26 bits, at most 2^32 sub-pixels per frame)
+		}
+		constants[group] = { work, cost_total, hit_total };
+		segment += tiles_here;
+	}
+	installOrder(order, constants);
+}
+
+// Claim order of one group's tiles from their MEASURED costs (device-clock ticks a tile's 28 packets kept a workgroup
+// busy, measureTileCosts): `cost` in the tiles' spatial order, returns the indices in claim order.
+// What matters is how the pass ENDS: a claim is a whole tile for a workgroup's four waves, a costly tile keeps them
+// busy ~0.15 ms of a 1 ms pass and some tiles cost four times the median -- claimed in spatial order, a third of the
+// pass ran at falling occupancy (profiles/r05_notes.md).  So: tiles whose cost stands out (beyond `heavy` x the
+// median of the costly half) go first, the costly ones follow IN SPATIAL ORDER up to the point where what is left
+// would keep the group's workgroups busy for about `runway` median claims each, from there on by falling cost.
+std::vector<uint32_t> DeviceRenderer::orderByMeasuredCost(const std::vector<float> &cost) const {
+	const size_t n = cost.size();
+	std::vector<uint32_t> out;
+	out.reserve(n);
+	if (n == 0)
+		return out;
+	std::vector<float> sorted(cost);
+	std::sort(sorted.begin(), sorted.end());
+	const float median_costly = sorted[n - 1 - (n - 1) / 4];  // median of the costly half = the upper quartile
+	const float heavy_from = order_policy.heavy * median_costly;
+	std::vector<uint32_t> heavy_ones, rest;
+	for (uint32_t i = 0; i < n; ++i)
+		(cost[i] > heavy_from ? heavy_ones : rest).push_back(i);
+	std::stable_sort(heavy_ones.begin(), heavy_ones.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+	// the runway: the cheapest-to-finish-on part of what is left, `runway` median claims per workgroup of the group
+	double budget = (double) order_policy.runway * median_costly * (double) (aoWorkgroups() / XCD_GROUPS ? aoWorkgroups() / XCD_GROUPS : 1u);
+	std::vector<uint32_t> by_cost(rest);
+	std::stable_sort(by_cost.begin(), by_cost.end(), [&](uint32_t a, uint32_t b) { return cost[a] < cost[b]; });
+	std::vector<char> in_runway(n, 0);
+	// spatial part first: everything that is costly (above the lower quartile) stays in spatial order until the budget of
+	// the runway is what remains; the runway holds the LAST costly tiles in spatial order plus all cheap ones
+	double total_rest = 0.0;
+	for (uint32_t i : rest)
+		total_rest += cost[i];
+	double ahead = 0.0;
+	std::vector<uint32_t> spatial, runway;
+	for (uint32_t i : rest) {
+		if (total_rest - ahead > budget)
+			spatial.push_back(i);
+		else
+			runway.push_back(i);
+		ahead += cost[i];
+	}
+	(void) by_cost;
+	(void) in_runway;
+	std::stable_sort(runway.begin(), runway.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+	// cheap tiles inside the spatial part would hold up nothing, but they are worth more at the end: move those below a
+	// quarter of the median to the runway's tail
+	std::vector<uint32_t> spatial_costly, cheap;
+	for (uint32_t i : spatial)
+		(cost[i] < 0.25f * median_costly ? cheap : spatial_costly).push_back(i);
+	std::stable_sort(cheap.begin(), cheap.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+	out.insert(out.end(), heavy_ones.begin(), heavy_ones.end());
+	out.insert(out.end(), spatial_costly.begin(), spatial_costly.end());
+	// runway and cheap tiles merged by falling cost
+	std::vector<uint32_t> tail(runway);
+	tail.insert(tail.end(), cheap.begin(), cheap.end());
+	std::stable_sort(tail.begin(), tail.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+	out.insert(out.end(), tail.begin(), tail.end());
+	return out;
+}
+
+void DeviceRenderer::installOrder(const std::vector<uint32_t> &order, const std::array<std::array<uint32_t, 3>, XCD_GROUPS> &constants) {
+	order_host = order;
+	queue_static = constants;
+	OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));
+	OCRT_HIP(hipMemcpy(d_order, order_host.data(), order_host.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	FrameCounters fresh{};
+	for (uint32_t g = 0; g < XCD_GROUPS; ++g) {
+		fresh.queue[g].work_tiles = constants[g][0];
+		fresh.queue[g].cost_sum = constants[g][1];
+		fresh.queue[g].hits = constants[g][2];
+	}
+	OCRT_HIP(hipMemcpy(d_counters, &fresh, sizeof fresh, hipMemcpyHostToDevice));
+	++scene_version;  // (nothing a captured frame bakes in has changed, but a frame in flight must not see the list change: callers synchronise)
 }
 
 DeviceRenderer::FrameEvents DeviceRenderer::takeEvents() {
@@ -547,7 +715,7 @@ void DeviceRenderer::launchFrame(void *device_u8, void *ao_start, void *ao_stop)
 	hipStream_t s = (hipStream_t) stream;
 #endif
 	const SceneBuffers scene = scene_on_device->buffers();
-	launch_primary(scene, (float *) d_image, d_hits, d_occluded, d_tile_hits, d_order, d_tile_base, d_counters, kp, stream);
+	launch_primary(scene, (float *) d_image, d_hits, d_occluded, d_tile_hits, d_tile_base, d_counters, kp, stream);
 	OCRT_HIP(hipGetLastError());
 #ifdef OCRT_STAMPS  // (instrumented build: the AO pass takes the minimum of its waves' start times into this slot)
 	OCRT_HIP(hipMemsetAsync((char *) d_counters + offsetof(FrameCounters, stamp) + 7 * sizeof(unsigned long long), 0xFF, sizeof(unsigned long long), s));
@@ -789,9 +957,7 @@ void DeviceRenderer::synchronize() {
 		} else if (ev.graph_ao && newest && keep_stamps) {
 			FrameCounters c{};
 			OCRT_HIP(hipMemcpy(&c, d_counters, sizeof c, hipMemcpyDeviceToHost));
-			unsigned long long tick[3] = { c.tick_begin, 0, c.tick_ao_end };
-			for (const GroupQueue &q : c.queue)  // the ambient-occlusion pass may begin when the last group is ordered
-				tick[1] = q.tick_ordered > tick[1] ? q.tick_ordered : tick[1];
+			const unsigned long long tick[3] = { c.tick_begin, c.tick_ao_begin, c.tick_ao_end };
 			if (tick[2] >= tick[1] && tick[1] >= tick[0] && tick[0] != 0) {
 				ao_ms = (float) ((double) (tick[2] - tick[1]) * 1e-5);  // 100 MHz clock -> ms
 				ao_begin_after_start = (float) ((double) (tick[1] - tick[0]) * 1e-5);
@@ -884,11 +1050,15 @@ RenderStats DeviceRenderer::stats() {
 	}
 	FrameCounters c{};
 	OCRT_HIP(hipMemcpy(&c, d_counters, sizeof c, hipMemcpyDeviceToHost));
-	for (const GroupQueue &q : c.queue)
-		out.primary_hits += q.hits;
+	{  // hit sub-pixels: the low byte of the words the frame's primary pass left per tile
+		std::vector<uint32_t> words(tile_count);
+		OCRT_HIP(hipMemcpy(words.data(), d_tile_hits, tile_count * sizeof(uint32_t), hipMemcpyDeviceToHost));
+		for (uint32_t w : words)
+			out.primary_hits += w & 0xFFu;
+	}
 	out.ao_occluded = has_ao ? c.occluded : 0;
 #ifdef OCRT_TAIL
-	std::fprintf(stderr, "AO pass: last wave ended %.3f ms after the ordering step; waves by the time they ended at (0.05 ms buckets):", (c.stamp[8] - c.stamp[7]) * 1e-5);
+	std::fprintf(stderr, "AO pass: last wave ended %.3f ms after the pass began; waves by the time they ended at (0.05 ms buckets):", (c.stamp[8] - c.tick_ao_begin) * 1e-5);
 	for (int k = 0; k < 32; ++k)
 		if (c.stamp[10 + k])
 			std::fprintf(stderr, " %.2f:%llu", k * 0.05, c.stamp[10 + k]);

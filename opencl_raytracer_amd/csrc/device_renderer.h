@@ -4,6 +4,7 @@
 // (HipHost with the reference's print-and-exit convention, the C ABI with
 // return codes) decide what to do with them.
 #pragma once
+#include <array>
 #include <cstdint>
 #include <memory>
 #include <stdexcept>
@@ -212,6 +213,18 @@ class DeviceRenderer {
 		std::shared_ptr<void> tile_entry_owner;  // d_tile_entry: one table for the hosts of a ring (sizeHitList)
 		void allocEntries(size_t bytes);
 		void sizeHitList(const DeviceRenderer *layout_from);  // counts the hits per tile with one pass of the primary kernel (or copies another renderer's count) and sizes the list by them
+		// The order the ambient-occlusion pass claims the tiles in, made once per upload on the host (orderTiles): from the
+		// tile words of the pass that sizes the hit list (hit count | cost class), or from measured costs per tile.
+		std::vector<uint32_t> tile_words, order_host;
+		std::vector<float> tile_cost;  // measured: device-clock ticks per tile (empty: not measured)
+		std::array<std::array<uint32_t, 3>, XCD_GROUPS> queue_static{};  // per group: non-empty tiles, sum of cost classes, hit sub-pixels
+		struct OrderPolicy {
+			float heavy = 1.6f;   // tiles beyond this many median (costly-half) costs are claimed first
+			float runway = 2.0f;  // what is left for the end, by falling cost: this many median claims per workgroup
+		} order_policy;
+		void orderTiles();
+		std::vector<uint32_t> orderByMeasuredCost(const std::vector<float> &cost) const;
+		void installOrder(const std::vector<uint32_t> &order, const std::array<std::array<uint32_t, 3>, XCD_GROUPS> &constants);
 		size_t image_bytes;  // float image of this rank's bands
 		size_t tile_count;
 		uint32_t compute_units;
@@ -251,7 +264,7 @@ class DeviceRenderer {
 
 // kernels.hip
 void preload_kernels();
-void launch_primary(const SceneBuffers &scene, float *image, void *hits, void *occluded_of, void *tile_hits, void *order,
+void launch_primary(const SceneBuffers &scene, float *image, void *hits, void *occluded_of, void *tile_hits,
                     const void *tile_base, void *counters, const KernelParams &P, void *stream);
 void launch_entries(const SceneBuffers &scene, const void *hits, const void *tile_hits, const void *tile_base, void *tile_entry,
                     const KernelParams &P, void *stream);

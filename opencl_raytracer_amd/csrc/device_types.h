@@ -56,32 +56,30 @@ struct HitRec {
 };
 static_assert(sizeof(HitRec) == 32, "HitRec is two float4");
 
-// Device-side counters of one frame.  Nothing here needs clearing between frames by a kernel of its own: what the
-// primary pass's tail writes it writes whole (plain stores), the running sums are zeroed by the first workgroup of the
-// primary pass before any of the later kernels that add to them can run, and `done` returns to 0 by itself.  (The
-// buffer is zeroed once, when it is allocated.)
-// Each group's queue sits in its own 128-byte line: the heads are hammered with
-// returning atomics by every wave of the AO pass.
+// Device-side counters of one frame.  Nothing here needs clearing between frames by a kernel of its own: the queues'
+// heads and the running sums are put back by the first workgroup of the primary pass, before any of the later kernels
+// that add to them can run.  (The buffer is zeroed once, when it is allocated.)
+// Each group's queue sits in its own 128-byte line: the heads are hammered with returning atomics by every workgroup
+// of the AO pass.  What a queue holds is the same in every frame of an uploaded scene (camera, scene and options are
+// fixed, so the tiles that are hit and what their any-hit rays cost are too): the ordered tile lists and the three
+// constants below are made ONCE per upload, on the host, from the pass that sizes the hit list (DeviceRenderer::
+// orderTiles) -- until round 4 the last workgroup of every frame's primary pass sorted its group's tiles again.
 struct alignas(128) GroupQueue {
-	uint32_t head;        // next unclaimed entry of the group's ordered tile list
-	uint32_t work_tiles;  // non-empty tiles of the group (written by the ordering step)
-	uint32_t cost_sum;    // sum of their AO cost classes (ditto)
-	uint32_t hits;        // hit sub-pixels in the group's tiles (ditto)
-	uint32_t done;        // workgroups of the primary pass that are through: the last one runs the group's ordering step
-	                      // (kernels.hip, primary_kernel) and puts this back to 0
-	uint32_t pad0;
-	unsigned long long tick_ordered;  // device clock when the group's ordering step ended
-	uint32_t pad[24];
+	uint32_t head;        // next unclaimed (tile, table direction) unit of the group's ordered tile list (per frame)
+	uint32_t work_tiles;  // non-empty tiles of the group (per upload)
+	uint32_t cost_sum;    // sum of their AO cost classes (per upload)
+	uint32_t hits;        // hit sub-pixels in the group's tiles (per upload)
+	uint32_t pad[28];
 };
 static_assert(sizeof(GroupQueue) == 128, "one line per queue");
 struct FrameCounters {
 	GroupQueue queue[XCD_GROUPS];
 	unsigned long long occluded;  // occluded AO rays: summed from the hit list's counts when the statistic is asked for (occluded_sum_kernel)
 	// The device's own 100 MHz clock (s_memrealtime) read by the kernels: when the primary pass began (its first
-	// workgroup), when the last workgroup of the ambient-occlusion pass ended; the ordering steps' ends are in the
-	// queues.  A frame replayed from a captured hipGraph has no HIP events inside it that could be timed
-	// (hipEventElapsedTime refuses event-record nodes); these say when its passes ran.
-	unsigned long long tick_begin, tick_ao_end;
+	// workgroup), when the first workgroup of the ambient-occlusion pass began and when its last one ended.  A frame
+	// replayed from a captured hipGraph has no HIP events inside it that could be timed (hipEventElapsedTime refuses
+	// event-record nodes); these say when its passes ran.
+	unsigned long long tick_begin, tick_ao_begin, tick_ao_end;
 #if defined(OCRT_STAMPS) || defined(OCRT_TAIL)
 	unsigned long long stamp[10 + 32 + 7 + 16];  // debug build: wave-time (10 ns ticks) per phase of the AO pass, jobs, packets
 #endif

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void clear_stamps_kernel(FrameCounters *counte
 
 // The frame is three kernels (two without ambient occlusion): primary pass (+ ordering step in its tail), the
 // ambient-occlusion pass, the finishing kernel (AO factor + box filter + quantisation).
-void launch_primary(const SceneBuffers &scene, float *image, void *hits, void *occluded_of, void *tile_hits, void *order,
+void launch_primary(const SceneBuffers &scene, float *image, void *hits, void *occluded_of, void *tile_hits,
                     const void *tile_base, void *counters, const KernelParams &P, void *stream) {
 	hipStream_t s = (hipStream_t) stream;
 #if defined(OCRT_STAMPS) || defined(OCRT_TAIL)
@@ -107,7 +107,6 @@ void launch_primary(const SceneBuffers &scene, float *image, void *hits, void *o
 		args.hits = (HitRec *) hits;
 		args.occluded_of = (uint32_t *) occluded_of;
 		args.tile_hits = (uint32_t *) tile_hits;
-		args.order = (uint32_t *) order;
 		args.tile_base = (const uint32_t *) tile_base;
 		args.counters = (FrameCounters *) counters;
 		args.P = P;

@@ -99,6 +99,8 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 	unsigned long long walk_prof_store[7] = { 0, 0, 0, 0, 0, 0, 0 };
 	unsigned long long *walk_prof = walk_prof_store;
 #endif
+	if (blockIdx.x == 0u && threadIdx.x == 0u)  // (when the pass began, by the device's clock: frames replayed from a graph have no events inside)
+		__hip_atomic_store(&OCRT_COLD_PTR(FrameCounters *, counters)->tick_ao_begin, (unsigned long long) __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	// Workgroups b and b+8 share an XCD: start with that group's queue, then help the others.
 	const uint32_t home = blockIdx.x & (XCD_GROUPS - 1u);
 	for (uint32_t turn = 0; turn < XCD_GROUPS; ++turn) {
@@ -500,7 +502,7 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 #ifdef OCRT_TAIL  // minimal: nothing is kept across the pass, one load and two atomics when the wave ends
 	if (fresh_lane() == 0u) {
 		const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
-		const unsigned long long origin = __hip_atomic_load(&A.counters->stamp[7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const unsigned long long origin = __hip_atomic_load(&A.counters->tick_ao_begin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		const unsigned long long end_bucket = (t_end - origin) / 5000ull;  // 0.05 ms
 		atomicAdd(&A.counters->stamp[10 + (end_bucket > 31 ? 31 : end_bucket)], 1ull);
 		atomicMax(&A.counters->stamp[8], t_end);

@@ -40,7 +40,7 @@ struct PrimaryArgs {
 	const float4 *nodes_ptr, *shade;
 	float *image;
 	HitRec *hits;
-	uint32_t *occluded_of, *tile_hits, *order;
+	uint32_t *occluded_of, *tile_hits;
 	const uint32_t *tile_base;  // first slot of each tile in the hit list (DeviceRenderer: a prefix sum of the tiles' hit counts)
 	FrameCounters *counters;
 	KernelParams P;
@@ -276,9 +276,7 @@ __device__ __forceinline__ void primary_tile(const PrimaryArgs &A, ClosestBatch 
 		uint32_t cost = SHARED ? leaf_stops : hit_count;
 		cost = cost < 1u ? 1u : cost;
 		cost = cost > 64u ? 64u : cost;
-		// (a store that is coherent across the device: the workgroup that orders the group's tiles at the end of this very
-		// kernel reads the word with a load of the same kind -- primary_kernel's tail)
-		__hip_atomic_store(&OCRT_PCOLD_PTR(uint32_t *, tile_hits)[tile], hit_count | ((want_ao && hit_count) ? cost << 8 : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		OCRT_PCOLD_PTR(uint32_t *, tile_hits)[tile] = hit_count | ((want_ao && hit_count) ? cost << 8 : 0u);
 	}
 	// The hit list holds a tile's hits at tile_base[tile] ..., in the order of the lanes.  (tile_base is the exclusive
 	// prefix sum of the tiles' hit counts -- a function of scene, options and the fixed camera, counted once per upload by
@@ -297,128 +295,13 @@ __device__ __forceinline__ void primary_tile(const PrimaryArgs &A, ClosestBatch 
 }
 
 // ---------------------------------------------------------------------------
-// Ordering step of one XCD group, run by the LAST workgroup of the primary pass that finishes in the group (below):
-// blocks of 64 neighbouring tiles sorted by their AO cost (sum of the tiles' cost classes >> KernelParams::cost_shift,
-// capped: the costly blocks share the top key and keep their spatial order, the cheap ones follow by cost --
-// scene_pack.cc says why); the tiles of a block stay together and in spatial order (counting sort, one wave per
-// block).  Also sums the group's hit sub-pixels.  Every tile word is read with a device-coherent load: the words were
-// written by other workgroups of this kernel.
-// ---------------------------------------------------------------------------
-struct OrderScratch {
-	unsigned int bucket[65];  // non-empty tiles per key, then the keys' write cursors
-	unsigned int cost_total;  // sum of the group's tiles' cost classes
-	unsigned int hit_total;   // hit sub-pixels of the group
-	unsigned int last;        // (primary_kernel's tail: this workgroup is the group's last)
-};
-__device__ __forceinline__ void order_group(const uint32_t *__restrict__ tile_hits, uint32_t *__restrict__ order,
-                                            FrameCounters *__restrict__ counters, uint32_t tiles_x, uint32_t local_tile_rows,
-                                            uint32_t strip_tiles, bool no_sort, uint32_t cost_shift, uint32_t group,
-                                            OrderScratch &scratch, uint32_t waves) {
-	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-	const uint32_t strips = (tiles_x + strip_tiles - 1u) / strip_tiles;
-	const uint32_t strips_here = (strips + XCD_GROUPS - 1u - group) >> 3;
-	const uint32_t tiles_here = strips_here * strip_tiles * local_tile_rows;  // incl. possible columns past the image
-	// this group's segment of `order` starts where the previous groups' capacity ends
-	uint32_t segment = 0u;
-	for (uint32_t g = 0; g < group; ++g)
-		segment += ((strips + XCD_GROUPS - 1u - g) >> 3) * strip_tiles * local_tile_rows;
-	if (threadIdx.x < 65u)
-		scratch.bucket[threadIdx.x] = 0u;
-	if (threadIdx.x == 0u) {
-		scratch.cost_total = 0u;
-		scratch.hit_total = 0u;
-	}
-	__syncthreads();
-	// tile e of the group: strip (e / (strip_tiles * rows)), then row-major across the strip; returns its word (0: nothing there)
-	auto word_of = [&](uint32_t e, uint32_t &tile) -> uint32_t {
-		if (e >= tiles_here)
-			return 0u;
-		const uint32_t per_strip = strip_tiles * local_tile_rows;
-		const uint32_t strip_index = e / per_strip, within = e - strip_index * per_strip;
-		const uint32_t local_row = within / strip_tiles;
-		const uint32_t tile_x = strip_tiles * (group + XCD_GROUPS * strip_index) + (within - local_row * strip_tiles);
-		tile = local_row * tiles_x + tile_x;
-		if (tile_x >= tiles_x)
-			return 0u;
-		return __hip_atomic_load(&tile_hits[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	};
-	// One wave per block of 64 spatially consecutive tiles (a strip wide, 64 / strip_tiles high).  key: the block's cost, 1..64.
-	const uint32_t n_blocks = (tiles_here + 63u) >> 6;
-	auto block_key = [&](uint32_t block, uint32_t &tile, uint32_t &word, unsigned long long &work_mask, uint32_t &cost) -> uint32_t {
-		word = word_of(block * 64u + lane, tile);
-		const uint32_t cls = word >> 8;
-		work_mask = wave_ballot(cls != 0u);
-		cost = cls;
-		for (int offset = 32; offset >= 1; offset >>= 1)
-			cost += (uint32_t) __shfl_xor((int) cost, offset);
-		const uint32_t key = no_sort ? 1u : 1u + (cost >> cost_shift);
-		return key > 64u ? 64u : key;
-	};
-	for (uint32_t block = wave; block < n_blocks; block += waves) {
-		uint32_t tile = 0u, word, cost;
-		unsigned long long work_mask;
-		const uint32_t key = block_key(block, tile, word, work_mask, cost);
-		uint32_t hit_sum = word & 0xFFu;
-		for (int offset = 32; offset >= 1; offset >>= 1)
-			hit_sum += (uint32_t) __shfl_xor((int) hit_sum, offset);
-		if (lane == 0u) {
-			if (work_mask != 0ull) {
-				atomicAdd(&scratch.bucket[key], (uint32_t) __popcll(work_mask));
-				atomicAdd(&scratch.cost_total, cost);
-			}
-			if (hit_sum)
-				atomicAdd(&scratch.hit_total, hit_sum);
-		}
-	}
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		// exclusive prefix over descending keys: costly regions first, so that the frame ends on short claims
-		uint32_t running = 0u;
-		for (int k = 64; k >= 1; --k) {
-			const uint32_t n = scratch.bucket[k];
-			scratch.bucket[k] = running;
-			running += n;
-		}
-		counters->queue[group].work_tiles = running;
-		counters->queue[group].cost_sum = scratch.cost_total;
-		counters->queue[group].hits = scratch.hit_total;
-		counters->queue[group].head = 0u;
-	}
-	__syncthreads();
-	for (uint32_t block = wave; block < n_blocks; block += waves) {
-		uint32_t tile = 0u, word, cost;
-		unsigned long long work_mask;
-		const uint32_t key = block_key(block, tile, word, work_mask, cost);
-		if (work_mask == 0ull)
-			continue;
-		uint32_t base = 0u;
-		if (lane == 0u)
-			base = atomicAdd(&scratch.bucket[key], (uint32_t) __popcll(work_mask));
-		base = (uint32_t) __builtin_amdgcn_readfirstlane((int) base);
-		// entry = tile (26 bits: at most 2^32 sub-pixels per frame) | hit count - 1 (6 bits); inside a block
-		// the tiles keep their spatial order
-		if (word >> 8)
-			order[segment + base + rank_in(work_mask)] = tile | (((word & 0xFFu) - 1u) << 26);
-	}
-	if (threadIdx.x == 0) {
-		counters->queue[group].tick_ordered = (unsigned long long) __builtin_amdgcn_s_memrealtime();
-#ifdef OCRT_TAIL  // (the AO pass starts right after this kernel: its waves' end times are counted from here)
-		atomicMax(&counters->stamp[7], __builtin_amdgcn_s_memrealtime());
-#endif
-	}
-}
-
-// ---------------------------------------------------------------------------
-// Pass 1: primary rays, then -- the last workgroup of each XCD group -- the group's ordering step.  Four waves per
-// workgroup, one tile each; they meet once, at the end.
+// Pass 1: primary rays.  Four waves per workgroup, one tile each; they never meet.
 //
-// Why the ordering step lives here and not in a kernel of its own: it is 8 workgroups of work, and as a kernel it cost
-// a frame that shares its GPU ~0.2 ms of waiting (a launch boundary on either side, and workgroups of 1024 threads that
-// need 16 free wave slots on one CU while other frames' persistent passes hold them).  The hand-over inside the kernel:
-// every wave's tile word is a device-coherent store (primary_tile), drained (s_waitcnt vmcnt(0)) before the workgroup's
-// barrier; then ONE returning atomic per workgroup on the group's `done` counter -- whoever takes it to the number of
-// the group's workgroups is the last, reads the words with device-coherent loads and puts the counter back to 0 for the
-// next frame.  (MI355X_MICROARCH.md, inter-workgroup visibility: sc1 stores drained before the counter, sc1 loads after it.)
+// Until round 4 this kernel had a tail: the last workgroup of each XCD group to finish sorted the group's tiles by
+// their ambient-occlusion cost for the next pass.  Camera, scene and options are fixed per upload, so that order is
+// the same in every frame: it is now made once per upload, on the host (DeviceRenderer::orderTiles), and the
+// hand-over between workgroups inside the kernel (device-coherent tile words, a `done` counter per group) is gone
+// with it.  What is left of the tile word is a statistic: hit count | cost class, read by the host on demand.
 // ---------------------------------------------------------------------------
 #ifndef OCRT_PRIMARY_WAVES
 #define OCRT_PRIMARY_WAVES 4
@@ -429,14 +312,16 @@ constexpr uint32_t PRIMARY_ROWS = PRIMARY_WAVES / 2u;
 template <bool SHARED>
 __global__ __launch_bounds__(64 * PRIMARY_WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void primary_kernel(PrimaryArgs A) {
 	__shared__ ClosestBatch closest_batches[PRIMARY_WAVES];
-	__shared__ OrderScratch scratch;
 	const uint32_t wave = threadIdx.x >> 6;
-	if (blockIdx.x == 0u && threadIdx.x == 0u) {
+	if (blockIdx.x == 0u && threadIdx.x < XCD_GROUPS) {
 		FrameCounters *const counters = A.counters;
-		counters->tick_begin = __builtin_amdgcn_s_memrealtime();
-		// the sums the LATER kernels of this frame add to (nobody touches them before this kernel has ended)
-		counters->occluded = 0ull;
-		counters->tick_ao_end = 0ull;
+		// what the LATER kernels of this frame add to or count up (nobody touches it before this kernel has ended)
+		counters->queue[threadIdx.x].head = 0u;
+		if (threadIdx.x == 0u) {
+			counters->tick_begin = __builtin_amdgcn_s_memrealtime();
+			counters->occluded = 0ull;
+			counters->tick_ao_end = 0ull;
+		}
 	}
 	const uint32_t group = blockIdx.x & (XCD_GROUPS - 1u), seq = blockIdx.x >> 3;
 	{
@@ -453,23 +338,6 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) __attribute__((amdgpu_waves_per
 		if (seq < strips_here * per_strip && tile_x < A.P.tiles_x && local_row < A.P.local_tile_rows)
 			primary_tile<SHARED>(A, closest_batches, tile_x, local_row);
 	}
-	// ---- the tail: is this the group's last workgroup? ----
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (this wave's tile word has left)
-	__syncthreads();
-	if (threadIdx.x == 0u) {
-		FrameCounters *const counters = OCRT_PCOLD_PTR(FrameCounters *, counters);
-		const uint32_t before = __hip_atomic_fetch_add(&counters->queue[group].done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		scratch.last = before + 1u == gridDim.x / XCD_GROUPS ? 1u : 0u;
-	}
-	__syncthreads();
-	if (scratch.last == 0u)
-		return;
-	FrameCounters *const counters = OCRT_PCOLD_PTR(FrameCounters *, counters);
-	order_group(OCRT_PCOLD_PTR(const uint32_t *, tile_hits), OCRT_PCOLD_PTR(uint32_t *, order), counters, OCRT_PCOLD_U32(P.tiles_x),
-	            OCRT_PCOLD_U32(P.local_tile_rows), OCRT_PCOLD_U32(P.strip_tiles), OCRT_PCOLD_U32(P.debug_no_sort) != 0u,
-	            OCRT_PCOLD_U32(P.cost_shift), group, scratch, PRIMARY_WAVES);
-	if (threadIdx.x == 0u)
-		__hip_atomic_store(&counters->queue[group].done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace ocrt
