@@ -148,6 +148,11 @@ int rt_get_stream(rt_host *h, void **hip_stream);
 /* Tell a host that `hosts` of them (it included) take frames in turn on its GPU: its persistent ambient-occlusion pass
  * then leaves part of the chip to the other frames' passes instead of filling it (1, the default: alone). */
 int rt_set_device_share(rt_host *h, unsigned int hosts);
+/* New: announce how many frames of the uploaded scene this host is going to render (default 1 -- the reference's use:
+ * one frame per process, src/render.cc:86-111).  From 16 frames on an upload also prepares the walk intervals of the
+ * tiles' any-hit packets (~0.5 ms once, 3 ... 16 % per frame after); before or after rt_upload.  Results never depend on
+ * it.  A frame ring announces a stream by itself. */
+int rt_expect_frames(rt_host *h, uint64_t frames);
 
 /* Ray counts of the last frame and HIP-event timing of the ray-casting passes
  * on the launch stream (last frame, running total in ms and number of frames

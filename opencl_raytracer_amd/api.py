@@ -4,6 +4,7 @@ from __future__ import annotations
 import ctypes as C
 import weakref
 import os
+import sys
 from typing import Optional
 
 import numpy as np
@@ -121,6 +122,7 @@ _SIGNATURES = {
     "rt_use_private_stream": (C.c_int, [C.c_void_p]),
     "rt_get_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "rt_set_device_share": (C.c_int, [C.c_void_p, C.c_uint]),
+    "rt_expect_frames": (C.c_int, [C.c_void_p, C.c_uint64]),
     "rt_get_stats": (C.c_int, [C.c_void_p, C.POINTER(_Stats)]),
     "rt_last_kernel_ms": (C.c_float, [C.c_void_p]),
     "rt_total_kernel_ms": (C.c_double, [C.c_void_p]),
@@ -171,6 +173,13 @@ _SIGNATURES = {
     "rt_ring_rccl_self_test": (C.c_int, [C.c_void_p]),
     "rt_print_info": (None, []),
     "rt_device_count": (C.c_int, []),
+    # include/rt_hip_debug.h
+    "rt_debug_measure_tile_costs": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int]),
+    "rt_debug_set_order_policy": (C.c_int, [C.c_void_p, C.c_float, C.c_float]),
+    "rt_debug_tile_order_slots": (C.c_uint32, [C.c_void_p]),
+    "rt_debug_tiles": (C.c_uint32, [C.c_void_p]),
+    "rt_debug_tile_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rt_debug_set_tile_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
 }
 
 
@@ -189,9 +198,11 @@ def load_library() -> C.CDLL:
             try:
                 fn = getattr(lib, name)
             except AttributeError:
-                # an OLDER build of the library loaded on purpose for an A/B run (OCRT_LIB_DIR): it may lack the newest
-                # entry points, which such a run does not call; the product library must export every one of them
-                if os.environ.get("OCRT_LIB_DIR"):
+                # an OLDER build of the library loaded on purpose for an A/B run (OCRT_LIB_DIR + OCRT_ALLOW_OLD_LIB=1, set by
+                # the A/B tools): it may lack the newest entry points, which such a run does not call.  Every other library
+                # -- the product one, and one that OCRT_LIB_DIR merely locates -- must export every one of them.
+                if os.environ.get("OCRT_LIB_DIR") and os.environ.get("OCRT_ALLOW_OLD_LIB") == "1":
+                    print(f"opencl_raytracer_amd: {path} lacks {name} (OCRT_ALLOW_OLD_LIB=1: skipped)", file=sys.stderr)
                     continue
                 raise
             fn.restype = restype
@@ -411,6 +422,31 @@ class Host:
     def set_ao_prefetch(self, on: bool) -> None:
         """Which form of the AO pass's node loop this host launches (include/rt_hip.h, rt_set_ao_prefetch); same results."""
         _check(load_library().rt_set_ao_prefetch(self._h, int(on)))
+
+    def expect_frames(self, frames: int) -> None:
+        """Announces a stream of frames (include/rt_hip.h, rt_expect_frames): uploads then prepare the walk intervals."""
+        _check(load_library().rt_expect_frames(self._h, int(frames)))
+
+    def measure_tile_costs(self, frames: int = 2, reorder: bool = True) -> None:
+        """Measures what the tiles' AO packets cost (include/rt_hip_debug.h) and, with `reorder`, claims them by that."""
+        _check(load_library().rt_debug_measure_tile_costs(self._h, int(frames), int(reorder)))
+
+    def set_order_policy(self, heavy: float, runway: float) -> None:
+        _check(load_library().rt_debug_set_order_policy(self._h, float(heavy), float(runway)))
+
+    def tile_order(self) -> dict:
+        """The AO pass's claim order: list (eight segments), 8 x 3 constants, tile words, measured costs per tile."""
+        lib = load_library()
+        slots, tiles = lib.rt_debug_tile_order_slots(self._h), lib.rt_debug_tiles(self._h)
+        order, constants = np.zeros(slots, np.uint32), np.zeros(24, np.uint32)
+        words, costs = np.zeros(tiles, np.uint32), np.zeros(tiles, np.float32)
+        _check(lib.rt_debug_tile_order(self._h, order.ctypes.data, constants.ctypes.data, words.ctypes.data, costs.ctypes.data))
+        return {"order": order, "constants": constants.reshape(8, 3), "words": words, "costs": costs}
+
+    def set_tile_order(self, order, constants) -> None:
+        order = np.ascontiguousarray(order, np.uint32)
+        constants = np.ascontiguousarray(constants, np.uint32).reshape(24)
+        _check(load_library().rt_debug_set_tile_order(self._h, order.ctypes.data, len(order), constants.ctypes.data))
 
     def walk_entries(self) -> dict:
         """The intervals of the node array the tiles' any-hit packets walk (include/rt_hip.h, rt_walk_entries)."""

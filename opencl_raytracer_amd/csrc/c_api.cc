@@ -1,5 +1,6 @@
 // c_api.cc -- the extern "C" boundary declared in include/rt_hip.h.
 #include "../../include/rt_hip.h"
+#include "../../include/rt_hip_debug.h"
 
 #include <algorithm>
 #include <hip/hip_runtime.h>
@@ -330,6 +331,12 @@ int rt_set_device_share(rt_host *h, unsigned int hosts) {
 	return RT_OK;
 }
 
+int rt_expect_frames(rt_host *h, uint64_t frames) {
+	if (!h)
+		return fail(RT_E_INVALID, "null host");
+	return guarded([&] { h->dev->expectFrames(frames); });
+}
+
 int rt_use_private_stream(rt_host *h) {
 	if (!h)
 		return fail(RT_E_INVALID, "null host");
@@ -464,6 +471,74 @@ int rt_set_ao_prefetch(rt_host *h, int on) {
 	if (!h)
 		return fail(RT_E_INVALID, "null argument");
 	return guarded([&] { h->dev->setAoPrefetch(on != 0); });
+}
+
+// ---- include/rt_hip_debug.h ----
+int rt_debug_measure_tile_costs(rt_host *h, uint32_t frames, int reorder) {
+	if (!h)
+		return fail(RT_E_INVALID, "null argument");
+	return guarded([&] {
+		if (reorder) {
+			h->dev->measureTileCosts(frames);
+			return;
+		}
+		std::vector<uint32_t> order, constants, words;
+		std::vector<float> cost;
+		h->dev->tileOrder(order, constants, words, cost);
+		h->dev->measureTileCosts(frames);      // (measures and reorders ...)
+		h->dev->setTileOrder(order, constants);  // (... and the list that was in place goes back)
+	});
+}
+
+int rt_debug_set_order_policy(rt_host *h, float heavy, float runway) {
+	if (!h)
+		return fail(RT_E_INVALID, "null argument");
+	return guarded([&] { h->dev->setOrderPolicy(heavy, runway); });
+}
+
+uint32_t rt_debug_tile_order_slots(rt_host *h) {
+	if (!h)
+		return 0;
+	std::vector<uint32_t> order, constants, words;
+	std::vector<float> cost;
+	h->dev->tileOrder(order, constants, words, cost);
+	return (uint32_t) order.size();
+}
+
+uint32_t rt_debug_tiles(rt_host *h) {
+	if (!h)
+		return 0;
+	const ocrt::KernelParams &kp = h->dev->params();
+	return kp.tiles_x * kp.local_tile_rows;
+}
+
+int rt_debug_tile_order(rt_host *h, uint32_t *order_out, uint32_t *constants24, uint32_t *tile_words, float *tile_costs) {
+	if (!h)
+		return fail(RT_E_INVALID, "null argument");
+	return guarded([&] {
+		std::vector<uint32_t> order, constants, words;
+		std::vector<float> cost;
+		h->dev->tileOrder(order, constants, words, cost);
+		if (order_out)
+			std::copy(order.begin(), order.end(), order_out);
+		if (constants24)
+			std::copy(constants.begin(), constants.end(), constants24);
+		const uint32_t tiles = rt_debug_tiles(h);
+		if (tile_words)
+			for (uint32_t t = 0; t < tiles; ++t)
+				tile_words[t] = t < words.size() ? words[t] : 0u;
+		if (tile_costs)
+			for (uint32_t t = 0; t < tiles; ++t)
+				tile_costs[t] = t < cost.size() ? cost[t] : 0.0f;
+	});
+}
+
+int rt_debug_set_tile_order(rt_host *h, const uint32_t *order, uint32_t slots, const uint32_t *constants24) {
+	if (!h || !order || !constants24)
+		return fail(RT_E_INVALID, "null argument");
+	return guarded([&] {
+		h->dev->setTileOrder(std::vector<uint32_t>(order, order + slots), std::vector<uint32_t>(constants24, constants24 + 24));
+	});
 }
 
 uint32_t rt_ring_size(const rt_ring *r) { return r ? r->ring->size() : 0; }

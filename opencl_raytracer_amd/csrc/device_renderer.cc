@@ -402,7 +402,10 @@ size_t DeviceRenderer::adopt(std::shared_ptr<const DeviceScene> scene, const Dev
 	// profiles/r04_notes.md) -- as long as the image is wide enough for every group to keep two strips.
 	// The walk intervals (kernels.hip, entry_kernel): one per tile and table direction -- unless that table would be out of
 	// proportion (many samples per pixel AND many directions: 64 x 301 at 1080p would be 5 GB), then the tiles' own only.
-	if (kp.ao_mode != AO_UNIFORM || (size_t) tile_count * (1 + (size_t) kp.ao_dirs) * 2 * sizeof(uint32_t) > MAX_ENTRY_TABLE_BYTES)
+	// ... and for a caller that has not announced enough frames for the table to pay (expectFrames): one whole-array
+	// interval per tile, nothing to compute.
+	if (kp.ao_mode != AO_UNIFORM || (size_t) tile_count * (1 + (size_t) kp.ao_dirs) * 2 * sizeof(uint32_t) > MAX_ENTRY_TABLE_BYTES ||
+	    expected_frames < FRAMES_WORTH_INTERVALS)
 		kp.entry_stride = 1u;
 #ifdef OCRT_DEBUG_KNOBS
 	if (std::getenv("OCRT_ENTRY_PER_TILE"))  // the tiles' own intervals only (what a frame with too large a table gets)
@@ -426,7 +429,8 @@ size_t DeviceRenderer::adopt(std::shared_ptr<const DeviceScene> scene, const Dev
 	if (layout_from && (layout_from == this || layout_from->scene_on_device != scene_on_device || layout_from->device != device ||
 	                    layout_from->tile_count != tile_count || layout_from->part.rank != part.rank ||
 	                    layout_from->part.nranks != part.nranks || layout_from->rt.totalWidth != rt.totalWidth ||
-	                    layout_from->rt.totalHeight != rt.totalHeight))
+	                    layout_from->rt.totalHeight != rt.totalHeight || layout_from->kp.entry_stride != kp.entry_stride ||
+	                    (layout_from->expected_frames >= FRAMES_WORTH_INTERVALS) != (expected_frames >= FRAMES_WORTH_INTERVALS)))
 		layout_from = nullptr;  // (not the same frame after all: count)
 	sizeHitList(layout_from);
 	return image_bytes + (size_t) local_out_rows * opts.width + hit_slots * (sizeof(HitRec) + sizeof(uint32_t)) +
@@ -469,6 +473,7 @@ void DeviceRenderer::sizeHitList(const DeviceRenderer *layout_from) {
 		// the walk intervals are read-only between uploads: the ring's hosts share ONE table (like the scene's arrays)
 		tile_entry_owner = layout_from->tile_entry_owner;
 		d_tile_entry = tile_entry_owner.get();
+		intervals_in_use = layout_from->intervals_in_use;
 		// (on this renderer's stream, and waited for: the stream is a non-blocking one, which work on the null stream is not
 		// ordered against, and a copy or fill between device buffers need not have finished when its call returns)
 		OCRT_HIP(hipMemcpyAsync(d_tile_base, layout_from->d_tile_base, tile_count * sizeof(uint32_t), hipMemcpyDeviceToDevice, (hipStream_t) stream));
@@ -514,7 +519,8 @@ void DeviceRenderer::sizeHitList(const DeviceRenderer *layout_from) {
 	// ... and, now that there is a hit list, where each tile's any-hit rays enter the walk tree: a second pass of the
 	// primary kernel fills the list, entry_kernel reads the tiles' hit points (kernels.hip; the whole array where the
 	// fast walk is not used).  Like the bases: once per upload.
-	if (kp.fast_walk && scene_on_device->buffers().walk) {
+	intervals_in_use = kp.fast_walk && scene_on_device->buffers().walk && expected_frames >= FRAMES_WORTH_INTERVALS;
+	if (intervals_in_use) {
 		launch_primary(scene_on_device->buffers(), (float *) d_image, d_hits, d_occluded, d_tile_hits, d_tile_base, d_counters, kp, stream);
 		launch_entries(scene_on_device->buffers(), d_hits, d_tile_hits, d_tile_base, d_tile_entry, kp, stream);
 		OCRT_HIP(hipGetLastError());
@@ -616,13 +622,16 @@ void DeviceRenderer::orderTiles() {
 	installOrder(order, constants);
 }
 
-// Claim order of one group's tiles from their MEASURED costs (device-clock ticks a tile's 28 packets kept a workgroup
+// Claim order of one group's tiles from their MEASURED costs (device-clock ticks a tile's claims kept their workgroups
 // busy, measureTileCosts): `cost` in the tiles' spatial order, returns the indices in claim order.
 // What matters is how the pass ENDS: a claim is a whole tile for a workgroup's four waves, a costly tile keeps them
-// busy ~0.15 ms of a 1 ms pass and some tiles cost four times the median -- claimed in spatial order, a third of the
-// pass ran at falling occupancy (profiles/r05_notes.md).  So: tiles whose cost stands out (beyond `heavy` x the
-// median of the costly half) go first, the costly ones follow IN SPATIAL ORDER up to the point where what is left
-// would keep the group's workgroups busy for about `runway` median claims each, from there on by falling cost.
+// busy ~0.15 ms of a 1 ms pass and some tiles cost four times the median -- claimed in spatial order, the last third of
+// the pass ran at falling occupancy (profiles/r05_notes.md).  So:
+//   1. tiles whose cost stands out (beyond `heavy` x the reference cost = the upper quartile) go first, costliest first;
+//   2. the others follow IN SPATIAL ORDER (neighbouring claims walk the same part of the tree) ...
+//   3. ... up to the RUNWAY: what would keep each workgroup of the group busy for about `runway` reference claims is held
+//      back and claimed last by falling cost, so that the pass ends on its cheapest tiles; tiles below a quarter of the
+//      reference cost anywhere in the list are moved there too.
 std::vector<uint32_t> DeviceRenderer::orderByMeasuredCost(const std::vector<float> &cost) const {
 	const size_t n = cost.size();
 	std::vector<uint32_t> out;
@@ -631,47 +640,26 @@ std::vector<uint32_t> DeviceRenderer::orderByMeasuredCost(const std::vector<floa
 		return out;
 	std::vector<float> sorted(cost);
 	std::sort(sorted.begin(), sorted.end());
-	const float median_costly = sorted[n - 1 - (n - 1) / 4];  // median of the costly half = the upper quartile
-	const float heavy_from = order_policy.heavy * median_costly;
-	std::vector<uint32_t> heavy_ones, rest;
+	const float reference = sorted[n - 1 - (n - 1) / 4];
+	const auto falling = [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; };
+	std::vector<uint32_t> heavy, rest;
 	for (uint32_t i = 0; i < n; ++i)
-		(cost[i] > heavy_from ? heavy_ones : rest).push_back(i);
-	std::stable_sort(heavy_ones.begin(), heavy_ones.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
-	// the runway: the cheapest-to-finish-on part of what is left, `runway` median claims per workgroup of the group
-	double budget = (double) order_policy.runway * median_costly * (double) (aoWorkgroups() / XCD_GROUPS ? aoWorkgroups() / XCD_GROUPS : 1u);
-	std::vector<uint32_t> by_cost(rest);
-	std::stable_sort(by_cost.begin(), by_cost.end(), [&](uint32_t a, uint32_t b) { return cost[a] < cost[b]; });
-	std::vector<char> in_runway(n, 0);
-	// spatial part first: everything that is costly (above the lower quartile) stays in spatial order until the budget of
-	// the runway is what remains; the runway holds the LAST costly tiles in spatial order plus all cheap ones
-	double total_rest = 0.0;
+		(cost[i] > order_policy.heavy * reference ? heavy : rest).push_back(i);
+	std::stable_sort(heavy.begin(), heavy.end(), falling);
+	const uint32_t workgroups = aoWorkgroups() / XCD_GROUPS ? aoWorkgroups() / XCD_GROUPS : 1u;
+	const double budget = (double) order_policy.runway * reference * workgroups;
+	double left = 0.0;
 	for (uint32_t i : rest)
-		total_rest += cost[i];
-	double ahead = 0.0;
+		left += cost[i];
 	std::vector<uint32_t> spatial, runway;
 	for (uint32_t i : rest) {
-		if (total_rest - ahead > budget)
-			spatial.push_back(i);
-		else
-			runway.push_back(i);
-		ahead += cost[i];
+		(left > budget && cost[i] >= 0.25f * reference ? spatial : runway).push_back(i);
+		left -= cost[i];
 	}
-	(void) by_cost;
-	(void) in_runway;
-	std::stable_sort(runway.begin(), runway.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
-	// cheap tiles inside the spatial part would hold up nothing, but they are worth more at the end: move those below a
-	// quarter of the median to the runway's tail
-	std::vector<uint32_t> spatial_costly, cheap;
-	for (uint32_t i : spatial)
-		(cost[i] < 0.25f * median_costly ? cheap : spatial_costly).push_back(i);
-	std::stable_sort(cheap.begin(), cheap.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
-	out.insert(out.end(), heavy_ones.begin(), heavy_ones.end());
-	out.insert(out.end(), spatial_costly.begin(), spatial_costly.end());
-	// runway and cheap tiles merged by falling cost
-	std::vector<uint32_t> tail(runway);
-	tail.insert(tail.end(), cheap.begin(), cheap.end());
-	std::stable_sort(tail.begin(), tail.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
-	out.insert(out.end(), tail.begin(), tail.end());
+	std::stable_sort(runway.begin(), runway.end(), falling);
+	out.insert(out.end(), heavy.begin(), heavy.end());
+	out.insert(out.end(), spatial.begin(), spatial.end());
+	out.insert(out.end(), runway.begin(), runway.end());
 	return out;
 }
 
@@ -710,7 +698,7 @@ DeviceRenderer::FrameEvents DeviceRenderer::takeEvents() {
 // The launches of one frame on the stream: primary pass (with the ordering step in its tail), ambient-occlusion pass,
 // finishing kernel (AO factor into the float image and -- with a destination -- the device resize in the same sweep).
 // `ao_start` / `ao_stop` bracket the ao_kernel launch.
-void DeviceRenderer::launchFrame(void *device_u8, void *ao_start, void *ao_stop) {
+void DeviceRenderer::launchFrame(void *device_u8, void *ao_start, void *ao_stop, void *tile_cost_out) {
 #ifdef OCRT_STAMPS
 	hipStream_t s = (hipStream_t) stream;
 #endif
@@ -721,7 +709,7 @@ void DeviceRenderer::launchFrame(void *device_u8, void *ao_start, void *ao_stop)
 	OCRT_HIP(hipMemsetAsync((char *) d_counters + offsetof(FrameCounters, stamp) + 7 * sizeof(unsigned long long), 0xFF, sizeof(unsigned long long), s));
 #endif
 	launch_ao(scene, d_hits, d_occluded, d_order, d_tile_base, d_tile_entry, d_counters, kp, ao_blocks_override ? ao_blocks_override : aoWorkgroups(), ao_prefetch,
-	          stream, ao_start, ao_stop);
+	          stream, ao_start, ao_stop, tile_cost_out);
 	OCRT_HIP(hipGetLastError());
 	launch_finish((float *) d_image, d_hits, d_occluded, d_tile_base, (unsigned char *) device_u8, kp, opts.width, grid, local_out_rows, stream);
 	OCRT_HIP(hipGetLastError());
@@ -763,6 +751,96 @@ DeviceRenderer::WalkEntries DeviceRenderer::walkEntries() const {
 	out.mean_share = out.tiles_hit ? sum / out.tiles_hit : 1.0;
 	out.mean_packet_share = packets ? sum_packets / (double) packets : 1.0;
 	return out;
+}
+
+void DeviceRenderer::expectFrames(uint64_t frames) {
+	const bool before = expected_frames >= FRAMES_WORTH_INTERVALS, after = frames >= FRAMES_WORTH_INTERVALS;
+	expected_frames = frames;
+	if (before == after || !scene_ready)
+		return;
+	// the scene is on the device already: lay the hit list out again, with or without the table (adopt() decides)
+	std::shared_ptr<const DeviceScene> scene = scene_on_device;
+	adopt(std::move(scene));
+}
+
+bool DeviceRenderer::measureTileCosts(unsigned frames) {
+	if (!scene_ready)
+		throw std::logic_error("measurement before upload");
+	const bool has_ao = kp.ao_mode != AO_NONE && kp.ao_dirs > 0 && tile_count > 0 && tile_words.size() == tile_count;
+	if (!has_ao || frames == 0)
+		return false;
+	useDevice();
+	synchronize();
+	void *d_cost = device_alloc(tile_count * sizeof(uint32_t));
+	std::vector<uint32_t> ticks(tile_count);
+	std::vector<float> sum(tile_count, 0.0f);
+	try {
+		for (unsigned f = 0; f <= frames; ++f) {  // (the first frame is not counted: code object pages, caches)
+			OCRT_HIP(hipMemsetAsync(d_cost, 0, tile_count * sizeof(uint32_t), (hipStream_t) stream));
+			launchFrame(nullptr, nullptr, nullptr, d_cost);
+			OCRT_HIP(hipMemcpyAsync(ticks.data(), d_cost, tile_count * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t) stream));
+			OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));
+			if (f > 0)
+				for (size_t t = 0; t < tile_count; ++t)
+					sum[t] += (float) ticks[t];
+		}
+	} catch (...) {
+		device_free(d_cost);
+		throw;
+	}
+	device_free(d_cost);
+	tile_cost = std::move(sum);
+	orderTiles();
+	frame_ready = false;
+	return true;
+}
+
+void DeviceRenderer::takeOrderFrom(const DeviceRenderer &other) {
+	if (&other == this || other.tile_count != tile_count || other.order_host.empty())
+		return;
+	useDevice();
+	synchronize();
+	tile_cost = other.tile_cost;
+	installOrder(other.order_host, other.queue_static);
+}
+
+void DeviceRenderer::tileOrder(std::vector<uint32_t> &order, std::vector<uint32_t> &constants, std::vector<uint32_t> &words, std::vector<float> &cost) const {
+	order = order_host;
+	constants.clear();
+	for (const auto &q : queue_static)
+		constants.insert(constants.end(), q.begin(), q.end());
+	words = tile_words;
+	cost = tile_cost;
+}
+
+void DeviceRenderer::setTileOrder(const std::vector<uint32_t> &order, const std::vector<uint32_t> &constants) {
+	if (!scene_ready || order.size() != order_host.size() || constants.size() != 3 * XCD_GROUPS)
+		throw std::invalid_argument("setTileOrder: a list of another frame");
+	// every entry must be a tile of this frame (the kernel indexes the hit list's bases with it) and every group's count
+	// must stay inside its segment
+	for (uint32_t entry : order)
+		if ((entry & 0x03FFFFFFu) >= tile_count && tile_count)
+			throw std::invalid_argument("setTileOrder: no such tile");
+	std::array<std::array<uint32_t, 3>, XCD_GROUPS> c{};
+	const uint32_t strips = (kp.tiles_x + kp.strip_tiles - 1u) / kp.strip_tiles;
+	for (uint32_t g = 0; g < XCD_GROUPS; ++g) {
+		c[g] = { constants[3 * g], constants[3 * g + 1], constants[3 * g + 2] };
+		if (c[g][0] > ((strips + XCD_GROUPS - 1u - g) >> 3) * kp.strip_tiles * kp.local_tile_rows)
+			throw std::invalid_argument("setTileOrder: more tiles than the group's segment holds");
+	}
+	useDevice();
+	synchronize();
+	installOrder(order, c);
+}
+
+void DeviceRenderer::setOrderPolicy(float heavy, float runway) {
+	order_policy.heavy = heavy;
+	order_policy.runway = runway;
+	if (scene_ready && orderIsMeasured()) {
+		useDevice();
+		synchronize();
+		orderTiles();
+	}
 }
 
 void DeviceRenderer::setAoPrefetch(bool on) {

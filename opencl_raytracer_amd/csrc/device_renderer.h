@@ -157,6 +157,29 @@ class DeviceRenderer {
 		};
 		WalkEntries walkEntries() const;
 		bool aoPrefetch() const { return ao_prefetch; }
+		// How many frames of the scene the caller is going to render (default 1: the reference's use, one frame per
+		// process, src/render.cc:86-111).  What an upload prepares beyond the scene itself only pays over a stream of frames:
+		// the walk intervals (a second pass of the primary kernel + entry_kernel: ~0.55 ms at 1080p, worth ~0.04 ms per
+		// headline frame, ~0.15 ms per frame of the interior scene) are made from FRAMES_WORTH_INTERVALS announced frames on,
+		// and a frame ring -- which announces a stream -- also measures the tiles' costs and the form of the node loop.
+		// Callable before or after the upload (after: the hit list is laid out again if the answer changes).
+		static constexpr uint64_t FRAMES_WORTH_INTERVALS = 16;
+		void expectFrames(uint64_t frames);
+		uint64_t expectedFrames() const { return expected_frames; }
+		bool walkIntervalsInUse() const { return intervals_in_use; }
+		// What the tiles' ambient-occlusion packets really cost, and the order the pass claims them in made from that
+		// (orderByMeasuredCost): `frames` frames one at a time (plain launches) whose AO pass books every claim's duration
+		// -- device clock, between the workgroup's barriers -- to the claim's tiles.  Once per upload, for callers that
+		// announce a stream of frames (a frame ring); returns false where there is nothing to measure.
+		bool measureTileCosts(unsigned frames = 2);
+		// ... and the order another renderer of the same frame (scene, options, partition) has arrived at
+		void takeOrderFrom(const DeviceRenderer &other);
+		bool orderIsMeasured() const { return tile_cost.size() == tile_count && tile_count != 0; }
+		void setOrderPolicy(float heavy, float runway);
+		// (diagnostics / experiments, include/rt_hip_debug.h: the list as it is, and a list made elsewhere put in its place --
+		// any order of the same tiles renders the same image)
+		void tileOrder(std::vector<uint32_t> &order, std::vector<uint32_t> &constants, std::vector<uint32_t> &words, std::vector<float> &cost) const;
+		void setTileOrder(const std::vector<uint32_t> &order, const std::vector<uint32_t> &constants);
 		bool calibrateAoPrefetch(float *ms_without = nullptr, float *ms_with = nullptr);
 		// (A scene far beyond the caches is another matter: its pass waits for memory, and what it needs is loads in
 		// flight -- every host keeps the full grid: 2 M-triangle field, three hosts, 11.93 ms per frame with 4.5 per CU,
@@ -218,9 +241,9 @@ class DeviceRenderer {
 		std::vector<uint32_t> tile_words, order_host;
 		std::vector<float> tile_cost;  // measured: device-clock ticks per tile (empty: not measured)
 		std::array<std::array<uint32_t, 3>, XCD_GROUPS> queue_static{};  // per group: non-empty tiles, sum of cost classes, hit sub-pixels
-		struct OrderPolicy {
-			float heavy = 1.6f;   // tiles beyond this many median (costly-half) costs are claimed first
-			float runway = 2.0f;  // what is left for the end, by falling cost: this many median claims per workgroup
+		struct OrderPolicy {  // (orderByMeasuredCost; swept in profiles/r05_order_policies.txt)
+			float heavy = 2.0f;   // tiles beyond this many reference costs (the upper quartile) are claimed first
+			float runway = 2.0f;  // what is held back for the end, by falling cost: this many reference claims per workgroup
 		} order_policy;
 		void orderTiles();
 		std::vector<uint32_t> orderByMeasuredCost(const std::vector<float> &cost) const;
@@ -238,7 +261,7 @@ class DeviceRenderer {
 		};
 		std::vector<FrameEvents> pending_events, free_events;
 		FrameEvents takeEvents();
-		void launchFrame(void *device_u8, void *ao_start, void *ao_stop);  // the launches of one frame, resize included
+		void launchFrame(void *device_u8, void *ao_start, void *ao_stop, void *tile_cost = nullptr);  // the launches of one frame, resize included
 		// the captured frame (enqueueFrame) and what it was captured for
 		struct FrameGraph {
 			void *graph = nullptr, *exec = nullptr;
@@ -251,6 +274,8 @@ class DeviceRenderer {
 		const FrameGraph *frameGraphFor(void *dst);
 		void dropFrameGraphs();
 		bool graph_mode;
+		uint64_t expected_frames = 1;
+		bool intervals_in_use = false;
 		bool ao_prefetch;
 		uint64_t scene_version;
 		uint32_t ao_blocks_override;  // (debug-knob builds: OCRT_AO_BLOCKS)
@@ -270,7 +295,7 @@ void launch_entries(const SceneBuffers &scene, const void *hits, const void *til
                     const KernelParams &P, void *stream);
 void launch_ao(const SceneBuffers &scene, void *hits, void *occluded_of, void *order, const void *tile_base, const void *tile_entry,
                void *counters, const KernelParams &P, uint32_t workgroups, bool prefetch, void *stream, void *event_before_ao,
-               void *event_after_ao);
+               void *event_after_ao, void *tile_cost = nullptr);
 void launch_finish(float *image, const void *hits, const void *occluded_of, const void *tile_base,
                    unsigned char *out, const KernelParams &P, uint32_t out_width, uint32_t n, uint32_t local_out_rows, void *stream);
 void launch_occluded_sum(const void *occluded_of, size_t slots, void *counters, void *stream);

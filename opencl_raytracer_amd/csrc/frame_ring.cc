@@ -33,6 +33,7 @@ FrameRing::FrameRing(const RayTracer::Options &options, int device, unsigned int
 		// hosts are dealt over the others -- DeviceRenderer's constructor)
 		hosts.emplace_back(new DeviceRenderer(options, device, rank, nranks, count > 1 ? (int) k : -1, nranks > 1));
 		hosts.back()->setDeviceShare(count);
+		hosts.back()->expectFrames(~0ull);  // (a ring is a stream of frames: what an upload can prepare for them pays)
 	}
 	bound.assign(2 * count, nullptr);
 	gather_pending.assign(2 * count, false);
@@ -88,6 +89,11 @@ size_t FrameRing::upload(const PackedScene &scene) {
 	// few frames of measuring (DeviceRenderer::calibrateAoPrefetch: ~15 ms once per upload).  The first host measures on
 	// the idle device, all hosts follow.
 	if (calibrate_at_upload) {
+		// ... and so is the order its tiles are claimed in: three frames whose pass books every claim's duration to its tiles
+		// (DeviceRenderer::measureTileCosts, ~4 ms; headline pass 1.02 -> 0.93 ms, profiles/r05_notes.md)
+		if (hosts.front()->measureTileCosts(3))
+			for (auto &h : hosts)
+				h->takeOrderFrom(*hosts.front());
 		const bool prefetch = hosts.front()->calibrateAoPrefetch(&calibration_ms[0], &calibration_ms[1]);
 		for (auto &h : hosts)
 			h->setAoPrefetch(prefetch);

@@ -134,7 +134,7 @@ void launch_entries(const SceneBuffers &scene, const void *hits, const void *til
 
 void launch_ao(const SceneBuffers &scene, void *hits, void *occluded_of, void *order, const void *tile_base, const void *tile_entry,
                void *counters, const KernelParams &params, uint32_t workgroups, bool prefetch, void *stream, void *event_before_ao,
-               void *event_after_ao) {
+               void *event_after_ao, void *tile_cost) {
 	if (params.tiles_x * params.local_tile_rows == 0 || params.ao_mode == AO_NONE || params.ao_dirs == 0)
 		return;
 	hipStream_t s = (hipStream_t) stream;
@@ -163,6 +163,7 @@ void launch_ao(const SceneBuffers &scene, void *hits, void *occluded_of, void *o
 		args.tile_base = (const uint32_t *) tile_base;
 		args.tile_entry = (const uint2 *) tile_entry;
 		args.counters = (FrameCounters *) counters;
+		args.tile_cost = (uint32_t *) tile_cost;
 		args.P = P;
 		hipLaunchKernelGGL(kernel, dim3(ao_blocks), dim3(64 * AO_WAVES), 0, s, args);
 		if (event_after_ao)

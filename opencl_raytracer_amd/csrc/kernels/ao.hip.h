@@ -69,6 +69,7 @@ struct AoArgs {
 	const uint32_t *tile_base;  // first slot of each tile in the hit list
 	const uint2 *tile_entry;    // per tile, 1 + ao_dirs byte ranges of the walk records: what its any-hit rays have to walk (entry_kernel)
 	FrameCounters *counters;
+	uint32_t *tile_cost;        // null but in a measuring frame (DeviceRenderer::measureTileCosts): per tile, the device-clock ticks its claims kept their workgroups
 	KernelParams P;
 };
 #define OCRT_COLD_U32(FIELD) cold_u32<(uint32_t) offsetof(AoArgs, FIELD)>()
@@ -79,7 +80,7 @@ struct AoArgs {
 template <int MODE, bool SHARED, bool PREFETCH = false>
 __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void ao_kernel(AoArgs A) {
 	__shared__ TileShared shared_tiles[AO_WAVES];
-	__shared__ unsigned int wg_claim[4];  // the workgroup's current claim: first unit, units per wave, end (if dealt by cursor), cursor
+	__shared__ unsigned int wg_claim[8];  // the workgroup's current claim: first unit, units per wave, end (if dealt by cursor), cursor; [4..7]: the claim before it, for measureTileCosts
 	const uint32_t wave = (uint32_t) __builtin_amdgcn_readfirstlane((int) threadIdx.x) >> 6;  // (scalar)
 	TileShared &sh = shared_tiles[wave];
 	const float4 *__restrict__ const walk_ptr = A.walk_ptr, *__restrict__ const tris_ptr = A.tris_ptr;
@@ -101,6 +102,8 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 #endif
 	if (blockIdx.x == 0u && threadIdx.x == 0u)  // (when the pass began, by the device's clock: frames replayed from a graph have no events inside)
 		__hip_atomic_store(&OCRT_COLD_PTR(FrameCounters *, counters)->tick_ao_begin, (unsigned long long) __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	if (threadIdx.x == 0u)
+		wg_claim[4] = wg_claim[5] = 0u;  // (no claim before the first; read by the same thread only)
 	// Workgroups b and b+8 share an XCD: start with that group's queue, then help the others.
 	const uint32_t home = blockIdx.x & (XCD_GROUPS - 1u);
 	for (uint32_t turn = 0; turn < XCD_GROUPS; ++turn) {
@@ -187,6 +190,27 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 				// the cursor, in directions of the tile: end << 16 | next (both 0 for fixed shares: nothing to take)
 				const uint32_t base = first - first / ao_dirs * ao_dirs;
 				wg_claim[3] = one_tile ? (base + (end - first)) << 16 | base : 0u;
+				// A measuring frame (once per upload, DeviceRenderer::measureTileCosts): how long the claim BEFORE this one kept
+				// the workgroup -- every wave has left it, that is what the barrier above says -- goes to its tiles, by their
+				// share of its units; this claim's first unit, its end and the clock go where the next one finds them.
+				uint32_t *const tile_cost = OCRT_COLD_PTR(uint32_t *, tile_cost);
+				if (tile_cost) {
+					const uint32_t now = (uint32_t) __builtin_amdgcn_s_memrealtime();
+					const uint32_t before_first = wg_claim[4], before_end = wg_claim[5], before_clock = wg_claim[6], before_segment = wg_claim[7];
+					if (before_end > before_first) {
+						const uint32_t ticks = now - before_clock, all = before_end - before_first;
+						const uint32_t *const order = OCRT_COLD_PTR(const uint32_t *, order);
+						for (uint32_t u = before_first; u < before_end;) {
+							const uint32_t t = u / ao_dirs, stop = (t + 1u) * ao_dirs < before_end ? (t + 1u) * ao_dirs : before_end;
+							atomicAdd(&tile_cost[order[before_segment + t] & 0x03FFFFFFu], (uint32_t) ((unsigned long long) ticks * (stop - u) / all));
+							u = stop;
+						}
+					}
+					wg_claim[4] = first < units ? first : 0u;
+					wg_claim[5] = first < units ? end : 0u;
+					wg_claim[6] = now;
+					wg_claim[7] = segment;
+				}
 			}
 			__syncthreads();
 			const uint32_t wg_claimed = (uint32_t) __builtin_amdgcn_readfirstlane((int) wg_claim[0]);

@@ -24,9 +24,11 @@ def _check(rt, oracle, vertices, faces, **options):
     arrays = orc.SceneArrays.from_scene(scene)
     opt = rt.Options.defaults(**options)
     ref_img, counters, _ = oracle.render(orc.params_from_options(opt), arrays)
-    for hosts in (0, 3):  # a host on its own (plain launches), a ring of three replaying its graphs
-        if hosts == 0:
+    for hosts in (0, -1, 3):  # a host on its own (plain launches) -- one-shot, then with a stream announced --, a ring of three replaying its graphs
+        if hosts <= 0:
             host = rt.Host(opt, 0)
+            if hosts < 0:
+                host.expect_frames(1000)  # (the walk intervals: entry_kernel)
             host.upload_scene(scene)
             host.render()
             img, u8, st = host.download(), host.download_u8(), host.stats()

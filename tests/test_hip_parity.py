@@ -22,21 +22,29 @@ DIGEST_CASES = ["bunny_1080p_s1_a0", "bunny_1080p_s1_a3", "bunny_600_defaults", 
                 "interior_4k_s1_a3", "bunny_1080p_s64_a3"]
 
 
-def render_hip(rt, scene, opt, rank=0, nranks=1):
+def render_hip(rt, scene, opt, rank=0, nranks=1, frames=None):
+    """`frames`: announced to the host before the upload (rt_expect_frames) -- None: nothing is, the host is the
+    reference's one-shot OpenCLHost and its upload prepares no walk intervals; many: it does."""
     host = rt.Host(opt, 0, rank, nranks)
+    if frames is not None:
+        host.expect_frames(frames)
     host.upload_scene(scene)
     host.render()
     return host
 
 
+STREAM = 1000  # frames announced by the tests that want what an upload prepares for a stream of frames
+
+
+@pytest.mark.parametrize("frames", [None, STREAM], ids=["one_shot", "stream"])
 @pytest.mark.parametrize("name", ORACLE_CASES)
-def test_matches_oracle_and_golden(rt, oracle, golden, scene_for, name):
+def test_matches_oracle_and_golden(rt, oracle, golden, scene_for, name, frames):
     import orc
 
     c = golden["renders"][name]
     opt = options_for(rt, c)
     scene, arrays = scene_for(c["mesh"], c["bvh"])
-    host = render_hip(rt, scene, opt)
+    host = render_hip(rt, scene, opt, frames=frames)
     img = host.download()
     u8 = host.download_u8()
     ref_img, counters, _ = oracle.render(orc.params_from_options(opt), arrays)
@@ -58,7 +66,8 @@ def test_full_size_golden_digests(rt, golden, scene_for, name):
     c = golden["renders"][name]
     opt = options_for(rt, c)
     scene, _ = scene_for(c["mesh"], c["bvh"])
-    host = render_hip(rt, scene, opt)
+    # (the 1080p frames as the one-shot host renders them, the others with what a stream's upload prepares)
+    host = render_hip(rt, scene, opt, frames=None if "1080p_s1" in name else STREAM)
     img = host.download()
     assert hashlib.sha256(img.tobytes()).hexdigest() == c["float_sha256"]
     assert hashlib.md5(rt.pgm_bytes(host.download_u8())).hexdigest() == c["pgm_md5"]
@@ -250,6 +259,46 @@ def test_interior_standin_matches_oracle(rt, oracle):
         host.close()
 
 
+@pytest.mark.parametrize("name", ["bunny_256_s1_a3", "blob_128x96_s4_a3", "ties_64_s4_a3", "bunny_600_defaults"])
+def test_measured_tile_order_changes_nothing(rt, golden, scene_for, name):
+    """What the AO pass claims first is decided once per upload -- by the cost classes of the counting pass, or, for a
+    stream of frames, by what the tiles' claims were measured to take (rt_debug_measure_tile_costs) -- and is nobody's
+    business but the scheduler's: the same tiles in another order, the same floats.  Also with a list turned round."""
+    c = golden["renders"][name]
+    opt = options_for(rt, c)
+    scene, _ = scene_for(c["mesh"], c["bvh"])
+    host = render_hip(rt, scene, opt, frames=STREAM)
+    before = host.tile_order()
+    assert hashlib.sha256(host.download().tobytes()).hexdigest() == c["float_sha256"]
+    host.measure_tile_costs(2)
+    after = host.tile_order()
+    work = after["words"] >> 8 != 0
+    assert work.any() and (after["costs"][work] > 0).all() and (after["costs"][~work] == 0).all()
+    assert np.array_equal(after["constants"], before["constants"])
+    assert sorted(after["order"].tolist()) == sorted(before["order"].tolist())  # the same entries ...
+    host.render()
+    assert hashlib.sha256(host.download().tobytes()).hexdigest() == c["float_sha256"]
+    assert host.stats()["ao_occluded"] == c["counters"]["ao_occluded"]
+    # ... and each group's list backwards (cheapest first: the worst order there is)
+    order, at = after["order"].copy(), 0
+    n = int(np.sqrt(opt.n_super_samples))
+    tiles_x, rows = (opt.width * n + 7) // 8, (opt.height * n + 7) // 8
+    for g in range(8):
+        count = int(after["constants"][g][0])
+        order[at:at + count] = order[at:at + count][::-1].copy()
+        at += (((tiles_x + 1) // 2 + 7 - g) >> 3) * 2 * rows
+    host.set_tile_order(order, after["constants"])
+    host.render()
+    assert hashlib.sha256(host.download().tobytes()).hexdigest() == c["float_sha256"]
+    with pytest.raises(rt.RtError):
+        host.set_tile_order(order[:-1], after["constants"])
+    bad = order.copy()
+    bad[0] = 0x03FFFFFF
+    with pytest.raises(rt.RtError):
+        host.set_tile_order(bad, after["constants"])
+    host.close()
+
+
 @pytest.mark.parametrize("mesh", ["interior", "bunny"])
 def test_walk_intervals_confine_the_walks_and_change_nothing(rt, oracle, scene_for, mesh):
     """An upload finds, per tile and per table direction of a full tile, the interval of the node array its any-hit rays
@@ -262,8 +311,13 @@ def test_walk_intervals_confine_the_walks_and_change_nothing(rt, oracle, scene_f
     shares = []
     for distance in (0.02, 0.2, 0.9, 50.0):
         opt = rt.Options.defaults(width=128, height=72, n_super_samples=4, ao_num_samples=2, ao_max_distance=distance)
-        host = render_hip(rt, scene, opt)
+        host = render_hip(rt, scene, opt)  # nothing announced: the whole array for every packet
         ref_img, counters, _ = oracle.render(orc.params_from_options(opt), arrays)
+        assert np.array_equal(bits(host.download()), bits(ref_img)), distance
+        e = host.walk_entries()
+        assert e["tiles_narrowed"] == 0 and e["mean_share"] == 1.0 and e["mean_packet_share"] == 1.0
+        host.expect_frames(STREAM)  # announced after the upload: the hit list is laid out again, with the table
+        host.render()
         assert np.array_equal(bits(host.download()), bits(ref_img)), distance
         assert host.stats()["ao_occluded"] == counters["ao_occluded"]
         e = host.walk_entries()

@@ -166,15 +166,20 @@ def test_partition_rows_cover_image(rt):
             assert np.all(seen == 1), (w, h, ss, nranks)
 
 
-def header_symbols():
-    text = open(os.path.join(ROOT, "include", "rt_hip.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", text)))
+def header_symbols(name=None):
+    """Entry points declared by include/<name> (all of include/rt_hip*.h when no name is given)."""
+    import glob
+
+    names = set()
+    for path in sorted(glob.glob(os.path.join(ROOT, "include", name or "rt_hip*.h"))):
+        text = re.sub(r"/\*.*?\*/", "", open(path).read(), flags=re.S)
+        names.update(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
 
 
 def test_library_exports_every_declared_symbol(rt):
     """The C-ABI library loads without a GPU and exports exactly what
-    include/rt_hip.h declares (no compute is called here)."""
+    include/rt_hip*.h declare (no compute is called here)."""
     lib = C.CDLL(rt.lib_path())
     names = header_symbols()
     assert len(names) >= 40

@@ -49,7 +49,7 @@ def _run_bench(nproc, extra_env=None, bare=False, extra_args=()):
 def test_rccl_world_of_one_runs_the_gather(golden):
     out = _run_bench(1)
     assert out["n_gpus"] == 1 and "RCCL gather" in out["config"]["parallelism"]
-    assert out["blocking"]["pgm_md5"] == golden["renders"]["bunny_600_defaults"]["pgm_md5"] and out["blocking"]["value"] > 0
+    assert out["pipelined"]["pgm_md5"] == golden["renders"]["bunny_600_defaults"]["pgm_md5"] and out["pipelined"]["value"] > 0
     assert out["config"]["pgm_md5"] == golden["renders"]["bunny_600_defaults"]["pgm_md5"]
     assert out["config"]["pgm_matches_golden"] is True and out["value"] > 0
 
@@ -62,7 +62,7 @@ def test_the_job_survives_a_gather_that_cannot_be_set_up(golden):
     assert out["n_gpus"] == 1 and "could not be set up" in out["config"]["parallelism"]
     assert out["config"]["rccl"]["failed"] and "OCRT_BENCH_FAIL_RCCL" in out["config"]["rccl"]["failed"]
     assert out["config"]["pgm_md5"] == golden["renders"]["bunny_600_defaults"]["pgm_md5"]
-    assert out["blocking"]["pgm_md5"] == golden["renders"]["bunny_600_defaults"]["pgm_md5"] and out["value"] > 0
+    assert out["pipelined"]["pgm_md5"] == golden["renders"]["bunny_600_defaults"]["pgm_md5"] and out["value"] > 0
 
 
 def test_rccl_two_ranks_assemble_the_golden_frame(golden):
@@ -98,5 +98,5 @@ def test_four_gloo_ranks_rehearse_the_eight_gpu_run(golden):
     out = _run_bench(4, extra_env={"OCRT_BENCH_BACKEND": "gloo"}, bare=True, extra_args=["--in-flight", "8"])
     assert out["n_gpus"] == 4 and out["config"]["frames_in_flight"] == 8
     assert out["config"]["pgm_md5"] == golden["renders"]["bunny_600_defaults"]["pgm_md5"]
-    assert out["blocking"]["pgm_md5"] == golden["renders"]["bunny_600_defaults"]["pgm_md5"]
+    assert out["pipelined"]["pgm_md5"] == golden["renders"]["bunny_600_defaults"]["pgm_md5"]
     assert out["config"]["rays_per_frame"] == 1440000 + 28 * golden["renders"]["bunny_600_defaults"]["counters"]["primary_hits"]

@@ -79,7 +79,7 @@ def main():
         for w in workloads:
             for v in variants:  # "lib_dir" or "lib_dir:KNOB=value,KNOB=value" (knobs: the A/B build lib_knobs reads them)
                 lib_dir, _, knobs = v.partition(":")
-                env = dict(os.environ, OCRT_LIB_DIR=lib_dir, OCRT_AB_LABEL=v)
+                env = dict(os.environ, OCRT_LIB_DIR=lib_dir, OCRT_AB_LABEL=v, OCRT_ALLOW_OLD_LIB="1")
                 for item in filter(None, knobs.split(",")):
                     key, _, value = item.partition("=")
                     env[key] = value

@@ -1,0 +1,119 @@
+"""Which order should the ambient-occlusion pass claim a frame's tiles in?  (GPU box.)
+Measures the tiles' costs (rt_debug_measure_tile_costs), makes claim orders by several rules HERE, installs each
+(rt_debug_set_tile_order: any order renders the same image) and times blocking frames with it.
+
+    python3 tools/analysis/order_policies.py [workload ...]
+"""
+import os
+import statistics
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+
+def spatial_index(tile, tiles_x, rows, strip_tiles):
+    x, row = tile % tiles_x, tile // tiles_x
+    strip = x // strip_tiles
+    return ((strip // 8) * rows + row) * strip_tiles + x % strip_tiles
+
+
+def segments(order, constants, tiles_x, rows, strip_tiles):
+    strips = (tiles_x + strip_tiles - 1) // strip_tiles
+    out, at = [], 0
+    for g in range(8):
+        size = ((strips + 7 - g) >> 3) * strip_tiles * rows
+        out.append((at, size, order[at:at + constants[g][0]].copy()))
+        at += size
+    return out
+
+
+def make_order(base, segs, costs, rule, workgroups_per_group, tiles_x, rows, strip_tiles):
+    order = base.copy()
+    for at, size, entries in segs:
+        tiles = entries & 0x03FFFFFF
+        spatial = np.argsort([spatial_index(int(t), tiles_x, rows, strip_tiles) for t in tiles], kind="stable")
+        entries, tiles = entries[spatial], tiles[spatial]
+        c = costs[tiles].astype(np.float64)
+        n = len(c)
+        if n == 0:
+            continue
+        kind = rule[0]
+        if kind == "spatial":
+            pick = np.arange(n)
+        elif kind == "lpt":
+            pick = np.argsort(-c, kind="stable")
+        else:  # ("mixed", heavy, runway, cheap)
+            _, heavy, runway, cheap = rule
+            reference = np.sort(c)[n - 1 - (n - 1) // 4]
+            is_heavy = c > heavy * reference
+            heavy_ones = np.flatnonzero(is_heavy)
+            heavy_ones = heavy_ones[np.argsort(-c[heavy_ones], kind="stable")]
+            rest = np.flatnonzero(~is_heavy)
+            left = c[rest].sum() - np.concatenate(([0.0], np.cumsum(c[rest])[:-1]))
+            budget = runway * reference * workgroups_per_group
+            in_spatial = (left > budget) & (c[rest] >= cheap * reference)
+            sp, rw = rest[in_spatial], rest[~in_spatial]
+            rw = rw[np.argsort(-c[rw], kind="stable")]
+            pick = np.concatenate((heavy_ones, sp, rw))
+        order[at:at + n] = entries[pick]
+    return order
+
+
+def timed(host, frames=30):
+    for _ in range(5):
+        host.render()
+    total, ao = [], []
+    for _ in range(frames):
+        host.render()
+        total.append(host.last_kernel_ms)
+        ao.append(host.last_ao_ms)
+    return statistics.median(total), statistics.median(ao), min(total)
+
+
+def main():
+    import opencl_raytracer_amd as rt
+    from bench import WORKLOADS, load_scene, workload_options
+
+    for name in sys.argv[1:] or ["bunny_1080p_ao"]:
+        w = WORKLOADS[name]
+        opt = workload_options(rt, w)
+        scene = load_scene(rt, w).build_bvh(opt.bvh_method)
+        host = rt.Host(opt, 0)
+        host.upload_scene(scene)
+        base_ms = timed(host)
+        host.measure_tile_costs(3, reorder=False)
+        info = host.tile_order()
+        costs, words = info["costs"] / 3.0, info["words"]
+        n = int(np.sqrt(opt.n_super_samples))
+        tiles_x, rows = (opt.width * n + 7) // 8, (opt.height * n + 7) // 8
+        strip_tiles = 2
+        hit = words >> 8 != 0
+        c = costs[hit]
+        q = np.percentile(c, [5, 25, 50, 75, 90, 95, 99, 100])
+        print(f"{name}: {hit.sum()} tiles with AO work; measured cost per tile (us, 10 ns ticks / 100): "
+              f"5/25/50/75/90/95/99/100 % = " + " ".join(f"{v / 100:.1f}" for v in q) + f"; sum {c.sum() / 1e5:.1f} ms of workgroup time")
+        cls = (words[hit] >> 8).astype(np.float64)
+        print(f"   correlation of the measured cost with the cost class (primary packet's leaf stops): {np.corrcoef(cls, c)[0, 1]:.3f}")
+        segs = segments(info["order"], info["constants"], tiles_x, rows, strip_tiles)
+        print(f"   {'as installed (blocks of 64 by cost class)':58s} frame {base_ms[0]:.4f} ms (min {base_ms[2]:.4f}), ao {base_ms[1]:.4f}", flush=True)
+        rules = [("spatial",), ("lpt",)]
+        for heavy in (1.3, 1.6, 2.0, 1e9):
+            for runway in (0.0, 1.0, 2.0, 3.0):
+                rules.append(("mixed", heavy, runway, 0.25))
+        rules += [("mixed", 1.6, 2.0, 0.0), ("mixed", 1.6, 2.0, 0.5), ("mixed", 1.3, 4.0, 0.25), ("mixed", 1.0, 2.0, 0.25)]
+        for rule in rules:
+            order = make_order(info["order"], segs, costs, rule, 256, tiles_x, rows, strip_tiles)
+            host.set_tile_order(order, info["constants"])
+            ms = timed(host)
+            print(f"   {str(rule):58s} frame {ms[0]:.4f} ms (min {ms[2]:.4f}), ao {ms[1]:.4f}", flush=True)
+        host.set_tile_order(info["order"], info["constants"])
+        again = timed(host)
+        print(f"   {'as installed, again':58s} frame {again[0]:.4f} ms (min {again[2]:.4f}), ao {again[1]:.4f}", flush=True)
+        host.close()
+
+
+if __name__ == "__main__":
+    main()

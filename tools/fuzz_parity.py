@@ -50,7 +50,8 @@ def draw_case(rng):
         amax=rng.choice([90, 90, 60]),
         share=rng.choice([1, 1, 3, 6]),  # (a host that is told it shares its GPU launches a smaller AO grid and keeps its claim size)
         ring=rng.choice([0, 0, 0, 2]),   # (0: one blocking host; n: a ring of n hosts, graph replay, three frames)
-        lookahead=rng.choice([0, 1, 2]))  # (the form of the AO pass: without / with look-ahead loads / as calibrated or by default)
+        lookahead=rng.choice([0, 1, 2]),  # (the form of the AO pass: without / with look-ahead loads / as calibrated or by default)
+        announce=rng.choice([0, 1, 1]))  # (a blocking host: one-shot, or with a stream of frames announced -- its upload then prepares the walk intervals)
 
 
 def run_case(rt, orc, oracle, scenes, case):
@@ -89,6 +90,8 @@ def run_case(rt, orc, oracle, scenes, case):
             ring.close()
         else:
             host = rt.Host(opt, 0)
+            if case.get("announce") and hasattr(host, "expect_frames"):
+                host.expect_frames(1000)  # (an upload then prepares the walk intervals; without: the one-shot host)
             if case["lookahead"] < 2 and hasattr(host, "set_ao_prefetch"):
                 host.set_ao_prefetch(bool(case["lookahead"]))
             host.upload_scene(scene)
