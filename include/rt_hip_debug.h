@@ -29,6 +29,16 @@ uint32_t rt_debug_tiles(rt_host *h);
 int rt_debug_tile_order(rt_host *h, uint32_t *order, uint32_t *constants24, uint32_t *tile_words, float *tile_costs);
 int rt_debug_set_tile_order(rt_host *h, const uint32_t *order, uint32_t slots, const uint32_t *constants24);
 
+/* Which form a frame with UNIFORM ambient occlusion takes on this host: 0 = the library's rule (two kernels), 1 = the
+ * fused frame kernel (primary rays and ambient occlusion in one persistent launch, kernels/frame.hip.h: an experiment
+ * that renders the same bits and measured 2-9 % slower, profiles/r05_notes.md), 2 = two kernels.  Same image either way.
+ * rt_debug_frame_is_fused: what the next frame will be.  rt_debug_poison_hit_list: overwrites the hit list (the hand-over
+ * between the two ray passes) with NaN patterns -- a fused frame that read a record before its own primary work had
+ * written it would show; frames of one scene are otherwise identical, and a stale record could never be seen. */
+int rt_debug_set_frame_form(rt_host *h, int form);
+int rt_debug_frame_is_fused(rt_host *h);
+int rt_debug_poison_hit_list(rt_host *h);
+
 #ifdef __cplusplus
 }
 #endif

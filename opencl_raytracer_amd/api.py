@@ -180,6 +180,9 @@ _SIGNATURES = {
     "rt_debug_tiles": (C.c_uint32, [C.c_void_p]),
     "rt_debug_tile_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rt_debug_set_tile_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "rt_debug_set_frame_form": (C.c_int, [C.c_void_p, C.c_int]),
+    "rt_debug_frame_is_fused": (C.c_int, [C.c_void_p]),
+    "rt_debug_poison_hit_list": (C.c_int, [C.c_void_p]),
 }
 
 
@@ -422,6 +425,17 @@ class Host:
     def set_ao_prefetch(self, on: bool) -> None:
         """Which form of the AO pass's node loop this host launches (include/rt_hip.h, rt_set_ao_prefetch); same results."""
         _check(load_library().rt_set_ao_prefetch(self._h, int(on)))
+
+    def set_frame_form(self, form: str) -> None:
+        """"auto" (the library's rule), "fused" (both ray passes in one persistent launch) or "separate" (two kernels)."""
+        _check(load_library().rt_debug_set_frame_form(self._h, {"auto": 0, "fused": 1, "separate": 2}[form]))
+
+    @property
+    def frame_is_fused(self) -> bool:
+        return bool(load_library().rt_debug_frame_is_fused(self._h))
+
+    def poison_hit_list(self) -> None:
+        _check(load_library().rt_debug_poison_hit_list(self._h))
 
     def expect_frames(self, frames: int) -> None:
         """Announces a stream of frames (include/rt_hip.h, rt_expect_frames): uploads then prepare the walk intervals."""

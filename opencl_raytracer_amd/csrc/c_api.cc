@@ -541,6 +541,20 @@ int rt_debug_set_tile_order(rt_host *h, const uint32_t *order, uint32_t slots, c
 	});
 }
 
+int rt_debug_set_frame_form(rt_host *h, int form) {
+	if (!h)
+		return fail(RT_E_INVALID, "null argument");
+	return guarded([&] { h->dev->setFrameForm(form); });
+}
+
+int rt_debug_frame_is_fused(rt_host *h) { return h && h->dev->frameIsFused() ? 1 : 0; }
+
+int rt_debug_poison_hit_list(rt_host *h) {
+	if (!h)
+		return fail(RT_E_INVALID, "null argument");
+	return guarded([&] { h->dev->poisonHitList(); });
+}
+
 uint32_t rt_ring_size(const rt_ring *r) { return r ? r->ring->size() : 0; }
 uint32_t rt_ring_slots(const rt_ring *r) { return r ? r->ring->slots() : 0; }
 uint32_t rt_ring_local_rows(const rt_ring *r) { return r ? r->ring->localRows() : 0; }

@@ -166,6 +166,13 @@ DeviceRenderer::DeviceRenderer(const RayTracer::Options &options, int device_, u
 	d_tile_hits = device_alloc(tile_count * sizeof(uint32_t));
 	d_tile_base = device_alloc(tile_count * sizeof(uint32_t));
 	d_order = device_alloc(order_slots * sizeof(uint32_t));
+	d_order_need = device_alloc((order_slots ? order_slots : 1) * sizeof(uint32_t));
+	{  // (2 x 2 tile blocks: whole strips x pairs of rows)
+		const size_t padded_x = (size_t) ((kp.tiles_x + MAX_STRIP_TILES - 1) / MAX_STRIP_TILES) * MAX_STRIP_TILES;
+		d_primary_order = device_alloc((padded_x / 2 * ((kp.local_tile_rows + 1) / 2) + 1) * sizeof(uint32_t));
+	}
+	d_tile_ready = device_alloc((tile_count ? tile_count : 1) * sizeof(uint32_t));
+	OCRT_HIP(hipMemsetAsync(d_tile_ready, 0, (tile_count ? tile_count : 1) * sizeof(uint32_t), (hipStream_t) stream));
 	d_counters = device_alloc(sizeof(FrameCounters));
 	OCRT_HIP(hipMemsetAsync(d_counters, 0, sizeof(FrameCounters), (hipStream_t) stream));  // (once: the kernels keep it clean, device_types.h)
 	{
@@ -203,6 +210,9 @@ DeviceRenderer::~DeviceRenderer() {
 	device_free(d_tile_hits);
 	device_free(d_tile_base);
 	device_free(d_order);
+	device_free(d_primary_order);
+	device_free(d_order_need);
+	device_free(d_tile_ready);
 	device_free(d_counters);
 	if (own_stream)
 		(void) hipStreamDestroy((hipStream_t) own_stream);
@@ -663,18 +673,116 @@ std::vector<uint32_t> DeviceRenderer::orderByMeasuredCost(const std::vector<floa
 	return out;
 }
 
+// The fused frame kernel's primary work (kernels/primary.hip.h, primary_top_up): per XCD group the 2 x 2 tile blocks of
+// its strips, entry = first tile column | first tile row << 16, IN THE ORDER THE AMBIENT-OCCLUSION CLAIMS WANT THEM --
+// a block is listed when the first of its tiles comes up in the group's claim order (`order_host`) -- and the blocks no
+// claim ever wants (the background, tiles without hits) last, in spatial order.  order_need[j], beside entry j of the claim
+// order: how many blocks the entries 0 ... j need, i.e. how far the block cursor must have come before entry j's tile may
+// be waited for.
+void DeviceRenderer::orderPrimaryBlocks() {
+	const uint32_t strip_tiles = kp.strip_tiles, columns = strip_tiles >> 1, rows = kp.local_tile_rows, tiles_x = kp.tiles_x;
+	const uint32_t strips = (tiles_x + strip_tiles - 1u) / strip_tiles, row_blocks = (rows + 1u) >> 1;
+	const uint32_t blocks_x = (tiles_x + 1u) >> 1;
+	primary_order_host.clear();
+	order_need_host.assign(order_host.size(), 0u);
+	std::vector<char> listed((size_t) blocks_x * row_blocks, 0);
+	size_t ao_segment = 0;
+	for (uint32_t group = 0; group < XCD_GROUPS; ++group) {
+		const uint32_t strips_here = (strips + XCD_GROUPS - 1u - group) >> 3;
+		const size_t segment = (size_t) strips_here * row_blocks * columns, at = primary_order_host.size();
+		primary_order_host.resize(at + segment, 0u);
+		uint32_t count = 0;
+		// in the order of the claims
+		for (uint32_t j = 0; j < queue_static[group][0]; ++j) {
+			const uint32_t tile = order_host[ao_segment + j] & 0x03FFFFFFu, x = tile % tiles_x, row = tile / tiles_x;
+			const size_t block = (size_t) (row >> 1) * blocks_x + (x >> 1);
+			if (!listed[block]) {
+				listed[block] = 1;
+				primary_order_host[at + count++] = (x & ~1u) | (row & ~1u) << 16;
+			}
+			order_need_host[ao_segment + j] = count;
+		}
+		// ... then whatever no claim wants
+		for (uint32_t strip_index = 0; strip_index < strips_here; ++strip_index)
+			for (uint32_t rb = 0; rb < row_blocks; ++rb)
+				for (uint32_t c = 0; c < columns; ++c) {
+					const uint32_t x0 = strip_tiles * (group + XCD_GROUPS * strip_index) + 2u * c, row0 = 2u * rb;
+					if (x0 >= tiles_x)
+						continue;
+					const size_t block = (size_t) rb * blocks_x + (x0 >> 1);
+					if (!listed[block]) {
+						listed[block] = 1;
+						primary_order_host[at + count++] = x0 | row0 << 16;
+					}
+				}
+		primary_blocks[group] = count;
+		ao_segment += (size_t) strips_here * strip_tiles * rows;
+	}
+	if (primary_order_host.empty())
+		primary_order_host.push_back(0u);
+}
+
+bool DeviceRenderer::fusedFrame() const {
+	const bool possible = kp.ao_mode == AO_UNIFORM && kp.ao_dirs > 0 && kp.shared_walk && tile_count > 0 && kp.tiles_x < 65536u &&
+	                      kp.local_tile_rows < 65536u && !primary_order_host.empty();
+	// Measured and NOT the rule (profiles/r05_notes.md): the fused frame renders the same bits, but a frame on its own takes
+	// 2-9 % LONGER with it than as two kernels -- headline 1.09 against 1.07 ms, interior 1080p 1.08 against 1.02, 4K 3.74
+	// against 3.43 -- whether the primary work is taken at the head of a group's turn or a little ahead of the any-hit work
+	// all through the frame: primary waves that are tied to a persistent workgroup's barriers hold their wave slots for the
+	// block's slowest tile, and what the launch boundary cost (the chip draining and filling once) is less than that.  The
+	// kernel stays reachable for experiments (rt_debug_set_frame_form) and under test (tests/test_fused_frame.py).
+	return possible && frame_form == FrameForm::FUSED;
+}
+
+void DeviceRenderer::setFrameForm(int form) {
+	const FrameForm want = form == 1 ? FrameForm::FUSED : form == 2 ? FrameForm::SEPARATE : FrameForm::AUTO;
+	if (want == frame_form)
+		return;
+	frame_form = want;
+	++scene_version;  // (a captured frame bakes its kernels in)
+}
+
+void DeviceRenderer::poisonHitList() {
+	useDevice();
+	synchronize();
+	if (d_hits && hit_slots) {
+		// (on the renderer's own stream and waited for: a fill on the null stream is not ordered against a non-blocking
+		// stream's work and need not have finished when its call returns)
+		OCRT_HIP(hipMemsetAsync(d_hits, 0xFF, hit_slots * sizeof(HitRec), (hipStream_t) stream));
+		OCRT_HIP(hipMemsetAsync(d_occluded, 0xFF, hit_slots * sizeof(uint32_t), (hipStream_t) stream));
+		OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));
+	}
+}
+
+void DeviceRenderer::checkFrameHealth() {
+	uint32_t stalled = 0;
+	OCRT_HIP(hipMemcpy(&stalled, (const char *) d_counters + offsetof(FrameCounters, stalled), sizeof stalled, hipMemcpyDeviceToHost));
+	if (stalled) {
+		OCRT_HIP(hipMemsetAsync((char *) d_counters + offsetof(FrameCounters, stalled), 0, sizeof stalled, (hipStream_t) stream));
+		OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));
+		throw DeviceError("the fused frame kernel waited in vain for a tile's hit records (" + std::to_string(stalled) + " waves gave up): the frame is not valid");
+	}
+}
+
 void DeviceRenderer::installOrder(const std::vector<uint32_t> &order, const std::array<std::array<uint32_t, 3>, XCD_GROUPS> &constants) {
 	order_host = order;
 	queue_static = constants;
 	OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));
 	OCRT_HIP(hipMemcpy(d_order, order_host.data(), order_host.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	orderPrimaryBlocks();
+	OCRT_HIP(hipMemcpy(d_primary_order, primary_order_host.data(), primary_order_host.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	OCRT_HIP(hipMemcpy(d_order_need, order_need_host.data(), order_need_host.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	FrameCounters fresh{};
 	for (uint32_t g = 0; g < XCD_GROUPS; ++g) {
 		fresh.queue[g].work_tiles = constants[g][0];
 		fresh.queue[g].cost_sum = constants[g][1];
 		fresh.queue[g].hits = constants[g][2];
+		fresh.queue[g].primary_blocks = primary_blocks[g];
 	}
 	OCRT_HIP(hipMemcpy(d_counters, &fresh, sizeof fresh, hipMemcpyHostToDevice));
+	// (the frame count starts again at 0: no tile's flag may claim a frame)
+	OCRT_HIP(hipMemsetAsync(d_tile_ready, 0, (tile_count ? tile_count : 1) * sizeof(uint32_t), (hipStream_t) stream));
+	OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));
 	++scene_version;  // (nothing a captured frame bakes in has changed, but a frame in flight must not see the list change: callers synchronise)
 }
 
@@ -703,15 +811,23 @@ void DeviceRenderer::launchFrame(void *device_u8, void *ao_start, void *ao_stop,
 	hipStream_t s = (hipStream_t) stream;
 #endif
 	const SceneBuffers scene = scene_on_device->buffers();
-	launch_primary(scene, (float *) d_image, d_hits, d_occluded, d_tile_hits, d_tile_base, d_counters, kp, stream);
-	OCRT_HIP(hipGetLastError());
+	const uint32_t workgroups = ao_blocks_override ? ao_blocks_override : aoWorkgroups();
+	if (fusedFrame() && !tile_cost_out) {
+		// the two ray passes as one persistent launch (kernels/frame.hip.h); the events bracket it
+		launch_frame(scene, (float *) d_image, d_hits, d_occluded, d_tile_hits, d_order, d_primary_order, d_order_need, d_tile_ready, d_tile_base,
+		             d_tile_entry, d_counters, kp, workgroups, ao_prefetch, stream, ao_start, ao_stop);
+		OCRT_HIP(hipGetLastError());
+	} else {
+		launch_primary(scene, (float *) d_image, d_hits, d_occluded, d_tile_hits, d_tile_base, d_counters, kp, stream);
+		OCRT_HIP(hipGetLastError());
 #ifdef OCRT_STAMPS  // (instrumented build: the AO pass takes the minimum of its waves' start times into this slot)
-	OCRT_HIP(hipMemsetAsync((char *) d_counters + offsetof(FrameCounters, stamp) + 7 * sizeof(unsigned long long), 0xFF, sizeof(unsigned long long), s));
+		OCRT_HIP(hipMemsetAsync((char *) d_counters + offsetof(FrameCounters, stamp) + 7 * sizeof(unsigned long long), 0xFF, sizeof(unsigned long long), s));
 #endif
-	launch_ao(scene, d_hits, d_occluded, d_order, d_tile_base, d_tile_entry, d_counters, kp, ao_blocks_override ? ao_blocks_override : aoWorkgroups(), ao_prefetch,
-	          stream, ao_start, ao_stop, tile_cost_out);
-	OCRT_HIP(hipGetLastError());
-	launch_finish((float *) d_image, d_hits, d_occluded, d_tile_base, (unsigned char *) device_u8, kp, opts.width, grid, local_out_rows, stream);
+		launch_ao(scene, d_hits, d_occluded, d_order, d_tile_base, d_tile_entry, d_counters, kp, workgroups, ao_prefetch, stream, ao_start, ao_stop,
+		          tile_cost_out);
+		OCRT_HIP(hipGetLastError());
+	}
+	launch_finish((float *) d_image, d_hits, d_occluded, d_tile_base, (unsigned char *) device_u8, kp, opts.width, grid, local_out_rows, stream, d_counters);
 	OCRT_HIP(hipGetLastError());
 }
 
@@ -1064,6 +1180,7 @@ void DeviceRenderer::synchronize() {
 
 void DeviceRenderer::downloadFloat(float *host_image) {
 	synchronize();
+	checkFrameHealth();
 	const size_t row_bytes = (size_t) rt.totalWidth * sizeof(float);
 	if (part.nranks == 1) {  // local rows are the image's rows (plus, possibly, padding below it)
 		OCRT_HIP(hipMemcpy(host_image, d_image, row_bytes * rt.totalHeight, hipMemcpyDeviceToHost));
@@ -1128,6 +1245,8 @@ RenderStats DeviceRenderer::stats() {
 	}
 	FrameCounters c{};
 	OCRT_HIP(hipMemcpy(&c, d_counters, sizeof c, hipMemcpyDeviceToHost));
+	if (c.stalled)
+		checkFrameHealth();
 	{  // hit sub-pixels: the low byte of the words the frame's primary pass left per tile
 		std::vector<uint32_t> words(tile_count);
 		OCRT_HIP(hipMemcpy(words.data(), d_tile_hits, tile_count * sizeof(uint32_t), hipMemcpyDeviceToHost));

@@ -176,6 +176,12 @@ class DeviceRenderer {
 		void takeOrderFrom(const DeviceRenderer &other);
 		bool orderIsMeasured() const { return tile_cost.size() == tile_count && tile_count != 0; }
 		void setOrderPolicy(float heavy, float runway);
+		// 0: the library's rule (two kernels), 1: fused, 2: two kernels -- same results
+		void setFrameForm(int form);
+		bool frameIsFused() const { return fusedFrame(); }
+		// (test aid, include/rt_hip_debug.h: fills the hit list with NaN patterns between frames -- a fused frame that read a
+		// record its own primary work had not written yet would show it)
+		void poisonHitList();
 		// (diagnostics / experiments, include/rt_hip_debug.h: the list as it is, and a list made elsewhere put in its place --
 		// any order of the same tiles renders the same image)
 		void tileOrder(std::vector<uint32_t> &order, std::vector<uint32_t> &constants, std::vector<uint32_t> &words, std::vector<float> &cost) const;
@@ -231,6 +237,7 @@ class DeviceRenderer {
 		void *own_stream, *stream;
 		std::shared_ptr<const DeviceScene> scene_on_device;
 		void *d_image, *d_u8, *d_hits, *d_occluded, *d_tile_hits, *d_tile_base, *d_tile_entry, *d_order, *d_counters;
+		void *d_primary_order = nullptr, *d_order_need = nullptr, *d_tile_ready = nullptr;  // the fused frame kernel's block order, what every claim needs of it, and the flags (kernels/frame.hip.h)
 		size_t hit_slots;     // slots of the hit list: the scene's hit sub-pixels in this rank's bands (sizeHitList)
 		size_t entryBytes() const { return (size_t) tile_count * kp.entry_stride * 2 * sizeof(uint32_t); }  // the tiles' walk intervals (entry_kernel)
 		std::shared_ptr<void> tile_entry_owner;  // d_tile_entry: one table for the hosts of a ring (sizeHitList)
@@ -241,6 +248,14 @@ class DeviceRenderer {
 		std::vector<uint32_t> tile_words, order_host;
 		std::vector<float> tile_cost;  // measured: device-clock ticks per tile (empty: not measured)
 		std::array<std::array<uint32_t, 3>, XCD_GROUPS> queue_static{};  // per group: non-empty tiles, sum of cost classes, hit sub-pixels
+		std::vector<uint32_t> primary_order_host, order_need_host;  // fused frame kernel: the groups' 2 x 2 tile blocks in the order the AO claims want them; per AO entry the blocks needed so far
+		std::array<uint32_t, XCD_GROUPS> primary_blocks{};    // ... and how many each group has
+		void orderPrimaryBlocks();
+		// Which form a frame with UNIFORM ambient occlusion takes: two kernels (the rule), or the two ray passes as one
+		// persistent launch (kernels/frame.hip.h: built, bit-exact, measured slower -- fusedFrame() says by how much).
+		enum class FrameForm { AUTO, FUSED, SEPARATE } frame_form = FrameForm::AUTO;
+		bool fusedFrame() const;
+		void checkFrameHealth();  // throws DeviceError if a wave of the fused frame kernel ever gave up waiting (FrameCounters::stalled)
 		struct OrderPolicy {  // (orderByMeasuredCost; swept in profiles/r05_order_policies.txt)
 			float heavy = 2.0f;   // tiles beyond this many reference costs (the upper quartile) are claimed first
 			float runway = 2.0f;  // what is held back for the end, by falling cost: this many reference claims per workgroup
@@ -296,8 +311,12 @@ void launch_entries(const SceneBuffers &scene, const void *hits, const void *til
 void launch_ao(const SceneBuffers &scene, void *hits, void *occluded_of, void *order, const void *tile_base, const void *tile_entry,
                void *counters, const KernelParams &P, uint32_t workgroups, bool prefetch, void *stream, void *event_before_ao,
                void *event_after_ao, void *tile_cost = nullptr);
+void launch_frame(const SceneBuffers &scene, float *image, void *hits, void *occluded_of, void *tile_hits, void *order,
+                  const void *primary_order, const void *order_need, void *tile_ready, const void *tile_base, const void *tile_entry,
+                  void *counters, const KernelParams &P, uint32_t workgroups, bool prefetch, void *stream, void *event_before, void *event_after);
 void launch_finish(float *image, const void *hits, const void *occluded_of, const void *tile_base,
-                   unsigned char *out, const KernelParams &P, uint32_t out_width, uint32_t n, uint32_t local_out_rows, void *stream);
+                   unsigned char *out, const KernelParams &P, uint32_t out_width, uint32_t n, uint32_t local_out_rows, void *stream,
+                   void *counters);
 void launch_occluded_sum(const void *occluded_of, size_t slots, void *counters, void *stream);
 void launch_resize(const float *tmp, unsigned char *out, const KernelParams &P, uint32_t out_width, uint32_t n,
                    uint32_t local_out_rows, void *stream);

@@ -69,9 +69,15 @@ struct alignas(128) GroupQueue {
 	uint32_t work_tiles;  // non-empty tiles of the group (per upload)
 	uint32_t cost_sum;    // sum of their AO cost classes (per upload)
 	uint32_t hits;        // hit sub-pixels in the group's tiles (per upload)
-	uint32_t pad[28];
+	// the fused frame kernel's primary work of the group (kernels/frame.hip.h): 2 x 2 tile blocks, in the order of
+	// FrameArgs::primary_order
+	uint32_t primary_blocks;  // how many (per upload)
+	uint32_t pad0[27];
+	// ... and their claim cursor, in a line of its own: it is hammered at the beginning of a frame, the head at its end
+	uint32_t primary_head;
+	uint32_t pad1[31];
 };
-static_assert(sizeof(GroupQueue) == 128, "one line per queue");
+static_assert(sizeof(GroupQueue) == 256, "two lines per queue");
 struct FrameCounters {
 	GroupQueue queue[XCD_GROUPS];
 	unsigned long long occluded;  // occluded AO rays: summed from the hit list's counts when the statistic is asked for (occluded_sum_kernel)
@@ -80,6 +86,8 @@ struct FrameCounters {
 	// replayed from a captured hipGraph has no HIP events inside it that could be timed (hipEventElapsedTime refuses
 	// event-record nodes); these say when its passes ran.
 	unsigned long long tick_begin, tick_ao_begin, tick_ao_end;
+	uint32_t frame_seq;  // frames finished on these counters (the finishing kernel counts): what the fused frame kernel's flags are compared with
+	uint32_t stalled;    // fused frame kernel: waves that gave up waiting for a tile's hit records (0 in every healthy frame; DeviceRenderer reports it)
 #if defined(OCRT_STAMPS) || defined(OCRT_TAIL)
 	unsigned long long stamp[10 + 32 + 7 + 16];  // debug build: wave-time (10 ns ticks) per phase of the AO pass, jobs, packets
 #endif
@@ -133,6 +141,7 @@ struct KernelParams {
 	uint32_t strip_tiles;  // width, in tiles, of the vertical strips the image is dealt to the XCD groups in: a power of two,
 	                       // 2 by default (the finest deal: best balance, and a cache-resident scene does not care), wider for
 	                       // scenes far beyond the L2s, whose XCDs should not all fetch the same geometry (device_renderer.cc)
+	uint32_t primary_ahead; // fused frame kernel: how many 2 x 2 blocks beyond what a claim needs the group's primary work is taken (kernels/primary.hip.h, primary_top_up)
 	uint32_t entry_stride; // walk intervals per tile (kernels.hip, entry_kernel): 1 + ao_dirs, or 1 where that table would be too large
 	uint32_t tiles_x;      // tiles per image row
 	uint32_t local_tile_rows;  // tile rows this rank owns

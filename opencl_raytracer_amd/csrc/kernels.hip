@@ -61,6 +61,7 @@
 #include "kernels/walk.hip.h"
 #include "kernels/primary.hip.h"
 #include "kernels/ao.hip.h"
+#include "kernels/frame.hip.h"
 #include "kernels/entry.hip.h"
 #include "kernels/finish.hip.h"
 
@@ -98,7 +99,7 @@ void launch_primary(const SceneBuffers &scene, float *image, void *hits, void *o
 	const uint32_t strips = (P.tiles_x + P.strip_tiles - 1u) / P.strip_tiles, row_blocks = (P.local_tile_rows + PRIMARY_ROWS - 1u) / PRIMARY_ROWS;
 	const uint32_t blocks = XCD_GROUPS * ((strips + XCD_GROUPS - 1u) >> 3) * row_blocks * (P.strip_tiles >> 1);
 	auto launch = [&](auto kernel) {
-		PrimaryArgs args;
+		FrameArgs args{};
 		args.walk_ptr = (const float4 *) scene.walk;
 		args.tris_ptr = (const float4 *) scene.tris;
 		args.nodes_ptr = (const float4 *) scene.nodes;
@@ -152,12 +153,12 @@ void launch_ao(const SceneBuffers &scene, void *hits, void *occluded_of, void *o
 		// (the events bracket the ao_kernel launch alone: its duration is the one the roofline is quoted for)
 		if (event_before_ao)
 			(void) hipEventRecord((hipEvent_t) event_before_ao, s);
-		AoArgs args;
+		FrameArgs args{};
 		args.walk_ptr = (const float4 *) scene.walk;
 		args.tris_ptr = (const float4 *) scene.tris;
 		args.nodes_ptr = (const float4 *) scene.nodes;
 		args.ao_table = (const float4 *) scene.ao_table;
-		args.hits = (const HitRec *) hits;
+		args.hits = (HitRec *) hits;
 		args.occluded_of = (uint32_t *) occluded_of;
 		args.order = (const uint32_t *) order;
 		args.tile_base = (const uint32_t *) tile_base;
@@ -186,9 +187,60 @@ void launch_ao(const SceneBuffers &scene, void *hits, void *occluded_of, void *o
 		launch(ao_kernel<AO_RANDOM, true>);
 }
 
+// The two ray passes as ONE persistent launch (kernels/frame.hip.h): UNIFORM ambient occlusion, the shared walk.
+// `primary_order`, `tile_ready`: DeviceRenderer::orderTiles / its flag array.
+void launch_frame(const SceneBuffers &scene, float *image, void *hits, void *occluded_of, void *tile_hits, void *order,
+                  const void *primary_order, const void *order_need, void *tile_ready, const void *tile_base, const void *tile_entry, void *counters,
+                  const KernelParams &params, uint32_t workgroups, bool prefetch, void *stream, void *event_before, void *event_after) {
+	if (params.tiles_x * params.local_tile_rows == 0)
+		return;
+	hipStream_t s = (hipStream_t) stream;
+	KernelParams P = params;
+	// persistent grid: what the chip holds, or -- a small image -- what there is to do: a workgroup per 2 x 2 tile block
+	// of the primary work or per (tile, four directions) of the ambient-occlusion work, whichever is more
+	{
+		const uint64_t blocks = (uint64_t) ((P.tiles_x + 1u) / 2u) * ((P.local_tile_rows + 1u) / 2u);
+		const uint64_t units = ((uint64_t) P.tiles_x * P.local_tile_rows * P.ao_dirs + AO_WAVES - 1) / AO_WAVES;
+		const uint64_t most = blocks > units ? blocks : units;
+		if (most < workgroups)
+			workgroups = (uint32_t) (most ? most : 1u);
+	}
+	const uint32_t waves_per_group = (workgroups * AO_WAVES + XCD_GROUPS - 1u) / XCD_GROUPS;
+	P.ao_guide = P.ao_guide * (waves_per_group ? waves_per_group : 1u);
+	P.ao_claim_div = waves_per_group ? waves_per_group : 1u;
+	FrameArgs args{};
+	args.walk_ptr = (const float4 *) scene.walk;
+	args.tris_ptr = (const float4 *) scene.tris;
+	args.nodes_ptr = (const float4 *) scene.nodes;
+	args.shade = (const float4 *) scene.shade;
+	args.ao_table = (const float4 *) scene.ao_table;
+	args.image = image;
+	args.hits = (HitRec *) hits;
+	args.occluded_of = (uint32_t *) occluded_of;
+	args.tile_hits = (uint32_t *) tile_hits;
+	args.order = (const uint32_t *) order;
+	args.tile_base = (const uint32_t *) tile_base;
+	args.tile_entry = (const uint2 *) tile_entry;
+	args.counters = (FrameCounters *) counters;
+	args.primary_order = (const uint32_t *) primary_order;
+	args.order_need = (const uint32_t *) order_need;
+	args.tile_ready = (uint32_t *) tile_ready;
+	if (P.primary_ahead == 0u)  // the rule: a block per workgroup of the group
+		P.primary_ahead = (workgroups + XCD_GROUPS - 1u) / XCD_GROUPS;
+	args.P = P;
+	if (event_before)
+		(void) hipEventRecord((hipEvent_t) event_before, s);
+	if (prefetch)
+		hipLaunchKernelGGL((frame_kernel<AO_UNIFORM, true>), dim3(workgroups), dim3(64 * AO_WAVES), 0, s, args);
+	else
+		hipLaunchKernelGGL((frame_kernel<AO_UNIFORM, false>), dim3(workgroups), dim3(64 * AO_WAVES), 0, s, args);
+	if (event_after)
+		(void) hipEventRecord((hipEvent_t) event_after, s);
+}
+
 // `out`: this rank's 8-bit bands (local_out_rows x out_width), or null for a frame without the device resize.
 void launch_finish(float *image, const void *hits, const void *occluded_of, const void *tile_base, unsigned char *out,
-                   const KernelParams &P, uint32_t out_width, uint32_t n, uint32_t local_out_rows, void *stream) {
+                   const KernelParams &P, uint32_t out_width, uint32_t n, uint32_t local_out_rows, void *stream, void *counters) {
 	if (local_out_rows == 0 || out_width == 0 || n == 0)
 		return;
 	const bool has_ao = P.ao_mode != AO_NONE && P.ao_dirs > 0;
@@ -203,13 +255,13 @@ void launch_finish(float *image, const void *hits, const void *occluded_of, cons
 		hipLaunchKernelGGL(finish_wide_kernel<true>, dim3((out_width + pixels_per_block - 1u) / pixels_per_block, local_out_rows), dim3(256), 0,
 		                   (hipStream_t) stream, image, (const HitRec *) hits, (const uint32_t *) occluded_of, (const uint32_t *) tile_base,
 		                   out, out_width, P.height / n, P.width, n, P.tiles_x, P.part, rows_per_band,
-		                   P.ao_divisor ? P.ao_divisor : 1u, pixels_per_block);
+		                   P.ao_divisor ? P.ao_divisor : 1u, pixels_per_block, (FrameCounters *) counters);
 		return;
 	}
 	hipLaunchKernelGGL(finish_kernel, dim3((out_width + 255) / 256, local_out_rows), dim3(256), 0, (hipStream_t) stream, image,
 	                   (const HitRec *) hits, (const uint32_t *) occluded_of, (const uint32_t *) tile_base, out,
 	                   out_width, P.height / n,
-	                   P.width, n, P.tiles_x, P.part, rows_per_band, P.ao_divisor ? P.ao_divisor : 1u);
+	                   P.width, n, P.tiles_x, P.part, rows_per_band, P.ao_divisor ? P.ao_divisor : 1u, (FrameCounters *) counters);
 }
 
 // counters->occluded = the sum of the hit list's `slots` occlusion counts (stream-ordered: after the frames enqueued so far).
@@ -236,7 +288,7 @@ void launch_resize(const float *tmp, unsigned char *out, const KernelParams &P, 
 		hipLaunchKernelGGL(finish_wide_kernel<false>, dim3((out_width + pixels_per_block - 1u) / pixels_per_block, local_out_rows), dim3(256), 0,
 		                   (hipStream_t) stream, const_cast<float *>(tmp), (const HitRec *) nullptr, (const uint32_t *) nullptr,
 		                   (const uint32_t *) nullptr, out, out_width, P.height / n, P.width, n, P.tiles_x, P.part, rows_per_band, 1u,
-		                   pixels_per_block);
+		                   pixels_per_block, (FrameCounters *) nullptr);
 		return;
 	}
 	hipLaunchKernelGGL(resize_kernel, dim3((out_width + 255) / 256, local_out_rows), dim3(256), 0,

@@ -53,34 +53,15 @@ struct TileShared {
 #define OCRT_STAMP_ADD(slot, value)
 #endif
 
-// The pass's arguments as ONE block.  The walks leave the kernel some 40 scalar registers for everything it holds across
-// them (80 per wave at 8 waves per SIMD, 22 of them the node loop's own and 14 its operands), and what does not fit is
-// spilled to VGPR lanes: v_writelane / v_readlane -- VECTOR instructions, the resource the pass is bound by (round 3:
-// 33 per packet and 9 per leaf stop or batch, a tenth of the pass's vector instructions).  So only what every leaf stop
-// needs is held in registers (the two pointers at the head, node_count, ao_below, batch_below); every other argument is
-// READ AGAIN from the kernel-argument segment where it is used -- one scalar load (asm volatile: the compiler can neither
-// hoist it out of a loop nor merge it with another) that hits the scalar cache and costs no vector issue slot.
-struct AoArgs {
-	const float4 *walk_ptr, *tris_ptr;
-	const float4 *nodes_ptr, *ao_table;
-	const HitRec *hits;
-	uint32_t *occluded_of;
-	const uint32_t *order;
-	const uint32_t *tile_base;  // first slot of each tile in the hit list
-	const uint2 *tile_entry;    // per tile, 1 + ao_dirs byte ranges of the walk records: what its any-hit rays have to walk (entry_kernel)
-	FrameCounters *counters;
-	uint32_t *tile_cost;        // null but in a measuring frame (DeviceRenderer::measureTileCosts): per tile, the device-clock ticks its claims kept their workgroups
-	KernelParams P;
-};
-#define OCRT_COLD_U32(FIELD) cold_u32<(uint32_t) offsetof(AoArgs, FIELD)>()
-#define OCRT_COLD_F32(FIELD) __uint_as_float(cold_u32<(uint32_t) offsetof(AoArgs, FIELD)>())
-#define OCRT_COLD_PTR(TYPE, FIELD) ((TYPE) cold_u64<(uint32_t) offsetof(AoArgs, FIELD)>())
-
 // PREFETCH: the node loop touches a pair's two successors ahead of time (OCRT_PF_SUCCESSORS): a launch-time choice.
-template <int MODE, bool SHARED, bool PREFETCH = false>
-__global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void ao_kernel(AoArgs A) {
-	__shared__ TileShared shared_tiles[AO_WAVES];
-	__shared__ unsigned int wg_claim[8];  // the workgroup's current claim: first unit, units per wave, end (if dealt by cursor), cursor; [4..7]: the claim before it, for measureTileCosts
+// FUSED: the pass runs inside the fused frame kernel (kernels/frame.hip.h): with every claim the workgroup first takes
+// the group's PRIMARY work as far as the claim's tiles need it (primary_top_up), and a tile's hit records are only read
+// once the workgroup that cast its primary rays has said they are there (tile_is_ready).
+// `wg_claim`: the workgroup's current claim in LDS -- first unit, units per wave, end (if dealt by cursor), cursor;
+// [4..7]: the claim before it, for measureTileCosts.
+template <int MODE, bool SHARED, bool PREFETCH, bool FUSED>
+__device__ __forceinline__ void ao_pass(const FrameArgs &A, TileShared *shared_tiles, unsigned int *wg_claim, unsigned int *wg_primary) {
+	(void) wg_primary;
 	const uint32_t wave = (uint32_t) __builtin_amdgcn_readfirstlane((int) threadIdx.x) >> 6;  // (scalar)
 	TileShared &sh = shared_tiles[wave];
 	const float4 *__restrict__ const walk_ptr = A.walk_ptr, *__restrict__ const tris_ptr = A.tris_ptr;
@@ -100,8 +81,18 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 	unsigned long long walk_prof_store[7] = { 0, 0, 0, 0, 0, 0, 0 };
 	unsigned long long *walk_prof = walk_prof_store;
 #endif
-	if (blockIdx.x == 0u && threadIdx.x == 0u)  // (when the pass began, by the device's clock: frames replayed from a graph have no events inside)
-		__hip_atomic_store(&OCRT_COLD_PTR(FrameCounters *, counters)->tick_ao_begin, (unsigned long long) __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	if (blockIdx.x == 0u && threadIdx.x == 0u) {  // (when the pass began, by the device's clock: frames replayed from a graph have no events inside)
+		FrameCounters *const counters = OCRT_COLD_PTR(FrameCounters *, counters);
+		const unsigned long long now = (unsigned long long) __builtin_amdgcn_s_memrealtime();
+		__hip_atomic_store(&counters->tick_ao_begin, now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (FUSED) {  // (the frame begins here; the sums only the finishing kernel's successors add to)
+			counters->tick_begin = now;
+			counters->occluded = 0ull;
+			counters->tick_ao_end = 0ull;
+		}
+	}
+	bool gave_up = false;  // (FUSED: this wave has waited in vain for a tile once -- tile_is_ready)
+	(void) gave_up;
 	if (threadIdx.x == 0u)
 		wg_claim[4] = wg_claim[5] = 0u;  // (no claim before the first; read by the same thread only)
 	// Workgroups b and b+8 share an XCD: start with that group's queue, then help the others.
@@ -190,6 +181,16 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 				// the cursor, in directions of the tile: end << 16 | next (both 0 for fixed shares: nothing to take)
 				const uint32_t base = first - first / ao_dirs * ao_dirs;
 				wg_claim[3] = one_tile ? (base + (end - first)) << 16 | base : 0u;
+				if (FUSED) {
+					// how far the group's PRIMARY work has to be taken before this claim's tiles may be waited for: the blocks the
+					// list needs up to the claim's last tile, and primary_ahead more; all of it once this queue is drained
+					uint32_t target = OCRT_COLD_PTR(FrameCounters *, counters)->queue[group].primary_blocks;
+					if (first < units) {
+						const uint32_t need = OCRT_COLD_PTR(const uint32_t *, order_need)[segment + (end - 1u) / ao_dirs] + OCRT_COLD_U32(P.primary_ahead);
+						target = need < target ? need : target;
+					}
+					wg_primary[1] = target;
+				}
 				// A measuring frame (once per upload, DeviceRenderer::measureTileCosts): how long the claim BEFORE this one kept
 				// the workgroup -- every wave has left it, that is what the barrier above says -- goes to its tiles, by their
 				// share of its units; this claim's first unit, its end and the clock go where the next one finds them.
@@ -213,6 +214,8 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 				}
 			}
 			__syncthreads();
+			if (FUSED)  // (returns when the blocks this claim needs are in the hands of RUNNING workgroups, this one's included)
+				primary_top_up(A, group, *(ClosestBatch *) &shared_tiles[wave], wg_primary);
 			const uint32_t wg_claimed = (uint32_t) __builtin_amdgcn_readfirstlane((int) wg_claim[0]);
 			const uint32_t want = (uint32_t) __builtin_amdgcn_readfirstlane((int) wg_claim[1]);
 			if (wg_claimed >= units)
@@ -276,11 +279,18 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 				// ---- the tile's tangent frames -> this wave's LDS slice (reference :215-236) ----
 				{
 				const uint32_t lane = fresh_lane();  // (recomputed where it is needed: no register held across the walks)
+				if (FUSED)  // (the records come from another workgroup of this very launch)
+					gave_up = !tile_is_ready(OCRT_COLD_PTR(const uint32_t *, tile_ready), tile, OCRT_COLD_PTR(FrameCounters *, counters), gave_up) || gave_up;
 				if (lane < hit_count) {
 					const size_t slot = (size_t) OCRT_COLD_PTR(const uint32_t *, tile_base)[tile] + lane;
 					const float4 *const hits = OCRT_COLD_PTR(const float4 *, hits);
-					const float4 q0 = hits[2 * slot];
-					const float4 q1 = hits[2 * slot + 1];
+					float4 q0, q1;
+					if (FUSED) {
+						load_2f4_device_coherent(hits + 2 * slot, q0, q1);
+					} else {
+						q0 = hits[2 * slot];
+						q1 = hits[2 * slot + 1];
+					}
 					float nx = q1.x, ny = q1.y, nz = q1.z;
 					// p = point + normal * (1.0f / 100000.0f)
 					const float eps = 1.0f / 100000.0f;
@@ -552,6 +562,13 @@ __global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8
 		atomicAdd(&A.counters->stamp[10 + (end_bucket > 31 ? 31 : end_bucket)], 1ull);
 	}
 #endif
+}
+
+template <int MODE, bool SHARED, bool PREFETCH = false>
+__global__ __launch_bounds__(64 * AO_WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void ao_kernel(FrameArgs A) {
+	__shared__ TileShared shared_tiles[AO_WAVES];
+	__shared__ unsigned int wg_claim[8];
+	ao_pass<MODE, SHARED, PREFETCH, false>(A, shared_tiles, wg_claim, nullptr);
 }
 
 }  // namespace ocrt

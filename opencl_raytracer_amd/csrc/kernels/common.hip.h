@@ -287,12 +287,15 @@ struct SceneViews {
 	__amdgpu_buffer_rsrc_t tris;   // TriRec[tri_count]
 };
 
-__device__ __forceinline__ SceneViews make_views(const float4 *nodes_ptr, const float4 *tris_ptr, const KernelParams &P) {
+__device__ __forceinline__ SceneViews make_views(const float4 *nodes_ptr, const float4 *tris_ptr, uint32_t node_count, uint32_t tri_count) {
 	// descriptors are built from kernel arguments only, so they live in SGPRs
 	SceneViews scene;
-	scene.nodes = __builtin_amdgcn_make_buffer_rsrc((void *) nodes_ptr, 0, (int) (P.node_count * 32u), 0x00020000);
-	scene.tris = __builtin_amdgcn_make_buffer_rsrc((void *) tris_ptr, 0, (int) (P.tri_count * LEAF_BYTES), 0x00020000);
+	scene.nodes = __builtin_amdgcn_make_buffer_rsrc((void *) nodes_ptr, 0, (int) (node_count * 32u), 0x00020000);
+	scene.tris = __builtin_amdgcn_make_buffer_rsrc((void *) tris_ptr, 0, (int) (tri_count * LEAF_BYTES), 0x00020000);
 	return scene;
+}
+__device__ __forceinline__ SceneViews make_views(const float4 *nodes_ptr, const float4 *tris_ptr, const KernelParams &P) {
+	return make_views(nodes_ptr, tris_ptr, P.node_count, P.tri_count);
 }
 
 }  // namespace ocrt

@@ -6,6 +6,19 @@
 
 namespace ocrt {
 
+// The frame's last kernel also closes the frame's books: the claim cursors of the ray passes go back to 0 and the frame
+// is counted -- the fused frame kernel (kernels/frame.hip.h) compares its tiles' flags with that count, and a replayed
+// graph cannot be handed a new number.  Everything that claimed from those cursors has ended: this kernel follows the ray
+// passes in the stream.  One workgroup, eight lanes.
+__device__ __forceinline__ void frame_is_over(FrameCounters *counters) {
+	if (counters && blockIdx.x == 0u && blockIdx.y == 0u && threadIdx.x < XCD_GROUPS) {
+		counters->queue[threadIdx.x].head = 0u;
+		counters->queue[threadIdx.x].primary_head = 0u;
+		if (threadIdx.x == 0u)
+			counters->frame_seq += 1u;
+	}
+}
+
 // Pass 3, the frame's last kernel: value *= 1 - hits / n (reference :256 and :305-307) for the sub-pixels that wait
 // for it, and the supersample box filter + 8-bit quantisation (reference src/ray_tracer.cc:3-16) in the same sweep
 // over the float image.  One thread per OUTPUT pixel of this rank's bands: it visits its n x n sub-pixels in the
@@ -21,7 +34,9 @@ __global__ __launch_bounds__(256) void finish_kernel(float *__restrict__ image, 
                                                      const uint32_t *__restrict__ occluded_of,
                                                      const uint32_t *__restrict__ tile_base, unsigned char *__restrict__ out,
                                                      uint32_t width, uint32_t height, uint32_t total_width, uint32_t n,
-                                                     uint32_t tiles_x, Partition part, uint32_t rows_per_band, uint32_t ao_divisor) {
+                                                     uint32_t tiles_x, Partition part, uint32_t rows_per_band, uint32_t ao_divisor,
+                                                     FrameCounters *__restrict__ counters) {
+	frame_is_over(counters);
 	const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t j = blockIdx.y;
 	const uint32_t band_local = j / rows_per_band;
@@ -66,8 +81,10 @@ __global__ __launch_bounds__(256) void finish_wide_kernel(float *__restrict__ im
                                                           const uint32_t *__restrict__ tile_base, unsigned char *__restrict__ out,
                                                           uint32_t width, uint32_t height, uint32_t total_width, uint32_t n,
                                                           uint32_t tiles_x, Partition part, uint32_t rows_per_band, uint32_t ao_divisor,
-                                                          uint32_t pixels_per_block) {
+                                                          uint32_t pixels_per_block, FrameCounters *__restrict__ counters) {
 	__shared__ float cell[FINISH_CELL_FLOATS];
+	if (RESOLVE)
+		frame_is_over(counters);
 	const uint32_t x0 = blockIdx.x * pixels_per_block;
 	const uint32_t pixels = width - x0 < pixels_per_block ? width - x0 : pixels_per_block;
 	const uint32_t columns = pixels * n;

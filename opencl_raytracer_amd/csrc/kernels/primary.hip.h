@@ -2,6 +2,7 @@
 // (part of the one translation unit kernels.hip; see its head for the passes and the arithmetic contract)
 #pragma once
 #include "walk.hip.h"
+#include "handoff.hip.h"
 
 namespace ocrt {
 
@@ -32,21 +33,37 @@ __device__ __forceinline__ unsigned long long cold_u64() {
 	return v;
 }
 
-// The primary pass's arguments as one block (see AoArgs for why): the walk holds the two pointers at the head,
-// node_count, primary_below and batch_below in registers; what the tile's epilogue and the kernel's tail need is read
-// again there.
-struct PrimaryArgs {
+// The ray passes' arguments as ONE block, the same for the primary pass, the ambient-occlusion pass and the fused
+// frame kernel (kernels/frame.hip.h).  The walks leave a kernel some 40 scalar registers for everything it holds across
+// them (80 per wave at 8 waves per SIMD, 22 of them the node loop's own and 14 its operands), and what does not fit is
+// spilled to VGPR lanes: v_writelane / v_readlane -- VECTOR instructions, the resource the AO pass is bound by (round 3:
+// 33 per packet and 9 per leaf stop or batch, a tenth of the pass's vector instructions).  So only what every leaf stop
+// needs is held in registers (the two pointers at the head, node_count, the `below` limits, batch_below); every other
+// argument is READ AGAIN from the kernel-argument segment where it is used -- one scalar load (cold_u32 / cold_u64 above)
+// that hits the scalar cache and costs no vector issue slot.
+struct FrameArgs {
 	const float4 *walk_ptr, *tris_ptr;
-	const float4 *nodes_ptr, *shade;
+	const float4 *nodes_ptr, *shade, *ao_table;
 	float *image;
 	HitRec *hits;
 	uint32_t *occluded_of, *tile_hits;
+	const uint32_t *order;      // the AO pass's claim order (DeviceRenderer::orderTiles)
 	const uint32_t *tile_base;  // first slot of each tile in the hit list (DeviceRenderer: a prefix sum of the tiles' hit counts)
+	const uint2 *tile_entry;    // per tile, 1 + ao_dirs byte ranges of the walk records: what its any-hit rays have to walk (entry_kernel)
 	FrameCounters *counters;
+	uint32_t *tile_cost;        // null but in a measuring frame (DeviceRenderer::measureTileCosts): per tile, the device-clock ticks its claims kept their workgroups
+	const uint32_t *primary_order;  // fused frame kernel: the order its workgroups take the 2 x 2 tile blocks of the primary pass in
+	const uint32_t *order_need;     // ... and, beside every entry of `order`, how many of those blocks the entries up to it need
+	uint32_t *tile_ready;           // ... and per tile the frame number whose hit records are in the list (kernels/frame.hip.h)
 	KernelParams P;
 };
-#define OCRT_PCOLD_U32(FIELD) cold_u32<(uint32_t) offsetof(PrimaryArgs, FIELD)>()
-#define OCRT_PCOLD_PTR(TYPE, FIELD) ((TYPE) cold_u64<(uint32_t) offsetof(PrimaryArgs, FIELD)>())
+using PrimaryArgs = FrameArgs;
+using AoArgs = FrameArgs;
+#define OCRT_PCOLD_U32(FIELD) cold_u32<(uint32_t) offsetof(FrameArgs, FIELD)>()
+#define OCRT_PCOLD_PTR(TYPE, FIELD) ((TYPE) cold_u64<(uint32_t) offsetof(FrameArgs, FIELD)>())
+#define OCRT_COLD_U32(FIELD) cold_u32<(uint32_t) offsetof(FrameArgs, FIELD)>()
+#define OCRT_COLD_F32(FIELD) __uint_as_float(cold_u32<(uint32_t) offsetof(FrameArgs, FIELD)>())
+#define OCRT_COLD_PTR(TYPE, FIELD) ((TYPE) cold_u64<(uint32_t) offsetof(FrameArgs, FIELD)>())
 
 // A hit sub-pixel that still waits for its ambient-occlusion factor holds, in the float image, a TAG instead of a value:
 // a negative quiet NaN whose low six bits are the sub-pixel's slot in its tile's part of the hit list (no value the
@@ -57,14 +74,36 @@ __device__ __forceinline__ bool is_pending(uint32_t bits) { return (bits & 0xFFF
 // SHARED: the shared walk.  (The A/B build also instantiates the first generation, SHARED = false; two instantiations,
 // so that its per-lane state stays out of the default path's register budget.)
 // One tile of the primary pass, one wave.
-template <bool SHARED>
-__device__ __forceinline__ void primary_tile(const PrimaryArgs &A, ClosestBatch *closest_batches, uint32_t tile_x, uint32_t local_row) {
-	const KernelParams &P = A.P;  // (fields used BEFORE or IN the walk only; the epilogue reads its own again)
+// HANDOFF: the tile's hit records are read by another workgroup of the SAME launch (the fused frame kernel): they are
+// stored device-coherently (kernels/handoff.hip.h); the caller drains the stores and raises the tile's flag.
+// `cb`: this wave's LDS slice for the leaves it tests 64 pairs at a time.
+template <bool SHARED, bool HANDOFF = false>
+__device__ __forceinline__ void primary_tile(const FrameArgs &A, ClosestBatch &cb, uint32_t tile_x, uint32_t local_row) {
+	// What the tile needs of the launch constants is READ HERE, by loads the compiler can neither hoist nor merge (cold_u32):
+	// in the fused frame kernel this function sits inside the claim loops of a persistent workgroup, and constants held
+	// across the ambient-occlusion pass's walks would be spilled to VGPR lanes there (FrameArgs); a wave of primary_kernel
+	// casts one tile and reads them once either way.  (Fields used BEFORE or IN the walk; the epilogue reads its own.)
+	struct {
+		uint32_t tiles_x, width, height, node_count, tri_count, fast_walk, batch_below;
+		float a, half_w, half_h, origin_limit, primary_below;
+		Partition part;
+#ifdef OCRT_DEBUG_KNOBS
+		uint32_t scene_regular, leaf_min;
+#endif
+	} P;
+	P.tiles_x = OCRT_PCOLD_U32(P.tiles_x); P.width = OCRT_PCOLD_U32(P.width); P.height = OCRT_PCOLD_U32(P.height);
+	P.node_count = OCRT_PCOLD_U32(P.node_count); P.tri_count = OCRT_PCOLD_U32(P.tri_count); P.fast_walk = OCRT_PCOLD_U32(P.fast_walk);
+	P.batch_below = OCRT_PCOLD_U32(P.batch_below);
+	P.a = OCRT_COLD_F32(P.a); P.half_w = OCRT_COLD_F32(P.half_w); P.half_h = OCRT_COLD_F32(P.half_h);
+	P.origin_limit = OCRT_COLD_F32(P.origin_limit); P.primary_below = OCRT_COLD_F32(P.primary_below);
+	P.part.rank = OCRT_PCOLD_U32(P.part.rank); P.part.nranks = OCRT_PCOLD_U32(P.part.nranks); P.part.band_tile_rows = OCRT_PCOLD_U32(P.part.band_tile_rows);
+#ifdef OCRT_DEBUG_KNOBS
+	P.scene_regular = OCRT_PCOLD_U32(P.scene_regular); P.leaf_min = OCRT_PCOLD_U32(P.leaf_min);
+#endif
 	const float4 *__restrict__ const walk_ptr = A.walk_ptr, *__restrict__ const tris_ptr = A.tris_ptr;
-	const float4 *__restrict__ const nodes_ptr = A.nodes_ptr;  // (exact form and first-generation walk only)
+	const float4 *__restrict__ const nodes_ptr = OCRT_PCOLD_PTR(const float4 *, nodes_ptr);  // (exact form and first-generation walk only)
 	const uint32_t lane = threadIdx.x & 63u;
-	const uint32_t wave = threadIdx.x >> 6;
-	const SceneViews scene = make_views(nodes_ptr, tris_ptr, P);
+	const SceneViews scene = make_views(nodes_ptr, tris_ptr, P.node_count, P.tri_count);
 	const uint32_t tile = local_row * P.tiles_x + tile_x;
 	const uint32_t tile_y = global_tile_row(P.part, local_row);
 	const uint32_t x = tile_x * TILE_W + (lane & 7u);
@@ -109,7 +148,6 @@ __device__ __forceinline__ void primary_tile(const PrimaryArgs &A, ClosestBatch 
 		};
 		if (!exact) {
 			// Leaves hit by few lanes are collected and tested 64 pairs at a time (see ClosestBatch).
-			ClosestBatch &cb = closest_batches[wave];
 			cb.best_key[lane] = KEY_NONE;
 			if (lane < 2u)
 				cb.hit_bits[lane] = 0u;
@@ -289,8 +327,14 @@ __device__ __forceinline__ void primary_tile(const PrimaryArgs &A, ClosestBatch 
 		rec.nx = nx; rec.ny = ny; rec.nz = nz;
 		rec.pixel = local_y * image_width + x;  // index into this rank's band image
 		const size_t slot = (size_t) OCRT_PCOLD_PTR(const uint32_t *, tile_base)[tile] + slot_in_tile;
-		hit_list[slot] = rec;
-		OCRT_PCOLD_PTR(uint32_t *, occluded_of)[slot] = 0u;
+		if (HANDOFF) {
+			store_f4_device_coherent(&hit_list[slot], make_float4(rec.ox, rec.oy, rec.oz, rec.value));
+			store_f4_device_coherent((char *) &hit_list[slot] + 16, make_float4(rec.nx, rec.ny, rec.nz, __uint_as_float(rec.pixel)));
+			store_u32_device_coherent(&OCRT_PCOLD_PTR(uint32_t *, occluded_of)[slot], 0u);
+		} else {
+			hit_list[slot] = rec;
+			OCRT_PCOLD_PTR(uint32_t *, occluded_of)[slot] = 0u;
+		}
 	}
 }
 
@@ -336,7 +380,66 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) __attribute__((amdgpu_waves_per
 		const uint32_t tile_x = strip_tiles * (group + XCD_GROUPS * strip_index) + 2u * (rest - row_block * columns) + (wave & 1u);
 		const uint32_t local_row = PRIMARY_ROWS * row_block + (wave >> 1);
 		if (seq < strips_here * per_strip && tile_x < A.P.tiles_x && local_row < A.P.local_tile_rows)
-			primary_tile<SHARED>(A, closest_batches, tile_x, local_row);
+			primary_tile<SHARED>(A, closest_batches[wave], tile_x, local_row);
+	}
+}
+
+// ---------------------------------------------------------------------------
+// The primary pass INSIDE the fused frame kernel (kernels/frame.hip.h): the group's 2 x 2 tile blocks are taken one by
+// one from FrameArgs::primary_order -- a cursor per XCD group, the blocks in the order the ambient-occlusion pass will
+// want their tiles, the background's last -- by whichever persistent workgroup finds the cursor BELOW ITS TARGET when it
+// has made an ambient-occlusion claim: target = the blocks the claim's tiles need + primary_ahead (the whole list once the
+// group's ambient-occlusion queue is drained).  So the primary work stays a little ahead of the any-hit work all through
+// the frame instead of before it: at any time a few of a CU's waves walk primary packets -- latency-bound, ~50 dependent
+// loads and ~30 leaf stops per model tile -- beside the vector-issue-bound any-hit packets of the others.
+// A workgroup that takes a block casts its primary rays (one wave per tile, as in primary_kernel) and hands the tiles'
+// hit records over: every wave drains its stores, the workgroup meets, one store instruction raises the tiles' flags
+// (kernels/handoff.hip.h).  Returning from here means: the cursor has passed the target, i.e. every block the claim needs
+// is in the hands of a workgroup that is RUNNING -- which is what makes waiting for a flag safe.
+// `cb`: this wave's LDS slice for the leaves tested in batches (nothing of the caller's lives there at this point);
+// `wg_primary`: two LDS words -- [0] the block taken, [1] the target (written by the caller before its barrier).
+// ---------------------------------------------------------------------------
+constexpr uint32_t NO_BLOCK = 0xFFFFFFFFu;
+__device__ __forceinline__ void primary_top_up(const FrameArgs &A, uint32_t group, ClosestBatch &cb, unsigned int *wg_primary) {
+	const uint32_t wave = (uint32_t) __builtin_amdgcn_readfirstlane((int) threadIdx.x) >> 6;
+	for (;;) {
+		if (wave == 0u && fresh_lane() == 0u) {
+			FrameCounters *const counters = OCRT_PCOLD_PTR(FrameCounters *, counters);
+			const uint32_t target = wg_primary[1];
+			uint32_t got = NO_BLOCK;
+			// (a load first: a cursor beyond the target is not worth an atomic -- the common case)
+			if (target != 0u && __hip_atomic_load(&counters->queue[group].primary_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+				got = atomicAdd(&counters->queue[group].primary_head, 1u);
+				if (got >= counters->queue[group].primary_blocks)
+					got = NO_BLOCK;
+			}
+			wg_primary[0] = got;
+		}
+		__syncthreads();
+		const uint32_t index = (uint32_t) __builtin_amdgcn_readfirstlane((int) wg_primary[0]);
+		if (index == NO_BLOCK)
+			break;  // (the same for all four waves; the word is not written again before the caller's next barrier)
+		// where the group's blocks start in primary_order: the groups' segments follow each other, each as long as the
+		// group's share of the strips x the block rows x the block columns of a strip
+		uint32_t segment = 0u;
+		{
+			const uint32_t strip_tiles = OCRT_PCOLD_U32(P.strip_tiles), columns = strip_tiles >> 1;
+			const uint32_t strips = (OCRT_PCOLD_U32(P.tiles_x) + strip_tiles - 1u) / strip_tiles;
+			const uint32_t row_blocks = (OCRT_PCOLD_U32(P.local_tile_rows) + 1u) >> 1;
+			for (uint32_t g = 0; g < group; ++g)
+				segment += ((strips + XCD_GROUPS - 1u - g) >> 3) * row_blocks * columns;
+		}
+		const uint32_t block = (uint32_t) __builtin_amdgcn_readfirstlane((int) OCRT_PCOLD_PTR(const uint32_t *, primary_order)[segment + index]);
+		const uint32_t tile_x = (block & 0xFFFFu) + (wave & 1u), local_row = (block >> 16) + (wave >> 1);
+		if (tile_x < OCRT_PCOLD_U32(P.tiles_x) && local_row < OCRT_PCOLD_U32(P.local_tile_rows))
+			primary_tile<true, true>(A, cb, tile_x, local_row);
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (this wave's records have left)
+		__syncthreads();
+		if (threadIdx.x < 4u) {  // one lane per tile of the block, one store instruction: the tiles' flags
+			const uint32_t x = (block & 0xFFFFu) + (threadIdx.x & 1u), row = (block >> 16) + (threadIdx.x >> 1);
+			if (x < OCRT_PCOLD_U32(P.tiles_x) && row < OCRT_PCOLD_U32(P.local_tile_rows))
+				store_u32_device_coherent(&OCRT_PCOLD_PTR(uint32_t *, tile_ready)[row * OCRT_PCOLD_U32(P.tiles_x) + x], frame_number(OCRT_PCOLD_PTR(FrameCounters *, counters)));
+		}
 	}
 }
 

@@ -27,6 +27,8 @@ def one(workload, frames):
     scene = load_scene(rt, w).build_bvh(opt.bvh_method)
     ring = rt.FrameRing(opt, scene, hosts=1)
     ring.set_graph_mode(False)
+    if "OCRT_AB_FRAME_FORM" in os.environ and hasattr(ring.host(0), "set_frame_form"):  # (a tool's own variable: "fused" / "separate")
+        ring.host(0).set_frame_form(os.environ["OCRT_AB_FRAME_FORM"])
     ring.run(10)
     ring.drain()
     ring.reset_clock()
