@@ -28,6 +28,8 @@ void hip_check(hipError_t err, const char *what) {
 #define OCRT_HIP(call) hip_check((call), #call)
 
 constexpr size_t MAX_ENTRY_TABLE_BYTES = (size_t) 2 << 30;
+// (the blocks' coordinates are packed into 16 bits each)
+#define PRIMARY_BY_COST_OK(kp) ((kp).tiles_x < 65536u && (kp).local_tile_rows < 65536u && (kp).shared_walk)
 constexpr uint32_t MAX_STRIP_TILES = 32u;
 constexpr size_t BIG_SCENE_BYTES = (size_t) 96 << 20;  // three times the L2s
 
@@ -170,6 +172,7 @@ DeviceRenderer::DeviceRenderer(const RayTracer::Options &options, int device_, u
 	{  // (2 x 2 tile blocks: whole strips x pairs of rows)
 		const size_t padded_x = (size_t) ((kp.tiles_x + MAX_STRIP_TILES - 1) / MAX_STRIP_TILES) * MAX_STRIP_TILES;
 		d_primary_order = device_alloc((padded_x / 2 * ((kp.local_tile_rows + 1) / 2) + 1) * sizeof(uint32_t));
+		d_blocks_by_cost = device_alloc((padded_x / 2 * ((kp.local_tile_rows + 1) / 2) + 1) * sizeof(uint32_t));
 	}
 	d_tile_ready = device_alloc((tile_count ? tile_count : 1) * sizeof(uint32_t));
 	OCRT_HIP(hipMemsetAsync(d_tile_ready, 0, (tile_count ? tile_count : 1) * sizeof(uint32_t), (hipStream_t) stream));
@@ -185,6 +188,8 @@ DeviceRenderer::DeviceRenderer(const RayTracer::Options &options, int device_, u
 #ifdef OCRT_DEBUG_KNOBS
 	if (const char *env = std::getenv("OCRT_AO_BLOCKS"))  // workgroups of the persistent ambient-occlusion pass
 		ao_blocks_override = (uint32_t) std::atoi(env);
+	if (const char *env = std::getenv("OCRT_PRIMARY_BY_COST"))  // 0: the primary pass's workgroups take their blocks in spatial order
+		primary_by_cost = std::atoi(env) != 0;
 #endif
 }
 
@@ -212,6 +217,7 @@ DeviceRenderer::~DeviceRenderer() {
 	device_free(d_order);
 	device_free(d_primary_order);
 	device_free(d_order_need);
+	device_free(d_blocks_by_cost);
 	device_free(d_tile_ready);
 	device_free(d_counters);
 	if (own_stream)
@@ -471,6 +477,9 @@ void DeviceRenderer::sizeHitList(const DeviceRenderer *layout_from) {
 	hit_slots = 0;
 	const bool has_ao = kp.ao_mode != AO_NONE && kp.ao_dirs > 0;
 	if (tile_count == 0 || !has_ao) {
+		blocks_by_cost_host.clear();  // (no pass has counted anything: the primary pass keeps its spatial mapping)
+		order_host.clear();
+		primary_order_host.clear();
 		d_hits = device_alloc(sizeof(HitRec));  // (never read: no sub-pixel is left pending)
 		d_occluded = device_alloc(sizeof(uint32_t));
 		allocEntries(sizeof(uint32_t) * 2);
@@ -492,6 +501,7 @@ void DeviceRenderer::sizeHitList(const DeviceRenderer *layout_from) {
 		OCRT_HIP(hipMemcpyAsync(d_tile_hits, layout_from->d_tile_hits, tile_count * sizeof(uint32_t), hipMemcpyDeviceToDevice, (hipStream_t) stream));
 		OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));
 		// ... and the order its tiles are claimed in by the ambient-occlusion pass
+		tile_words = layout_from->tile_words;
 		tile_cost = layout_from->tile_cost;
 		installOrder(layout_from->order_host, layout_from->queue_static);
 		d_hits = device_alloc((hit_slots ? hit_slots : 1) * sizeof(HitRec));
@@ -718,6 +728,37 @@ void DeviceRenderer::orderPrimaryBlocks() {
 		primary_blocks[group] = count;
 		ao_segment += (size_t) strips_here * strip_tiles * rows;
 	}
+	// The same blocks for primary_kernel, whose workgroup `seq` of a group takes entry `seq` of the group's list: by falling
+	// cost (the largest cost class among a block's tiles = the leaves its primary packet stops at; a tile without
+	// ambient-occlusion work carries none: its hit count stands in), spatial order among equals, the background last.
+	blocks_by_cost_host.clear();
+	for (uint32_t group = 0; group < XCD_GROUPS; ++group) {
+		const uint32_t strips_here = (strips + XCD_GROUPS - 1u - group) >> 3;
+		std::vector<std::pair<uint32_t, uint32_t>> blocks;  // (cost, entry)
+		for (uint32_t strip_index = 0; strip_index < strips_here; ++strip_index)
+			for (uint32_t rb = 0; rb < row_blocks; ++rb)
+				for (uint32_t c = 0; c < columns; ++c) {
+					const uint32_t x0 = strip_tiles * (group + XCD_GROUPS * strip_index) + 2u * c, row0 = 2u * rb;
+					if (x0 >= tiles_x)
+						continue;
+					uint32_t cost = 0;
+					for (uint32_t k = 0; k < 4u; ++k) {
+						const uint32_t x = x0 + (k & 1u), row = row0 + (k >> 1);
+						if (x < tiles_x && row < rows && (size_t) row * tiles_x + x < tile_words.size()) {
+							const uint32_t word = tile_words[(size_t) row * tiles_x + x];
+							cost = std::max(cost, word >> 8 ? word >> 8 : (word & 0xFFu) ? 1u : 0u);
+						}
+					}
+					blocks.push_back({ cost, x0 | row0 << 16 });
+				}
+		std::stable_sort(blocks.begin(), blocks.end(), [](const auto &a, const auto &b) { return a.first > b.first; });
+		const size_t at = blocks_by_cost_host.size();
+		blocks_by_cost_host.resize(at + (size_t) strips_here * row_blocks * columns, 0xFFFFFFFFu);
+		for (size_t i = 0; i < blocks.size(); ++i)
+			blocks_by_cost_host[at + i] = blocks[i].second;
+	}
+	if (blocks_by_cost_host.empty())
+		blocks_by_cost_host.push_back(0xFFFFFFFFu);
 	if (primary_order_host.empty())
 		primary_order_host.push_back(0u);
 }
@@ -772,6 +813,7 @@ void DeviceRenderer::installOrder(const std::vector<uint32_t> &order, const std:
 	orderPrimaryBlocks();
 	OCRT_HIP(hipMemcpy(d_primary_order, primary_order_host.data(), primary_order_host.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	OCRT_HIP(hipMemcpy(d_order_need, order_need_host.data(), order_need_host.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	OCRT_HIP(hipMemcpy(d_blocks_by_cost, blocks_by_cost_host.data(), blocks_by_cost_host.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	FrameCounters fresh{};
 	for (uint32_t g = 0; g < XCD_GROUPS; ++g) {
 		fresh.queue[g].work_tiles = constants[g][0];
@@ -818,7 +860,8 @@ void DeviceRenderer::launchFrame(void *device_u8, void *ao_start, void *ao_stop,
 		             d_tile_entry, d_counters, kp, workgroups, ao_prefetch, stream, ao_start, ao_stop);
 		OCRT_HIP(hipGetLastError());
 	} else {
-		launch_primary(scene, (float *) d_image, d_hits, d_occluded, d_tile_hits, d_tile_base, d_counters, kp, stream);
+		launch_primary(scene, (float *) d_image, d_hits, d_occluded, d_tile_hits, d_tile_base, d_counters, kp, stream,
+		               primary_by_cost && PRIMARY_BY_COST_OK(kp) && blocks_by_cost_host.size() > 1 ? d_blocks_by_cost : nullptr);
 		OCRT_HIP(hipGetLastError());
 #ifdef OCRT_STAMPS  // (instrumented build: the AO pass takes the minimum of its waves' start times into this slot)
 		OCRT_HIP(hipMemsetAsync((char *) d_counters + offsetof(FrameCounters, stamp) + 7 * sizeof(unsigned long long), 0xFF, sizeof(unsigned long long), s));
@@ -916,6 +959,7 @@ void DeviceRenderer::takeOrderFrom(const DeviceRenderer &other) {
 		return;
 	useDevice();
 	synchronize();
+	tile_words = other.tile_words;
 	tile_cost = other.tile_cost;
 	installOrder(other.order_host, other.queue_static);
 }

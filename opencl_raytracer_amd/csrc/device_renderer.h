@@ -250,6 +250,9 @@ class DeviceRenderer {
 		std::array<std::array<uint32_t, 3>, XCD_GROUPS> queue_static{};  // per group: non-empty tiles, sum of cost classes, hit sub-pixels
 		std::vector<uint32_t> primary_order_host, order_need_host;  // fused frame kernel: the groups' 2 x 2 tile blocks in the order the AO claims want them; per AO entry the blocks needed so far
 		std::array<uint32_t, XCD_GROUPS> primary_blocks{};    // ... and how many each group has
+		std::vector<uint32_t> blocks_by_cost_host;            // primary_kernel: the groups' 2 x 2 blocks by falling cost (0xFFFFFFFF: no block)
+		void *d_blocks_by_cost = nullptr;
+		bool primary_by_cost = true;
 		void orderPrimaryBlocks();
 		// Which form a frame with UNIFORM ambient occlusion takes: two kernels (the rule), or the two ray passes as one
 		// persistent launch (kernels/frame.hip.h: built, bit-exact, measured slower -- fusedFrame() says by how much).
@@ -305,7 +308,7 @@ class DeviceRenderer {
 // kernels.hip
 void preload_kernels();
 void launch_primary(const SceneBuffers &scene, float *image, void *hits, void *occluded_of, void *tile_hits,
-                    const void *tile_base, void *counters, const KernelParams &P, void *stream);
+                    const void *tile_base, void *counters, const KernelParams &P, void *stream, const void *blocks_by_cost = nullptr);
 void launch_entries(const SceneBuffers &scene, const void *hits, const void *tile_hits, const void *tile_base, void *tile_entry,
                     const KernelParams &P, void *stream);
 void launch_ao(const SceneBuffers &scene, void *hits, void *occluded_of, void *order, const void *tile_base, const void *tile_entry,

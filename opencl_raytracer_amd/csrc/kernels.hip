@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void clear_stamps_kernel(FrameCounters *counte
 // The frame is three kernels (two without ambient occlusion): primary pass (+ ordering step in its tail), the
 // ambient-occlusion pass, the finishing kernel (AO factor + box filter + quantisation).
 void launch_primary(const SceneBuffers &scene, float *image, void *hits, void *occluded_of, void *tile_hits,
-                    const void *tile_base, void *counters, const KernelParams &P, void *stream) {
+                    const void *tile_base, void *counters, const KernelParams &P, void *stream, const void *blocks_by_cost) {
 	hipStream_t s = (hipStream_t) stream;
 #if defined(OCRT_STAMPS) || defined(OCRT_TAIL)
 	hipLaunchKernelGGL(clear_stamps_kernel, dim3(1), dim3(256), 0, s, (FrameCounters *) counters);
@@ -110,6 +110,7 @@ void launch_primary(const SceneBuffers &scene, float *image, void *hits, void *o
 		args.tile_hits = (uint32_t *) tile_hits;
 		args.tile_base = (const uint32_t *) tile_base;
 		args.counters = (FrameCounters *) counters;
+		args.primary_order = (const uint32_t *) blocks_by_cost;  // (null: the spatial mapping)
 		args.P = P;
 		hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64 * PRIMARY_WAVES), 0, s, args);
 	};

@@ -377,9 +377,22 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) __attribute__((amdgpu_waves_per
 		const uint32_t strip_index = seq / per_strip;
 		const uint32_t rest = seq - strip_index * per_strip;
 		const uint32_t row_block = rest / columns;
-		const uint32_t tile_x = strip_tiles * (group + XCD_GROUPS * strip_index) + 2u * (rest - row_block * columns) + (wave & 1u);
-		const uint32_t local_row = PRIMARY_ROWS * row_block + (wave >> 1);
-		if (seq < strips_here * per_strip && tile_x < A.P.tiles_x && local_row < A.P.local_tile_rows)
+		uint32_t tile_x = strip_tiles * (group + XCD_GROUPS * strip_index) + 2u * (rest - row_block * columns) + (wave & 1u);
+		uint32_t local_row = PRIMARY_ROWS * row_block + (wave >> 1);
+		bool there = seq < strips_here * per_strip;
+		// With a list of the group's 2 x 2 blocks by falling cost (DeviceRenderer::orderPrimaryBlocks, once per upload: the
+		// leaves each tile's primary packet stops at are the same in every frame) workgroup `seq` of the group takes entry
+		// `seq`: the model's blocks -- 50-140 us of dependent loads each -- start first, the background's fill in behind them.
+		if (PRIMARY_WAVES == 4u && A.primary_order != nullptr && there) {
+			uint32_t segment = 0u;
+			for (uint32_t g = 0; g < group; ++g)
+				segment += ((strips + XCD_GROUPS - 1u - g) >> 3) * per_strip;
+			const uint32_t block = A.primary_order[segment + seq];
+			there = block != 0xFFFFFFFFu;
+			tile_x = (block & 0xFFFFu) + (wave & 1u);
+			local_row = (block >> 16) + (wave >> 1);
+		}
+		if (there && tile_x < A.P.tiles_x && local_row < A.P.local_tile_rows)
 			primary_tile<SHARED>(A, closest_batches[wave], tile_x, local_row);
 	}
 }

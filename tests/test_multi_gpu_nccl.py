@@ -96,7 +96,7 @@ def test_four_gloo_ranks_rehearse_the_eight_gpu_run(golden):
     them, bands of 4 rows dealt round-robin, the gather, barriers and all-reduces of the timing contract.  The assembled
     PGM is the golden one in both modes."""
     out = _run_bench(4, extra_env={"OCRT_BENCH_BACKEND": "gloo"}, bare=True, extra_args=["--in-flight", "8"])
-    assert out["n_gpus"] == 4 and out["config"]["frames_in_flight"] == 8
+    assert out["n_gpus"] == 4 and out["config"]["frames_in_flight"] == 1 and out["pipelined"]["frames_in_flight"] == 8
     assert out["config"]["pgm_md5"] == golden["renders"]["bunny_600_defaults"]["pgm_md5"]
     assert out["pipelined"]["pgm_md5"] == golden["renders"]["bunny_600_defaults"]["pgm_md5"]
     assert out["config"]["rays_per_frame"] == 1440000 + 28 * golden["renders"]["bunny_600_defaults"]["counters"]["primary_hits"]

@@ -45,6 +45,24 @@ def make_order(base, segs, costs, rule, workgroups_per_group, tiles_x, rows, str
             pick = np.arange(n)
         elif kind == "lpt":
             pick = np.argsort(-c, kind="stable")
+        elif kind == "blocks":  # ("blocks", heavy, runway, size): like "mixed", but the runway falls by the mean cost of BLOCKS of `size` spatial neighbours
+            _, heavy, runway, size = rule
+            reference = np.sort(c)[n - 1 - (n - 1) // 4]
+            is_heavy = c > heavy * reference
+            heavy_ones = np.flatnonzero(is_heavy)
+            heavy_ones = heavy_ones[np.argsort(-c[heavy_ones], kind="stable")]
+            rest = np.flatnonzero(~is_heavy)
+            left = c[rest].sum() - np.concatenate(([0.0], np.cumsum(c[rest])[:-1]))
+            budget = runway * reference * workgroups_per_group
+            in_spatial = left > budget
+            sp, rw = rest[in_spatial], rest[~in_spatial]
+            # cheap tiles of the spatial part join the runway, in place (spatial order is the index order)
+            cheap = sp[c[sp] < 0.25 * reference]
+            sp = sp[c[sp] >= 0.25 * reference]
+            rw = np.sort(np.concatenate((rw, cheap)))
+            blocks = [rw[i:i + size] for i in range(0, len(rw), size)]
+            blocks.sort(key=lambda b: -float(c[b].mean()))
+            pick = np.concatenate([heavy_ones, sp] + blocks) if blocks else np.concatenate((heavy_ones, sp))
         else:  # ("mixed", heavy, runway, cheap)
             _, heavy, runway, cheap = rule
             reference = np.sort(c)[n - 1 - (n - 1) // 4]
@@ -60,6 +78,30 @@ def make_order(base, segs, costs, rule, workgroups_per_group, tiles_x, rows, str
             pick = np.concatenate((heavy_ones, sp, rw))
         order[at:at + n] = entries[pick]
     return order
+
+
+def simulate(order, segs, costs, workgroups_per_group=256):
+    """List scheduling by the kernel's rules: every group's workgroups claim from their own queue, then help the others in
+    turn.  Returns (makespan, mean end, first end) in ms of the measured costs (10 ns ticks)."""
+    import heapq
+
+    queues = [list(costs[order[at:at + len(e)] & 0x03FFFFFF]) for at, _, e in segs]
+    heads = [0] * 8
+    free = [(0.0, g, w) for g in range(8) for w in range(workgroups_per_group)]
+    heapq.heapify(free)
+    ends = []
+    while free:
+        t, home, w = heapq.heappop(free)
+        for turn in range(8):
+            g = (home + turn) % 8
+            if heads[g] < len(queues[g]):
+                c = queues[g][heads[g]]
+                heads[g] += 1
+                heapq.heappush(free, (t + c, home, w))
+                break
+        else:
+            ends.append(t)
+    return max(ends) / 1e5, sum(ends) / len(ends) / 1e5, min(ends) / 1e5
 
 
 def timed(host, frames=30):
@@ -98,17 +140,21 @@ def main():
         cls = (words[hit] >> 8).astype(np.float64)
         print(f"   correlation of the measured cost with the cost class (primary packet's leaf stops): {np.corrcoef(cls, c)[0, 1]:.3f}")
         segs = segments(info["order"], info["constants"], tiles_x, rows, strip_tiles)
+        sums = [float(costs[e & 0x03FFFFFF].sum()) / 1e5 for _, _, e in segs]
+        print("   workgroup time per XCD group's queue (ms): " + " ".join(f"{v:.1f}" for v in sums) +
+              f"; ideal pass with 256 workgroups each: {max(sums) / 256:.4f} ms (largest group), {sum(sums) / 2048:.4f} ms (all groups level)")
         print(f"   {'as installed (blocks of 64 by cost class)':58s} frame {base_ms[0]:.4f} ms (min {base_ms[2]:.4f}), ao {base_ms[1]:.4f}", flush=True)
-        rules = [("spatial",), ("lpt",)]
-        for heavy in (1.3, 1.6, 2.0, 1e9):
-            for runway in (0.0, 1.0, 2.0, 3.0):
-                rules.append(("mixed", heavy, runway, 0.25))
-        rules += [("mixed", 1.6, 2.0, 0.0), ("mixed", 1.6, 2.0, 0.5), ("mixed", 1.3, 4.0, 0.25), ("mixed", 1.0, 2.0, 0.25)]
+        rules = [("spatial",), ("lpt",), ("mixed", 2.0, 2.0, 0.25), ("mixed", 1.6, 2.0, 0.25)]
+        for size in (4, 8, 16, 32, 64):
+            for runway in (2.0, 3.0, 6.0):
+                rules.append(("blocks", 2.0, runway, size))
+        rules += [("mixed", 2.0, 2.0, 0.25)]
         for rule in rules:
             order = make_order(info["order"], segs, costs, rule, 256, tiles_x, rows, strip_tiles)
             host.set_tile_order(order, info["constants"])
             ms = timed(host)
-            print(f"   {str(rule):58s} frame {ms[0]:.4f} ms (min {ms[2]:.4f}), ao {ms[1]:.4f}", flush=True)
+            sim = simulate(order, segs, costs)
+            print(f"   {str(rule):58s} frame {ms[0]:.4f} ms (min {ms[2]:.4f}), ao {ms[1]:.4f}   model: last workgroup ends {sim[0]:.4f}, mean {sim[1]:.4f}, first {sim[2]:.4f}", flush=True)
         host.set_tile_order(info["order"], info["constants"])
         again = timed(host)
         print(f"   {'as installed, again':58s} frame {again[0]:.4f} ms (min {again[2]:.4f}), ao {again[1]:.4f}", flush=True)

@@ -18,7 +18,7 @@ def main():
         w = WORKLOADS[name]
         opt = workload_options(rt, w)
         scene = load_scene(rt, w).build_bvh(opt.bvh_method)
-        ring = rt.FrameRing(opt, scene, hosts=1)
+        ring = rt.FrameRing(opt, scene, hosts=1)  # (its upload measures the tiles' costs and orders them by that)
         ring.set_graph_mode(False)
         ring.run(10)
         ring.drain()
