@@ -15,7 +15,7 @@ set) any-hit rays per hit sub-pixel.
 `python -m torch.distributed.run`, before this process touches torch or the GPU);
 under an external torchrun (RANK / WORLD_SIZE in the environment) it is a rank.
 
-The frames go through the library's frame ring (include/rt_hip.h, rt_ring_*): several
+The frames go through the library's frame ring (include/rt_hip_ring.h, rt_ring_*): several
 render hosts per GPU take them in turn, each replaying its captured hipGraph, and the
 ring itself runs the RCCL gather behind the next frames -- a timed block is ONE call
 into the library (rt_ring_run), Python is not on the per-frame path.  In the same run
@@ -314,6 +314,35 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     args.gpus = world
+
+    # Every step of the set-up is named, logged (stderr, with the time since the step before) and TIME-BOXED: a rank that
+    # sits in one step longer than its limit says where -- a JSON line with "error" on stdout from rank 0, a line on stderr
+    # from every rank -- and the process ends with a non-zero status instead of hanging until somebody's patience runs out.
+    # (The first contact with an 8-GPU node is a run nobody has rehearsed on real hardware: RCCL's rendezvous, peer access and
+    # the dmabuf IPC mode are the places a multi-GPU job stalls in, and one log must be enough to tell which.)
+    import threading
+
+    stage = {"name": "start", "since": time.monotonic(), "limit": 300.0, "done": False}
+
+    def enter(name, limit=300.0):
+        now = time.monotonic()
+        if launched:
+            print(f"[bench rank {rank}/{world}] {stage['name']} took {now - stage['since']:.2f} s; now: {name}", file=sys.stderr, flush=True)
+        stage.update(name=name, since=now, limit=limit)
+
+    def watchdog():
+        while not stage["done"]:
+            time.sleep(1.0)
+            waited = time.monotonic() - stage["since"]
+            if not stage["done"] and waited > stage["limit"]:
+                message = (f"bench.py rank {rank}/{world}: step '{stage['name']}' has not finished after {waited:.0f} s "
+                           f"(limit {stage['limit']:.0f} s); HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}")
+                print(message, file=sys.stderr, flush=True)
+                if rank == 0:
+                    print(json.dumps({"error": message, "stage": stage["name"], "n_gpus": world, "rank": rank}), flush=True)
+                os._exit(3)
+
+    threading.Thread(target=watchdog, daemon=True).start()
     w = WORKLOADS[args.workload]
     golden_md5, counters = None, None
     if w["golden"]:
@@ -343,12 +372,21 @@ def main():
     if backend == "nccl" and world > torch.cuda.device_count():
         sys.exit(f"bench.py: {world} ranks but {torch.cuda.device_count()} visible GPU(s): one rank per GPU")
     if launched:  # also for a world of one: the RCCL communicator and the gather are then exercised on a one-GPU box
+        import datetime
+
+        enter(f"torch.distributed rendezvous ({backend}; HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')})", 180.0)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
+            dist.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(seconds=180))
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=datetime.timedelta(seconds=180))
+        enter("first collective (an all-reduce of one word over every rank)", 120.0)
+        probe = torch.ones(1, dtype=torch.int32, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(probe)
+        if int(probe[0]) != world:
+            sys.exit(f"bench.py: the first all-reduce counted {int(probe[0])} ranks, the job has {world}")
     reduce_device = device if backend == "nccl" else "cpu"
 
+    enter("scene: load, BVH", 300.0)
     opt = workload_options(rt, w)
     t0 = time.perf_counter()
     scene = load_scene(rt, w)
@@ -356,7 +394,7 @@ def main():
     scene.build_bvh(opt.bvh_method)
     t_scene = time.perf_counter() - t0
 
-    # The frame ring (include/rt_hip.h): `in_flight` render hosts of the scene on this GPU, each on its own stream
+    # The frame ring (include/rt_hip_ring.h): `in_flight` render hosts of the scene on this GPU, each on its own stream
     # (consecutive hosts in different priority classes, i.e. hardware queues) with its own captured hipGraph, take the
     # frames in turn: while frame i's ambient-occlusion pass runs out (its last quarter runs at falling occupancy: the
     # queues are drained, the workgroups end one by one) the next frames' passes fill the wave slots it frees, and the
@@ -381,6 +419,7 @@ def main():
                 ring.set_pacing(args.pacing)
         return made
 
+    enter("frame rings: upload, tile costs, calibration, graph capture", 300.0)
     rings = make_rings()
 
     # The exchange step of a multi-GPU frame: the ring's own RCCL gather (one process per GPU; the unique id is made on
@@ -413,28 +452,41 @@ def main():
     if launched:
         bind_bands()
     if rccl:
+        # Every collective below is entered by EVERY rank, whatever went wrong on it before: what can fail on one rank alone
+        # (loading RCCL, making an id, attaching a communicator) happens inside try blocks that only record the error, the
+        # ranks then agree on it (an all-reduce of a flag), and only a step every rank has passed is followed by the next.
+        enter("RCCL: library and unique id", 120.0)
         error = ""
-        try:  # (loads RCCL and makes an id: what can fail on one rank alone, before any rank waits for another)
-            if os.environ.get("OCRT_BENCH_FAIL_RCCL"):  # rehearsal knob: take the fallback
-                raise RuntimeError("OCRT_BENCH_FAIL_RCCL is set")
-            rt.rccl_unique_id()
-        except Exception as exc:  # noqa: BLE001
-            error = f"{type(exc).__name__}: {exc}"
-        failed = any_rank_failed(error)
         for name, ring in rings.items():
-            if failed:
-                break
-            try:
-                uid = torch.zeros(128, dtype=torch.uint8, device=device)
-                if rank == 0:
+            uid = torch.zeros(128, dtype=torch.uint8, device=device)
+            if rank == 0 and not error:
+                try:
+                    if os.environ.get("OCRT_BENCH_FAIL_RCCL"):  # rehearsal knob: take the fallback
+                        raise RuntimeError("OCRT_BENCH_FAIL_RCCL is set")
                     uid = torch.frombuffer(bytearray(rt.rccl_unique_id()), dtype=torch.uint8).to(device)
-                dist.broadcast(uid, 0)
+                except Exception as exc:  # noqa: BLE001
+                    error = f"{type(exc).__name__}: {exc}"
+            enter(f"RCCL: id of the {name} ring's communicator to every rank (torch.distributed.broadcast)", 120.0)
+            dist.broadcast(uid, 0)
+            if any_rank_failed(error):
+                break
+            enter(f"RCCL: ncclCommInitRank for the {name} ring ({world} ranks)", 180.0)
+            try:
                 ring.attach_rccl(bytes(uid.cpu().numpy().tobytes()))
+            except Exception as exc:  # noqa: BLE001
+                error = f"{type(exc).__name__}: {exc}"
+            if any_rank_failed(error):
+                break
+            enter(f"RCCL: self send / receive on the {name} ring's communicator", 120.0)
+            try:
                 ring.rccl_self_test()
             except Exception as exc:  # noqa: BLE001
                 error = f"{type(exc).__name__}: {exc}"
-            failed = any_rank_failed(error)
+            if any_rank_failed(error):
+                break
+        failed = any_rank_failed(error)
         if failed:
+            enter("RCCL could not be set up: rings again, without a gather (torch.distributed gathers instead)", 300.0)
             rccl_failure = error or "the set-up failed on another rank"
             rccl = False
             for ring in rings.values():
@@ -485,20 +537,26 @@ def main():
             return None
         return rings[name].download_last()
 
-    if rccl and world > 1:
-        # The library's own gather against torch.distributed's on the same frame, once, before anything is timed.
-        ring = rings["pipelined"]
-        ring.submit()
-        _, slot, _ = ring.collect_info()
-        ring.drain()
-        torch.cuda.synchronize(device)
-        theirs = gatherers["pipelined"](bands["pipelined"][slot])
-        ok = torch.ones(1, dtype=torch.int32, device=device)
-        if rank == 0 and not np.array_equal(theirs.cpu().numpy(), ring.download_last()):
-            ok[0] = 0
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok[0]) == 0:
-            sys.exit("bench.py: the ring's RCCL gather and torch.distributed's gather disagree")
+    if rccl:
+        # Pre-flight, before anything is timed: every band buffer of both rings once (2 x hosts frames each, the real band
+        # sizes: 259 KB per rank at 1080p over eight ranks, 1 MB at 4K) through the ring's own gather, and every assembled
+        # image on rank 0 against torch.distributed's gather of the same band buffers.  A peer that never posts its half
+        # fails the rank within the gather's deadline (rt_ring_set_gather_timeout) instead of hanging it.
+        for name, ring in rings.items():
+            enter(f"pre-flight: {ring.slots} frames through the {name} ring's RCCL gather, checked against torch.distributed's", 300.0)
+            ring.set_gather_timeout(60.0)
+            ok = torch.ones(1, dtype=torch.int32, device=device)
+            for _ in range(ring.slots):
+                ring.submit()
+                _, slot, _ = ring.collect_info()
+                ring.drain()
+                torch.cuda.synchronize(device)
+                theirs = gatherers[name](bands[name][slot])
+                if rank == 0 and not np.array_equal(theirs.cpu().numpy(), ring.download_last()):
+                    ok[0] = 0
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok[0]) == 0:
+                sys.exit(f"bench.py: the {name} ring's RCCL gather and torch.distributed's gather disagree")
 
     def timed_blocks(name):
         """Warm-up, then blocks of exactly --steps steps, each bracketed by barrier + synchronize, the MAX over ranks
@@ -525,6 +583,7 @@ def main():
 
     results = {}
     for name in ("pipelined", "blocking"):
+        enter(f"timed blocks, {name}", 900.0)
         seconds = timed_blocks(name)
         ring = rings[name]
         timers, cpu = ring.timers(), ring.cpu_times()
@@ -532,6 +591,7 @@ def main():
                          "cpu_us": {k: round(cpu[k + "_s"] / max(1, cpu["frames"]) * 1e6, 1) for k in ("submit", "collect", "wait")}}
     # The dominant kernel ALONE, by HIP events right around its launch on the launch stream (plain launches: the events
     # of a replayed graph cannot be timed), one frame at a time -- the duration the roofline is quoted for.
+    enter("the dominant kernel alone (plain launches, HIP events)", 600.0)
     ring = rings["blocking"]
     ring.set_graph_mode(False)
     run_steps("blocking", args.warmup)
@@ -556,6 +616,7 @@ def main():
         total_rays, total_hits, total_occluded = (int(x) for x in r)
     else:
         total_rays, total_hits, total_occluded = my_rays, st["primary_hits"], st["ao_occluded"]
+    enter("statistics, images, the line", 900.0)
     images = {name: final_image(name) for name in rings}
     rccl_described = {"failed": rccl_failure, "world_size": world} if rccl_failure else None
     if rccl:
@@ -610,6 +671,7 @@ def main():
                        # what the exchange step's communicator says about itself (ncclCommCount, ncclGetVersion): a scaling
                        # record can check that RCCL really saw `n_gpus` ranks; null without RCCL (a single unlaunched process)
                        "rccl": rccl_described,
+                       "ipc": {"HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")},
                        "frame_launch": "plain launches" if args.plain_launches else "hipGraph replay",
                        "pgm_md5": md5["blocking"], "pgm_matches_golden": golden_md5 is not None,
                        "scene_load_s": round(t_load, 3), "scene_build_s": round(t_scene, 3),
@@ -702,14 +764,22 @@ def main():
         out["roofline"] = roof
         if cpu is not None:
             out["cpu_baseline"] = cpu
+        if golden_md5 is None and cpu is None:
+            # a generated scene without a committed golden, and the CPU check of this run switched off: nothing in THIS run
+            # has compared the frame with the CPU's (tests/test_big_scenes.py does, at small sizes) -- the metric says so
+            out["metric"] = out["metric"].replace("PGM bit-exact vs CPU", "PGM not compared with the CPU in this run")
+        elif golden_md5 is None:
+            out["config"]["pgm_checked_against"] = "the oracle's rows of this run's cpu_baseline sample, byte for byte"
         if e2e is not None:
             out["end_to_end"] = e2e
         print(json.dumps(out), flush=True)
 
+    enter("closing", 120.0)
     for ring in rings.values():
         ring.close()
     if launched:
         dist.destroy_process_group()
+    stage["done"] = True
 
 
 if __name__ == "__main__":

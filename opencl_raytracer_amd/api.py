@@ -1,4 +1,4 @@
-"""ctypes binding of include/rt_hip.h (see that header for the contract)."""
+"""ctypes binding of include/rt_hip.h, rt_hip_ring.h and rt_hip_debug.h (see those headers for the contract)."""
 from __future__ import annotations
 
 import ctypes as C
@@ -423,7 +423,7 @@ class Host:
         return int(p.value or 0)
 
     def set_ao_prefetch(self, on: bool) -> None:
-        """Which form of the AO pass's node loop this host launches (include/rt_hip.h, rt_set_ao_prefetch); same results."""
+        """Which form of the AO pass's node loop this host launches (include/rt_hip_debug.h, rt_set_ao_prefetch); same results."""
         _check(load_library().rt_set_ao_prefetch(self._h, int(on)))
 
     def set_frame_form(self, form: str) -> None:
@@ -463,7 +463,7 @@ class Host:
         _check(load_library().rt_debug_set_tile_order(self._h, order.ctypes.data, len(order), constants.ctypes.data))
 
     def walk_entries(self) -> dict:
-        """The intervals of the node array the tiles' any-hit packets walk (include/rt_hip.h, rt_walk_entries)."""
+        """The intervals of the node array the tiles' any-hit packets walk (include/rt_hip_debug.h, rt_walk_entries)."""
         hit, narrowed, share, packet_share = C.c_uint32(), C.c_uint32(), C.c_double(), C.c_double()
         _check(load_library().rt_walk_entries(self._h, C.byref(hit), C.byref(narrowed), C.byref(share), C.byref(packet_share)))
         return {"tiles_hit": hit.value, "tiles_narrowed": narrowed.value, "mean_share": share.value,
@@ -499,7 +499,7 @@ class Host:
 
 
 class FrameRing:
-    """rt_ring: several render hosts of one scene on one GPU that take frames in turn (include/rt_hip.h, "frame
+    """rt_ring: several render hosts of one scene on one GPU that take frames in turn (include/rt_hip_ring.h, "frame
     ring").  The library owns the hosts, their streams and captured graphs, the frame bookkeeping and -- with a
     communicator attached -- the band gather; this class only forwards.  `submit()` enqueues a frame and returns at
     once, `collect()` waits for the oldest one, `run(k)` is k steps of a steady stream in ONE call into the library."""
@@ -597,7 +597,7 @@ class FrameRing:
         _check(load_library().rt_ring_set_graph_mode(self._r, int(on)))
 
     def set_pacing(self, beta: float) -> None:
-        """0: submit as soon as a host is free; default 0.5 (include/rt_hip.h, rt_ring_set_pacing)."""
+        """0: submit as soon as a host is free; default 0.5 (include/rt_hip_ring.h, rt_ring_set_pacing)."""
         _check(load_library().rt_ring_set_pacing(self._r, float(beta)))
 
     def bind_output(self, slot: int, device_ptr: int) -> None:

@@ -1,4 +1,4 @@
-// c_api.cc -- the extern "C" boundary declared in include/rt_hip.h.
+// c_api.cc -- the extern "C" boundary declared in include/rt_hip.h (the seam), rt_hip_ring.h (streams of frames, several GPUs) and rt_hip_debug.h.
 #include "../../include/rt_hip.h"
 #include "../../include/rt_hip_debug.h"
 

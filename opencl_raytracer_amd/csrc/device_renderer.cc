@@ -883,28 +883,38 @@ DeviceRenderer::WalkEntries DeviceRenderer::walkEntries() const {
 	if (tile_count == 0 || !has_ao || kp.node_count == 0)
 		return out;
 	const size_t stride = kp.entry_stride;  // (intervals per tile: entry_kernel)
-	std::vector<uint32_t> words(tile_count), ranges(entryBytes() / sizeof(uint32_t));
+	std::vector<uint32_t> words(tile_count);
 	OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));
 	OCRT_HIP(hipMemcpyAsync(words.data(), d_tile_hits, tile_count * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t) stream));
-	OCRT_HIP(hipMemcpyAsync(ranges.data(), d_tile_entry, ranges.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t) stream));
 	OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));
 	const double whole = (double) kp.node_count * sizeof(NodeRec);
 	double sum = 0.0, sum_packets = 0.0;
 	unsigned long long packets = 0;
-	for (size_t t = 0; t < tile_count; ++t) {
-		if ((words[t] & 0xFFu) == 0u)
-			continue;
-		++out.tiles_hit;
-		const uint32_t *const of_tile = &ranges[2 * stride * t];
-		const double bytes = std::min(whole, (double) of_tile[1]) - (double) of_tile[0];
-		out.tiles_narrowed += of_tile[0] != 0u || bytes < whole;
-		sum += bytes / whole;
-		// what the tile's packets walk: a full tile's, one table direction each, have intervals of their own
-		const bool per_direction = (words[t] & 0xFFu) == 64u && kp.ao_mode == AO_UNIFORM && stride > 1;
-		for (size_t k = 1; k <= kp.ao_dirs; ++k) {
-			const uint32_t *const r = per_direction ? of_tile + 2 * k : of_tile;
-			sum_packets += (std::min(whole, (double) r[1]) - (double) r[0]) / whole;
-			++packets;
+	// the table in pieces of at most 32 MB (it is 0.5 GB at 64 samples per pixel and may be 2 GB: a statistic is not worth
+	// a host copy of that size)
+	const size_t tiles_per_piece = std::max<size_t>(1, ((size_t) 32 << 20) / (stride * 2 * sizeof(uint32_t)));
+	std::vector<uint32_t> ranges;
+	for (size_t first = 0; first < tile_count; first += tiles_per_piece) {
+		const size_t count = std::min(tiles_per_piece, tile_count - first);
+		ranges.resize(count * stride * 2);
+		OCRT_HIP(hipMemcpyAsync(ranges.data(), (const uint32_t *) d_tile_entry + first * stride * 2, ranges.size() * sizeof(uint32_t), hipMemcpyDeviceToHost,
+		                        (hipStream_t) stream));
+		OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));
+		for (size_t t = first; t < first + count; ++t) {
+			if ((words[t] & 0xFFu) == 0u)
+				continue;
+			++out.tiles_hit;
+			const uint32_t *const of_tile = &ranges[2 * stride * (t - first)];
+			const double bytes = std::min(whole, (double) of_tile[1]) - (double) of_tile[0];
+			out.tiles_narrowed += of_tile[0] != 0u || bytes < whole;
+			sum += bytes / whole;
+			// what the tile's packets walk: a full tile's, one table direction each, have intervals of their own
+			const bool per_direction = (words[t] & 0xFFu) == 64u && kp.ao_mode == AO_UNIFORM && stride > 1;
+			for (size_t k = 1; k <= kp.ao_dirs; ++k) {
+				const uint32_t *const r = per_direction ? of_tile + 2 * k : of_tile;
+				sum_packets += (std::min(whole, (double) r[1]) - (double) r[0]) / whole;
+				++packets;
+			}
 		}
 	}
 	out.mean_share = out.tiles_hit ? sum / out.tiles_hit : 1.0;

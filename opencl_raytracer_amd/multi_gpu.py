@@ -3,7 +3,7 @@
 One process per GPU (torch.distributed, backend "nccl" = RCCL on ROCm; "gloo" in
 the CPU tests).  The image is cut into bands of lcm(8, n)/n output rows
 (n = supersample grid side) that are dealt round-robin to the ranks -- see
-ocrt::Partition / rt_partition_global_row in include/rt_hip.h; cost per row is
+ocrt::Partition / rt_partition_global_row in include/rt_hip_ring.h; cost per row is
 very uneven (background vs model), hence interleaving.  Every rank renders and
 box-filters its own bands into a compact uint8 buffer; ONE gather moves them to
 rank 0, which scatters the rows to their place.  There is no other exchange

@@ -1,4 +1,4 @@
-"""The frame ring (include/rt_hip.h, rt_ring_*) on the GPU: the library itself keeps several render hosts of one scene
+"""The frame ring (include/rt_hip_ring.h, rt_ring_*) on the GPU: the library itself keeps several render hosts of one scene
 busy on one GPU -- captured hipGraph per host, streams of different priority, frame bookkeeping, and, with a
 communicator attached, the RCCL band gather.  The reference renders one blocking frame per OpenCLHost::operator()()
 (src/opencl_host.cc:137-149); every frame of a ring must be exactly that frame, and the frames must really overlap."""

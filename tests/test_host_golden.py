@@ -188,6 +188,14 @@ def test_library_exports_every_declared_symbol(rt):
     from opencl_raytracer_amd import api
 
     assert sorted(api._SIGNATURES) == names
+    # the boundary itself -- what stands for the reference's OpenCLHost, its options and its mesh / BVH host API -- stays
+    # small; streams of frames, several GPUs and diagnostics are declared beside it (rt_hip_ring.h, rt_hip_debug.h)
+    seam = header_symbols("rt_hip.h")
+    assert len(seam) <= 40, len(seam)
+    for name in ("rt_create", "rt_upload", "rt_render", "rt_download", "rt_download_u8", "rt_destroy", "rt_print_info",
+                 "rt_scene_load_off", "rt_scene_build_bvh", "rt_resize_cpu", "rt_options_default", "rt_expect_frames"):
+        assert name in seam, name
+    assert not any(n.startswith(("rt_ring_", "rt_debug_", "rt_rccl_")) for n in seam)
 
 
 def test_no_device_behaviour(rt):
