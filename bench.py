@@ -82,6 +82,14 @@ WORKLOADS = {
     "interior_4k_ao": dict(
         mesh="interior", bvh="longest", width=3840, height=2160, ss=1, ao=3, golden="interior_4k_s1_a3",
         label="interior stand-in for the missing sibenik.off, 3840x2160 -s 1 -a 3"),
+    # the HARDER stand-in (tools/make_interior_mesh.py --hard): the nave's shell as a handful of huge triangles, long thin ones
+    # (mullions, steps, ribs), ornament 100 x denser than the shell -- what a midpoint-split BVH copes worst with
+    "interior_hard_1080p_ao": dict(
+        mesh="interior_hard", bvh="longest", width=1920, height=1080, ss=1, ao=3, golden="interior_hard_1080p_s1_a3",
+        label="HARDER interior stand-in for the missing sibenik.off (huge triangles beside fine ornament, slivers), 1920x1080 -s 1 -a 3"),
+    "interior_hard_4k_ao": dict(
+        mesh="interior_hard", bvh="longest", width=3840, height=2160, ss=1, ao=3, golden="interior_hard_4k_s1_a3",
+        label="HARDER interior stand-in for the missing sibenik.off (huge triangles beside fine ornament, slivers), 3840x2160 -s 1 -a 3"),
     "interior_1080p_ao": dict(
         mesh="interior", bvh="longest", width=1920, height=1080, ss=1, ao=3, golden="interior_1080p_s1_a3",
         label="interior stand-in for the missing sibenik.off, 1920x1080 -s 1 -a 3"),
@@ -104,9 +112,9 @@ def workload_options(rt, w):
 
 
 def mesh_path(name: str) -> str:
-    from tools.meshes import bunny_path, interior_path
+    from tools.meshes import bunny_path, interior_hard_path, interior_path
 
-    return bunny_path() if name == "bunny" else interior_path()
+    return bunny_path() if name == "bunny" else interior_hard_path() if name == "interior_hard" else interior_path()
 
 
 def load_scene(rt, w):

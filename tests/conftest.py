@@ -67,12 +67,14 @@ def rt_knobs():
 
 
 def mesh_file(name: str) -> str:
-    from tools.meshes import bunny_path, interior_path
+    from tools.meshes import bunny_path, interior_hard_path, interior_path
 
     if name == "bunny":
         return bunny_path()
     if name == "interior":  # the generated, labelled stand-in for the missing sibenik.off
         return interior_path()
+    if name == "interior_hard":  # ... and its harder variant (huge triangles beside fine ornament, slivers)
+        return interior_hard_path()
     return os.path.join(GOLDEN_DIR, "meshes", name + ".off")
 
 

@@ -35,7 +35,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import orc  # noqa: E402
-from tools.meshes import bunny_path, interior_path  # noqa: E402
+from tools.meshes import bunny_path, interior_hard_path, interior_path  # noqa: E402
 
 
 def mesh_file(name: str) -> str:
@@ -43,6 +43,8 @@ def mesh_file(name: str) -> str:
         return bunny_path()
     if name == "interior":  # generated, labelled stand-in for the missing sibenik.off; its arrays are pinned under "scenes"
         return interior_path()
+    if name == "interior_hard":  # ... and its harder variant (huge triangles beside fine ornament, slivers), pinned the same way
+        return interior_hard_path()
     return os.path.join(HERE, "meshes", name + ".off")
 
 
@@ -79,6 +81,11 @@ CASES = [
     case("interior_1080p_s1_a3", "interior", width=1920, height=1080, ao=3),
     case("interior_4k_s1_a3", "interior", width=3840, height=2160, ao=3),
     case("bunny_1080p_s64_a3", "bunny", width=1920, height=1080, ss=64, ao=3),
+    # the HARDER interior stand-in (tools/make_interior_mesh.py --hard: the shell as a handful of huge triangles, slivers,
+    # ornament 100 x denser): a small frame the oracle re-renders in the tests, and configs 3 / 4 at full size
+    case("interior_hard_160x90_s4_a3", "interior_hard", width=160, height=90, ss=4, ao=3),
+    case("interior_hard_1080p_s1_a3", "interior_hard", width=1920, height=1080, ao=3),
+    case("interior_hard_4k_s1_a3", "interior_hard", width=3840, height=2160, ao=3),
 ]
 
 
@@ -118,7 +125,8 @@ def main():
 
     # ---- scenes: mesh + BVH arrays from the reference's host code ----
     scenes = {}
-    wanted = sorted({(c["mesh"], c["bvh"]) for c in CASES} | ({("bunny", "sah")} if args.full_sah else set()))
+    selected = [c for c in CASES if not args.only or any(part in c["name"] for part in args.only.split(","))]
+    wanted = sorted({(c["mesh"], c["bvh"]) for c in selected} | ({("bunny", "sah")} if args.full_sah else set()))
     for mesh, bvh in wanted:
         t0 = time.time()
         h, v, n, f = ref.load(mesh_file(mesh))
@@ -130,7 +138,7 @@ def main():
             "vertices": sha(v), "vnormals": sha(n), "faces": sha(f), "nodes": sha(nodes), "aabbs": sha(aabbs),
             "triangles": sha(tris), "sorted_faces": sha(sorted_faces),
         }
-        if mesh not in ("bunny", "interior"):
+        if mesh not in ("bunny", "interior", "interior_hard"):
             np.savez_compressed(os.path.join(HERE, f"scene_{mesh}_{bvh}.npz"), vertices=v, vnormals=n, faces=f,
                                 nodes=nodes, aabbs=aabbs, triangles=tris, sorted_faces=sorted_faces)
         print(f"scene {mesh}/{bvh}: {nodes.size} nodes ({time.time() - t0:.1f}s)", flush=True)

@@ -15,11 +15,12 @@ ORACLE_CASES = [
     "bunny_256_s1_a0", "bunny_256_s1_a3", "bunny_64_s1_a3", "bunny_101x77_s9_a2", "bunny_50x40_s5_a1_f15",
     "bunny_96x54_s1_a4_alpha", "blob_128x96_s4_a3", "blob_128x96_s4_a3_sah", "blob_80_s1_a5_noshade",
     "blob_33x17_s1_a0", "ties_33_s1_a3", "ties_33_s1_a3_sah", "ties_64_s4_a3", "ties_5x3_s1_a1", "single_32_s1_a3",
+    "interior_hard_160x90_s4_a3",
 ]
 # full-size cases are checked against the committed digests only
 # (BASELINE.json configs 2-5: bunny 1080p, interior stand-in 1080p and 4K, bunny with 64 samples per pixel)
 DIGEST_CASES = ["bunny_1080p_s1_a0", "bunny_1080p_s1_a3", "bunny_600_defaults", "interior_1080p_s1_a3",
-                "interior_4k_s1_a3", "bunny_1080p_s64_a3"]
+                "interior_4k_s1_a3", "bunny_1080p_s64_a3", "interior_hard_1080p_s1_a3", "interior_hard_4k_s1_a3"]
 
 
 def render_hip(rt, scene, opt, rank=0, nranks=1, frames=None):
@@ -79,13 +80,14 @@ def test_full_size_golden_digests(rt, golden, scene_for, name):
     host.close()
 
 
-def test_interior_standin_is_the_pinned_mesh(rt, golden, scene_for):
-    """The interior stand-in is generated (tools/make_interior_mesh.py), not stored: its arrays must be the ones
+@pytest.mark.parametrize("mesh", ["interior", "interior_hard"])
+def test_interior_standin_is_the_pinned_mesh(rt, golden, scene_for, mesh):
+    """The interior stand-ins are generated (tools/make_interior_mesh.py), not stored: their arrays must be the ones
     the reference's loader and builder produced when the goldens were made."""
     import hashlib as h
 
-    scene, arrays = scene_for("interior", "longest")
-    g = golden["scenes"]["interior/longest"]
+    scene, arrays = scene_for(mesh, "longest")
+    g = golden["scenes"][f"{mesh}/longest"]
     assert h.sha256(arrays.vertices.tobytes()).hexdigest() == g["vertices"]
     assert h.sha256(arrays.nodes.tobytes()).hexdigest() == g["nodes"]
     assert h.sha256(arrays.aabbs.tobytes()).hexdigest() == g["aabbs"]

@@ -15,7 +15,7 @@ FAST = [
     "bunny_256_s1_a0", "bunny_256_s1_a3", "bunny_1080p_s1_a0", "bunny_64_s1_a3", "bunny_101x77_s9_a2",
     "bunny_50x40_s5_a1_f15", "bunny_96x54_s1_a4_alpha", "blob_128x96_s4_a3", "blob_128x96_s4_a3_sah",
     "blob_80_s1_a5_noshade", "blob_33x17_s1_a0", "ties_33_s1_a3", "ties_33_s1_a3_sah", "ties_64_s4_a3",
-    "ties_5x3_s1_a1", "single_32_s1_a3",
+    "ties_5x3_s1_a1", "single_32_s1_a3", "interior_hard_160x90_s4_a3",
 ]
 SLOW = ["bunny_1080p_s1_a3", "bunny_600_defaults"]
 

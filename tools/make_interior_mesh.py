@@ -9,6 +9,8 @@ to ~75 k triangles.  The camera of the renderer sits at (0, 0, 2) looking down
 where 44 % miss) and AO rays see close occluders everywhere.
 
     python tools/make_interior_mesh.py [out.off]
+    python tools/make_interior_mesh.py --hard [out.off]     the harder variant (build_hard): huge triangles beside fine
+                                                            ornament, slivers, density varying 100 x
 """
 from __future__ import annotations
 
@@ -123,8 +125,81 @@ def build():
     return np.array(b.verts), np.array(b.faces)
 
 
-def write_interior_mesh(path: str) -> None:
-    v, f = build()
+def box(b, lo, hi):
+    """Axis-aligned box as 12 triangles (two per face, outward)."""
+    (x0, y0, z0), (x1, y1, z1) = lo, hi
+    b.grid((x0, y0, z1), (x1 - x0, 0, 0), (0, y1 - y0, 0), 1, 1)             # front  (+z)
+    b.grid((x1, y0, z0), (x0 - x1, 0, 0), (0, y1 - y0, 0), 1, 1)             # back   (-z)
+    b.grid((x0, y0, z0), (0, 0, z1 - z0), (0, y1 - y0, 0), 1, 1)             # left   (-x)
+    b.grid((x1, y0, z1), (0, 0, z0 - z1), (0, y1 - y0, 0), 1, 1)             # right  (+x)
+    b.grid((x0, y1, z1), (x1 - x0, 0, 0), (0, 0, z0 - z1), 1, 1)             # top    (+y)
+    b.grid((x0, y0, z0), (x1 - x0, 0, 0), (0, 0, z1 - z0), 1, 1)             # bottom (-y)
+
+
+def build_hard():
+    """The same nave as build(), made the way a modelled interior (Sibenik) is rather than the way a generator likes it:
+    * floor, walls, end walls and the vault are A HANDFUL OF HUGE TRIANGLES (2 per wall, 8 x 17 units each; a vault of 12
+      flat panels) -- their one-triangle leaves span the whole room, which is what a midpoint-split BVH
+      (reference src/bvh.cc:59-94) copes worst with;
+    * long thin triangles: window mullions and transoms on both walls (bars 3 cm wide, 3 m tall), the steps of a staircase
+      before the apse (8 m wide, 6 cm deep), ribs along the vault;
+    * the ornament is tessellated 100 x more densely than the shell it stands in: finely fluted columns with stacked
+      capitals, chandeliers of small spheres, the apse's spheres -- ~97 % of the triangles in ~5 % of the surface.
+    ~75 k triangles like the other stand-in; every primary ray hits something."""
+    b = Builder()
+    x0, x1, y0, y1, z0, z1 = -4.0, 4.0, -2.0, 2.2, -14.0, 3.0
+    # the shell: two triangles per surface
+    b.grid((x0, y0, z1), (x1 - x0, 0, 0), (0, 0, z0 - z1), 1, 1)
+    b.grid((x0, y0, z0), (0, 0, z1 - z0), (0, y1 - y0, 0), 1, 1)
+    b.grid((x1, y0, z1), (0, 0, z0 - z1), (0, y1 - y0, 0), 1, 1)
+    b.grid((x0, y0, z0), (x1 - x0, 0, 0), (0, y1 - y0 + 4.0, 0), 1, 1, flip=True)
+    b.grid((x1, y0, z1), (x0 - x1, 0, 0), (0, y1 - y0 + 4.0, 0), 1, 1, flip=True)
+    # the vault: 12 flat panels running the whole length
+    panels = 12
+    for k in range(panels):
+        a0, a1 = math.pi * k / panels, math.pi * (k + 1) / panels
+        p0 = (4.0 * math.cos(a0), y1 + 4.0 * math.sin(a0), z1)
+        p1 = (4.0 * math.cos(a1), y1 + 4.0 * math.sin(a1), z1)
+        b.grid(p0, (p1[0] - p0[0], p1[1] - p0[1], 0.0), (0.0, 0.0, z0 - z1), 1, 1, flip=True)
+    # ribs along the vault: thin boxes, 17 m long
+    for k in range(1, panels):
+        a = math.pi * k / panels
+        cx, cy = 3.93 * math.cos(a), y1 + 3.93 * math.sin(a)
+        box(b, (cx - 0.03, cy - 0.03, z0), (cx + 0.03, cy + 0.03, z1))
+    # windows: a lattice of mullions (vertical) and transoms (horizontal) 3 cm wide, standing 2 cm off both walls
+    for side, xw in ((-1, x0 + 0.02), (1, x1 - 0.05)):
+        for zc in np.linspace(0.0, -12.0, 7):
+            for m in range(6):
+                zm = float(zc) - 0.6 + 0.24 * m
+                box(b, (xw, -0.6, zm - 0.015), (xw + 0.03, 2.0, zm + 0.015))
+            for t in range(5):
+                yt = -0.6 + 0.65 * t
+                box(b, (xw, yt - 0.015, float(zc) - 0.62), (xw + 0.03, yt + 0.015, float(zc) + 0.62))
+    # a staircase before the apse: twelve steps the whole width of the nave, 6 cm deep and 4 cm high each
+    for k in range(12):
+        box(b, (x0 + 0.3, y0 + 0.04 * k, -10.6 - 0.06 * k - 0.06), (x1 - 0.3, y0 + 0.04 * (k + 1), -10.6 - 0.06 * k))
+    # two rows of finely fluted columns with stacked capitals (the dense part)
+    shaft = [(0.36, 0.0), (0.36, 0.1), (0.3, 0.14), (0.3, 0.2), (0.27, 0.24)] + \
+            [(0.25 - 0.0006 * k, 0.24 + 0.0643 * k) for k in range(1, 50)] + \
+            [(0.27, 3.42), (0.31, 3.46), (0.29, 3.52), (0.35, 3.58), (0.33, 3.64), (0.38, 3.7), (0.38, 3.78)]
+    for zc in np.linspace(0.5, -12.5, 9):
+        for xc in (-2.3, 2.3):
+            b.revolve((xc, y0, float(zc)), shaft, 24, flute=0.05, flutes=12)
+    # chandeliers: rings of small spheres hanging over the nave's axis
+    for zc in (-2.0, -6.0, -10.0):
+        for ring, (radius, count, drop) in enumerate(((0.5, 10, 0.0), (0.3, 6, -0.25))):
+            for i in range(count):
+                ang = 2.0 * math.pi * i / count + 0.3 * ring
+                b.sphere((radius * math.cos(ang), 1.6 + drop, zc + radius * math.sin(ang)), 0.07, 8, 10)
+        box(b, (-0.01, 1.7, zc - 0.01), (0.01, y1 + 4.0, zc + 0.01))  # the chain: 4.5 m long, 2 cm thick
+    # apse: spheres at the far end and a font near the camera axis
+    for (c, r) in (((0.0, -0.9, -12.6), 1.0), ((-1.6, -1.4, -11.8), 0.55), ((1.6, -1.4, -11.8), 0.55), ((0.0, -1.55, -3.0), 0.45)):
+        b.sphere(c, r, 36, 44)
+    return np.array(b.verts), np.array(b.faces)
+
+
+def write_interior_mesh(path: str, hard: bool = False) -> None:
+    v, f = build_hard() if hard else build()
     with open(path, "w") as out:
         out.write("OFF\n%d %d 0\n" % (len(v), len(f)))
         for p in v:
@@ -134,7 +209,10 @@ def write_interior_mesh(path: str) -> None:
 
 
 if __name__ == "__main__":
-    target = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "meshes", "interior_standin.off")
-    write_interior_mesh(target)
-    v, f = build()
+    hard = "--hard" in sys.argv
+    args = [a for a in sys.argv[1:] if a != "--hard"]
+    name = "interior_hard.off" if hard else "interior_standin.off"
+    target = args[0] if args else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "meshes", name)
+    write_interior_mesh(target, hard)
+    v, f = build_hard() if hard else build()
     print(target, len(v), "vertices", len(f), "triangles")

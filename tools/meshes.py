@@ -36,3 +36,16 @@ def interior_path() -> str:
         write_interior_mesh(tmp)
         os.replace(tmp, dst)
     return dst
+
+
+def interior_hard_path() -> str:
+    """meshes/interior_hard.off: the HARDER labelled stand-in (tools/make_interior_mesh.py, build_hard): the same nave with
+    its shell as a handful of huge triangles, long thin ones (mullions, steps, ribs) and ornament 100 x denser."""
+    dst = os.path.join(MESH_DIR, "interior_hard.off")
+    if not os.path.exists(dst):
+        from tools.make_interior_mesh import write_interior_mesh
+
+        tmp = dst + f".tmp{os.getpid()}"
+        write_interior_mesh(tmp, hard=True)
+        os.replace(tmp, dst)
+    return dst
