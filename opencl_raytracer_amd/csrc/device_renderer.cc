@@ -344,6 +344,12 @@ std::shared_ptr<const DeviceScene> DeviceScene::create(int device, const PackedS
 	if (ao_bytes)
 		OCRT_HIP(hipMemcpy(out->d_ao, table.data(), ao_bytes, hipMemcpyHostToDevice));
 	OCRT_HIP(hipDeviceSynchronize());
+#ifdef OCRT_OCML_BUILTINS
+	// (test-only build: the table as the reference kernel's own float trigonometry makes it on this device, kernels.hip)
+	if (ao_bytes && opts.aoMethod == RayTracer::AmbientOcclusionMethod::UNIFORM &&
+	    ocml_ao_table(out->d_ao, opts.aoNumSamples, opts.aoAlphaMin, opts.aoAlphaMax, out->ao_dirs) != out->ao_dirs)
+		throw DeviceError("the device's trigonometry counts another number of ambient-occlusion directions than the host's");
+#endif
 	clock.mark("copies of walk array, nodes, leaf records, normals, table");
 	out->device_bytes = nodes_bytes + walk_bytes + tris_bytes + shade_bytes + ao_bytes;
 	return out;

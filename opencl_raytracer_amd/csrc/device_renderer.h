@@ -307,6 +307,9 @@ class DeviceRenderer {
 
 // kernels.hip
 void preload_kernels();
+#ifdef OCRT_OCML_BUILTINS
+uint32_t ocml_ao_table(void *table, uint32_t rings, int alpha_min, int alpha_max, uint32_t capacity);
+#endif
 void launch_primary(const SceneBuffers &scene, float *image, void *hits, void *occluded_of, void *tile_hits,
                     const void *tile_base, void *counters, const KernelParams &P, void *stream, const void *blocks_by_cost = nullptr);
 void launch_entries(const SceneBuffers &scene, const void *hits, const void *tile_hits, const void *tile_base, void *tile_entry,

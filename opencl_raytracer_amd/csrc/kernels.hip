@@ -86,6 +86,51 @@ __global__ __launch_bounds__(256) void clear_stamps_kernel(FrameCounters *counte
 }
 #endif
 
+#ifdef OCRT_OCML_BUILTINS
+// (test-only build: the UNIFORM direction table as the reference kernel computes it on the device -- per pixel, with the
+// library's own float sin / cos / cospi / sinpi, src/intersect_kernel.cl:237-246 -- instead of the host's libm: the same
+// expressions in the same order, one thread)
+extern "C" __device__ float ocl_sin(float);
+extern "C" __device__ float ocl_cos(float);
+extern "C" __device__ float ocl_cospi(float);
+extern "C" __device__ float ocl_sinpi(float);
+__global__ void ocml_ao_table_kernel(float4 *table, uint32_t *count, uint32_t rings, int alpha_min, int alpha_max, uint32_t capacity) {
+	if (threadIdx.x != 0 || blockIdx.x != 0)
+		return;
+	uint32_t n = 0;
+	const float degrees = (float) (M_PI / 180);
+	const float amin = (float) alpha_min * degrees;
+	const float amax = (float) alpha_max * degrees;
+	for (uint32_t ring = 0; ring < rings; ++ring) {
+		const float step = amax / rings;
+		const float angle = (step * ring) + amin;
+		const uint32_t ray_count = (uint32_t) ((2.0f * M_PI * ocl_cos(angle)) / step);
+		const float theta = (float) (M_PI_2 - angle);
+		for (uint32_t k = 0; k <= ray_count; ++k) {
+			const float phi = (float) ((2.0f * M_PI * k) / ray_count);
+			const float xs = ocl_sin(theta) * ocl_cospi(phi);
+			const float ys = ocl_cos(theta);
+			const float zs = ocl_sin(theta) * ocl_sinpi(phi);
+			if (n < capacity)
+				table[n] = make_float4(xs, ys, zs, 0.0f);
+			++n;
+		}
+	}
+	*count = n;
+}
+// Overwrites the `capacity` entries at `table` (device) with the device-made ones; returns how many the device counted.
+uint32_t ocml_ao_table(void *table, uint32_t rings, int alpha_min, int alpha_max, uint32_t capacity) {
+	uint32_t *d_count = nullptr, count = 0;
+	if (hipMalloc(&d_count, sizeof(uint32_t)) != hipSuccess)
+		return 0;
+	hipLaunchKernelGGL(ocml_ao_table_kernel, dim3(1), dim3(64), 0, nullptr, (float4 *) table, d_count, rings, alpha_min, alpha_max, capacity);
+	(void) hipDeviceSynchronize();
+	(void) hipMemcpy(&count, d_count, sizeof count, hipMemcpyDeviceToHost);
+	(void) hipFree(d_count);
+	return count;
+}
+#endif
+
 // The frame is three kernels (two without ambient occlusion): primary pass (+ ordering step in its tail), the
 // ambient-occlusion pass, the finishing kernel (AO factor + box filter + quantisation).
 void launch_primary(const SceneBuffers &scene, float *image, void *hits, void *occluded_of, void *tile_hits,

@@ -310,9 +310,11 @@ __device__ __forceinline__ void ao_pass(const FrameArgs &A, TileShared *shared_t
 					else if (az <= ax && az <= ay)
 						hz = 1.0f;
 					// basis_x = normalize(cross(h, basis_y)), basis_z = normalize(cross(basis_x, basis_y))
-					float bxx = hy * nz - hz * ny, bxy = hz * nx - hx * nz, bxz = hx * ny - hy * nx;
+					float bxx, bxy, bxz;
+					cross3(hx, hy, hz, nx, ny, nz, bxx, bxy, bxz);
 					normalize3(bxx, bxy, bxz);
-					float bzx = bxy * nz - bxz * ny, bzy = bxz * nx - bxx * nz, bzz = bxx * ny - bxy * nx;
+					float bzx, bzy, bzz;
+					cross3(bxx, bxy, bxz, nx, ny, nz, bzx, bzy, bzz);
 					normalize3(bzx, bzy, bzz);
 					sh.frame[3][lane] = bxx; sh.frame[4][lane] = bxy; sh.frame[5][lane] = bxz;
 					sh.frame[6][lane] = nx;  sh.frame[7][lane] = ny;  sh.frame[8][lane] = nz;

@@ -56,9 +56,38 @@ __device__ __forceinline__ bool nearer(float distance, uint32_t leaf, const Hit 
 	return best.distance > distance || (best.distance == distance && leaf < best.leaf && distance < __builtin_inff());
 }
 
+// dot / cross / length / normalize of the reference kernel's float4 values (src/intersect_kernel.cl:65-127, 215-236,
+// 284-304), which OpenCL leaves to the implementation (OpenCL 1.2 section 7.4).  The product fixes them to the IEEE
+// definitions of SURVEY.md 8a-0.3 -- what the reference's own host code uses (include/vec3.h:30-36,73-75) and the only
+// ones a CPU can reproduce.  The test-only build -DOCRT_OCML_BUILTINS calls ROCm's OWN library functions instead
+// (oracle/ocl_builtins.cl: fused multiply-add chains in dot and cross, v * rsqrt(dot(v, v)) in normalize, a scaled
+// square root in length), linked in as bitcode: that build must reproduce the reference kernel compiled against that
+// library for this GPU bit for bit (tests/test_ocml_pin.py) -- the HIP path checked against the reference itself.
+#ifdef OCRT_OCML_BUILTINS
+typedef float ocl_f4 __attribute__((ext_vector_type(4)));
+extern "C" __device__ float ocl_dot(ocl_f4, ocl_f4);
+extern "C" __device__ ocl_f4 ocl_cross(ocl_f4, ocl_f4);
+extern "C" __device__ ocl_f4 ocl_normalize(ocl_f4);
+extern "C" __device__ float ocl_length(ocl_f4);
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
+	return ocl_dot(ocl_f4{ ax, ay, az, 0.0f }, ocl_f4{ bx, by, bz, 0.0f });
+}
+__device__ __forceinline__ void cross3(float ax, float ay, float az, float bx, float by, float bz, float &cx, float &cy, float &cz) {
+	const ocl_f4 c = ocl_cross(ocl_f4{ ax, ay, az, 0.0f }, ocl_f4{ bx, by, bz, 0.0f });
+	cx = c.x; cy = c.y; cz = c.z;
+}
+__device__ __forceinline__ float length3(float x, float y, float z) { return ocl_length(ocl_f4{ x, y, z, 0.0f }); }
+#else
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
 	return (ax * bx + ay * by) + az * bz;
 }
+__device__ __forceinline__ void cross3(float ax, float ay, float az, float bx, float by, float bz, float &cx, float &cy, float &cz) {
+	cx = ay * bz - az * by;
+	cy = az * bx - ax * bz;
+	cz = ax * by - ay * bx;
+}
+__device__ __forceinline__ float length3(float x, float y, float z) { return sqrtf(dot3(x, y, z, x, y, z)); }
+#endif
 
 __device__ __forceinline__ Ray make_ray(float ox, float oy, float oz, float dx, float dy, float dz) {
 	Ray r;
@@ -174,10 +203,15 @@ __device__ __forceinline__ float4 load_f4(__amdgpu_buffer_rsrc_t rsrc, uint32_t 
 }
 
 __device__ __forceinline__ void normalize3(float &x, float &y, float &z) {
+#ifdef OCRT_OCML_BUILTINS
+	const ocl_f4 n = ocl_normalize(ocl_f4{ x, y, z, 0.0f });
+	x = n.x; y = n.y; z = n.z;
+#else
 	const float l = sqrtf(dot3(x, y, z, x, y, z));
 	x = x / l;
 	y = y / l;
 	z = z / l;
+#endif
 }
 
 // Maps a rank-local tile row to the global tile row under the band partition.
@@ -237,7 +271,7 @@ __device__ __forceinline__ TriResult tri_eval(const float4 q0, const float4 q1, 
 	out.px = ipx; out.py = ipy; out.pz = ipz;
 	if (CLOSEST) {
 		const float ex = ipx - r.ox, ey = ipy - r.oy, ez = ipz - r.oz;
-		out.distance = sqrtf(dot3(ex, ey, ez, ex, ey, ez));
+		out.distance = length3(ex, ey, ez);
 	}
 	return out;
 }

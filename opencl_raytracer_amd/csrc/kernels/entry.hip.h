@@ -56,9 +56,11 @@ __global__ __launch_bounds__(64 * ENTRY_WAVES) void entry_kernel(const NodeRec *
 			hy = 1.0f;
 		else if (az <= ax && az <= ay)
 			hz = 1.0f;
-		float bxx = hy * nz - hz * ny, bxy = hz * nx - hx * nz, bxz = hx * ny - hy * nx;
+		float bxx, bxy, bxz;
+					cross3(hx, hy, hz, nx, ny, nz, bxx, bxy, bxz);
 		normalize3(bxx, bxy, bxz);
-		float bzx = bxy * nz - bxz * ny, bzy = bxz * nx - bxx * nz, bzz = bxx * ny - bxy * nx;
+		float bzx, bzy, bzz;
+					cross3(bxx, bxy, bxz, nx, ny, nz, bzx, bzy, bzz);
 		normalize3(bzx, bzy, bzz);
 		frame[wave][0][lane] = bxx; frame[wave][1][lane] = bxy; frame[wave][2][lane] = bxz;
 		frame[wave][3][lane] = nx;  frame[wave][4][lane] = ny;  frame[wave][5][lane] = nz;

@@ -146,6 +146,24 @@ PackedScene pack_scene(const std::vector<uint32_t> &faces, const std::vector<uin
 		});
 	}
 
+#ifdef OCRT_OCML_BUILTINS
+	// (test-only build, kernels/common.hip.h: the triangle records' cross and dot products as ROCm's OpenCL library
+	// computes them on the device -- fused multiply-add chains over the four lanes of a float4 whose w is 0, see
+	// oracle/ocl_builtins.cl -- reproduced here with std::fmaf, which is exact)
+	const auto lib_dot = [](const Vec3f &a, const Vec3f &b) {
+		return std::fmaf(0.0f, 0.0f, std::fmaf(a.z, b.z, std::fmaf(a.y, b.y, a.x * b.x)));
+	};
+	const auto lib_cross = [](const Vec3f &a, const Vec3f &b) {
+		Vec3f c;
+		c.x = std::fmaf(a.y, b.z, b.y * (-a.z));
+		c.y = std::fmaf(a.z, b.x, b.z * (-a.x));
+		c.z = std::fmaf(a.x, b.y, b.x * (-a.y));
+		return c;
+	};
+#else
+	const auto lib_dot = [](const Vec3f &a, const Vec3f &b) { return a.dot(b); };
+	const auto lib_cross = [](const Vec3f &a, const Vec3f &b) { return a.cross(b); };
+#endif
 	out.tris.resize(tri_count);
 	out.shade.resize(tri_count);
 	for (size_t t = 0; t < tri_count; ++t) {
@@ -153,7 +171,7 @@ PackedScene pack_scene(const std::vector<uint32_t> &faces, const std::vector<uin
 		const Vec3f ta = vertices[i0];
 		const Vec3f u = vertices[i1] - ta;
 		const Vec3f v = vertices[i2] - ta;
-		const Vec3f n = u.cross(v);
+		const Vec3f n = lib_cross(u, v);
 		TriRec &r = out.tris[t];
 		for (unsigned k = 0; k < 3; ++k) {
 			r.ta[k] = ta[k];
@@ -162,9 +180,9 @@ PackedScene pack_scene(const std::vector<uint32_t> &faces, const std::vector<uin
 			r.n[k] = n[k];
 		}
 		r.pad0 = 0.0f;
-		r.uu = u.dot(u);
-		r.uv = u.dot(v);
-		r.vv = v.dot(v);
+		r.uu = lib_dot(u, u);
+		r.uv = lib_dot(u, v);
+		r.vv = lib_dot(v, v);
 		r.D = r.uv * r.uv - r.uu * r.vv;
 		r.inv_d = tri_inverse_d(r.D);
 		ShadeRec &s = out.shade[t];

@@ -66,6 +66,39 @@ def rt_knobs():
     return mod
 
 
+def second_binding(lib_dir: str, module_name: str):
+    """An independent ctypes binding of the same api.py on another build of the library (opencl_raytracer_amd/<lib_dir>)."""
+    import importlib.util
+
+    path = os.path.join(ROOT, "opencl_raytracer_amd", lib_dir, "libocrt_hip.so")
+    if not os.path.exists(path):
+        pytest.fail(f"opencl_raytracer_amd/{lib_dir}/libocrt_hip.so is missing: run __graft_entry__.build()")
+    spec = importlib.util.spec_from_file_location(module_name, os.path.join(ROOT, "opencl_raytracer_amd", "api.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = mod
+    old = os.environ.get("OCRT_LIB_DIR")
+    os.environ["OCRT_LIB_DIR"] = lib_dir
+    try:
+        spec.loader.exec_module(mod)
+        mod.load_library()
+        assert mod.lib_path() == path
+    finally:
+        if old is None:
+            del os.environ["OCRT_LIB_DIR"]
+        else:
+            os.environ["OCRT_LIB_DIR"] = old
+    return mod
+
+
+@pytest.fixture(scope="session")
+def rt_ocml():
+    """A binding on the TEST-ONLY build whose dot / cross / normalize / length and ring-angle trigonometry are ROCm's own
+    OpenCL library functions (make EXTRA_DEFS=-DOCRT_OCML_BUILTINS DEVICE_BITCODE=oracle/_ref/ocl_builtins_gfx950.bc ->
+    opencl_raytracer_amd/lib_ocml; kernels/common.hip.h): the build that must equal the reference kernel compiled
+    against that library bit for bit (tests/test_ocml_pin.py)."""
+    return second_binding("lib_ocml", "ocrt_api_ocml")
+
+
 def mesh_file(name: str) -> str:
     from tools.meshes import bunny_path, interior_hard_path, interior_path
 
