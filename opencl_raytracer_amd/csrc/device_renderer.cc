@@ -491,6 +491,20 @@ void DeviceRenderer::sizeHitList(const DeviceRenderer *layout_from) {
 		allocEntries(sizeof(uint32_t) * 2);
 		OCRT_HIP(hipMemsetAsync(d_tile_base, 0, tile_count * sizeof(uint32_t), (hipStream_t) stream));
 		OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));
+		// A stream of frames without ambient occlusion: one pass of the primary kernel tells what its tiles cost (the leaves
+		// their packets stop at), and the frames' workgroups take the costly 2 x 2 blocks first (orderPrimaryBlocks).
+		if (tile_count != 0 && expected_frames >= FRAMES_WORTH_INTERVALS && PRIMARY_BY_COST_OK(kp) && primary_by_cost && scene_on_device) {
+			launch_primary(scene_on_device->buffers(), (float *) d_image, nullptr, nullptr, d_tile_hits, d_tile_base, d_counters, kp, stream);
+			OCRT_HIP(hipGetLastError());
+			tile_words.assign(tile_count, 0u);
+			OCRT_HIP(hipMemcpyAsync(tile_words.data(), d_tile_hits, tile_count * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t) stream));
+			OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));
+			queue_static = {};
+			order_host.assign(1, 0u);
+			orderPrimaryBlocks();
+			order_host.clear();
+			OCRT_HIP(hipMemcpy(d_blocks_by_cost, blocks_by_cost_host.data(), blocks_by_cost_host.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+		}
 		return;
 	}
 	if (layout_from) {  // (the same frame of the same scene: the same hits)

@@ -314,7 +314,7 @@ __device__ __forceinline__ void primary_tile(const FrameArgs &A, ClosestBatch &c
 		uint32_t cost = SHARED ? leaf_stops : hit_count;
 		cost = cost < 1u ? 1u : cost;
 		cost = cost > 64u ? 64u : cost;
-		OCRT_PCOLD_PTR(uint32_t *, tile_hits)[tile] = hit_count | ((want_ao && hit_count) ? cost << 8 : 0u);
+		OCRT_PCOLD_PTR(uint32_t *, tile_hits)[tile] = hit_count | (hit_count ? cost << 8 : 0u);
 	}
 	// The hit list holds a tile's hits at tile_base[tile] ..., in the order of the lanes.  (tile_base is the exclusive
 	// prefix sum of the tiles' hit counts -- a function of scene, options and the fixed camera, counted once per upload by
