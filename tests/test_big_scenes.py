@@ -69,6 +69,17 @@ def test_two_million_triangles(rt, oracle):
     assert c["primary_hits"] == 192 * 108 and c["ao_occluded"] > 0  # the field fills the view
 
 
+def test_wide_strips_of_a_scene_beyond_the_caches(rt, oracle):
+    """A scene of several times the L2s in an image wide enough (>= 64 tiles across) gets strips of FOUR tiles instead of
+    two in the PRODUCT build (DeviceRenderer::adopt: scene_beyond_caches) -- the tile <-> workgroup mapping, the claim
+    orders and the block lists all depend on the strip width; the knob build's OCRT_STRIP_TILES is not what runs here."""
+    from tools.big_meshes import terrain
+
+    v, f = terrain(420)  # 352 800 triangles: ~120 MB on the device, beyond BIG_SCENE_BYTES (96 MB)
+    c = _check(rt, oracle, v, f, width=640, height=104, n_super_samples=1, ao_num_samples=2)
+    assert c["primary_hits"] > 0 and c["ao_occluded"] > 0
+
+
 def test_twenty_million_triangles(rt, oracle):
     """6 GB of scene: beyond every cache of the device.  (Building it takes the CPU some tens of seconds.)"""
     from tools.big_meshes import terrain

@@ -32,10 +32,10 @@ def main():
         json.dump(lines, f, indent=1)
     for w, b in lines.items():
         r = b["roofline"]
-        print(f"{w:22s} {b['value']:9.1f} Mrays/s  {b['ms_per_step']:8.4f} ms/step (blocking {b['blocking']['value']:9.1f}, "
-              f"{b['blocking']['ms_per_frame']['median']:8.4f} ms)  kernel {r['kernel_ms']:8.4f} ms  VALU {r['achieved']} "
+        print(f"{w:24s} {b['value']:9.1f} Mrays/s  {b['ms_per_step']:8.4f} ms per frame, one at a time (pipelined {b['pipelined']['value']:9.1f}, "
+              f"{b['pipelined']['ms_per_frame']['median']:8.4f} ms)  kernel {r['kernel_ms']:8.4f} ms  VALU {r['achieved']} "
               f"(frac {r['frac']}, of measured ceiling {r.get('frac_of_measured_ceiling')}, nominal issue share {r.get('valu_nominal_issue_share')})  "
-              f"HBM {r['hbm'].get('measured_frac')}  pipelined frame {r.get('frame_pipelined')}")
+              f"HBM {r['hbm'].get('measured_frac')}")
 
 
 if __name__ == "__main__":

@@ -25,7 +25,20 @@ def parse(path):
         m = re.match(r"\s+(\S+)\s+mean\s+([0-9.eE+-]+)\s+n=(\d+)", line)
         if m and current is not None:
             current[m.group(1)] = float(m.group(2))
+            current["_dispatches"] = max(current.get("_dispatches", 0), int(m.group(3)))
     return kernels
+
+
+def frame_kernels(kernels):
+    """The kernels of ONE frame among what a run dispatched: of the ambient-occlusion pass's two forms (with / without
+    look-ahead loads: a ring's calibration at upload launches both) the one the frames were rendered with, i.e. the one with
+    the most dispatches; never what an upload runs once (entry_kernel) or a statistic asks for (occluded_sum_kernel)."""
+    names = [n for n in kernels if "ocrt::" in n and "entry_kernel" not in n and "occluded_sum" not in n and "frame_kernel" not in n]
+    ao = [n for n in names if "ao_kernel" in n]
+    if len(ao) > 1:
+        keep = max(ao, key=lambda n: kernels[n].get("_dispatches", 0))
+        names = [n for n in names if n not in ao or n == keep]
+    return names
 
 
 def in_frame(name):
@@ -37,14 +50,14 @@ def main():
     out_dir, workloads = sys.argv[1], sys.argv[2:]
     result = {
         "kernel_source_sha256": kernel_source_sha(),
-        "source": "profiles/r04_pmc_<workload>.txt (rocprofv3 --pmc, one pass per counter group, tools/pmc_collect.sh)",
+        "source": "profiles/r05_pmc_<workload>.txt (rocprofv3 --pmc, one pass per counter group, tools/pmc_collect.sh)",
         "units": "per launch of the dominant kernel; SQ_*_CYCLES and SQ_WAIT_* count quad-cycles",
         "workloads": {},
     }
     for w in workloads:
         kernels = parse(os.path.join(out_dir, f"pmc_{w}.txt"))
         want = "ao_kernel" if WORKLOADS[w]["ao"] else "primary_kernel"
-        names = [k for k in kernels if want in k]
+        names = [k for k in frame_kernels(kernels) if want in k]
         if not names:
             continue
         c = kernels[names[0]]
@@ -53,7 +66,7 @@ def main():
             "kernel": names[0],
             "valu_insts": c.get("SQ_INSTS_VALU"), "salu_insts": c.get("SQ_INSTS_SALU"), "smem_insts": c.get("SQ_INSTS_SMEM"),
             # every kernel of a frame together (primary pass with the ordering step, ambient-occlusion pass, finishing kernel)
-            "frame_valu_insts": sum(k.get("SQ_INSTS_VALU", 0.0) for name, k in kernels.items() if in_frame(name)),
+            "frame_valu_insts": sum(kernels[name].get("SQ_INSTS_VALU", 0.0) for name in frame_kernels(kernels)),
             "vmem_rd_insts": c.get("SQ_INSTS_VMEM_RD"), "lds_insts": c.get("SQ_INSTS_LDS"), "branch_insts": c.get("SQ_INSTS_BRANCH"),
             "waves": c.get("SQ_WAVES"), "wave_quad_cycles": c.get("SQ_WAVE_CYCLES"), "busy_cycles": c.get("SQ_BUSY_CYCLES"),
             "wait_any_quad_cycles": c.get("SQ_WAIT_ANY"), "wait_inst_any_quad_cycles": c.get("SQ_WAIT_INST_ANY"),
@@ -84,7 +97,7 @@ def main():
             if names:
                 entry["shared_valu_insts"] = shared[names[0]].get("SQ_INSTS_VALU")
                 entry["shared_waves"] = shared[names[0]].get("SQ_WAVES")
-                entry["shared_frame_valu_insts"] = sum(k.get("SQ_INSTS_VALU", 0.0) for name, k in shared.items() if in_frame(name))
+                entry["shared_frame_valu_insts"] = sum(shared[name].get("SQ_INSTS_VALU", 0.0) for name in frame_kernels(shared))
         result["workloads"][w] = entry
     json.dump(result, sys.stdout, indent=1)
     print()

@@ -27,15 +27,24 @@ def main():
         w["bvh"] = args.bvh
     opt = workload_options(rt, w)
     scene = load_scene(rt, w).build_bvh(opt.bvh_method)
-    host = rt.Host(opt, 0)
-    host.upload_scene(scene)
-    host.set_device_share(args.share)
-    for _ in range(args.frames):
-        host.render()
+    # a ring of ONE host = the blocking frame of bench.py's `value`: its upload prepares what a stream of frames gets (walk
+    # intervals, the tiles' measured costs and the claim order made from them, the form of the node loop); plain launches,
+    # so that every kernel of a frame is a dispatch of its own in the profiler's output.  (The upload's own measuring and
+    # calibrating frames are dispatches of the same kernels: ~20 more launches with the same instruction counts to within
+    # the claim order's effect.)
+    ring = rt.FrameRing(opt, scene, hosts=1)
+    ring.set_graph_mode(False)
+    host = ring.host(0)
+    if args.share != 1:
+        host.set_device_share(args.share)
+    ring.run(args.frames)
+    ring.drain()
     st = host.stats()
     rays = st["primary_rays"] + st["ao_rays"]
-    ms = host.total_kernel_ms / host.kernel_launches
-    print(f"{args.workload}: {rays} rays, kernel {ms:.4f} ms avg over {host.kernel_launches}, {rays / ms / 1e3:.1f} Mrays/s")
+    timers = ring.timers()
+    ms = timers["kernel_ms"] / max(1, timers["frames"])
+    print(f"{args.workload}: {rays} rays, kernel {ms:.4f} ms avg over {timers['frames']} frames, {rays / ms / 1e3:.1f} Mrays/s")
+    ring.close()
 
 
 if __name__ == "__main__":
