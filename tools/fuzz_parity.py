@@ -51,7 +51,9 @@ def draw_case(rng):
         share=rng.choice([1, 1, 3, 6]),  # (a host that is told it shares its GPU launches a smaller AO grid and keeps its claim size)
         ring=rng.choice([0, 0, 0, 2]),   # (0: one blocking host; n: a ring of n hosts, graph replay, three frames)
         lookahead=rng.choice([0, 1, 2]),  # (the form of the AO pass: without / with look-ahead loads / as calibrated or by default)
-        announce=rng.choice([0, 1, 1]))  # (a blocking host: one-shot, or with a stream of frames announced -- its upload then prepares the walk intervals)
+        announce=rng.choice([0, 1, 1]),  # (a blocking host: one-shot, or with a stream of frames announced -- its upload then prepares the walk intervals)
+        form=rng.choice(["auto", "auto", "fused"]),  # (a blocking host's frame: two kernels, or both ray passes in one persistent launch -- kernels/frame.hip.h)
+        measure=rng.choice([0, 0, 1]))  # (a blocking host: its tiles claimed by measured cost -- rt_debug_measure_tile_costs)
 
 
 def run_case(rt, orc, oracle, scenes, case):
@@ -96,6 +98,13 @@ def run_case(rt, orc, oracle, scenes, case):
                 host.set_ao_prefetch(bool(case["lookahead"]))
             host.upload_scene(scene)
             host.set_device_share(case["share"])
+            if case.get("measure") and hasattr(host, "measure_tile_costs"):
+                host.measure_tile_costs(1)
+            if case.get("form", "auto") != "auto" and hasattr(host, "set_frame_form"):
+                host.set_frame_form(case["form"])
+                if hasattr(host, "poison_hit_list"):
+                    host.render()
+                    host.poison_hit_list()  # (a fused frame must not read a record before it is handed over)
             host.render()
             got, got_u8, st = host.download(), host.download_u8(), host.stats()
             host.close()
