@@ -1,4 +1,4 @@
-#include "device_renderer.h"
+#include "device_internal.h"
 
 #include <algorithm>
 #include <array>
@@ -16,36 +16,6 @@
 
 namespace ocrt {
 
-namespace {
-
-void hip_check(hipError_t err, const char *what) {
-	if (err != hipSuccess) {
-		std::ostringstream ss;
-		ss << "HIP error: " << hipGetErrorName(err) << " (" << hipGetErrorString(err) << ") in " << what;
-		throw DeviceError(ss.str());
-	}
-}
-#define OCRT_HIP(call) hip_check((call), #call)
-
-constexpr size_t MAX_ENTRY_TABLE_BYTES = (size_t) 2 << 30;
-// (the blocks' coordinates are packed into 16 bits each)
-#define PRIMARY_BY_COST_OK(kp) ((kp).tiles_x < 65536u && (kp).local_tile_rows < 65536u && (kp).shared_walk)
-constexpr uint32_t MAX_STRIP_TILES = 32u;
-constexpr size_t BIG_SCENE_BYTES = (size_t) 96 << 20;  // three times the L2s
-
-void *device_alloc(size_t bytes) {
-	void *p = nullptr;
-	OCRT_HIP(hipMalloc(&p, bytes ? bytes : 1));
-	return p;
-}
-
-void device_free(void *&p) {
-	if (p)
-		(void) hipFree(p);
-	p = nullptr;
-}
-
-}  // namespace
 
 int visible_device_count() {
 	int count = 0;
@@ -238,165 +208,6 @@ std::string DeviceRenderer::deviceName() const {
 	return prop.name;
 }
 
-namespace {
-// the allocation made ahead of time by DeviceScene::reserve, waiting for the scene it was made for
-std::mutex reserved_mutex;
-void *reserved_arena = nullptr;
-size_t reserved_bytes = 0;
-int reserved_device = -1;
-
-size_t round_up(size_t bytes) { return (bytes + 255) & ~(size_t) 255; }
-
-// (A/B build: OCRT_UPLOAD_TIMINGS=1 prints where an upload's time goes)
-struct UploadClock {
-#ifdef OCRT_DEBUG_KNOBS
-	std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
-	const bool on = std::getenv("OCRT_UPLOAD_TIMINGS") != nullptr;
-	void mark(const char *what) {
-		if (!on)
-			return;
-		const auto now = std::chrono::steady_clock::now();
-		std::fprintf(stderr, "upload: %s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
-		last = now;
-	}
-#else
-	void mark(const char *) {}
-#endif
-};
-}  // namespace
-
-std::shared_ptr<const DeviceScene> DeviceScene::create(int device, const PackedScene &scene, const RayTracer::Options &opts) {
-	UploadClock clock;
-	OCRT_HIP(hipSetDevice(device));
-	std::shared_ptr<DeviceScene> out(new DeviceScene());
-	out->device_index = device;
-	std::vector<float> table;
-	out->ao_on = opts.enableAO && opts.aoNumSamples > 0;
-	out->ao_method = (int) opts.aoMethod;
-	out->ao_samples = opts.aoNumSamples;
-	out->ao_alpha_min = opts.aoAlphaMin;
-	out->ao_alpha_max = opts.aoAlphaMax;
-	if (out->ao_on) {
-		if (opts.aoMethod == RayTracer::AmbientOcclusionMethod::UNIFORM) {
-			// The reference's order, ring by ring.  (The occlusion count of a hit is a sum over the directions, so the order is
-			// free: while a workgroup's four waves took FIXED quarters of a tile's directions the table was dealt round-robin
-			// to the quarters so that they cost about the same; with the claim's cursor -- kernels.hip, ao_kernel -- the waves
-			// balance themselves, and neighbouring directions cast at the same time are worth 0.5-2 %.)
-			table = uniform_ao_table(opts.aoNumSamples, opts.aoAlphaMin, opts.aoAlphaMax);
-			out->ao_dirs = (uint32_t) (table.size() / 4);
-		} else {
-			// RANDOM casts the normal ray plus AO_NUM_SAMPLES + 1 random ones (reference :260-275)
-			out->ao_dirs = opts.aoNumSamples + 2;
-		}
-	}
-	out->walk_distance = out->ao_on ? kernel_float(opts.aoMaxDistance) : 0.0f;
-	const std::shared_ptr<const WalkArray> made = (scene.walk && scene.walk_max_distance == out->walk_distance)
-	                                                  ? scene.walk : std::make_shared<const WalkArray>(make_walk_array(scene, out->walk_distance));
-	const WalkArray &walk = *made;
-	clock.mark("direction table + walk array (made here unless prepared)");
-	out->scene_facts_ = scene_facts(scene, walk);
-	out->node_count = (uint32_t) scene.nodes.size();
-	out->tri_count = (uint32_t) scene.tris.size();
-	const size_t nodes_bytes = scene.nodes.size() * sizeof(NodeRec);
-	const size_t tris_bytes = scene.tris.size() * sizeof(TriRec);
-	const size_t shade_bytes = scene.shade.size() * sizeof(ShadeRec);
-	const size_t ao_bytes = table.size() * sizeof(float);
-	// One allocation for the five arrays (each starts on a 256-byte boundary) -- the one made ahead of time if there is
-	// one and it is large enough.  One node of zero padding behind the exact nodes: the shared walk fetches a node
-	// together with its successor.
-	const size_t walk_bytes = walk.nodes.size() * sizeof(NodeRec);
-	const size_t need = round_up(nodes_bytes + sizeof(NodeRec)) + round_up(walk_bytes) + round_up(tris_bytes) + round_up(shade_bytes) +
-	                    round_up(ao_bytes) + 256;
-	{
-		std::lock_guard<std::mutex> lock(reserved_mutex);
-		if (reserved_arena && reserved_device == device && reserved_bytes >= need) {
-			out->arena = reserved_arena;
-		} else if (reserved_arena && reserved_device == device) {
-			(void) hipFree(reserved_arena);  // (too small after all)
-		}
-		if (reserved_device == device) {
-			reserved_arena = nullptr;
-			reserved_bytes = 0;
-			reserved_device = -1;
-		}
-	}
-	if (!out->arena)
-		out->arena = device_alloc(need);
-	char *at = (char *) out->arena;
-	auto take = [&](size_t bytes) {
-		void *p = at;
-		at += round_up(bytes);
-		return p;
-	};
-	out->d_nodes = take(nodes_bytes + sizeof(NodeRec));
-	out->d_walk = walk_bytes ? take(walk_bytes) : nullptr;
-	out->d_tris = take(tris_bytes);
-	out->d_shade = take(shade_bytes);
-	out->d_ao = take(ao_bytes ? ao_bytes : 1);
-	clock.mark("allocation");
-	const NodeRec zero{};
-	OCRT_HIP(hipMemcpy((char *) out->d_nodes + nodes_bytes, &zero, sizeof zero, hipMemcpyHostToDevice));
-	if (walk_bytes)
-		OCRT_HIP(hipMemcpy(out->d_walk, walk.nodes.data(), walk_bytes, hipMemcpyHostToDevice));
-	OCRT_HIP(hipMemcpy(out->d_nodes, scene.nodes.data(), nodes_bytes, hipMemcpyHostToDevice));
-	OCRT_HIP(hipMemcpy(out->d_tris, scene.tris.data(), tris_bytes, hipMemcpyHostToDevice));
-	OCRT_HIP(hipMemcpy(out->d_shade, scene.shade.data(), shade_bytes, hipMemcpyHostToDevice));
-	if (ao_bytes)
-		OCRT_HIP(hipMemcpy(out->d_ao, table.data(), ao_bytes, hipMemcpyHostToDevice));
-	OCRT_HIP(hipDeviceSynchronize());
-#ifdef OCRT_OCML_BUILTINS
-	// (test-only build: the table as the reference kernel's own float trigonometry makes it on this device, kernels.hip)
-	if (ao_bytes && opts.aoMethod == RayTracer::AmbientOcclusionMethod::UNIFORM &&
-	    ocml_ao_table(out->d_ao, opts.aoNumSamples, opts.aoAlphaMin, opts.aoAlphaMax, out->ao_dirs) != out->ao_dirs)
-		throw DeviceError("the device's trigonometry counts another number of ambient-occlusion directions than the host's");
-#endif
-	clock.mark("copies of walk array, nodes, leaf records, normals, table");
-	out->device_bytes = nodes_bytes + walk_bytes + tris_bytes + shade_bytes + ao_bytes;
-	return out;
-}
-
-DeviceScene::~DeviceScene() {
-	if (hipSetDevice(device_index) != hipSuccess)
-		return;
-	device_free(arena);
-}
-
-void DeviceScene::reserve(int device, size_t bytes) {
-	if (bytes == 0 || hipSetDevice(device) != hipSuccess)
-		return;
-	void *p = nullptr;
-	if (hipMalloc(&p, bytes) != hipSuccess) {
-		(void) hipGetLastError();
-		return;  // (create() allocates for itself)
-	}
-	std::lock_guard<std::mutex> lock(reserved_mutex);
-	if (reserved_arena) {
-		(void) hipSetDevice(reserved_device);
-		(void) hipFree(reserved_arena);
-		(void) hipSetDevice(device);
-	}
-	reserved_arena = p;
-	reserved_bytes = bytes;
-	reserved_device = device;
-}
-
-size_t DeviceScene::bytesFor(size_t triangles, size_t ao_directions) {
-	const size_t nodes = triangles ? 2 * triangles - 1 : 0;
-	// exact nodes + padding, two copies of the walk records with their END records and slack, leaf records, normals, table
-	return round_up((nodes + 1) * sizeof(NodeRec)) + round_up((2 * (nodes + 2) + 2) * sizeof(NodeRec)) + round_up(triangles * sizeof(TriRec)) +
-	       round_up(triangles * sizeof(ShadeRec)) + round_up(ao_directions * 4 * sizeof(float) + 1) + 256;
-}
-
-bool DeviceScene::servesOptions(const RayTracer::Options &opts) const {
-	const bool on = opts.enableAO && opts.aoNumSamples > 0;
-	if (on != ao_on)
-		return false;
-	if (!on)
-		return true;
-	return (int) opts.aoMethod == ao_method && opts.aoNumSamples == ao_samples && opts.aoAlphaMin == ao_alpha_min &&
-	       opts.aoAlphaMax == ao_alpha_max && kernel_float(opts.aoMaxDistance) == walk_distance;
-}
-
 size_t DeviceRenderer::upload(const PackedScene &scene) {
 	useDevice();
 	synchronize();
@@ -581,208 +392,6 @@ void DeviceRenderer::sizeHitList(const DeviceRenderer *layout_from) {
 	clock.mark("entries of the tiles' any-hit walks");
 }
 
-// The order in which the ambient-occlusion pass claims the tiles (kernels/ao.hip.h): per XCD group -- the image's strips
-// are dealt round-robin to eight groups, kernels/primary.hip.h -- a list of the group's non-empty tiles, entry = tile |
-// (hit count - 1) << 26, costly tiles first so that the pass ends on short claims.  Camera, scene and options are fixed
-// per upload, so the list is too: it is made here, once, on the host (until round 4 the last workgroup of every frame's
-// primary pass sorted its group's tiles again).
-// The rule (`tile_cost` empty): blocks of 64 neighbouring tiles -- a strip wide, 64 / strip_tiles high -- by the sum of
-// their tiles' cost classes >> cost_shift, capped: every block of the model shares the top key and those blocks keep
-// their spatial order (neighbouring claims walk the same part of the tree: scalar cache and L2 see it again; a finer
-// key cost 3-10 % per frame, scene_pack.cc), the cheap blocks follow by cost; inside a block the tiles stay in spatial
-// order.  With measured costs per tile (`tile_cost`, DeviceRenderer::measureTileCosts): see orderByMeasuredCost.
-void DeviceRenderer::orderTiles() {
-	const uint32_t strip_tiles = kp.strip_tiles, rows = kp.local_tile_rows, tiles_x = kp.tiles_x;
-	const uint32_t strips = (tiles_x + strip_tiles - 1u) / strip_tiles;
-	const size_t order_slots = (size_t) ((tiles_x + MAX_STRIP_TILES - 1) / MAX_STRIP_TILES) * MAX_STRIP_TILES * rows;
-	std::vector<uint32_t> order(order_slots ? order_slots : 1, 0u);
-	std::array<std::array<uint32_t, 3>, XCD_GROUPS> constants{};
-	const bool measured = tile_cost.size() == tile_count;
-	size_t segment = 0;
-	for (uint32_t group = 0; group < XCD_GROUPS; ++group) {
-		const uint32_t strips_here = (strips + XCD_GROUPS - 1u - group) >> 3;
-		const uint32_t per_strip = strip_tiles * rows;
-		const uint32_t tiles_here = strips_here * per_strip;  // incl. possible columns past the image
-		// element e of the group: strip e / per_strip, then row-major across the strip
-		struct Element {
-			uint32_t tile, word;
-		};
-		std::vector<Element> elements;
-		elements.reserve(tiles_here);
-		for (uint32_t e = 0; e < tiles_here; ++e) {
-			const uint32_t strip_index = e / per_strip, within = e - strip_index * per_strip;
-			const uint32_t local_row = within / strip_tiles;
-			const uint32_t tile_x = strip_tiles * (group + XCD_GROUPS * strip_index) + (within - local_row * strip_tiles);
-			const uint32_t tile = local_row * tiles_x + tile_x;
-			elements.push_back(Element{ tile, tile_x < tiles_x ? tile_words[tile] : 0u });
-		}
-		uint32_t work = 0, cost_total = 0, hit_total = 0;
-		for (const Element &el : elements) {
-			hit_total += el.word & 0xFFu;
-			if (el.word >> 8) {
-				++work;
-				cost_total += el.word >> 8;
-			}
-		}
-		std::vector<uint32_t> listed;  // indices into `elements`, in claim order
-		listed.reserve(work);
-		if (measured) {
-			std::vector<uint32_t> candidates;
-			for (uint32_t e = 0; e < tiles_here; ++e)
-				if (elements[e].word >> 8)
-					candidates.push_back(e);
-			std::vector<float> cost(candidates.size());
-			for (size_t i = 0; i < candidates.size(); ++i)
-				cost[i] = tile_cost[elements[candidates[i]].tile];
-			for (uint32_t at : orderByMeasuredCost(cost))
-				listed.push_back(candidates[at]);
-		} else {
-			const uint32_t n_blocks = (tiles_here + 63u) >> 6;
-			std::vector<std::pair<uint32_t, uint32_t>> blocks;  // (key, block), stable by block
-			for (uint32_t block = 0; block < n_blocks; ++block) {
-				uint32_t cost = 0;
-				for (uint32_t e = block * 64u; e < tiles_here && e < block * 64u + 64u; ++e)
-					cost += elements[e].word >> 8;
-				uint32_t key = kp.debug_no_sort ? 1u : 1u + (cost >> kp.cost_shift);
-				blocks.push_back({ key > 64u ? 64u : key, block });
-			}
-			std::stable_sort(blocks.begin(), blocks.end(), [](const auto &a, const auto &b) { return a.first > b.first; });
-			for (const auto &b : blocks)
-				for (uint32_t e = b.second * 64u; e < tiles_here && e < b.second * 64u + 64u; ++e)
-					if (elements[e].word >> 8)
-						listed.push_back(e);
-		}
-		for (size_t i = 0; i < listed.size(); ++i) {
-			const Element &el = elements[listed[i]];
-			order[segment + i] = el.tile | (((el.word & 0xFFu) - 1u) << 26);  // (tile: 26 bits, at most 2^32 sub-pixels per frame)
-		}
-		constants[group] = { work, cost_total, hit_total };
-		segment += tiles_here;
-	}
-	installOrder(order, constants);
-}
-
-// Claim order of one group's tiles from their MEASURED costs (device-clock ticks a tile's claims kept their workgroups
-// busy, measureTileCosts): `cost` in the tiles' spatial order, returns the indices in claim order.
-// What matters is how the pass ENDS: a claim is a whole tile for a workgroup's four waves, a costly tile keeps them
-// busy ~0.15 ms of a 1 ms pass and some tiles cost four times the median -- claimed in spatial order, the last third of
-// the pass ran at falling occupancy (profiles/r05_notes.md).  So:
-//   1. tiles whose cost stands out (beyond `heavy` x the reference cost = the upper quartile) go first, costliest first;
-//   2. the others follow IN SPATIAL ORDER (neighbouring claims walk the same part of the tree) ...
-//   3. ... up to the RUNWAY: what would keep each workgroup of the group busy for about `runway` reference claims is held
-//      back and claimed last by falling cost, so that the pass ends on its cheapest tiles; tiles below a quarter of the
-//      reference cost anywhere in the list are moved there too.
-std::vector<uint32_t> DeviceRenderer::orderByMeasuredCost(const std::vector<float> &cost) const {
-	const size_t n = cost.size();
-	std::vector<uint32_t> out;
-	out.reserve(n);
-	if (n == 0)
-		return out;
-	std::vector<float> sorted(cost);
-	std::sort(sorted.begin(), sorted.end());
-	const float reference = sorted[n - 1 - (n - 1) / 4];
-	const auto falling = [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; };
-	std::vector<uint32_t> heavy, rest;
-	for (uint32_t i = 0; i < n; ++i)
-		(cost[i] > order_policy.heavy * reference ? heavy : rest).push_back(i);
-	std::stable_sort(heavy.begin(), heavy.end(), falling);
-	const uint32_t workgroups = aoWorkgroups() / XCD_GROUPS ? aoWorkgroups() / XCD_GROUPS : 1u;
-	const double budget = (double) order_policy.runway * reference * workgroups;
-	double left = 0.0;
-	for (uint32_t i : rest)
-		left += cost[i];
-	std::vector<uint32_t> spatial, runway;
-	for (uint32_t i : rest) {
-		(left > budget && cost[i] >= 0.25f * reference ? spatial : runway).push_back(i);
-		left -= cost[i];
-	}
-	std::stable_sort(runway.begin(), runway.end(), falling);
-	out.insert(out.end(), heavy.begin(), heavy.end());
-	out.insert(out.end(), spatial.begin(), spatial.end());
-	out.insert(out.end(), runway.begin(), runway.end());
-	return out;
-}
-
-// The fused frame kernel's primary work (kernels/primary.hip.h, primary_top_up): per XCD group the 2 x 2 tile blocks of
-// its strips, entry = first tile column | first tile row << 16, IN THE ORDER THE AMBIENT-OCCLUSION CLAIMS WANT THEM --
-// a block is listed when the first of its tiles comes up in the group's claim order (`order_host`) -- and the blocks no
-// claim ever wants (the background, tiles without hits) last, in spatial order.  order_need[j], beside entry j of the claim
-// order: how many blocks the entries 0 ... j need, i.e. how far the block cursor must have come before entry j's tile may
-// be waited for.
-void DeviceRenderer::orderPrimaryBlocks() {
-	const uint32_t strip_tiles = kp.strip_tiles, columns = strip_tiles >> 1, rows = kp.local_tile_rows, tiles_x = kp.tiles_x;
-	const uint32_t strips = (tiles_x + strip_tiles - 1u) / strip_tiles, row_blocks = (rows + 1u) >> 1;
-	const uint32_t blocks_x = (tiles_x + 1u) >> 1;
-	primary_order_host.clear();
-	order_need_host.assign(order_host.size(), 0u);
-	std::vector<char> listed((size_t) blocks_x * row_blocks, 0);
-	size_t ao_segment = 0;
-	for (uint32_t group = 0; group < XCD_GROUPS; ++group) {
-		const uint32_t strips_here = (strips + XCD_GROUPS - 1u - group) >> 3;
-		const size_t segment = (size_t) strips_here * row_blocks * columns, at = primary_order_host.size();
-		primary_order_host.resize(at + segment, 0u);
-		uint32_t count = 0;
-		// in the order of the claims
-		for (uint32_t j = 0; j < queue_static[group][0]; ++j) {
-			const uint32_t tile = order_host[ao_segment + j] & 0x03FFFFFFu, x = tile % tiles_x, row = tile / tiles_x;
-			const size_t block = (size_t) (row >> 1) * blocks_x + (x >> 1);
-			if (!listed[block]) {
-				listed[block] = 1;
-				primary_order_host[at + count++] = (x & ~1u) | (row & ~1u) << 16;
-			}
-			order_need_host[ao_segment + j] = count;
-		}
-		// ... then whatever no claim wants
-		for (uint32_t strip_index = 0; strip_index < strips_here; ++strip_index)
-			for (uint32_t rb = 0; rb < row_blocks; ++rb)
-				for (uint32_t c = 0; c < columns; ++c) {
-					const uint32_t x0 = strip_tiles * (group + XCD_GROUPS * strip_index) + 2u * c, row0 = 2u * rb;
-					if (x0 >= tiles_x)
-						continue;
-					const size_t block = (size_t) rb * blocks_x + (x0 >> 1);
-					if (!listed[block]) {
-						listed[block] = 1;
-						primary_order_host[at + count++] = x0 | row0 << 16;
-					}
-				}
-		primary_blocks[group] = count;
-		ao_segment += (size_t) strips_here * strip_tiles * rows;
-	}
-	// The same blocks for primary_kernel, whose workgroup `seq` of a group takes entry `seq` of the group's list: by falling
-	// cost (the largest cost class among a block's tiles = the leaves its primary packet stops at; a tile without
-	// ambient-occlusion work carries none: its hit count stands in), spatial order among equals, the background last.
-	blocks_by_cost_host.clear();
-	for (uint32_t group = 0; group < XCD_GROUPS; ++group) {
-		const uint32_t strips_here = (strips + XCD_GROUPS - 1u - group) >> 3;
-		std::vector<std::pair<uint32_t, uint32_t>> blocks;  // (cost, entry)
-		for (uint32_t strip_index = 0; strip_index < strips_here; ++strip_index)
-			for (uint32_t rb = 0; rb < row_blocks; ++rb)
-				for (uint32_t c = 0; c < columns; ++c) {
-					const uint32_t x0 = strip_tiles * (group + XCD_GROUPS * strip_index) + 2u * c, row0 = 2u * rb;
-					if (x0 >= tiles_x)
-						continue;
-					uint32_t cost = 0;
-					for (uint32_t k = 0; k < 4u; ++k) {
-						const uint32_t x = x0 + (k & 1u), row = row0 + (k >> 1);
-						if (x < tiles_x && row < rows && (size_t) row * tiles_x + x < tile_words.size()) {
-							const uint32_t word = tile_words[(size_t) row * tiles_x + x];
-							cost = std::max(cost, word >> 8 ? word >> 8 : (word & 0xFFu) ? 1u : 0u);
-						}
-					}
-					blocks.push_back({ cost, x0 | row0 << 16 });
-				}
-		std::stable_sort(blocks.begin(), blocks.end(), [](const auto &a, const auto &b) { return a.first > b.first; });
-		const size_t at = blocks_by_cost_host.size();
-		blocks_by_cost_host.resize(at + (size_t) strips_here * row_blocks * columns, 0xFFFFFFFFu);
-		for (size_t i = 0; i < blocks.size(); ++i)
-			blocks_by_cost_host[at + i] = blocks[i].second;
-	}
-	if (blocks_by_cost_host.empty())
-		blocks_by_cost_host.push_back(0xFFFFFFFFu);
-	if (primary_order_host.empty())
-		primary_order_host.push_back(0u);
-}
-
 bool DeviceRenderer::fusedFrame() const {
 	const bool possible = kp.ao_mode == AO_UNIFORM && kp.ao_dirs > 0 && kp.shared_walk && tile_count > 0 && kp.tiles_x < 65536u &&
 	                      kp.local_tile_rows < 65536u && !primary_order_host.empty();
@@ -823,29 +432,6 @@ void DeviceRenderer::checkFrameHealth() {
 		OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));
 		throw DeviceError("the fused frame kernel waited in vain for a tile's hit records (" + std::to_string(stalled) + " waves gave up): the frame is not valid");
 	}
-}
-
-void DeviceRenderer::installOrder(const std::vector<uint32_t> &order, const std::array<std::array<uint32_t, 3>, XCD_GROUPS> &constants) {
-	order_host = order;
-	queue_static = constants;
-	OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));
-	OCRT_HIP(hipMemcpy(d_order, order_host.data(), order_host.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-	orderPrimaryBlocks();
-	OCRT_HIP(hipMemcpy(d_primary_order, primary_order_host.data(), primary_order_host.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-	OCRT_HIP(hipMemcpy(d_order_need, order_need_host.data(), order_need_host.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-	OCRT_HIP(hipMemcpy(d_blocks_by_cost, blocks_by_cost_host.data(), blocks_by_cost_host.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-	FrameCounters fresh{};
-	for (uint32_t g = 0; g < XCD_GROUPS; ++g) {
-		fresh.queue[g].work_tiles = constants[g][0];
-		fresh.queue[g].cost_sum = constants[g][1];
-		fresh.queue[g].hits = constants[g][2];
-		fresh.queue[g].primary_blocks = primary_blocks[g];
-	}
-	OCRT_HIP(hipMemcpy(d_counters, &fresh, sizeof fresh, hipMemcpyHostToDevice));
-	// (the frame count starts again at 0: no tile's flag may claim a frame)
-	OCRT_HIP(hipMemsetAsync(d_tile_ready, 0, (tile_count ? tile_count : 1) * sizeof(uint32_t), (hipStream_t) stream));
-	OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));
-	++scene_version;  // (nothing a captured frame bakes in has changed, but a frame in flight must not see the list change: callers synchronise)
 }
 
 DeviceRenderer::FrameEvents DeviceRenderer::takeEvents() {
@@ -950,87 +536,6 @@ void DeviceRenderer::expectFrames(uint64_t frames) {
 	// the scene is on the device already: lay the hit list out again, with or without the table (adopt() decides)
 	std::shared_ptr<const DeviceScene> scene = scene_on_device;
 	adopt(std::move(scene));
-}
-
-bool DeviceRenderer::measureTileCosts(unsigned frames) {
-	if (!scene_ready)
-		throw std::logic_error("measurement before upload");
-	const bool has_ao = kp.ao_mode != AO_NONE && kp.ao_dirs > 0 && tile_count > 0 && tile_words.size() == tile_count;
-	if (!has_ao || frames == 0)
-		return false;
-	useDevice();
-	synchronize();
-	void *d_cost = device_alloc(tile_count * sizeof(uint32_t));
-	std::vector<uint32_t> ticks(tile_count);
-	std::vector<float> sum(tile_count, 0.0f);
-	try {
-		for (unsigned f = 0; f <= frames; ++f) {  // (the first frame is not counted: code object pages, caches)
-			OCRT_HIP(hipMemsetAsync(d_cost, 0, tile_count * sizeof(uint32_t), (hipStream_t) stream));
-			launchFrame(nullptr, nullptr, nullptr, d_cost);
-			OCRT_HIP(hipMemcpyAsync(ticks.data(), d_cost, tile_count * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t) stream));
-			OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));
-			if (f > 0)
-				for (size_t t = 0; t < tile_count; ++t)
-					sum[t] += (float) ticks[t];
-		}
-	} catch (...) {
-		device_free(d_cost);
-		throw;
-	}
-	device_free(d_cost);
-	tile_cost = std::move(sum);
-	orderTiles();
-	frame_ready = false;
-	return true;
-}
-
-void DeviceRenderer::takeOrderFrom(const DeviceRenderer &other) {
-	if (&other == this || other.tile_count != tile_count || other.order_host.empty())
-		return;
-	useDevice();
-	synchronize();
-	tile_words = other.tile_words;
-	tile_cost = other.tile_cost;
-	installOrder(other.order_host, other.queue_static);
-}
-
-void DeviceRenderer::tileOrder(std::vector<uint32_t> &order, std::vector<uint32_t> &constants, std::vector<uint32_t> &words, std::vector<float> &cost) const {
-	order = order_host;
-	constants.clear();
-	for (const auto &q : queue_static)
-		constants.insert(constants.end(), q.begin(), q.end());
-	words = tile_words;
-	cost = tile_cost;
-}
-
-void DeviceRenderer::setTileOrder(const std::vector<uint32_t> &order, const std::vector<uint32_t> &constants) {
-	if (!scene_ready || order.size() != order_host.size() || constants.size() != 3 * XCD_GROUPS)
-		throw std::invalid_argument("setTileOrder: a list of another frame");
-	// every entry must be a tile of this frame (the kernel indexes the hit list's bases with it) and every group's count
-	// must stay inside its segment
-	for (uint32_t entry : order)
-		if ((entry & 0x03FFFFFFu) >= tile_count && tile_count)
-			throw std::invalid_argument("setTileOrder: no such tile");
-	std::array<std::array<uint32_t, 3>, XCD_GROUPS> c{};
-	const uint32_t strips = (kp.tiles_x + kp.strip_tiles - 1u) / kp.strip_tiles;
-	for (uint32_t g = 0; g < XCD_GROUPS; ++g) {
-		c[g] = { constants[3 * g], constants[3 * g + 1], constants[3 * g + 2] };
-		if (c[g][0] > ((strips + XCD_GROUPS - 1u - g) >> 3) * kp.strip_tiles * kp.local_tile_rows)
-			throw std::invalid_argument("setTileOrder: more tiles than the group's segment holds");
-	}
-	useDevice();
-	synchronize();
-	installOrder(order, c);
-}
-
-void DeviceRenderer::setOrderPolicy(float heavy, float runway) {
-	order_policy.heavy = heavy;
-	order_policy.runway = runway;
-	if (scene_ready && orderIsMeasured()) {
-		useDevice();
-		synchronize();
-		orderTiles();
-	}
 }
 
 void DeviceRenderer::setAoPrefetch(bool on) {
