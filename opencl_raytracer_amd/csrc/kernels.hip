@@ -90,10 +90,6 @@ __global__ __launch_bounds__(256) void clear_stamps_kernel(FrameCounters *counte
 // (test-only build: the UNIFORM direction table as the reference kernel computes it on the device -- per pixel, with the
 // library's own float sin / cos / cospi / sinpi, src/intersect_kernel.cl:237-246 -- instead of the host's libm: the same
 // expressions in the same order, one thread)
-extern "C" __device__ float ocl_sin(float);
-extern "C" __device__ float ocl_cos(float);
-extern "C" __device__ float ocl_cospi(float);
-extern "C" __device__ float ocl_sinpi(float);
 __global__ void ocml_ao_table_kernel(float4 *table, uint32_t *count, uint32_t rings, int alpha_min, int alpha_max, uint32_t capacity) {
 	if (threadIdx.x != 0 || blockIdx.x != 0)
 		return;

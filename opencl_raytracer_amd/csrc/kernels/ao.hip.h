@@ -361,7 +361,10 @@ __device__ __forceinline__ void ao_pass(const FrameArgs &A, TileShared *shared_t
 					if (MODE != AO_UNIFORM) {
 						// RANDOM (reference :153-183, :257-276): ray 0 goes along the normal, ray
 						// j >= 1 uses draws 2j-2 and 2j-1 of the sub-pixel's generator.  Device libm
-						// rounds differently from the host's: this mode is outside the bit-exact contract.
+						// rounds differently from the host's: this mode is outside the bit-exact contract with the CPU
+						// -- but not with the reference kernel on this GPU: in the test-only library-builtins build the
+						// trigonometry below is ROCm's OpenCL library's own (OCRT_SIN ..., kernels/common.hip.h) and the
+						// frame equals the reference's bit for bit (tests/test_ocml_pin.py).
 						const uint32_t j = dir0 + k;
 						along_normal = j == 0u;
 						// the generator is seeded with the sub-pixel's index in the WHOLE image (reference :169, :279-281)
@@ -374,11 +377,11 @@ __device__ __forceinline__ void ao_pass(const FrameArgs &A, TileShared *shared_t
 						}
 						const float xi1 = rng_float(rng);
 						const float xi2 = rng_float(rng);
-						const float theta = acosf(sqrtf(1.0f - xi1));
+						const float theta = OCRT_ACOS(sqrtf(1.0f - xi1));
 						const float phi = (float) (2.0 * (double) xi2);
-						xs = sinf(theta) * cospif(phi);
-						ys = cosf(theta);
-						zs = sinf(theta) * sinpif(phi);
+						xs = OCRT_SIN(theta) * OCRT_COSPI(phi);
+						ys = OCRT_COS(theta);
+						zs = OCRT_SIN(theta) * OCRT_SINPI(phi);
 					}
 					// ray_dir = basis_x * xs + basis_y * ys + basis_z * zs, lane by lane
 					float rx = (sh.frame[3][h] * xs + sh.frame[6][h] * ys) + sh.frame[9][h] * zs;

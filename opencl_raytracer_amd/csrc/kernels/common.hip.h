@@ -69,6 +69,16 @@ extern "C" __device__ float ocl_dot(ocl_f4, ocl_f4);
 extern "C" __device__ ocl_f4 ocl_cross(ocl_f4, ocl_f4);
 extern "C" __device__ ocl_f4 ocl_normalize(ocl_f4);
 extern "C" __device__ float ocl_length(ocl_f4);
+extern "C" __device__ float ocl_sin(float);
+extern "C" __device__ float ocl_cos(float);
+extern "C" __device__ float ocl_cospi(float);
+extern "C" __device__ float ocl_sinpi(float);
+extern "C" __device__ float ocl_acos(float);
+#define OCRT_SIN ocl_sin
+#define OCRT_COS ocl_cos
+#define OCRT_COSPI ocl_cospi
+#define OCRT_SINPI ocl_sinpi
+#define OCRT_ACOS ocl_acos
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
 	return ocl_dot(ocl_f4{ ax, ay, az, 0.0f }, ocl_f4{ bx, by, bz, 0.0f });
 }
@@ -87,6 +97,11 @@ __device__ __forceinline__ void cross3(float ax, float ay, float az, float bx, f
 	cz = ax * by - ay * bx;
 }
 __device__ __forceinline__ float length3(float x, float y, float z) { return sqrtf(dot3(x, y, z, x, y, z)); }
+#define OCRT_SIN sinf
+#define OCRT_COS cosf
+#define OCRT_COSPI cospif
+#define OCRT_SINPI sinpif
+#define OCRT_ACOS acosf
 #endif
 
 __device__ __forceinline__ Ray make_ray(float ox, float oy, float oz, float dx, float dy, float dz) {

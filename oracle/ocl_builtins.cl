@@ -24,3 +24,4 @@ float ocl_sin(float x) { return sin(x); }
 float ocl_cos(float x) { return cos(x); }
 float ocl_cospi(float x) { return cospi(x); }
 float ocl_sinpi(float x) { return sinpi(x); }
+float ocl_acos(float x) { return acos(x); }

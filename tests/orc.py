@@ -212,6 +212,9 @@ def ref_kernel(p: OrcParams, n_super_samples: int, build: bool = True) -> Option
 REFKERNEL_CASES_16 = ["bunny_256_s1_a0", "bunny_256_s1_a3", "blob_128x96_s4_a3", "ties_64_s4_a3", "bunny_600_defaults"]
 REFKERNEL_CASES_OTHER = {"bunny_1080p_s1_a0": (16, 8), "bunny_1080p_s1_a3": (16, 8)}
 REFKERNEL_ALL_CASES = REFKERNEL_CASES_16 + sorted(REFKERNEL_CASES_OTHER)
+# ... and golden cases rendered once more with `-m random` (AO_METHOD=1: the one sampling mode the reference compiles with
+# on ROCm as it is): the strict gfx950 build only, for tests/test_ocml_pin.py
+REFKERNEL_RANDOM_CASES = ["bunny_256_s1_a3", "blob_128x96_s4_a3", "ties_64_s4_a3"]
 
 GFX950_MODES = ("default", "strict", "ieee_dot", "ieee_cross", "ieee_normalize", "ieee_length", "ieee_geom", "ieee_all")
 

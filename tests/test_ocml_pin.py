@@ -68,3 +68,40 @@ def test_hip_path_with_the_library_builtins_equals_the_reference_kernel(rt_ocml,
         committed = json.load(f)[name]["strict"]["float_words_differ"]
     assert (hashlib.sha256(img.tobytes()).hexdigest() != c["float_sha256"]) == (committed != 0)
     host.close()
+
+
+@pytest.mark.parametrize("name", __import__("orc").REFKERNEL_RANDOM_CASES)
+def test_random_sampling_equals_the_reference_kernel_too(rt_ocml, golden, name):
+    """`-m random` (reference src/intersect_kernel.cl:128-183, 257-276: xorshift128 per sub-pixel, acos / sin / cos / cospi /
+    sinpi of the draws) is outside the bit-exact contract with a CPU -- device and host libm round differently, the product
+    is only checked statistically (tests/test_hip_parity.py).  Against the reference kernel ON THIS GPU there is no such
+    excuse: with the library's own trigonometry (OCRT_SIN ..., kernels/common.hip.h) the frame must be the reference's bit
+    for bit -- generator, draw order, the extra ray along the normal, the divisor AO_NUM_SAMPLES + 1 and all."""
+    import os
+
+    import orc
+    from conftest import mesh_file
+
+    if not os.path.exists(os.path.join(orc.ORACLE_DIR, "libref_launch.so")):
+        pytest.skip("oracle/libref_launch.so not built")
+    c = dict(golden["renders"][name])
+    opt = options_for(rt_ocml, c)
+    opt.ao_method = 1
+    p = orc.params_from_options(opt)
+    co = orc.ref_kernel_gfx950(p, c["ss"], "strict_static", build=False)  # (strict + `inline` read as `static`: oracle/Makefile)
+    if co is None:
+        pytest.skip("no strict gfx950 code object of the reference kernel with AO_METHOD=1 for this case under oracle/_ref/")
+    key = (c["mesh"], c["bvh"])
+    if key not in _SCENES:
+        sc = rt_ocml.Scene.load_off(mesh_file(c["mesh"])).build_bvh(0 if c["bvh"] == "longest" else 1)
+        _SCENES[key] = (sc, orc.SceneArrays.from_scene(sc))
+    scene, arrays = _SCENES[key]
+    ref_img, _ = orc.RefGpu().render(co, p, arrays, block=(16, 16), repeats=0)
+    host = rt_ocml.Host(opt, 0)
+    host.upload_scene(scene)
+    host.render()
+    img = host.download()
+    differ = int(np.count_nonzero(bits(img) != bits(ref_img)))
+    assert differ == 0, f"{differ} of {img.size} float words differ from the reference kernel's `-m random` frame"
+    assert np.count_nonzero(img) > 0
+    host.close()
