@@ -69,14 +69,14 @@ int rt_ring_rccl_self_test(rt_ring *r);  /* grouped self send/recv on the ring's
 /* The order in which the ambient-occlusion pass claims a frame's tiles (made once per upload on the host,
  * DeviceRenderer::orderTiles).  rt_debug_measure_tile_costs renders `frames` frames whose AO pass books every claim's
  * duration to its tiles (device-clock ticks of 10 ns), and, with `reorder` != 0, makes the order from them
- * (rt_debug_set_order_policy: `heavy`, `runway`, see DeviceRenderer::orderByMeasuredCost).
+ * (rt_debug_set_order_policy: `heavy`, `runway`, `split_above`, see DeviceRenderer::orderByMeasuredCost).
  * rt_debug_tile_order copies out: the list (`order`, rt_debug_tile_order_slots() words: eight segments, entry = tile |
  * (hit count - 1) << 26), 24 constants (per group: non-empty tiles, sum of cost classes, hit sub-pixels), the tile words
  * (hit count | cost class << 8) and the measured costs (`tiles` values each, 0 where nothing was measured); any pointer
  * may be null.  rt_debug_set_tile_order installs a list made by the caller (same size, same tiles: any order renders
  * the same image). */
 int rt_debug_measure_tile_costs(rt_host *h, uint32_t frames, int reorder);
-int rt_debug_set_order_policy(rt_host *h, float heavy, float runway);
+int rt_debug_set_order_policy(rt_host *h, float heavy, float runway, float split_above);  /* split_above < 0: unchanged */
 uint32_t rt_debug_tile_order_slots(rt_host *h);
 uint32_t rt_debug_tiles(rt_host *h);
 int rt_debug_tile_order(rt_host *h, uint32_t *order, uint32_t *constants24, uint32_t *tile_words, float *tile_costs);

@@ -175,7 +175,7 @@ _SIGNATURES = {
     "rt_device_count": (C.c_int, []),
     # include/rt_hip_debug.h
     "rt_debug_measure_tile_costs": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int]),
-    "rt_debug_set_order_policy": (C.c_int, [C.c_void_p, C.c_float, C.c_float]),
+    "rt_debug_set_order_policy": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float]),
     "rt_debug_tile_order_slots": (C.c_uint32, [C.c_void_p]),
     "rt_debug_tiles": (C.c_uint32, [C.c_void_p]),
     "rt_debug_tile_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -445,8 +445,9 @@ class Host:
         """Measures what the tiles' AO packets cost (include/rt_hip_debug.h) and, with `reorder`, claims them by that."""
         _check(load_library().rt_debug_measure_tile_costs(self._h, int(frames), int(reorder)))
 
-    def set_order_policy(self, heavy: float, runway: float) -> None:
-        _check(load_library().rt_debug_set_order_policy(self._h, float(heavy), float(runway)))
+    def set_order_policy(self, heavy: float, runway: float, split_above: float = -1.0) -> None:
+        """How orders are made from measured costs (DeviceRenderer::orderByMeasuredCost); re-orders if costs have been measured."""
+        _check(load_library().rt_debug_set_order_policy(self._h, float(heavy), float(runway), float(split_above)))
 
     def tile_order(self) -> dict:
         """The AO pass's claim order: list (eight segments), 8 x 3 constants, tile words, measured costs per tile."""

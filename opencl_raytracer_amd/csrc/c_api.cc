@@ -490,10 +490,10 @@ int rt_debug_measure_tile_costs(rt_host *h, uint32_t frames, int reorder) {
 	});
 }
 
-int rt_debug_set_order_policy(rt_host *h, float heavy, float runway) {
+int rt_debug_set_order_policy(rt_host *h, float heavy, float runway, float split_above) {
 	if (!h)
 		return fail(RT_E_INVALID, "null argument");
-	return guarded([&] { h->dev->setOrderPolicy(heavy, runway); });
+	return guarded([&] { h->dev->setOrderPolicy(heavy, runway, split_above); });
 }
 
 uint32_t rt_debug_tile_order_slots(rt_host *h) {

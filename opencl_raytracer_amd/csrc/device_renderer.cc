@@ -334,7 +334,7 @@ void DeviceRenderer::sizeHitList(const DeviceRenderer *layout_from) {
 		// ... and the order its tiles are claimed in by the ambient-occlusion pass
 		tile_words = layout_from->tile_words;
 		tile_cost = layout_from->tile_cost;
-		installOrder(layout_from->order_host, layout_from->queue_static);
+		installOrder(layout_from->order_host, layout_from->queue_static, layout_from->split_tiles);
 		d_hits = device_alloc((hit_slots ? hit_slots : 1) * sizeof(HitRec));
 		d_occluded = device_alloc((hit_slots ? hit_slots : 1) * sizeof(uint32_t));
 		clock.mark("hit list laid out like the ring's first host");

@@ -175,7 +175,7 @@ class DeviceRenderer {
 		// ... and the order another renderer of the same frame (scene, options, partition) has arrived at
 		void takeOrderFrom(const DeviceRenderer &other);
 		bool orderIsMeasured() const { return tile_cost.size() == tile_count && tile_count != 0; }
-		void setOrderPolicy(float heavy, float runway);
+		void setOrderPolicy(float heavy, float runway, float split_above = -1.0f);  // (split_above < 0: unchanged)
 		// 0: the library's rule (two kernels), 1: fused, 2: two kernels -- same results
 		void setFrameForm(int form);
 		bool frameIsFused() const { return fusedFrame(); }
@@ -259,13 +259,16 @@ class DeviceRenderer {
 		enum class FrameForm { AUTO, FUSED, SEPARATE } frame_form = FrameForm::AUTO;
 		bool fusedFrame() const;
 		void checkFrameHealth();  // throws DeviceError if a wave of the fused frame kernel ever gave up waiting (FrameCounters::stalled)
+		std::array<uint32_t, XCD_GROUPS> split_tiles{};  // per group: the tiles at the head of its list that are claimed half a tile at a time
 		struct OrderPolicy {  // (orderByMeasuredCost; swept in profiles/r05_order_policies.txt)
 			float heavy = 2.0f;   // tiles beyond this many reference costs (the upper quartile) are claimed first
 			float runway = 2.0f;  // what is held back for the end, by falling cost: this many reference claims per workgroup
+			float split_above = 0.25f;  // tiles that cost more than this share of the pass's ideal length: half a tile per claim (0: none)
 		} order_policy;
 		void orderTiles();
-		std::vector<uint32_t> orderByMeasuredCost(const std::vector<float> &cost) const;
-		void installOrder(const std::vector<uint32_t> &order, const std::array<std::array<uint32_t, 3>, XCD_GROUPS> &constants);
+		std::vector<uint32_t> orderByMeasuredCost(const std::vector<float> &cost, uint32_t *split = nullptr) const;
+		void installOrder(const std::vector<uint32_t> &order, const std::array<std::array<uint32_t, 3>, XCD_GROUPS> &constants,
+		                  const std::array<uint32_t, XCD_GROUPS> &splits = {});
 		size_t image_bytes;  // float image of this rank's bands
 		size_t tile_count;
 		uint32_t compute_units;

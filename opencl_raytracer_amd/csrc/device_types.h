@@ -72,10 +72,15 @@ struct alignas(128) GroupQueue {
 	// the fused frame kernel's primary work of the group (kernels/frame.hip.h): 2 x 2 tile blocks, in the order of
 	// FrameArgs::primary_order
 	uint32_t primary_blocks;  // how many (per upload)
-	uint32_t pad0[27];
-	// ... and their claim cursor, in a line of its own: it is hammered at the beginning of a frame, the head at its end
+	// The first `split_units` units of the list -- its heaviest tiles, by measured cost -- are claimed HALF A TILE at a time
+	// from a cursor of their own (kernels/ao.hip.h; per upload; 0: none).  `head` starts at split_units.
+	uint32_t split_units;
+	uint32_t pad0[26];
+	// ... the claim cursors of the beginning of a frame in a line of their own (`head` is hammered at its end): the fused
+	// kernel's block cursor, the cursor of the split tiles
 	uint32_t primary_head;
-	uint32_t pad1[31];
+	uint32_t split_head;
+	uint32_t pad1[30];
 };
 static_assert(sizeof(GroupQueue) == 256, "two lines per queue");
 struct FrameCounters {

@@ -107,10 +107,12 @@ __device__ __forceinline__ void ao_pass(const FrameArgs &A, TileShared *shared_t
 				segment += ((strips + XCD_GROUPS - 1u - g) >> 3) * strip_tiles * rows;
 		}
 		// the group's work in units of (tile, table direction), tile-major
-		uint32_t units, claim_max;
+		uint32_t units, claim_max, split_units;
 		{
 		FrameCounters *const counters = OCRT_COLD_PTR(FrameCounters *, counters);
 		const uint32_t ao_dirs = OCRT_COLD_U32(P.ao_dirs);
+		// (the heaviest tiles of the list, by measured cost: claimed half a tile at a time -- below)
+		split_units = (uint32_t) __builtin_amdgcn_readfirstlane((int) counters->queue[group].split_units);
 		// (loads through a re-read pointer are vector loads -- the compiler cannot know the memory to be constant --: what they
 		// return is made scalar again by hand)
 		const uint32_t queued_tiles = (uint32_t) __builtin_amdgcn_readfirstlane((int) counters->queue[group].work_tiles);
@@ -148,10 +150,34 @@ __device__ __forceinline__ void ao_pass(const FrameArgs &A, TileShared *shared_t
 			// single directions it hands out at the end cost a claim each, two barriers and a tile set-up, and
 			// lengthened the pass by 3-5 %; the costly tiles are claimed first anyway: order_group.)
 			uint32_t per_wave = 0u, first = units;  // (wave 0's, scalar; in registers until the siblings are done with the last claim)
+			uint32_t claim_limit = units;           // (where this claim must end at the latest)
 			if (wave == 0u) {
 				FrameCounters *const counters = OCRT_COLD_PTR(FrameCounters *, counters);
-				uint32_t seen = 0u;
-				if (fresh_lane() == 0u)
+				// The group's HEAVIEST tiles first, half a tile per claim (a cursor of their own: the two kinds of claims never
+				// straddle each other's tiles).  A tile whose packets keep a workgroup for a quarter of the pass or more decides
+				// when the pass ends -- at 600 x 600 -s 4 the costliest tile takes as long as the pass's ideal length, and so it
+				// does in one GPU's share of a frame split eight ways --: two workgroups share such a tile.  Which tiles: by
+				// measured cost, per upload (DeviceRenderer::orderByMeasuredCost).
+				if (split_units != 0u) {
+					uint32_t seen = split_units;
+					if (fresh_lane() == 0u)
+						seen = __hip_atomic_load(&counters->queue[group].split_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					seen = (uint32_t) __builtin_amdgcn_readfirstlane((int) seen);
+					if (seen < split_units) {
+						const uint32_t half = OCRT_COLD_U32(P.ao_dirs) >> 1;
+						uint32_t got = split_units;
+						if (fresh_lane() == 0u)
+							got = atomicAdd(&counters->queue[group].split_head, half);
+						got = (uint32_t) __builtin_amdgcn_readfirstlane((int) got);
+						if (got < split_units) {
+							first = got;
+							per_wave = (half + AO_WAVES - 1u) / AO_WAVES;
+							claim_limit = got + half;
+						}
+					}
+				}
+				uint32_t seen = units;
+				if (first >= units && fresh_lane() == 0u)
 					seen = __hip_atomic_load(&counters->queue[group].head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				seen = (uint32_t) __builtin_amdgcn_readfirstlane((int) seen);
 				if (seen < units) {
@@ -172,7 +198,7 @@ __device__ __forceinline__ void ao_pass(const FrameArgs &A, TileShared *shared_t
 				// slowest sibling at the barrier (profiles/r02_notes.md; what the cursor buys and where it does not:
 				// profiles/r03_notes.md).  Other claims (whole tiles per wave, the short ones of scarce work) keep fixed shares.
 				// wg_claim[2] = the claim's end, 0 for fixed shares.
-				const uint32_t end = first + per_wave * AO_WAVES < units ? first + per_wave * AO_WAVES : units;
+				const uint32_t end = first + per_wave * AO_WAVES < claim_limit ? first + per_wave * AO_WAVES : claim_limit;
 				const uint32_t ao_dirs = OCRT_COLD_U32(P.ao_dirs);
 				const bool one_tile = SHARED && first < units && first / ao_dirs == (end - 1u) / ao_dirs && ao_dirs < 0x8000u;
 				wg_claim[0] = first;

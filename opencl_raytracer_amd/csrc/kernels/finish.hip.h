@@ -12,7 +12,8 @@ namespace ocrt {
 // passes in the stream.  One workgroup, eight lanes.
 __device__ __forceinline__ void frame_is_over(FrameCounters *counters) {
 	if (counters && blockIdx.x == 0u && blockIdx.y == 0u && threadIdx.x < XCD_GROUPS) {
-		counters->queue[threadIdx.x].head = 0u;
+		counters->queue[threadIdx.x].head = counters->queue[threadIdx.x].split_units;
+		counters->queue[threadIdx.x].split_head = 0u;
 		counters->queue[threadIdx.x].primary_head = 0u;
 		if (threadIdx.x == 0u)
 			counters->frame_seq += 1u;

@@ -360,7 +360,8 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) __attribute__((amdgpu_waves_per
 	if (blockIdx.x == 0u && threadIdx.x < XCD_GROUPS) {
 		FrameCounters *const counters = A.counters;
 		// what the LATER kernels of this frame add to or count up (nobody touches it before this kernel has ended)
-		counters->queue[threadIdx.x].head = 0u;
+		counters->queue[threadIdx.x].head = counters->queue[threadIdx.x].split_units;
+		counters->queue[threadIdx.x].split_head = 0u;
 		if (threadIdx.x == 0u) {
 			counters->tick_begin = __builtin_amdgcn_s_memrealtime();
 			counters->occluded = 0ull;

@@ -24,6 +24,7 @@ void DeviceRenderer::orderTiles() {
 	const size_t order_slots = (size_t) ((tiles_x + MAX_STRIP_TILES - 1) / MAX_STRIP_TILES) * MAX_STRIP_TILES * rows;
 	std::vector<uint32_t> order(order_slots ? order_slots : 1, 0u);
 	std::array<std::array<uint32_t, 3>, XCD_GROUPS> constants{};
+	std::array<uint32_t, XCD_GROUPS> splits{};
 	const bool measured = tile_cost.size() == tile_count;
 	size_t segment = 0;
 	for (uint32_t group = 0; group < XCD_GROUPS; ++group) {
@@ -61,8 +62,10 @@ void DeviceRenderer::orderTiles() {
 			std::vector<float> cost(candidates.size());
 			for (size_t i = 0; i < candidates.size(); ++i)
 				cost[i] = tile_cost[elements[candidates[i]].tile];
-			for (uint32_t at : orderByMeasuredCost(cost))
+			uint32_t split = 0;
+			for (uint32_t at : orderByMeasuredCost(cost, &split))
 				listed.push_back(candidates[at]);
+			splits[group] = split;
 		} else {
 			const uint32_t n_blocks = (tiles_here + 63u) >> 6;
 			std::vector<std::pair<uint32_t, uint32_t>> blocks;  // (key, block), stable by block
@@ -86,7 +89,7 @@ void DeviceRenderer::orderTiles() {
 		constants[group] = { work, cost_total, hit_total };
 		segment += tiles_here;
 	}
-	installOrder(order, constants);
+	installOrder(order, constants, splits);
 }
 
 // Claim order of one group's tiles from their MEASURED costs (device-clock ticks a tile's claims kept their workgroups
@@ -99,10 +102,16 @@ void DeviceRenderer::orderTiles() {
 //   3. ... up to the RUNWAY: what would keep each workgroup of the group busy for about `runway` reference claims is held
 //      back and claimed last by falling cost, so that the pass ends on its cheapest tiles; tiles below a quarter of the
 //      reference cost anywhere in the list are moved there too.
-std::vector<uint32_t> DeviceRenderer::orderByMeasuredCost(const std::vector<float> &cost) const {
+//   4. `*split` (out): how many tiles at the head of the list -- heavy ones -- are to be claimed HALF A TILE at a time
+//      (kernels/ao.hip.h): those whose cost exceeds `split_above` x the pass's ideal length (the group's total cost over its
+//      workgroups).  A tile that keeps a workgroup for a quarter of the pass decides when the pass ends -- at 600 x 600 -s 4
+//      the costliest tile takes as long as the whole pass should, and so it does in one GPU's share of a frame split eight ways.
+std::vector<uint32_t> DeviceRenderer::orderByMeasuredCost(const std::vector<float> &cost, uint32_t *split) const {
 	const size_t n = cost.size();
 	std::vector<uint32_t> out;
 	out.reserve(n);
+	if (split)
+		*split = 0;
 	if (n == 0)
 		return out;
 	std::vector<float> sorted(cost);
@@ -110,10 +119,27 @@ std::vector<uint32_t> DeviceRenderer::orderByMeasuredCost(const std::vector<floa
 	const float reference = sorted[n - 1 - (n - 1) / 4];
 	const auto falling = [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; };
 	std::vector<uint32_t> heavy, rest;
+	double heavy_from = (double) order_policy.heavy * reference;
+	if (split && order_policy.split_above > 0.0f) {  // (whatever is to be split must stand in the heavy prefix)
+		double total = 0.0;
+		for (float c : cost)
+			total += c;
+		const uint32_t wg = aoWorkgroups() / XCD_GROUPS ? aoWorkgroups() / XCD_GROUPS : 1u;
+		heavy_from = std::min(heavy_from, (double) order_policy.split_above * total / wg);
+	}
 	for (uint32_t i = 0; i < n; ++i)
-		(cost[i] > order_policy.heavy * reference ? heavy : rest).push_back(i);
+		(cost[i] > heavy_from ? heavy : rest).push_back(i);
 	std::stable_sort(heavy.begin(), heavy.end(), falling);
 	const uint32_t workgroups = aoWorkgroups() / XCD_GROUPS ? aoWorkgroups() / XCD_GROUPS : 1u;
+	if (split && order_policy.split_above > 0.0f && kp.shared_walk && (kp.ao_dirs & 1u) == 0u && kp.ao_dirs >= 2u) {
+		double total = 0.0;
+		for (float c : cost)
+			total += c;
+		const double ideal = total / workgroups;  // what the pass takes when the group's workgroups share its work evenly
+		for (uint32_t i : heavy)  // (by falling cost: a prefix)
+			if (cost[i] > order_policy.split_above * ideal)
+				++*split;
+	}
 	const double budget = (double) order_policy.runway * reference * workgroups;
 	double left = 0.0;
 	for (uint32_t i : rest)
@@ -211,9 +237,11 @@ void DeviceRenderer::orderPrimaryBlocks() {
 }
 
 
-void DeviceRenderer::installOrder(const std::vector<uint32_t> &order, const std::array<std::array<uint32_t, 3>, XCD_GROUPS> &constants) {
+void DeviceRenderer::installOrder(const std::vector<uint32_t> &order, const std::array<std::array<uint32_t, 3>, XCD_GROUPS> &constants,
+                                  const std::array<uint32_t, XCD_GROUPS> &splits) {
 	order_host = order;
 	queue_static = constants;
+	split_tiles = splits;
 	OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));
 	OCRT_HIP(hipMemcpy(d_order, order_host.data(), order_host.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	orderPrimaryBlocks();
@@ -226,6 +254,8 @@ void DeviceRenderer::installOrder(const std::vector<uint32_t> &order, const std:
 		fresh.queue[g].cost_sum = constants[g][1];
 		fresh.queue[g].hits = constants[g][2];
 		fresh.queue[g].primary_blocks = primary_blocks[g];
+		fresh.queue[g].split_units = std::min(split_tiles[g], constants[g][0]) * kp.ao_dirs;
+		fresh.queue[g].head = fresh.queue[g].split_units;
 	}
 	OCRT_HIP(hipMemcpy(d_counters, &fresh, sizeof fresh, hipMemcpyHostToDevice));
 	// (the frame count starts again at 0: no tile's flag may claim a frame)
@@ -274,7 +304,7 @@ void DeviceRenderer::takeOrderFrom(const DeviceRenderer &other) {
 	synchronize();
 	tile_words = other.tile_words;
 	tile_cost = other.tile_cost;
-	installOrder(other.order_host, other.queue_static);
+	installOrder(other.order_host, other.queue_static, other.split_tiles);
 }
 
 void DeviceRenderer::tileOrder(std::vector<uint32_t> &order, std::vector<uint32_t> &constants, std::vector<uint32_t> &words, std::vector<float> &cost) const {
@@ -306,9 +336,11 @@ void DeviceRenderer::setTileOrder(const std::vector<uint32_t> &order, const std:
 	installOrder(order, c);
 }
 
-void DeviceRenderer::setOrderPolicy(float heavy, float runway) {
+void DeviceRenderer::setOrderPolicy(float heavy, float runway, float split_above) {
 	order_policy.heavy = heavy;
 	order_policy.runway = runway;
+	if (split_above >= 0.0f)
+		order_policy.split_above = split_above;
 	if (scene_ready && orderIsMeasured()) {
 		useDevice();
 		synchronize();

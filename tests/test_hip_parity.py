@@ -281,6 +281,13 @@ def test_measured_tile_order_changes_nothing(rt, golden, scene_for, name):
     host.render()
     assert hashlib.sha256(host.download().tobytes()).hexdigest() == c["float_sha256"]
     assert host.stats()["ao_occluded"] == c["counters"]["ao_occluded"]
+    # heavy tiles claimed half a tile at a time (kernels/ao.hip.h): with the threshold at a hundredth of the pass's ideal length
+    # that is most of the list's head, with it out of reach none -- the same floats
+    for split_above in (0.01, 0.25, 1e9, 0.0):
+        host.set_order_policy(2.0, 2.0, split_above)
+        host.render()
+        assert hashlib.sha256(host.download().tobytes()).hexdigest() == c["float_sha256"], split_above
+        assert host.stats()["ao_occluded"] == c["counters"]["ao_occluded"]
     # ... and each group's list backwards (cheapest first: the worst order there is)
     order, at = after["order"].copy(), 0
     n = int(np.sqrt(opt.n_super_samples))

@@ -45,6 +45,21 @@ def make_order(base, segs, costs, rule, workgroups_per_group, tiles_x, rows, str
             pick = np.arange(n)
         elif kind == "lpt":
             pick = np.argsort(-c, kind="stable")
+        elif kind == "buckets":  # ("buckets", heavy, runway, per_octave): like "mixed", but the runway falls by cost BUCKET
+            # (`per_octave` buckets per factor of two), spatial order inside a bucket
+            _, heavy, runway, per_octave = rule
+            reference = np.sort(c)[n - 1 - (n - 1) // 4]
+            is_heavy = c > heavy * reference
+            heavy_ones = np.flatnonzero(is_heavy)
+            heavy_ones = heavy_ones[np.argsort(-c[heavy_ones], kind="stable")]
+            rest = np.flatnonzero(~is_heavy)
+            left = c[rest].sum() - np.concatenate(([0.0], np.cumsum(c[rest])[:-1]))
+            budget = runway * reference * workgroups_per_group
+            in_spatial = (left > budget) & (c[rest] >= 0.25 * reference)
+            sp, rw = rest[in_spatial], np.sort(rest[~in_spatial])
+            bucket = np.floor(np.log2(np.maximum(c[rw], 1.0) / reference) * per_octave)
+            rw = rw[np.argsort(-bucket, kind="stable")]
+            pick = np.concatenate((heavy_ones, sp, rw))
         elif kind == "blocks":  # ("blocks", heavy, runway, size): like "mixed", but the runway falls by the mean cost of BLOCKS of `size` spatial neighbours
             _, heavy, runway, size = rule
             reference = np.sort(c)[n - 1 - (n - 1) // 4]
@@ -145,9 +160,14 @@ def main():
               f"; ideal pass with 256 workgroups each: {max(sums) / 256:.4f} ms (largest group), {sum(sums) / 2048:.4f} ms (all groups level)")
         print(f"   {'as installed (blocks of 64 by cost class)':58s} frame {base_ms[0]:.4f} ms (min {base_ms[2]:.4f}), ao {base_ms[1]:.4f}", flush=True)
         rules = [("spatial",), ("lpt",), ("mixed", 2.0, 2.0, 0.25), ("mixed", 1.6, 2.0, 0.25)]
-        for size in (4, 8, 16, 32, 64):
-            for runway in (2.0, 3.0, 6.0):
-                rules.append(("blocks", 2.0, runway, size))
+        if os.environ.get("OCRT_ORDER_BLOCKS"):
+            for size in (4, 8, 16, 32, 64):
+                for runway in (2.0, 3.0, 6.0):
+                    rules.append(("blocks", 2.0, runway, size))
+        if os.environ.get("OCRT_ORDER_BUCKETS"):
+            for per_octave in (1, 2, 4):
+                for runway in (2.0, 3.0, 100.0):
+                    rules.append(("buckets", 2.0, runway, per_octave))
         rules += [("mixed", 2.0, 2.0, 0.25)]
         for rule in rules:
             order = make_order(info["order"], segs, costs, rule, 256, tiles_x, rows, strip_tiles)
@@ -155,6 +175,27 @@ def main():
             ms = timed(host)
             sim = simulate(order, segs, costs)
             print(f"   {str(rule):58s} frame {ms[0]:.4f} ms (min {ms[2]:.4f}), ao {ms[1]:.4f}   model: last workgroup ends {sim[0]:.4f}, mean {sim[1]:.4f}, first {sim[2]:.4f}", flush=True)
+        # iterate: the costs measured UNDER the mixed order (the runway's tiles cost more when their neighbours are not being
+        # walked beside them), the mixed order made again from those, measured again ...
+        if os.environ.get("OCRT_ORDER_ITERATE"):
+            current = costs.copy()
+            for it in range(4):
+                order = make_order(info["order"], segs, current, ("mixed", 2.0, 2.0, 0.25), 256, tiles_x, rows, strip_tiles)
+                host.set_tile_order(order, info["constants"])
+                ms = timed(host)
+                sim = simulate(order, segs, current)
+                print(f"   iteration {it}: mixed(2, 2) from the costs of iteration {it - 1 if it else 'spatial'}: frame {ms[0]:.4f} ms (min {ms[2]:.4f}), ao {ms[1]:.4f}"
+                      f"   model: last {sim[0]:.4f}, mean {sim[1]:.4f}", flush=True)
+                host.measure_tile_costs(3, reorder=False)
+                current = host.tile_order()["costs"] / 3.0
+                print(f"      costs under that order: sum {current[hit].sum() / 1e5:.1f} ms of workgroup time (under the first order {costs[hit].sum() / 1e5:.1f})", flush=True)
+        # the library's own rule (DeviceRenderer::orderByMeasuredCost), with the heaviest tiles claimed half a tile at a time
+        if os.environ.get("OCRT_ORDER_SPLIT"):
+            host.measure_tile_costs(3, reorder=True)
+            for split_above in (0.0, 1.0, 0.5, 0.35, 0.25, 0.18, 0.12, 0.08, 0.0):
+                host.set_order_policy(2.0, 2.0, split_above)
+                ms = timed(host)
+                print(f"   library rule, tiles above {split_above:4.2f} of the pass's ideal length in halves: frame {ms[0]:.4f} ms (min {ms[2]:.4f}), ao {ms[1]:.4f}", flush=True)
         host.set_tile_order(info["order"], info["constants"])
         again = timed(host)
         print(f"   {'as installed, again':58s} frame {again[0]:.4f} ms (min {again[2]:.4f}), ao {again[1]:.4f}", flush=True)
