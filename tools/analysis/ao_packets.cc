@@ -76,6 +76,9 @@ struct Events {
 	unsigned long long fat_appends = 0, fat_pairs = 0, fat_batches = 0, fat_box_tests = 0;  // fat-leaf expansion
 	unsigned long long occluded = 0;
 	unsigned long long own_nodes = 0;                        // node tests of the rays' individual walks (lane work)
+	unsigned long long loads[5] = { 0, 0, 0, 0, 0 };        // dependent loads if one load fetched 2 (the kernel), 3, 4, 6, 8 consecutive nodes
+	unsigned long long odd_loads = 0;                        // ... of the kernel's, those that begin at an odd node: two 64-byte lines
+	unsigned long long line_loads = 0;                       // loads if every load fetched the ALIGNED 64-byte line of the node wanted
 	void add(const Events &e) {
 		const unsigned long long *s = &e.packets;
 		unsigned long long *d = &packets;
@@ -165,6 +168,7 @@ static void walk_packet(const Tree &T, const R *rays, int n, float D, int batch_
 		fat_waiting.erase(fat_waiting.begin(), fat_waiting.begin() + count);
 	};
 	if (to > N.size()) to = N.size();
+	size_t window[5] = { (size_t) -100, (size_t) -100, (size_t) -100, (size_t) -100, (size_t) -100 }, line = (size_t) -1;
 	const size_t n_ranges = ranges ? ranges->size() : 1;
 	for (size_t range = 0; range < n_ranges && live; ++range) {
 	if (ranges) { from = (*ranges)[range].first; to = (*ranges)[range].second; }
@@ -180,6 +184,11 @@ static void walk_packet(const Tree &T, const R *rays, int n, float D, int batch_
 			if (!meets) { i += N[i].skip; continue; }
 			if (holds && N[i].skip > 1) { ++i; continue; }
 		}
+		for (int w = 0; w < 5; ++w) {
+			static const size_t WIDTH[5] = { 2, 3, 4, 6, 8 };
+			if (i < window[w] || i >= window[w] + WIDTH[w]) { ++ev.loads[w]; window[w] = i; if (w == 0) ev.odd_loads += i & 1; }
+		}
+		if ((i >> 1) != line) { ++ev.line_loads; line = i >> 1; }
 		bool hit[64];
 		int hits = 0;
 		for (int l = 0; l < n; ++l) {
@@ -604,6 +613,10 @@ int main(int argc, char **argv) {
 		printf("%-8s %-4s %9s %6s %6s %7s %7s %6s %7s %7s %7s %7s %7s %8s %8s\n", "packets", "fat", "packets", "rays/p", "coh%", "nodes/p", "lanes%", "spot/p", "app/p", "pairs/p", "bat/p", "fatp/p", "fatb/p", "VALU/p", "M VALU");
 		if (entry_ev[c].packets) {
 			const Events &e = entry_ev[c];
+			printf("ENTRY    dependent loads per packet with 2 / 3 / 4 / 6 / 8 consecutive nodes per load: %.1f / %.1f / %.1f / %.1f / %.1f\n", e.loads[0] / (double) e.packets,
+			       e.loads[1] / (double) e.packets, e.loads[2] / (double) e.packets, e.loads[3] / (double) e.packets, e.loads[4] / (double) e.packets);
+			printf("ENTRY    of the kernel's loads %.1f %% begin at an odd node (two lines); fetching the aligned line of the node wanted instead: %.1f loads per packet\n",
+			       100.0 * e.odd_loads / (double) e.loads[0], e.line_loads / (double) e.packets);
 			const double pk = (double) e.packets, cost = M.cost(e, tiles_in[c] * 4);
 			printf("%-8s %-4d %9.0f %6.1f %6.1f %7.1f %7.1f %6.2f %7.1f %7.1f %7.2f %7.1f %7.2f %8.0f %8.1f\n", "ENTRY", 0, pk * scale, e.rays / pk,
 			       100.0 * e.coherent_packets / pk, (e.nodes_coherent + e.nodes_mixed) / pk, 100.0 * e.lane_hits / (double) (e.lane_alive ? e.lane_alive : 1), e.spot_leaves / pk,
