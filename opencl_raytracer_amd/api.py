@@ -176,6 +176,7 @@ _SIGNATURES = {
     # include/rt_hip_debug.h
     "rt_debug_measure_tile_costs": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int]),
     "rt_debug_set_order_policy": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float]),
+    "rt_debug_set_primary_split": (C.c_int, [C.c_void_p, C.c_uint32]),
     "rt_debug_tile_order_slots": (C.c_uint32, [C.c_void_p]),
     "rt_debug_tiles": (C.c_uint32, [C.c_void_p]),
     "rt_debug_tile_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -444,6 +445,10 @@ class Host:
     def measure_tile_costs(self, frames: int = 2, reorder: bool = True) -> None:
         """Measures what the tiles' AO packets cost (include/rt_hip_debug.h) and, with `reorder`, claims them by that."""
         _check(load_library().rt_debug_measure_tile_costs(self._h, int(frames), int(reorder)))
+
+    def set_primary_split(self, above: int) -> None:
+        """Primary pass: tiles of cost class `above` or more are cast in quarters (DeviceRenderer::setPrimarySplit; 0: none)."""
+        _check(load_library().rt_debug_set_primary_split(self._h, int(above)))
 
     def set_order_policy(self, heavy: float, runway: float, split_above: float = -1.0) -> None:
         """How orders are made from measured costs (DeviceRenderer::orderByMeasuredCost); re-orders if costs have been measured."""

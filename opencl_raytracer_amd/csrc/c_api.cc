@@ -490,6 +490,12 @@ int rt_debug_measure_tile_costs(rt_host *h, uint32_t frames, int reorder) {
 	});
 }
 
+int rt_debug_set_primary_split(rt_host *h, uint32_t above) {
+	if (!h)
+		return fail(RT_E_INVALID, "null argument");
+	return guarded([&] { h->dev->setPrimarySplit(above); });
+}
+
 int rt_debug_set_order_policy(rt_host *h, float heavy, float runway, float split_above) {
 	if (!h)
 		return fail(RT_E_INVALID, "null argument");

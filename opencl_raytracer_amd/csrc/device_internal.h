@@ -24,7 +24,7 @@ inline void hip_check(hipError_t err, const char *what) {
 
 constexpr size_t MAX_ENTRY_TABLE_BYTES = (size_t) 2 << 30;
 // (the blocks' coordinates are packed into 16 bits each)
-#define PRIMARY_BY_COST_OK(kp) ((kp).tiles_x < 65536u && (kp).local_tile_rows < 65536u && (kp).shared_walk)
+#define PRIMARY_BY_COST_OK(kp) ((kp).tiles_x < 8192u && (kp).local_tile_rows < 8192u && (kp).shared_walk)  // (13 bits each in an entry of the list)
 constexpr uint32_t MAX_STRIP_TILES = 32u;
 constexpr size_t BIG_SCENE_BYTES = (size_t) 96 << 20;  // three times the L2s
 

@@ -142,7 +142,8 @@ DeviceRenderer::DeviceRenderer(const RayTracer::Options &options, int device_, u
 	{  // (2 x 2 tile blocks: whole strips x pairs of rows)
 		const size_t padded_x = (size_t) ((kp.tiles_x + MAX_STRIP_TILES - 1) / MAX_STRIP_TILES) * MAX_STRIP_TILES;
 		d_primary_order = device_alloc((padded_x / 2 * ((kp.local_tile_rows + 1) / 2) + 1) * sizeof(uint32_t));
-		d_blocks_by_cost = device_alloc((padded_x / 2 * ((kp.local_tile_rows + 1) / 2) + 1) * sizeof(uint32_t));
+		blocks_by_cost_capacity = padded_x / 2 * ((kp.local_tile_rows + 1) / 2) + 8;
+		d_blocks_by_cost = device_alloc(blocks_by_cost_capacity * sizeof(uint32_t));
 	}
 	d_tile_ready = device_alloc((tile_count ? tile_count : 1) * sizeof(uint32_t));
 	OCRT_HIP(hipMemsetAsync(d_tile_ready, 0, (tile_count ? tile_count : 1) * sizeof(uint32_t), (hipStream_t) stream));
@@ -311,10 +312,8 @@ void DeviceRenderer::sizeHitList(const DeviceRenderer *layout_from) {
 			OCRT_HIP(hipMemcpyAsync(tile_words.data(), d_tile_hits, tile_count * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t) stream));
 			OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));
 			queue_static = {};
-			order_host.assign(1, 0u);
-			orderPrimaryBlocks();
-			order_host.clear();
-			OCRT_HIP(hipMemcpy(d_blocks_by_cost, blocks_by_cost_host.data(), blocks_by_cost_host.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+			orderBlocksByCost();
+			uploadBlocksByCost();
 		}
 		return;
 	}
@@ -467,7 +466,7 @@ void DeviceRenderer::launchFrame(void *device_u8, void *ao_start, void *ao_stop,
 		OCRT_HIP(hipGetLastError());
 	} else {
 		launch_primary(scene, (float *) d_image, d_hits, d_occluded, d_tile_hits, d_tile_base, d_counters, kp, stream,
-		               primary_by_cost && PRIMARY_BY_COST_OK(kp) && blocks_by_cost_host.size() > 1 ? d_blocks_by_cost : nullptr);
+		               primary_by_cost && PRIMARY_BY_COST_OK(kp) && kp.primary_list_stride ? d_blocks_by_cost : nullptr);
 		OCRT_HIP(hipGetLastError());
 #ifdef OCRT_STAMPS  // (instrumented build: the AO pass takes the minimum of its waves' start times into this slot)
 		OCRT_HIP(hipMemsetAsync((char *) d_counters + offsetof(FrameCounters, stamp) + 7 * sizeof(unsigned long long), 0xFF, sizeof(unsigned long long), s));

@@ -176,6 +176,9 @@ class DeviceRenderer {
 		void takeOrderFrom(const DeviceRenderer &other);
 		bool orderIsMeasured() const { return tile_cost.size() == tile_count && tile_count != 0; }
 		void setOrderPolicy(float heavy, float runway, float split_above = -1.0f);  // (split_above < 0: unchanged)
+		// primary pass: tiles of cost class `above` or more (the leaves their packet stops at, 1 ... 64) are cast in quarters by
+		// the four waves of a workgroup (0: none); re-makes the pass's list
+		void setPrimarySplit(uint32_t above);
 		// 0: the library's rule (two kernels), 1: fused, 2: two kernels -- same results
 		void setFrameForm(int form);
 		bool frameIsFused() const { return fusedFrame(); }
@@ -252,8 +255,11 @@ class DeviceRenderer {
 		std::array<uint32_t, XCD_GROUPS> primary_blocks{};    // ... and how many each group has
 		std::vector<uint32_t> blocks_by_cost_host;            // primary_kernel: the groups' 2 x 2 blocks by falling cost (0xFFFFFFFF: no block)
 		void *d_blocks_by_cost = nullptr;
+		size_t blocks_by_cost_capacity = 0;  // (entries)
 		bool primary_by_cost = true;
 		void orderPrimaryBlocks();
+		void orderBlocksByCost();
+		void uploadBlocksByCost();
 		// Which form a frame with UNIFORM ambient occlusion takes: two kernels (the rule), or the two ray passes as one
 		// persistent launch (kernels/frame.hip.h: built, bit-exact, measured slower -- fusedFrame() says by how much).
 		enum class FrameForm { AUTO, FUSED, SEPARATE } frame_form = FrameForm::AUTO;
@@ -263,6 +269,7 @@ class DeviceRenderer {
 		struct OrderPolicy {  // (orderByMeasuredCost; swept in profiles/r05_order_policies.txt)
 			float heavy = 2.0f;   // tiles beyond this many reference costs (the upper quartile) are claimed first
 			float runway = 2.0f;  // what is held back for the end, by falling cost: this many reference claims per workgroup
+			uint32_t primary_split_above = 64;  // primary pass: tiles of this cost class (leaves their packet stops at, 1 ... 64) or more are cast in quarters (0: none)
 			float split_above = 0.25f;  // tiles that cost more than this share of the pass's ideal length: half a tile per claim (0: none)
 		} order_policy;
 		void orderTiles();

@@ -147,6 +147,7 @@ struct KernelParams {
 	                       // 2 by default (the finest deal: best balance, and a cache-resident scene does not care), wider for
 	                       // scenes far beyond the L2s, whose XCDs should not all fetch the same geometry (device_renderer.cc)
 	uint32_t primary_ahead; // fused frame kernel: how many 2 x 2 blocks beyond what a claim needs the group's primary work is taken (kernels/primary.hip.h, primary_top_up)
+	uint32_t primary_list_stride;  // primary_kernel with a list of its groups' blocks (DeviceRenderer::orderPrimaryBlocks): entries per group -- the grid is 8 x this; 0: no list
 	uint32_t entry_stride; // walk intervals per tile (kernels.hip, entry_kernel): 1 + ao_dirs, or 1 where that table would be too large
 	uint32_t tiles_x;      // tiles per image row
 	uint32_t local_tile_rows;  // tile rows this rank owns

@@ -129,6 +129,9 @@ uint32_t ocml_ao_table(void *table, uint32_t rings, int alpha_min, int alpha_max
 
 // The frame is three kernels (two without ambient occlusion): primary pass (+ ordering step in its tail), the
 // ambient-occlusion pass, the finishing kernel (AO factor + box filter + quantisation).
+#ifdef OCRT_PRIMARY_TICKS
+extern void *primary_ticks_probe;
+#endif
 void launch_primary(const SceneBuffers &scene, float *image, void *hits, void *occluded_of, void *tile_hits,
                     const void *tile_base, void *counters, const KernelParams &P, void *stream, const void *blocks_by_cost) {
 	hipStream_t s = (hipStream_t) stream;
@@ -138,7 +141,9 @@ void launch_primary(const SceneBuffers &scene, float *image, void *hits, void *o
 	if (P.tiles_x * P.local_tile_rows == 0)
 		return;
 	const uint32_t strips = (P.tiles_x + P.strip_tiles - 1u) / P.strip_tiles, row_blocks = (P.local_tile_rows + PRIMARY_ROWS - 1u) / PRIMARY_ROWS;
-	const uint32_t blocks = XCD_GROUPS * ((strips + XCD_GROUPS - 1u) >> 3) * row_blocks * (P.strip_tiles >> 1);
+	// (with a list -- DeviceRenderer::orderPrimaryBlocks -- every group's workgroups take its entries one by one)
+	const uint32_t blocks = blocks_by_cost && P.primary_list_stride && PRIMARY_WAVES == 4u ? XCD_GROUPS * P.primary_list_stride
+	                                                                                        : XCD_GROUPS * ((strips + XCD_GROUPS - 1u) >> 3) * row_blocks * (P.strip_tiles >> 1);
 	auto launch = [&](auto kernel) {
 		FrameArgs args{};
 		args.walk_ptr = (const float4 *) scene.walk;
@@ -151,7 +156,10 @@ void launch_primary(const SceneBuffers &scene, float *image, void *hits, void *o
 		args.tile_hits = (uint32_t *) tile_hits;
 		args.tile_base = (const uint32_t *) tile_base;
 		args.counters = (FrameCounters *) counters;
-		args.primary_order = (const uint32_t *) blocks_by_cost;  // (null: the spatial mapping)
+		args.primary_order = P.primary_list_stride && PRIMARY_WAVES == 4u ? (const uint32_t *) blocks_by_cost : nullptr;  // (null: the spatial mapping)
+#ifdef OCRT_PRIMARY_TICKS
+		args.tile_cost = (uint32_t *) primary_ticks_probe;
+#endif
 		args.P = P;
 		hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64 * PRIMARY_WAVES), 0, s, args);
 	};
@@ -161,6 +169,10 @@ void launch_primary(const SceneBuffers &scene, float *image, void *hits, void *o
 #endif
 	launch(primary_kernel<true>);
 }
+
+#ifdef OCRT_PRIMARY_TICKS
+void *primary_ticks_probe = nullptr;  // (probe build: set by DeviceRenderer::measureTileCosts around its frames)
+#endif
 
 // Fills `tile_entry` (1 + ao_dirs intervals of two words per tile) for the frame whose hit list is in `hits`: once per
 // upload (entry_kernel).

@@ -221,7 +221,11 @@ __device__ __forceinline__ void ao_pass(const FrameArgs &A, TileShared *shared_t
 				// the workgroup -- every wave has left it, that is what the barrier above says -- goes to its tiles, by their
 				// share of its units; this claim's first unit, its end and the clock go where the next one finds them.
 				uint32_t *const tile_cost = OCRT_COLD_PTR(uint32_t *, tile_cost);
+#ifdef OCRT_PRIMARY_TICKS
+				if (false) {
+#else
 				if (tile_cost) {
+#endif
 					const uint32_t now = (uint32_t) __builtin_amdgcn_s_memrealtime();
 					const uint32_t before_first = wg_claim[4], before_end = wg_claim[5], before_clock = wg_claim[6], before_segment = wg_claim[7];
 					if (before_end > before_first) {

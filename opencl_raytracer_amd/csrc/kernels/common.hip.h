@@ -320,6 +320,44 @@ __device__ __forceinline__ bool tri_any_hit(const float4 q0, const float4 q1, co
 	return accepted & !reject;
 }
 
+// The closest-hit walk's form: a candidate is accepted or rejected as in tri_any_hit (the reference's decision, by products),
+// and what is kept of an accepted one is the reference's distance alone (src/intersect_kernel.cl:104-105) -- the
+// barycentrics are wanted for ONE triangle per ray, the nearest, and the walk's epilogue runs the reference's test on that
+// one (primary_tile): two divisions per ray instead of two per candidate.
+struct Candidate {
+	bool accepted;
+	float distance;
+};
+__device__ __forceinline__ Candidate tri_candidate(const float4 q0, const float4 q1, const float4 q2, const float4 q3, float inv_d,
+                                                   const Ray &r) {
+	const float tax = q0.x, tay = q0.y, taz = q0.z;
+	const float ux = q0.w, uy = q1.x, uz = q1.y;
+	const float vx = q1.z, vy = q1.w, vz = q2.x;
+	const float nx = q2.y, ny = q2.z, nz = q2.w;
+	const float uu = q3.x, uv = q3.y, vv = q3.z, D = q3.w;
+	Candidate out = { false, 0.0f };
+	const float a = -dot3(nx, ny, nz, r.ox - tax, r.oy - tay, r.oz - taz);
+	const float b = dot3(nx, ny, nz, r.dx, r.dy, r.dz);
+	const float rr = a / b;
+	const bool reject = (fabsf(b) < 0.000001f) | (rr < 0.0f);
+	if (wave_ballot(!reject) == 0ull)
+		return out;
+	const float ipx = r.ox + rr * r.dx, ipy = r.oy + rr * r.dy, ipz = r.oz + rr * r.dz;
+	const float wx = ipx - tax, wy = ipy - tay, wz = ipz - taz;
+	const float wu = dot3(ux, uy, uz, wx, wy, wz);
+	const float wv = dot3(wx, wy, wz, vx, vy, vz);
+	const float X = uv * wv - vv * wu, Y = uv * wu - uu * wv;  // the numerators of s and t
+	const unsigned int zone = tri_zone(X, Y, inv_d);
+	bool accepted = zone == 1u;
+	if (wave_ballot(!reject & (zone == 2u)) != 0ull)
+		accepted = zone == 2u ? tri_accepts_exact(X, Y, D) : accepted;
+	out.accepted = accepted & !reject;
+	if (wave_ballot(out.accepted) == 0ull)
+		return out;
+	out.distance = length3(ipx - r.ox, ipy - r.oy, ipz - r.oz);
+	return out;
+}
+
 // Leaf records are 96 bytes: the leaf's own box (float4 0, 1), then the triangle (float4 2..5).
 constexpr uint32_t LEAF_BYTES = 96u, LEAF_TRI_OFFSET = 32u, LEAF_F4 = 6u, LEAF_TRI_F4 = 2u;
 

@@ -77,8 +77,15 @@ __device__ __forceinline__ bool is_pending(uint32_t bits) { return (bits & 0xFFF
 // HANDOFF: the tile's hit records are read by another workgroup of the SAME launch (the fused frame kernel): they are
 // stored device-coherently (kernels/handoff.hip.h); the caller drains the stores and raises the tile's flag.
 // `cb`: this wave's LDS slice for the leaves it tests 64 pairs at a time.
+// `part`: WHOLE_TILE, or 0..3 -- one QUARTER of the tile (4 x 4 sub-pixels), the other three being cast by the other waves of
+// this workgroup at the same time (primary_kernel: the tiles whose packets stop at the most leaves are the critical path of
+// the pass -- one wave, up to ~120 us of dependent loads where the pass takes 120 -- and a quarter's packet stops at a
+// fraction of them).  The quarters meet once, for the tile's hit mask (`quarter_hits`: four LDS words): a hit's slot in the
+// list is its rank among ALL the tile's hits.  Which rays share a packet never changes what a ray finds.
+constexpr uint32_t WHOLE_TILE = 4u;
 template <bool SHARED, bool HANDOFF = false>
-__device__ __forceinline__ void primary_tile(const FrameArgs &A, ClosestBatch &cb, uint32_t tile_x, uint32_t local_row) {
+__device__ __forceinline__ void primary_tile(const FrameArgs &A, ClosestBatch &cb, uint32_t tile_x, uint32_t local_row, uint32_t part = WHOLE_TILE,
+                                             unsigned long long *quarter_hits = nullptr) {
 	// What the tile needs of the launch constants is READ HERE, by loads the compiler can neither hoist nor merge (cold_u32):
 	// in the fused frame kernel this function sits inside the claim loops of a persistent workgroup, and constants held
 	// across the ambient-occlusion pass's walks would be spilled to VGPR lanes there (FrameArgs); a wave of primary_kernel
@@ -108,7 +115,7 @@ __device__ __forceinline__ void primary_tile(const FrameArgs &A, ClosestBatch &c
 	const uint32_t tile_y = global_tile_row(P.part, local_row);
 	const uint32_t x = tile_x * TILE_W + (lane & 7u);
 	const uint32_t y = tile_y * TILE_H + (lane >> 3);
-	const bool active = x < P.width && y < P.height;
+	const bool active = x < P.width && y < P.height && (part == WHOLE_TILE || (((lane >> 2) & 1u) | ((lane >> 4) & 2u)) == part);
 	// the float image holds this rank's bands only, one after the other: row `local_y` of it is image row `y`
 	const uint32_t local_y = local_row * TILE_H + (lane >> 3);
 	const uint32_t count = P.node_count;
@@ -168,7 +175,9 @@ __device__ __forceinline__ void primary_tile(const FrameArgs &A, ClosestBatch &c
 					const uint32_t leaf = pair & 0x03FFFFFFu;
 					const float4 lo = load_f4(scene.tris, leaf * LEAF_BYTES), hi = load_f4(scene.tris, leaf * LEAF_BYTES + 16u);
 					if (exact_leaf_gate(lo, hi, theirs, P.primary_below)) {
-						const TriResult tr = tri_test<true>(scene.tris, leaf, theirs);
+						const uint32_t at = leaf * LEAF_BYTES + LEAF_TRI_OFFSET;
+						const Candidate tr = tri_candidate(load_f4(scene.tris, at), load_f4(scene.tris, at + 16u), load_f4(scene.tris, at + 32u),
+						                                   load_f4(scene.tris, at + 48u), hi.w, theirs);
 						if (tr.accepted) {
 							atomicMin(&cb.best_key[owner], key_of(tr.distance, leaf));
 							atomicOr(&cb.hit_bits[owner >> 5], 1u << (owner & 31));
@@ -195,7 +204,7 @@ __device__ __forceinline__ void primary_tile(const FrameArgs &A, ClosestBatch &c
 					const float4 *rec = tris_ptr + LEAF_F4 * leaf;
 					const float4 lo = rec[0], hi = rec[1], q0 = rec[2], q1 = rec[3], q2 = rec[4], q3 = rec[5];
 					if (((hit_mask >> lane) & 1ull) && exact_leaf_gate(lo, hi, ray, P.primary_below)) {
-						const TriResult tr = tri_eval<true>(q0, q1, q2, q3, ray);
+						const Candidate tr = tri_candidate(q0, q1, q2, q3, hi.w, ray);
 						if (tr.accepted) {
 							hit = true;
 							const unsigned long long key = key_of(tr.distance, leaf);
@@ -301,12 +310,18 @@ __device__ __forceinline__ void primary_tile(const FrameArgs &A, ClosestBatch &c
 	const bool want_ao = OCRT_PCOLD_U32(P.ao_mode) != (uint32_t) AO_NONE && OCRT_PCOLD_U32(P.ao_dirs) > 0u;
 	const uint32_t image_width = OCRT_PCOLD_U32(P.width);
 	// the tile's hits go into the tile's own 64 slots of the hit list, compacted
-	const unsigned long long hit_mask = wave_ballot(hit);
+	unsigned long long hit_mask = wave_ballot(hit);
+	if (part != WHOLE_TILE) {
+		if (lane == 0u)
+			quarter_hits[part] = hit_mask;
+		__syncthreads();
+		hit_mask = (quarter_hits[0] | quarter_hits[1]) | (quarter_hits[2] | quarter_hits[3]);
+	}
 	const uint32_t hit_count = (uint32_t) __popcll(hit_mask);
 	const uint32_t slot_in_tile = rank_in(hit_mask);
 	if (active)  // final already, or the tag that says which slot will bring the ambient-occlusion factor
 		OCRT_PCOLD_PTR(float *, image)[(size_t) local_y * image_width + x] = (hit && want_ao) ? __uint_as_float(PENDING_TAG | slot_in_tile) : value;
-	if (lane == 0u) {
+	if (lane == 0u && part == WHOLE_TILE) {  // (a tile cast in quarters keeps the word the upload's counting pass wrote: the same hits, its whole packet's leaves)
 		// hit count, and above it the tile's AO cost class 1..64 for the ordering step: its 28 AO packets
 		// walk about as far as the primary packet did (correlation 0.8-0.9, tools/analysis/packet_union.cc).
 		// The hit count does not predict the cost at all: a sparse tile's packets mix several directions
@@ -352,6 +367,7 @@ __device__ __forceinline__ void primary_tile(const FrameArgs &A, ClosestBatch &c
 #endif
 constexpr uint32_t PRIMARY_WAVES = OCRT_PRIMARY_WAVES;  // 4, 8 or 16: a workgroup covers a block of tiles 2 wide and PRIMARY_WAVES / 2 high
 constexpr uint32_t PRIMARY_ROWS = PRIMARY_WAVES / 2u;
+constexpr uint32_t PRIMARY_NO_ENTRY = 0xFFFFFFFFu;  // (an empty place in primary_kernel's list)
 
 template <bool SHARED>
 __global__ __launch_bounds__(64 * PRIMARY_WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void primary_kernel(PrimaryArgs A) {
@@ -369,7 +385,26 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) __attribute__((amdgpu_waves_per
 		}
 	}
 	const uint32_t group = blockIdx.x & (XCD_GROUPS - 1u), seq = blockIdx.x >> 3;
-	{
+	__shared__ unsigned long long quarter_hits[4];
+#ifdef OCRT_PRIMARY_TICKS  // (a probe build: how long each tile's wave lives, in 10 ns ticks, where a measuring frame's costs go)
+	__shared__ uint32_t tick0[PRIMARY_WAVES][2];  // (in LDS: scalar registers held across the walk would be spilled there)
+#endif
+	uint32_t tile_x, local_row, part = WHOLE_TILE;
+	bool there;
+	if (PRIMARY_WAVES == 4u && A.primary_order != nullptr) {
+		// With a list of the group's work by falling cost (DeviceRenderer::orderPrimaryBlocks, once per upload: the leaves each
+		// tile's primary packet stops at are the same in every frame) workgroup `seq` of the group takes entry `seq`: the
+		// model's tiles -- 50-120 us of dependent loads each -- start first, the background's fill in behind them.  An entry
+		// is a 2 x 2 block of tiles, a wave each (bits 26-29: the waves with nothing to do), or ONE tile for the four waves,
+		// a quarter each (bit 30).
+		const uint32_t entry = A.primary_order[group * A.P.primary_list_stride + seq];
+		there = entry != PRIMARY_NO_ENTRY;
+		const bool quarters = (entry >> 30) & 1u;
+		tile_x = (entry & 0x1FFFu) + (quarters ? 0u : wave & 1u);
+		local_row = ((entry >> 13) & 0x1FFFu) + (quarters ? 0u : wave >> 1);
+		there = there && (quarters || !((entry >> (26u + wave)) & 1u));
+		part = there && quarters ? wave : WHOLE_TILE;
+	} else {
 		const uint32_t strip_tiles = A.P.strip_tiles, columns = strip_tiles >> 1;  // (a workgroup is two tiles wide)
 		const uint32_t strips = (A.P.tiles_x + strip_tiles - 1u) / strip_tiles;
 		const uint32_t row_blocks = (A.P.local_tile_rows + PRIMARY_ROWS - 1u) / PRIMARY_ROWS;
@@ -378,24 +413,24 @@ __global__ __launch_bounds__(64 * PRIMARY_WAVES) __attribute__((amdgpu_waves_per
 		const uint32_t strip_index = seq / per_strip;
 		const uint32_t rest = seq - strip_index * per_strip;
 		const uint32_t row_block = rest / columns;
-		uint32_t tile_x = strip_tiles * (group + XCD_GROUPS * strip_index) + 2u * (rest - row_block * columns) + (wave & 1u);
-		uint32_t local_row = PRIMARY_ROWS * row_block + (wave >> 1);
-		bool there = seq < strips_here * per_strip;
-		// With a list of the group's 2 x 2 blocks by falling cost (DeviceRenderer::orderPrimaryBlocks, once per upload: the
-		// leaves each tile's primary packet stops at are the same in every frame) workgroup `seq` of the group takes entry
-		// `seq`: the model's blocks -- 50-140 us of dependent loads each -- start first, the background's fill in behind them.
-		if (PRIMARY_WAVES == 4u && A.primary_order != nullptr && there) {
-			uint32_t segment = 0u;
-			for (uint32_t g = 0; g < group; ++g)
-				segment += ((strips + XCD_GROUPS - 1u - g) >> 3) * per_strip;
-			const uint32_t block = A.primary_order[segment + seq];
-			there = block != 0xFFFFFFFFu;
-			tile_x = (block & 0xFFFFu) + (wave & 1u);
-			local_row = (block >> 16) + (wave >> 1);
-		}
-		if (there && tile_x < A.P.tiles_x && local_row < A.P.local_tile_rows)
-			primary_tile<SHARED>(A, closest_batches[wave], tile_x, local_row);
+		tile_x = strip_tiles * (group + XCD_GROUPS * strip_index) + 2u * (rest - row_block * columns) + (wave & 1u);
+		local_row = PRIMARY_ROWS * row_block + (wave >> 1);
+		there = seq < strips_here * per_strip;
 	}
+	there = there && tile_x < A.P.tiles_x && local_row < A.P.local_tile_rows;
+#ifdef OCRT_PRIMARY_TICKS
+	if ((threadIdx.x & 63u) == 0u) {
+		tick0[wave][0] = (uint32_t) __builtin_amdgcn_s_memrealtime();
+		tick0[wave][1] = there && (part == WHOLE_TILE || part == 0u) ? local_row * A.P.tiles_x + tile_x : 0xFFFFFFFFu;
+	}
+#endif
+	if (there)
+		primary_tile<SHARED>(A, closest_batches[wave], tile_x, local_row, part, quarter_hits);
+#ifdef OCRT_PRIMARY_TICKS
+	uint32_t *const ticks_out = *(uint32_t *const volatile *) ((const char *) __builtin_amdgcn_kernarg_segment_ptr() + offsetof(FrameArgs, tile_cost));
+	if (ticks_out && (threadIdx.x & 63u) == 0u && tick0[threadIdx.x >> 6][1] != 0xFFFFFFFFu)
+		ticks_out[tick0[threadIdx.x >> 6][1]] = (uint32_t) __builtin_amdgcn_s_memrealtime() - tick0[threadIdx.x >> 6][0];
+#endif
 }
 
 // ---------------------------------------------------------------------------

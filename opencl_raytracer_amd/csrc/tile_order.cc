@@ -201,40 +201,92 @@ void DeviceRenderer::orderPrimaryBlocks() {
 		primary_blocks[group] = count;
 		ao_segment += (size_t) strips_here * strip_tiles * rows;
 	}
-	// The same blocks for primary_kernel, whose workgroup `seq` of a group takes entry `seq` of the group's list: by falling
-	// cost (the largest cost class among a block's tiles = the leaves its primary packet stops at; a tile without
-	// ambient-occlusion work carries none: its hit count stands in), spatial order among equals, the background last.
+	if (primary_order_host.empty())
+		primary_order_host.push_back(0u);
+	orderBlocksByCost();
+}
+
+// primary_kernel's list: workgroup `seq` of a group takes entry `seq` of the group's part -- its 2 x 2 blocks of tiles by
+// falling cost (the largest cost class among a block's tiles = the leaves its primary packet stops at; a tile without
+// ambient-occlusion work carries none: its hit count stands in), spatial order among equals, the background last.  A tile
+// of cost class `primary_split_above` or more gets an entry of its own, in front: the four waves of a workgroup cast a
+// QUARTER of it each (kernels/primary.hip.h, primary_tile) -- such a tile's one wave would be the critical path of the pass.
+// Entry: x | row << 13 | (waves with nothing to do) << 26 | (quarters) << 30; `kp.primary_list_stride` entries per group.
+void DeviceRenderer::orderBlocksByCost() {
+	const uint32_t strip_tiles = kp.strip_tiles, columns = strip_tiles >> 1, rows = kp.local_tile_rows, tiles_x = kp.tiles_x;
+	const uint32_t strips = (tiles_x + strip_tiles - 1u) / strip_tiles, row_blocks = (rows + 1u) >> 1;
 	blocks_by_cost_host.clear();
+	kp.primary_list_stride = 0;
+	if (!PRIMARY_BY_COST_OK(kp) || tile_words.size() != (size_t) tiles_x * rows)
+		return;
+	std::array<std::vector<std::pair<uint32_t, uint32_t>>, XCD_GROUPS> lists;  // (cost, entry)
+	size_t stride = 0;
+	const uint32_t split_above = order_policy.primary_split_above;
 	for (uint32_t group = 0; group < XCD_GROUPS; ++group) {
 		const uint32_t strips_here = (strips + XCD_GROUPS - 1u - group) >> 3;
-		std::vector<std::pair<uint32_t, uint32_t>> blocks;  // (cost, entry)
+		auto &list = lists[group];
 		for (uint32_t strip_index = 0; strip_index < strips_here; ++strip_index)
 			for (uint32_t rb = 0; rb < row_blocks; ++rb)
 				for (uint32_t c = 0; c < columns; ++c) {
 					const uint32_t x0 = strip_tiles * (group + XCD_GROUPS * strip_index) + 2u * c, row0 = 2u * rb;
 					if (x0 >= tiles_x)
 						continue;
-					uint32_t cost = 0;
+					uint32_t cost = 0, idle = 0;
 					for (uint32_t k = 0; k < 4u; ++k) {
 						const uint32_t x = x0 + (k & 1u), row = row0 + (k >> 1);
-						if (x < tiles_x && row < rows && (size_t) row * tiles_x + x < tile_words.size()) {
-							const uint32_t word = tile_words[(size_t) row * tiles_x + x];
-							cost = std::max(cost, word >> 8 ? word >> 8 : (word & 0xFFu) ? 1u : 0u);
+						if (x >= tiles_x || row >= rows) {
+							idle |= 1u << k;
+							continue;
+						}
+						const uint32_t word = tile_words[(size_t) row * tiles_x + x];
+						const uint32_t tile_cost_class = word >> 8 ? word >> 8 : (word & 0xFFu) ? 1u : 0u;
+						if (split_above && tile_cost_class >= split_above) {
+							list.push_back({ tile_cost_class, x | row << 13 | 1u << 30 });
+							idle |= 1u << k;
+						} else {
+							cost = std::max(cost, tile_cost_class);
 						}
 					}
-					blocks.push_back({ cost, x0 | row0 << 16 });
+					if (idle != 15u)
+						list.push_back({ cost, x0 | row0 << 13 | idle << 26 });
 				}
-		std::stable_sort(blocks.begin(), blocks.end(), [](const auto &a, const auto &b) { return a.first > b.first; });
-		const size_t at = blocks_by_cost_host.size();
-		blocks_by_cost_host.resize(at + (size_t) strips_here * row_blocks * columns, 0xFFFFFFFFu);
-		for (size_t i = 0; i < blocks.size(); ++i)
-			blocks_by_cost_host[at + i] = blocks[i].second;
+		std::stable_sort(list.begin(), list.end(), [](const auto &a, const auto &b) { return a.first > b.first; });
+		stride = std::max(stride, list.size());
 	}
-	if (blocks_by_cost_host.empty())
-		blocks_by_cost_host.push_back(0xFFFFFFFFu);
-	if (primary_order_host.empty())
-		primary_order_host.push_back(0u);
+	if (stride == 0)
+		return;
+	blocks_by_cost_host.assign(XCD_GROUPS * stride, 0xFFFFFFFFu);
+	for (uint32_t group = 0; group < XCD_GROUPS; ++group)
+		for (size_t i = 0; i < lists[group].size(); ++i)
+			blocks_by_cost_host[group * stride + i] = lists[group][i].second;
+	kp.primary_list_stride = (uint32_t) stride;
 }
+
+// ... and onto the device (the list grows with the tiles cast in quarters)
+void DeviceRenderer::uploadBlocksByCost() {
+	if (blocks_by_cost_host.empty())
+		return;
+	if (blocks_by_cost_host.size() > blocks_by_cost_capacity) {
+		device_free(d_blocks_by_cost);
+		d_blocks_by_cost = nullptr;
+		blocks_by_cost_capacity = blocks_by_cost_host.size();
+		d_blocks_by_cost = device_alloc(blocks_by_cost_capacity * sizeof(uint32_t));
+	}
+	OCRT_HIP(hipMemcpy(d_blocks_by_cost, blocks_by_cost_host.data(), blocks_by_cost_host.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+}
+
+void DeviceRenderer::setPrimarySplit(uint32_t above) {
+	order_policy.primary_split_above = above;
+	if (!scene_ready || blocks_by_cost_host.empty())
+		return;
+	useDevice();
+	synchronize();
+	orderBlocksByCost();
+	uploadBlocksByCost();
+	frame_ready = false;
+	++scene_version;
+}
+
 
 
 void DeviceRenderer::installOrder(const std::vector<uint32_t> &order, const std::array<std::array<uint32_t, 3>, XCD_GROUPS> &constants,
@@ -247,7 +299,7 @@ void DeviceRenderer::installOrder(const std::vector<uint32_t> &order, const std:
 	orderPrimaryBlocks();
 	OCRT_HIP(hipMemcpy(d_primary_order, primary_order_host.data(), primary_order_host.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	OCRT_HIP(hipMemcpy(d_order_need, order_need_host.data(), order_need_host.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-	OCRT_HIP(hipMemcpy(d_blocks_by_cost, blocks_by_cost_host.data(), blocks_by_cost_host.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	uploadBlocksByCost();
 	FrameCounters fresh{};
 	for (uint32_t g = 0; g < XCD_GROUPS; ++g) {
 		fresh.queue[g].work_tiles = constants[g][0];
@@ -265,6 +317,9 @@ void DeviceRenderer::installOrder(const std::vector<uint32_t> &order, const std:
 }
 
 
+#ifdef OCRT_PRIMARY_TICKS
+extern void *primary_ticks_probe;  // (kernels.hip)
+#endif
 bool DeviceRenderer::measureTileCosts(unsigned frames) {
 	if (!scene_ready)
 		throw std::logic_error("measurement before upload");
@@ -279,7 +334,13 @@ bool DeviceRenderer::measureTileCosts(unsigned frames) {
 	try {
 		for (unsigned f = 0; f <= frames; ++f) {  // (the first frame is not counted: code object pages, caches)
 			OCRT_HIP(hipMemsetAsync(d_cost, 0, tile_count * sizeof(uint32_t), (hipStream_t) stream));
+#ifdef OCRT_PRIMARY_TICKS
+			primary_ticks_probe = d_cost;
+#endif
 			launchFrame(nullptr, nullptr, nullptr, d_cost);
+#ifdef OCRT_PRIMARY_TICKS
+			primary_ticks_probe = nullptr;
+#endif
 			OCRT_HIP(hipMemcpyAsync(ticks.data(), d_cost, tile_count * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t) stream));
 			OCRT_HIP(hipStreamSynchronize((hipStream_t) stream));
 			if (f > 0)

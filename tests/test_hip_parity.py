@@ -261,6 +261,28 @@ def test_interior_standin_matches_oracle(rt, oracle):
         host.close()
 
 
+@pytest.mark.parametrize("name", ["bunny_256_s1_a3", "bunny_256_s1_a0", "blob_128x96_s4_a3", "ties_64_s4_a3", "bunny_600_defaults"])
+def test_tiles_cast_in_quarters_change_nothing(rt, golden, scene_for, name):
+    """The primary pass of a stream of frames casts its costliest tiles in quarters, the four waves of a workgroup at once
+    (kernels/primary.hip.h): which rays share a packet never changes what a ray finds -- with every tile in quarters, with
+    some, with none: the same floats, the same hit list (the ambient-occlusion factors), the same tile words."""
+    c = golden["renders"][name]
+    opt = options_for(rt, c)
+    scene, _ = scene_for(c["mesh"], c["bvh"])
+    host = render_hip(rt, scene, opt, frames=STREAM)
+    assert hashlib.sha256(host.download().tobytes()).hexdigest() == c["float_sha256"]
+    words = host.tile_order()["words"].copy()
+    for above in (1, 8, 33, 64, 0):
+        host.set_primary_split(above)
+        for _ in range(2):
+            host.render()
+            assert hashlib.sha256(host.download().tobytes()).hexdigest() == c["float_sha256"], above
+        st = host.stats()
+        assert st["primary_hits"] == c["counters"]["primary_hits"] and st["ao_occluded"] == c["counters"]["ao_occluded"], above
+        assert np.array_equal(host.tile_order()["words"], words), above
+    host.close()
+
+
 @pytest.mark.parametrize("name", ["bunny_256_s1_a3", "blob_128x96_s4_a3", "ties_64_s4_a3", "bunny_600_defaults"])
 def test_measured_tile_order_changes_nothing(rt, golden, scene_for, name):
     """What the AO pass claims first is decided once per upload -- by the cost classes of the counting pass, or, for a
