@@ -53,7 +53,8 @@ def draw_case(rng):
         lookahead=rng.choice([0, 1, 2]),  # (the form of the AO pass: without / with look-ahead loads / as calibrated or by default)
         announce=rng.choice([0, 1, 1]),  # (a blocking host: one-shot, or with a stream of frames announced -- its upload then prepares the walk intervals)
         form=rng.choice(["auto", "auto", "fused"]),  # (a blocking host's frame: two kernels, or both ray passes in one persistent launch -- kernels/frame.hip.h)
-        measure=rng.choice([0, 0, 1]))  # (a blocking host: its tiles claimed by measured cost -- rt_debug_measure_tile_costs)
+        measure=rng.choice([0, 0, 1]),  # (a blocking host: its tiles claimed by measured cost -- rt_debug_measure_tile_costs)
+        quarters=rng.choice([None, None, 1, 4, 16, 40, 0]))  # (the primary pass casts tiles of this cost class or more in quarters -- rt_debug_set_primary_split; None: the default)
 
 
 def run_case(rt, orc, oracle, scenes, case):
@@ -100,6 +101,8 @@ def run_case(rt, orc, oracle, scenes, case):
             host.set_device_share(case["share"])
             if case.get("measure") and hasattr(host, "measure_tile_costs"):
                 host.measure_tile_costs(1)
+            if case.get("quarters") is not None and hasattr(host, "set_primary_split"):
+                host.set_primary_split(case["quarters"])
             if case.get("form", "auto") != "auto" and hasattr(host, "set_frame_form"):
                 host.set_frame_form(case["form"])
                 if hasattr(host, "poison_hit_list"):
