@@ -369,7 +369,9 @@ void DeviceRenderer::sizeHitList(const DeviceRenderer *layout_from) {
 	// ... and, now that there is a hit list, where each tile's any-hit rays enter the walk tree: a second pass of the
 	// primary kernel fills the list, entry_kernel reads the tiles' hit points (kernels.hip; the whole array where the
 	// fast walk is not used).  Like the bases: once per upload.
-	intervals_in_use = kp.fast_walk && scene_on_device->buffers().walk && expected_frames >= FRAMES_WORTH_INTERVALS;
+	// (the intervals are ranges of the centre / half-extent copy of the walk records -- the any-hit packets' --, which
+	// exists where the scaled node test may be used: walk_scale > 0)
+	intervals_in_use = kp.fast_walk && kp.walk_scale > 0.0f && scene_on_device->buffers().walk && expected_frames >= FRAMES_WORTH_INTERVALS;
 	if (intervals_in_use) {
 		launch_primary(scene_on_device->buffers(), (float *) d_image, d_hits, d_occluded, d_tile_hits, d_tile_base, d_counters, kp, stream);
 		launch_entries(scene_on_device->buffers(), d_hits, d_tile_hits, d_tile_base, d_tile_entry, kp, stream);

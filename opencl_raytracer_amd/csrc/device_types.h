@@ -148,6 +148,7 @@ struct KernelParams {
 	                       // scenes far beyond the L2s, whose XCDs should not all fetch the same geometry (device_renderer.cc)
 	uint32_t primary_ahead; // fused frame kernel: how many 2 x 2 blocks beyond what a claim needs the group's primary work is taken (kernels/primary.hip.h, primary_top_up)
 	uint32_t primary_list_stride;  // primary_kernel with a list of its groups' blocks (DeviceRenderer::orderPrimaryBlocks): entries per group -- the grid is 8 x this; 0: no list
+	float prune_margin;  // closest-hit walk: a node whose near distance exceeds a lane's nearest hit so far by more than 1e-5 of it plus this is not entered for that lane (scene_pack: what the reference's 1e-5 slack on s and t lets a hit lie outside its triangle's box)
 	uint32_t entry_stride; // walk intervals per tile (kernels.hip, entry_kernel): 1 + ao_dirs, or 1 where that table would be too large
 	uint32_t tiles_x;      // tiles per image row
 	uint32_t local_tile_rows;  // tile rows this rank owns

@@ -97,9 +97,13 @@ __global__ __launch_bounds__(64 * ENTRY_WAVES) void entry_kernel(const NodeRec *
 		}
 		// ---- its interval (node indices; the walk array keeps byte offsets) ----
 		const auto skip_of = [&](uint32_t n) { return walk[n].skip / (uint32_t) sizeof(NodeRec); };
+		// (`walk`: the records the any-hit packets walk -- the centre / half-extent copy, whose order of children need not be
+		// the plane form's (scene_pack.cc, make_walk_array): lo holds c, hi holds e, and e is padded far beyond the rounding
+		// of c -+ e)
 		const auto meets = [&](uint32_t n) {
 			const NodeRec box = walk[n];
-			return !(box.lo[0] > hi[0] || box.hi[0] < lo[0] || box.lo[1] > hi[1] || box.hi[1] < lo[1] || box.lo[2] > hi[2] || box.hi[2] < lo[2]);
+			return !(box.lo[0] - box.hi[0] > hi[0] || box.lo[0] + box.hi[0] < lo[0] || box.lo[1] - box.hi[1] > hi[1] || box.lo[1] + box.hi[1] < lo[1] ||
+			         box.lo[2] - box.hi[2] > hi[2] || box.lo[2] + box.hi[2] < lo[2]);
 		};
 		uint32_t begin = 0u, end = whole ? whole : 1u;
 		if (!odd && (j == 0u || one_direction)) {

@@ -83,6 +83,11 @@ __device__ __forceinline__ bool is_pending(uint32_t bits) { return (bits & 0xFFF
 // fraction of them).  The quarters meet once, for the tile's hit mask (`quarter_hits`: four LDS words): a hit's slot in the
 // list is its rank among ALL the tile's hits.  Which rays share a packet never changes what a ray finds.
 constexpr uint32_t WHOLE_TILE = 4u;
+// (a value read from LDS at a wave-uniform address, kept in a vector register: nothing makes the compiler look for a scalar one)
+__device__ __forceinline__ float lane_value(float x) {
+	asm volatile("" : "+v"(x));
+	return x;
+}
 template <bool SHARED, bool HANDOFF = false>
 __device__ __forceinline__ void primary_tile(const FrameArgs &A, ClosestBatch &cb, uint32_t tile_x, uint32_t local_row, uint32_t part = WHOLE_TILE,
                                              unsigned long long *quarter_hits = nullptr) {
@@ -193,10 +198,22 @@ __device__ __forceinline__ void primary_tile(const FrameArgs &A, ClosestBatch &c
 			const uint32_t list_lds_address = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (uintptr_t) &cb.entry[0]);  // (low half of the flat address; scalar)
 			const uint32_t end = first + count * 32u;
 			uint32_t at = first;  // byte offset
+			// What the reference does not do and no result can show: a lane that has a hit does not enter boxes that begin
+			// BEHIND it.  The reference walks every box its ray meets below 100000 and keeps the minimum of (distance, leaf);
+			// a triangle whose leaf box begins more than `prune_margin` + 1e-5 of the distance behind the nearest hit so far
+			// cannot bring a distance that is smaller or equal (the margin: how far outside its box the reference's slack of
+			// 1e-5 on s and t lets a hit lie -- scene_pack.cc -- and the rounding of the two distances).  `far_limit` is the
+			// node test's upper limit, per lane; it costs the loop nothing (the operand was a scalar register).
+			float far_limit = P.primary_below;
+			{
+				const float margin = OCRT_COLD_F32(P.prune_margin);
+				if (lane == 0u)
+					cb.prune_margin = margin;
+			}
 			while (alive_mask != 0ull && at < end) {
 				uint32_t leaf = 0u;
 				unsigned long long hit_mask = 0ull;
-				const uint32_t status = walk_collect<false>(variant, walk_ptr, at, walk_ray, sign, P.primary_below, alive_mask, hit_mask,
+				const uint32_t status = walk_collect<false>(variant, walk_ptr, at, walk_ray, sign, far_limit, alive_mask, hit_mask,
 				                                            leaf, waiting, leaf_stops, list_lds_address, lane << 26, P.batch_below);
 				if (status == 0u)
 					break;
@@ -209,6 +226,7 @@ __device__ __forceinline__ void primary_tile(const FrameArgs &A, ClosestBatch &c
 							hit = true;
 							const unsigned long long key = key_of(tr.distance, leaf);
 							my_key = key < my_key ? key : my_key;
+							far_limit = fminf(far_limit, tr.distance * 1.00001f + lane_value(cb.prune_margin));
 						}
 					}
 				} else {
@@ -216,6 +234,10 @@ __device__ __forceinline__ void primary_tile(const FrameArgs &A, ClosestBatch &c
 					waiting -= 64u;
 					if (lane < waiting)  // the pairs beyond the batch move to the front
 						cb.entry[lane] = cb.entry[64u + lane];
+					wave_lds_sync();
+					const uint32_t nearest = (uint32_t) (cb.best_key[lane] >> 32);  // (distance bits; KEY_NONE: all ones)
+					if (nearest < INF_BITS)
+						far_limit = fminf(far_limit, __uint_as_float(nearest) * 1.00001f + lane_value(cb.prune_margin));
 				}
 				at += 32u;
 			}

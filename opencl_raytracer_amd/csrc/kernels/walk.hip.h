@@ -276,7 +276,7 @@ __device__ __forceinline__ u32x8 scalar_load_node(const float4 *nodes_ptr, uint3
 	                                OCRT_FAR_##Y("s57", "s61"), OCRT_FAR_##Z("s58", "s62")), PF)                           \
 	             : [at] "+s"(at), [waiting] "+s"(waiting), [stops] "+s"(leaf_stops), [hit] "=&s"(hit_mask),               \
 	               [leaf] "=&s"(leaf), [status] "=&s"(status)                                                            \
-	             : [base] "s"(walk_ptr), [alive] "s"(alive_mask), [below] "s"(below), [batch_below] "s"(batch_below),     \
+	             : [base] "s"(walk_ptr), [alive] "s"(alive_mask), [below] "v"(below), [batch_below] "s"(batch_below),     \
 	               [list] "s"(list_lds_address), [tag] "v"(lane_tag), [ix] "v"(ray.ix), [iy] "v"(ray.iy), [iz] "v"(ray.iz), \
 	               [oix] "v"(ray.oix), [oiy] "v"(ray.oiy), [oiz] "v"(ray.oiz)                                             \
 	             : OCRT_WALK_CLOBBERS)
@@ -285,7 +285,7 @@ __device__ __forceinline__ u32x8 scalar_load_node(const float4 *nodes_ptr, uint3
 	asm volatile(OCRT_WALK_ASM(OCRT_HEAD_NONE, TEST("s48", "s49", "s50", "s52", "s53", "s54"), TEST("s56", "s57", "s58", "s60", "s61", "s62"), PF) \
 	             : [at] "+s"(at), [waiting] "+s"(waiting), [stops] "+s"(leaf_stops), [hit] "=&s"(hit_mask),               \
 	               [leaf] "=&s"(leaf), [status] "=&s"(status)                                                            \
-	             : [base] "s"(walk_ptr), [alive] "s"(alive_mask), [below] "s"(below), [batch_below] "s"(batch_below),     \
+	             : [base] "s"(walk_ptr), [alive] "s"(alive_mask), [below] "v"(below), [batch_below] "s"(batch_below),     \
 	               [px] "s"(sign.x), [py] "s"(sign.y), [pz] "s"(sign.z), [list] "s"(list_lds_address), [tag] "v"(lane_tag), \
 	               [ix] "v"(ray.ix), [iy] "v"(ray.iy), [iz] "v"(ray.iz), [oix] "v"(ray.oix), [oiy] "v"(ray.oiy),          \
 	               [oiz] "v"(ray.oiz)                                                                                    \
@@ -383,6 +383,8 @@ struct ClosestBatch {
 	unsigned int entry[128];
 	unsigned long long best_key[64];
 	unsigned int hit_bits[2];  // rays with an accepted triangle, whatever its distance (reference :108-113)
+	float prune_margin;        // KernelParams::prune_margin, kept HERE across the walk (a scalar register held across it would be spilled)
+	unsigned int pad;
 };
 constexpr unsigned long long KEY_NONE = ~0ull;
 constexpr uint32_t INF_BITS = 0x7F800000u;

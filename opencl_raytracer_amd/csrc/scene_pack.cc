@@ -166,6 +166,7 @@ PackedScene pack_scene(const std::vector<uint32_t> &faces, const std::vector<uin
 #endif
 	out.tris.resize(tri_count);
 	out.shade.resize(tri_count);
+	double widest_triangle = 0.0, largest_coordinate = 0.0;  // (for prune_margin)
 	for (size_t t = 0; t < tri_count; ++t) {
 		const uint32_t i0 = faces[3 * t], i1 = faces[3 * t + 1], i2 = faces[3 * t + 2];
 		const Vec3f ta = vertices[i0];
@@ -185,6 +186,14 @@ PackedScene pack_scene(const std::vector<uint32_t> &faces, const std::vector<uin
 		r.vv = lib_dot(v, v);
 		r.D = r.uv * r.uv - r.uu * r.vv;
 		r.inv_d = tri_inverse_d(r.D);
+		{
+			const double lu = std::sqrt((double) u.x * u.x + (double) u.y * u.y + (double) u.z * u.z);
+			const double lv = std::sqrt((double) v.x * v.x + (double) v.y * v.y + (double) v.z * v.z);
+			const double coordinate = std::fmax(std::fmax(std::fabs((double) ta.x), std::fabs((double) ta.y)), std::fabs((double) ta.z));
+			// (NaN-proof: a comparison with NaN is false, so a NaN makes the sum below NaN through the `+`)
+			widest_triangle = lu + lv > widest_triangle || !(lu + lv == lu + lv) ? lu + lv : widest_triangle;
+			largest_coordinate = coordinate + lu + lv > largest_coordinate || !(coordinate == coordinate) ? coordinate + lu + lv : largest_coordinate;
+		}
 		ShadeRec &s = out.shade[t];
 		const Vec3f *src[3] = { &vnormals[i0], &vnormals[i1], &vnormals[i2] };
 		float *dst[3] = { s.n0, s.n1, s.n2 };
@@ -194,6 +203,10 @@ PackedScene pack_scene(const std::vector<uint32_t> &faces, const std::vector<uin
 			dst[c][2] = src[c]->z;
 			dst[c][3] = 0.0f;
 		}
+	}
+	{
+		const double margin = 4e-5 * widest_triangle + 1e-5 * largest_coordinate;
+		out.prune_margin = margin == margin && margin < 1e30 ? (float) (margin * 1.0001) + 1e-30f : __builtin_inff();
 	}
 	if (rebuilding.valid()) {
 		std::vector<NodeRec> rebuilt = rebuilding.get();
@@ -343,20 +356,28 @@ WalkArray make_walk_array(const PackedScene &scene, float ao_max_distance) {
 	const bool with_ce = out.ao_scale > 0.0f;
 	const float scaled_reach_of = out.ao_scale > 0.0f ? ao_max_distance * 1.001f : 0.0f;
 	out.nodes.resize(with_ce ? 2 * records : records);
+	// The plane-form records -- the closest-hit walk's, i.e. the primary rays' -- list every node's children nearest to
+	// the camera first (walk_tree.h, nearest_children_first); the centre / half-extent copy -- the any-hit walk's -- keeps
+	// the builder's order (its rays start on the surfaces: measured 4.5 % slower on the bunny in the camera's order).
+	// Without that copy both walks read the one array, in the camera's order.
+	const std::vector<NodeRec> by_camera = debug_knob("OCRT_KEEP_CHILD_ORDER") ? nodes : nearest_children_first(nodes, camera);  // (debug knob)
+	auto padded = [&](const NodeRec &n, double origin[3]) {
+		NodeRec w = n;
+		for (unsigned k = 0; k < 3; ++k) {
+			const double box = std::fmax(std::fabs((double) n.lo[k]), std::fabs((double) n.hi[k]));
+			origin[k] = std::fmin((double) out.origin_limit, std::fmax(camera[k], box + reach));
+			w.lo[k] = padded_bound(n.lo[k], (float) origin[k], false, scaled_reach_of);
+			w.hi[k] = padded_bound(n.hi[k], (float) origin[k], true, scaled_reach_of);
+		}
+		w.skip = n.skip * (uint32_t) sizeof(NodeRec);  // (node count < 2^27, checked at pack time)
+		return w;
+	};
 	auto pad_slice = [&](size_t from, size_t to) {
 		for (size_t i = from; i < to; ++i) {
-			NodeRec w = nodes[i];
 			double origin[3];
-			for (unsigned k = 0; k < 3; ++k) {
-				const double box = std::fmax(std::fabs((double) nodes[i].lo[k]), std::fabs((double) nodes[i].hi[k]));
-				origin[k] = std::fmin((double) out.origin_limit, std::fmax(camera[k], box + reach));
-				w.lo[k] = padded_bound(nodes[i].lo[k], (float) origin[k], false, scaled_reach_of);
-				w.hi[k] = padded_bound(nodes[i].hi[k], (float) origin[k], true, scaled_reach_of);
-			}
-			w.skip = nodes[i].skip * (uint32_t) sizeof(NodeRec);  // (node count < 2^27, checked at pack time)
-			out.nodes[i] = w;
+			out.nodes[i] = padded(by_camera[i], origin);
 			if (with_ce)
-				out.nodes[records + i] = ce_record(w, origin);
+				out.nodes[records + i] = ce_record(padded(nodes[i], origin), origin);
 		}
 	};
 	{
@@ -469,6 +490,7 @@ SceneFacts scene_facts(const PackedScene &scene, const WalkArray &walk) {
 	f.has_walk = !walk.nodes.empty();
 	f.origin_limit = walk.origin_limit;
 	f.ao_scale = walk.ao_scale;
+	f.prune_margin = scene.prune_margin;
 	return f;
 }
 
@@ -492,6 +514,7 @@ KernelParams make_kernel_params(const RayTracer &rt, uint32_t node_count, uint32
 	p.ao_dirs = ao_dirs;
 	p.ao_divisor = p.ao_mode == AO_RANDOM ? ao_dirs - 1 : ao_dirs;
 	p.origin_limit = facts ? facts->origin_limit : 0.0f;
+	p.prune_margin = facts && !debug_knob("OCRT_NO_PRUNE") ? facts->prune_margin : __builtin_inff();  // (debug knob)
 	// (the array's margins hold for the max_distance it was made for: the renderer re-makes it when that changes)
 	p.walk_scale = (facts && facts->ao_scale > 0.0f && facts->ao_scale == walk_scale_for(p.ao_max_distance) &&
 	                walk_scale_usable(facts->ao_scale, facts->origin_limit) &&

@@ -36,6 +36,12 @@ struct PackedScene {
 	bool nested = false;       // ... and every node's box contains its children's boxes (true for any tree built by
 	                           // uniting child boxes; arbitrary uploaded arrays need not be)
 	bool rebuilt = false;      // `nodes` is the rebuilt tree, not the uploaded one
+	// How far in front of its leaf box's near plane a hit of the reference's triangle test can lie (KernelParams::prune_margin):
+	// the test accepts s, t in [-1e-5, 1.00001], i.e. points up to ~1e-5 (|u| + |v|) outside the triangle -- and so outside the
+	// box around its vertices --, and the point, the box planes and the two distances compared carry the rounding of
+	// coordinates of the scene's magnitude.  4e-5 of the largest |u| + |v| plus 1e-5 of the largest coordinate; +inf where
+	// that is not finite (then nothing is ever pruned).
+	float prune_margin = 0.0f;
 	// Optional: the walk array made ahead of the upload (prepare_walk_array) for this AO_MAX_DISTANCE -- CPU work that a
 	// caller can do before it has a device; DeviceRenderer::upload makes its own when this one is absent or was made for
 	// another distance.
@@ -92,6 +98,7 @@ struct SceneFacts {
 	bool regular = false, nested = false, binary_tree = false;  // PackedScene's flags
 	bool has_walk = false;                                       // the padded walk array exists
 	float origin_limit = 0.0f, ao_scale = 0.0f;                  // WalkArray's
+	float prune_margin = 0.0f;                                   // PackedScene's
 };
 SceneFacts scene_facts(const PackedScene &scene, const WalkArray &walk);
 KernelParams make_kernel_params(const RayTracer &rt, uint32_t node_count, uint32_t tri_count, uint32_t ao_dirs,

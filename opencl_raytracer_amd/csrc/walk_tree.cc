@@ -248,6 +248,46 @@ std::vector<NodeRec> contract_walk_tree(const std::vector<NodeRec> &nodes, doubl
 	return out;
 }
 
+std::vector<NodeRec> nearest_children_first(const std::vector<NodeRec> &nodes, const double eye[3]) {
+	std::vector<NodeRec> out;
+	out.reserve(nodes.size());
+	struct Child {
+		double outside, centre;  // squared distances from the eye: to the box, to its centre
+		size_t at;
+	};
+	// (an explicit stack of subtrees still to be written, children pushed farthest first: a degenerate array may be as
+	// deep as it is long)
+	std::vector<size_t> todo;
+	std::vector<Child> children;
+	if (!nodes.empty())
+		todo.push_back(0);
+	while (!todo.empty()) {
+		const size_t i = todo.back();
+		todo.pop_back();
+		out.push_back(nodes[i]);  // (its skip count is that of its subtree: the same nodes, whatever their order)
+		if (nodes[i].skip <= 1)
+			continue;
+		children.clear();
+		for (size_t c = i + 1; c < i + nodes[i].skip && c < nodes.size(); c += nodes[c].skip ? nodes[c].skip : 1) {
+			Child ch{ 0.0, 0.0, c };
+			for (int k = 0; k < 3; ++k) {
+				const double lo = nodes[c].lo[k], hi = nodes[c].hi[k];
+				const double d = eye[k] < lo ? lo - eye[k] : eye[k] > hi ? eye[k] - hi : 0.0;
+				const double m = 0.5 * lo + 0.5 * hi - eye[k];
+				ch.outside += d * d;
+				ch.centre += m * m;
+			}
+			children.push_back(ch);
+		}
+		std::stable_sort(children.begin(), children.end(), [](const Child &a, const Child &b) {
+			return a.outside < b.outside || (a.outside == b.outside && a.centre < b.centre);
+		});
+		for (size_t k = children.size(); k-- > 0;)
+			todo.push_back(children[k].at);
+	}
+	return out;
+}
+
 std::vector<NodeRec> rebuild_walk_tree(const std::vector<NodeRec> &packed) {
 	Builder b;
 	b.leaves.reserve((packed.size() + 1) / 2);

@@ -31,4 +31,12 @@ std::vector<NodeRec> contract_walk_tree(const std::vector<NodeRec> &nodes, doubl
 // is nested by construction.  `packed` must be a regular binary tree.
 std::vector<NodeRec> rebuild_walk_tree(const std::vector<NodeRec> &packed);
 
+// The same tree with every node's children in the order of their boxes' distance from `eye` (the nearest point of the
+// box; the box's centre among boxes the eye lies in), nearest first.  The order of a node's children is the order a walk
+// meets them in, and every PRIMARY ray starts at the eye (reference src/intersect_kernel.cl:284-286: (0, 0, 2),
+// whatever the options): a closest-hit walk then tends to find its nearest triangle before it meets the boxes behind it
+// -- which a lane with a hit does not enter (kernels/primary.hip.h, far_limit).  No result depends on the order: the
+// closest hit is the minimum of (distance, leaf), an any-hit ray needs some accepted triangle.
+std::vector<NodeRec> nearest_children_first(const std::vector<NodeRec> &nodes, const double eye[3]);
+
 }  // namespace ocrt

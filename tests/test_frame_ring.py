@@ -274,6 +274,10 @@ def test_full_size_frames_split_over_ranks_reassemble(rt, golden, scene_for, nam
         ring = rt.FrameRing(opt, scene, 0, rank, nranks, hosts=2)
         rows = rt.partition_rows(opt, rank, nranks)
         assert ring.local_rows == rows.size
+        if rank == 1:  # (one share with EVERY tile of its bands cast in quarters by the primary pass, one with none)
+            ring.host(1).set_primary_split(1)
+        elif rank == 2:
+            ring.host(1).set_primary_split(0)
         ring.submit()
         ring.submit()
         ring.collect_info()
