@@ -78,7 +78,9 @@ int rt_ring_rccl_self_test(rt_ring *r);  /* grouped self send/recv on the ring's
 int rt_debug_measure_tile_costs(rt_host *h, uint32_t frames, int reorder);
 int rt_debug_set_order_policy(rt_host *h, float heavy, float runway, float split_above);  /* split_above < 0: unchanged */
 /* The primary pass casts tiles whose packet stops at `above` leaves or more (their cost class, 1 ... 64) in quarters, the four
- * waves of a workgroup at once (DeviceRenderer::setPrimarySplit; 0: none).  Results never depend on it. */
+ * waves of a workgroup at once (DeviceRenderer::setPrimarySplit; 0: none) -- however many tiles that is: the rule an upload
+ * applies by itself (class 64) stands back where more than an eighth of the chip's wave slots' worth of tiles qualify.
+ * Results never depend on it. */
 int rt_debug_set_primary_split(rt_host *h, uint32_t above);
 uint32_t rt_debug_tile_order_slots(rt_host *h);
 uint32_t rt_debug_tiles(rt_host *h);

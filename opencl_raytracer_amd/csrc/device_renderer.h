@@ -256,6 +256,7 @@ class DeviceRenderer {
 		std::vector<uint32_t> blocks_by_cost_host;            // primary_kernel: the groups' 2 x 2 blocks by falling cost (0xFFFFFFFF: no block)
 		void *d_blocks_by_cost = nullptr;
 		size_t blocks_by_cost_capacity = 0;  // (entries)
+		size_t primary_quartered = 0;        // tiles the primary pass casts in quarters (orderBlocksByCost)
 		bool primary_by_cost = true;
 		void orderPrimaryBlocks();
 		void orderBlocksByCost();
@@ -269,6 +270,7 @@ class DeviceRenderer {
 		struct OrderPolicy {  // (orderByMeasuredCost; swept in profiles/r05_order_policies.txt)
 			float heavy = 2.0f;   // tiles beyond this many reference costs (the upper quartile) are claimed first
 			float runway = 2.0f;  // what is held back for the end, by falling cost: this many reference claims per workgroup
+			uint32_t primary_split_waves = 4096;  // ... unless those tiles, four waves each, are more than this many waves (half the chip's slots: then the slots are full anyway)
 			uint32_t primary_split_above = 64;  // primary pass: tiles of this cost class (leaves their packet stops at, 1 ... 64) or more are cast in quarters (0: none)
 			float split_above = 0.25f;  // tiles that cost more than this share of the pass's ideal length: half a tile per claim (0: none)
 		} order_policy;

@@ -221,7 +221,24 @@ void DeviceRenderer::orderBlocksByCost() {
 		return;
 	std::array<std::vector<std::pair<uint32_t, uint32_t>>, XCD_GROUPS> lists;  // (cost, entry)
 	size_t stride = 0;
-	const uint32_t split_above = order_policy.primary_split_above;
+	// Quarters shorten the pass where a FEW tiles are its critical path; they are extra work (a quarter's packet walks
+	// most of what the tile's did) where the chip's wave slots are full anyway: a 2 M-triangle height field, nearly every
+	// tile of which stops at 64 leaves or more, casts its primary rays in 0.31 ms whole and 0.42 ms in quarters.  So: only
+	// if the tiles that qualify, four waves each, take no more than `primary_split_waves` of the 8 192 wave slots the chip
+	// has at one time (256 CUs x 32 waves).
+	uint32_t split_above = order_policy.primary_split_above;
+	if (split_above) {
+		size_t qualifying = 0;
+		for (uint32_t word : tile_words)
+			qualifying += (word >> 8) >= split_above;
+		primary_quartered = qualifying;
+		if (qualifying * 4u > order_policy.primary_split_waves) {
+			split_above = 0;
+			primary_quartered = 0;
+		}
+	} else {
+		primary_quartered = 0;
+	}
 	for (uint32_t group = 0; group < XCD_GROUPS; ++group) {
 		const uint32_t strips_here = (strips + XCD_GROUPS - 1u - group) >> 3;
 		auto &list = lists[group];
@@ -277,6 +294,7 @@ void DeviceRenderer::uploadBlocksByCost() {
 
 void DeviceRenderer::setPrimarySplit(uint32_t above) {
 	order_policy.primary_split_above = above;
+	order_policy.primary_split_waves = 0xFFFFFFFFu;  // (asked for by name: however many tiles that is)
 	if (!scene_ready || blocks_by_cost_host.empty())
 		return;
 	useDevice();

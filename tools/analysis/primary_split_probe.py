@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import opencl_raytracer_amd as rt  # noqa: E402
 from bench import WORKLOADS, load_scene, workload_options  # noqa: E402
 
-ABOVE = [0, 64, 56, 48, 40, 32, 24, 16, 8]
+ABOVE = [0, 64, 56, 48, 40, 32, 24, 16, 8] if "OCRT_SWEEP_ALL" in os.environ else [0, 64, 48]
 for name in sys.argv[1:] or ["bunny_1080p_ao"]:
     w = WORKLOADS[name]
     opt = workload_options(rt, w)
@@ -19,6 +19,8 @@ for name in sys.argv[1:] or ["bunny_1080p_ao"]:
     host = ring.host(0)
     ring.run(20)
     ring.drain()
+    words = host.tile_order()["words"]
+    print(f"{name}: {int((words & 0xFF != 0).sum())} tiles with hits of {len(words)}, cost class 64: {int(((words >> 8) >= 64).sum())}, >= 48: {int(((words >> 8) >= 48).sum())}", flush=True)
     frame, primary = {a: [] for a in ABOVE}, {a: [] for a in ABOVE}
     for rep in range(5):
         for a in ABOVE:
