@@ -148,7 +148,10 @@ struct KernelParams {
 	                       // scenes far beyond the L2s, whose XCDs should not all fetch the same geometry (device_renderer.cc)
 	uint32_t primary_ahead; // fused frame kernel: how many 2 x 2 blocks beyond what a claim needs the group's primary work is taken (kernels/primary.hip.h, primary_top_up)
 	uint32_t primary_list_stride;  // primary_kernel with a list of its groups' blocks (DeviceRenderer::orderPrimaryBlocks): entries per group -- the grid is 8 x this; 0: no list
-	float prune_margin;  // closest-hit walk: a node whose near distance exceeds a lane's nearest hit so far by more than 1e-5 of it plus this is not entered for that lane (scene_pack: what the reference's 1e-5 slack on s and t lets a hit lie outside its triangle's box)
+	float prune_margin;  // closest-hit walk: a lane with a hit at distance d does not enter boxes whose near distance exceeds d (1 + 1e-5) + this (scene_pack.cc, make_walk_array: the rounding of the distances; +inf: no pruning in this scene)
+	uint32_t unpruned_bytes;  // ... and while the walk is below this byte offset of the plane-form records no lane's limit is lowered (the faces no box can promise anything about: make_walk_array)
+	uint32_t primary_walk_bytes;  // bytes of the plane-form walk records (the primary rays' tree; END records behind them)
+	uint32_t walk_ce_bytes;       // byte offset of the centre / half-extent records (the any-hit rays' tree) in the walk array; 0: none
 	uint32_t entry_stride; // walk intervals per tile (kernels.hip, entry_kernel): 1 + ao_dirs, or 1 where that table would be too large
 	uint32_t tiles_x;      // tiles per image row
 	uint32_t local_tile_rows;  // tile rows this rank owns

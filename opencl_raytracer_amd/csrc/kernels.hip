@@ -182,7 +182,7 @@ void launch_entries(const SceneBuffers &scene, const void *hits, const void *til
 	if (tiles == 0)
 		return;
 	hipLaunchKernelGGL(entry_kernel, dim3((tiles + ENTRY_WAVES - 1u) / ENTRY_WAVES), dim3(64 * ENTRY_WAVES), 0, (hipStream_t) stream,
-	                   (const NodeRec *) scene.walk + (P.node_count + 2u), (const HitRec *) hits, (const uint32_t *) tile_hits, (const uint32_t *) tile_base,
+	                   (const NodeRec *) ((const char *) scene.walk + P.walk_ce_bytes), (const HitRec *) hits, (const uint32_t *) tile_hits, (const uint32_t *) tile_base,
 	                   (const float4 *) scene.ao_table, (uint2 *) tile_entry, tiles, P.entry_stride, P.ao_mode == AO_UNIFORM && scene.ao_table ? 1 : 0,
 	                   P.ao_max_distance);
 }

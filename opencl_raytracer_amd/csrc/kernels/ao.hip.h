@@ -528,7 +528,7 @@ __device__ __forceinline__ void ao_pass(const FrameArgs &A, TileShared *shared_t
 						else
 							shared_walk_any_hit<false, PREFETCH>(nullptr, walk_ptr, tris_ptr, count, ray, sh.frame, h,
 							                           0.0f, A.P.ao_below, OCRT_COLD_F32(P.walk_scale), alive, tame, &sh.occluded[h], sh.batch,
-							                           A.P.batch_below, walk_prof, entry_begin, entry_end);
+							                           A.P.batch_below, walk_prof, entry_begin, entry_end, OCRT_COLD_U32(P.walk_ce_bytes));
 					}
 					take_from_cursor();  // (fixed shares: the cursor holds nothing)
 					} while (total != 0u);

@@ -196,7 +196,7 @@ __device__ __forceinline__ void primary_tile(const FrameArgs &A, ClosestBatch &c
 			const uint32_t first = 0u;  // (the plane-form records)
 			const WalkRay walk_ray = make_walk_ray(ray, 1.0f);
 			const uint32_t list_lds_address = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (uintptr_t) &cb.entry[0]);  // (low half of the flat address; scalar)
-			const uint32_t end = first + count * 32u;
+			const uint32_t end = first + OCRT_PCOLD_U32(P.primary_walk_bytes);
 			uint32_t at = first;  // byte offset
 			// What the reference does not do and no result can show: a lane that has a hit does not enter boxes that begin
 			// BEHIND it.  The reference walks every box its ray meets below 100000 and keeps the minimum of (distance, leaf);
@@ -207,8 +207,11 @@ __device__ __forceinline__ void primary_tile(const FrameArgs &A, ClosestBatch &c
 			float far_limit = P.primary_below;
 			{
 				const float margin = OCRT_COLD_F32(P.prune_margin);
-				if (lane == 0u)
+				const uint32_t unpruned = OCRT_PCOLD_U32(P.unpruned_bytes);
+				if (lane == 0u) {
 					cb.prune_margin = margin;
+					cb.unpruned_bytes = unpruned;
+				}
 			}
 			while (alive_mask != 0ull && at < end) {
 				uint32_t leaf = 0u;
@@ -226,7 +229,10 @@ __device__ __forceinline__ void primary_tile(const FrameArgs &A, ClosestBatch &c
 							hit = true;
 							const unsigned long long key = key_of(tr.distance, leaf);
 							my_key = key < my_key ? key : my_key;
-							far_limit = fminf(far_limit, tr.distance * 1.00001f + lane_value(cb.prune_margin));
+							// (not while the walk is among the faces no box promises anything about -- make_walk_array: they
+							// lie at the head of the records --; afterwards the lane's nearest hit so far counts, theirs included)
+							if (at >= (uint32_t) __float_as_uint(lane_value(__uint_as_float(cb.unpruned_bytes))))
+								far_limit = fminf(far_limit, __uint_as_float((uint32_t) (my_key >> 32)) * 1.00001f + lane_value(cb.prune_margin));
 						}
 					}
 				} else {
@@ -236,7 +242,7 @@ __device__ __forceinline__ void primary_tile(const FrameArgs &A, ClosestBatch &c
 						cb.entry[lane] = cb.entry[64u + lane];
 					wave_lds_sync();
 					const uint32_t nearest = (uint32_t) (cb.best_key[lane] >> 32);  // (distance bits; KEY_NONE: all ones)
-					if (nearest < INF_BITS)
+					if (nearest < INF_BITS && at >= (uint32_t) __float_as_uint(lane_value(__uint_as_float(cb.unpruned_bytes))))
 						far_limit = fminf(far_limit, __uint_as_float(nearest) * 1.00001f + lane_value(cb.prune_margin));
 				}
 				at += 32u;

@@ -384,7 +384,7 @@ struct ClosestBatch {
 	unsigned long long best_key[64];
 	unsigned int hit_bits[2];  // rays with an accepted triangle, whatever its distance (reference :108-113)
 	float prune_margin;        // KernelParams::prune_margin, kept HERE across the walk (a scalar register held across it would be spilled)
-	unsigned int pad;
+	unsigned int unpruned_bytes;  // KernelParams::unpruned_bytes, likewise
 };
 constexpr unsigned long long KEY_NONE = ~0ull;
 constexpr uint32_t INF_BITS = 0x7F800000u;
@@ -400,7 +400,8 @@ __device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ n
                                                     uint32_t count, const Ray &ray_in, const float (&frame)[12][64], uint32_t h,
                                                     float max_distance, float below, float walk_scale, bool alive, bool tame,
                                                     unsigned int *occluded, LeafBatch &batch, uint32_t batch_below,
-                                                    unsigned long long *prof, uint32_t entry_begin = 0u, uint32_t entry_end = 0xFFFFFFFFu) {
+                                                    unsigned long long *prof, uint32_t entry_begin = 0u, uint32_t entry_end = 0xFFFFFFFFu,
+                                                    uint32_t copy = 0u) {  // (`copy`: KernelParams::walk_ce_bytes, the fast form only)
 	(void) prof;  // (-DOCRT_STAMPS builds: time in the node loop / in batches, loop entries, batches, leaf stops)
 	// the live lanes as a scalar mask: the node steps then need no per-lane bookkeeping at all
 	unsigned long long alive_mask = wave_ballot(alive);
@@ -469,10 +470,9 @@ __device__ __forceinline__ void shared_walk_any_hit(const float4 *__restrict__ n
 		const SignMasks sign{ 0ull, 0ull, 0ull };  // (not looked at by the any-hit loop)
 		const uint32_t variant = WALK_MIXED;
 		// byte offset of the node: the walk reads the centre / half-extent copy of the records, which lies behind the plane
-		// form's and its two END records (scene_pack.cc, make_walk_array: 2 * (count + 2) * 32 < 2^32) -- and of that copy
+		// form's and its two END records (scene_pack.cc, make_walk_array; KernelParams::walk_ce_bytes) -- and of that copy
 		// only the tile's ENTRY subtree [entry_begin, entry_end): the deepest node under which every leaf lies that a ray
 		// of this tile can reach (entry_kernel)
-		const uint32_t copy = (count + 2u) * 32u;
 		uint32_t at = copy + entry_begin;
 		const uint32_t whole = count * 32u;
 		const uint32_t end = copy + (entry_end < whole ? entry_end : whole);

@@ -166,7 +166,6 @@ PackedScene pack_scene(const std::vector<uint32_t> &faces, const std::vector<uin
 #endif
 	out.tris.resize(tri_count);
 	out.shade.resize(tri_count);
-	double widest_triangle = 0.0, largest_coordinate = 0.0;  // (for prune_margin)
 	for (size_t t = 0; t < tri_count; ++t) {
 		const uint32_t i0 = faces[3 * t], i1 = faces[3 * t + 1], i2 = faces[3 * t + 2];
 		const Vec3f ta = vertices[i0];
@@ -186,14 +185,6 @@ PackedScene pack_scene(const std::vector<uint32_t> &faces, const std::vector<uin
 		r.vv = lib_dot(v, v);
 		r.D = r.uv * r.uv - r.uu * r.vv;
 		r.inv_d = tri_inverse_d(r.D);
-		{
-			const double lu = std::sqrt((double) u.x * u.x + (double) u.y * u.y + (double) u.z * u.z);
-			const double lv = std::sqrt((double) v.x * v.x + (double) v.y * v.y + (double) v.z * v.z);
-			const double coordinate = std::fmax(std::fmax(std::fabs((double) ta.x), std::fabs((double) ta.y)), std::fabs((double) ta.z));
-			// (NaN-proof: a comparison with NaN is false, so a NaN makes the sum below NaN through the `+`)
-			widest_triangle = lu + lv > widest_triangle || !(lu + lv == lu + lv) ? lu + lv : widest_triangle;
-			largest_coordinate = coordinate + lu + lv > largest_coordinate || !(coordinate == coordinate) ? coordinate + lu + lv : largest_coordinate;
-		}
 		ShadeRec &s = out.shade[t];
 		const Vec3f *src[3] = { &vnormals[i0], &vnormals[i1], &vnormals[i2] };
 		float *dst[3] = { s.n0, s.n1, s.n2 };
@@ -203,10 +194,6 @@ PackedScene pack_scene(const std::vector<uint32_t> &faces, const std::vector<uin
 			dst[c][2] = src[c]->z;
 			dst[c][3] = 0.0f;
 		}
-	}
-	{
-		const double margin = 4e-5 * widest_triangle + 1e-5 * largest_coordinate;
-		out.prune_margin = margin == margin && margin < 1e30 ? (float) (margin * 1.0001) + 1e-30f : __builtin_inff();
 	}
 	if (rebuilding.valid()) {
 		std::vector<NodeRec> rebuilt = rebuilding.get();
@@ -350,17 +337,157 @@ WalkArray make_walk_array(const PackedScene &scene, float ao_max_distance) {
 	const double camera[3] = { 0.0, 0.0, 2.0 };  // reference src/intersect_kernel.cl:284
 	// (both copies of the records are made in one sweep, the sweep cut into slices for a few threads: an upload's CPU
 	// time is the walk-tree rebuild and this)
-	const size_t records = nodes.size() + 2;
-	if (2 * records * sizeof(NodeRec) >= (size_t) 1 << 32)
+	if (2 * (nodes.size() + 4) * sizeof(NodeRec) >= (size_t) 1 << 32)
 		out.ao_scale = 0.0f;  // (no room for the centre / half-extent copy below 2^32 bytes: the any-hit rays of such a scene take the exact form)
 	const bool with_ce = out.ao_scale > 0.0f;
 	const float scaled_reach_of = out.ao_scale > 0.0f ? ao_max_distance * 1.001f : 0.0f;
-	out.nodes.resize(with_ce ? 2 * records : records);
 	// The plane-form records -- the closest-hit walk's, i.e. the primary rays' -- list every node's children nearest to
 	// the camera first (walk_tree.h, nearest_children_first); the centre / half-extent copy -- the any-hit walk's -- keeps
 	// the builder's order (its rays start on the surfaces: measured 4.5 % slower on the bunny in the camera's order).
 	// Without that copy both walks read the one array, in the camera's order.
-	const std::vector<NodeRec> by_camera = debug_knob("OCRT_KEEP_CHILD_ORDER") ? nodes : nearest_children_first(nodes, camera);  // (debug knob)
+	std::vector<NodeRec> by_camera;
+	// The closest-hit walk PRUNES: a lane with a hit at distance d does not enter a box of this copy whose near distance
+	// exceeds d (1 + 1e-5) + prune_margin (kernels/primary.hip.h, far_limit).  That is right if every hit the reference's
+	// triangle test can accept lies INSIDE its leaf's box of this copy (a point of the ray inside a box is not nearer than
+	// the box) -- so the leaves' boxes are grown here by how far outside the box around its vertices an accepted hit can lie:
+	//   * the test accepts s, t in [-1e-5, 1.00001] (src/intersect_kernel.cl:93-103): the point a + s u + t v lies up to
+	//     1e-5 (|u| + |v|) outside the triangle;
+	//   * s and t are float quotients by Cramer's rule, X / D and Y / D with X = uv wv - vv wu: with k = uu vv / |D| (1 / sin^2
+	//     of the angle between u and v), r = the longer over the shorter of |u|, |v| and rho = how far outside [0, 1] the
+	//     point's true parameters lie, |s_float - s_true| <= 41 * 2^-24 * k * r * rho (three-term dot products, the two
+	//     products and the difference of X, the same for D, the division; |w| <= rho (|u| + |v|)); with eta = 128 * 2^-24 * k * r
+	//     < 1/4 a point that passes has rho <= (1 + 1e-5) / (1 - eta) < 4/3 and lies within (1e-5 + 4/3 eta) (|u| + |v|) of
+	//     the triangle: grown by (2e-5 + 4 eta) (|u| + |v|) -- used up to eta = 1/32 --, plus 32 * 2^-24 of the coordinates (the hit point itself is
+	//     rounded);
+	//   * a triangle with |n| < 9.9e-7 is never accepted (|dot(n, d)| < 1e-6 for every unit d, :80) and needs nothing;
+	// and the inner boxes are the unions of their children's again.  In a scene with a triangle that can be accepted and
+	// whose eta is 1/4 or more (needles, long slivers: Cramer's rule makes their accepted region fuzzy by whole edge
+	// lengths) the closest-hit walk does NOT prune (prune_margin = +inf; both interior stand-ins are such scenes).  What
+	// is left for prune_margin otherwise: the rounding of the two distances compared, 1e-5 of the largest coordinate.
+	//   * the triangles left over -- needles, long slivers: Cramer's rule makes their accepted region fuzzy by a good part of
+	//     their edge lengths or more -- get no box that could promise anything.  They are taken out of this copy's tree and put into
+	//     a small tree of their own (their own boxes), which becomes the FIRST child of the root: the walk meets them before
+	//     anything else, and while it is in there (`unpruned_bytes`) no lane's limit is lowered -- they are tested as the
+	//     reference tests them.  (Both interior stand-ins have a few dozen such faces among 75 000.)
+	bool prunable = true;
+	out.unpruned_bytes = 0;
+	{
+		const auto never_accepted = [&](const TriRec &t) {
+			return std::sqrt((double) t.n[0] * t.n[0] + (double) t.n[1] * t.n[1] + (double) t.n[2] * t.n[2]) < 9.9e-7;
+		};
+		// how far a leaf's box has to grow; +inf: no bound
+		const auto growth_of = [&](uint32_t leaf) {
+			if (leaf >= scene.tris.size())
+				return std::numeric_limits<double>::infinity();
+			const TriRec &t = scene.tris[leaf];
+			if (never_accepted(t))
+				return 0.0;
+			const double uu = t.uu, vv = t.vv, area2 = std::fabs((double) t.D);
+			const double lu = std::sqrt(uu), lv = std::sqrt(vv);
+			double coordinate = 0.0;
+			for (unsigned k = 0; k < 3; ++k)
+				coordinate = std::fmax(coordinate, std::fabs((double) t.ta[k]));
+			const double k = area2 > 0.0 ? uu * vv / area2 : std::numeric_limits<double>::infinity();
+			const double r = lu > lv ? lu / lv : lv / lu;
+			const double eta = 128.0 * std::ldexp(1.0, -24) * k * r;
+			// (the bound holds up to eta = 1/4; but a box grown by a good part of its triangle's size is entered by packets that
+			// have no business with it -- the HARDER interior stand-in's 17-unit slivers at eta = 0.2 grew by 27 units and its
+			// primary pass from 0.098 to 0.156 ms --: from 1/32 on a face counts as one without a bound and keeps its own box)
+			if (!(eta < 1.0 / 32.0))  // (NaN too)
+				return std::numeric_limits<double>::infinity();
+			const double grow = (2e-5 + 4.0 * eta) * (lu + lv) + 32.0 * std::ldexp(1.0, -24) * (coordinate + lu + lv + 2.0);
+			return grow < 1e30 ? grow : std::numeric_limits<double>::infinity();
+		};
+		// the leaves without a bound: out of the tree (inner nodes left with one child go too), into a tree of their own
+		std::vector<NodeRec> loose;
+		for (const NodeRec &n : nodes)
+			if (n.skip == 1 && !(growth_of(n.leaf) < 1e30))
+				loose.push_back(n);
+		std::vector<NodeRec> rest;  // the tree of the others
+		if (loose.empty()) {
+			rest = nodes;
+		} else {
+			const size_t total = nodes.size();
+			std::vector<uint32_t> size(total, 0);
+			std::vector<char> keep(total, 0);
+			for (size_t i = total; i-- > 0;) {
+				if (nodes[i].skip == 1) {
+					keep[i] = growth_of(nodes[i].leaf) < 1e30;
+					size[i] = keep[i] ? 1u : 0u;
+					continue;
+				}
+				uint32_t below = 0, kids = 0;
+				for (size_t c = i + 1; c < i + nodes[i].skip && c < total; c += nodes[c].skip ? nodes[c].skip : 1) {
+					below += size[c];
+					kids += size[c] != 0;
+				}
+				keep[i] = kids >= 2;
+				size[i] = below + (keep[i] ? 1u : 0u);
+			}
+			rest.reserve(size[0]);
+			for (size_t i = 0; i < total; ++i)
+				if (keep[i]) {
+					rest.push_back(nodes[i]);
+					rest.back().skip = nodes[i].skip == 1 ? 1u : size[i];
+				}
+		}
+		// the others' boxes grown, leaves first, the inner ones as the unions of their children's
+		double largest = 2.0;  // (the camera's z)
+		for (size_t i = rest.size(); i-- > 0;) {
+			NodeRec &n = rest[i];
+			if (n.skip == 1) {
+				const double grow = growth_of(n.leaf);
+				if (!(grow < 1e30)) {
+					prunable = false;
+					break;
+				}
+				for (unsigned k = 0; k < 3; ++k) {
+					n.lo[k] = std::nextafterf((float) ((double) n.lo[k] - grow), -std::numeric_limits<float>::infinity());
+					n.hi[k] = std::nextafterf((float) ((double) n.hi[k] + grow), std::numeric_limits<float>::infinity());
+					largest = std::fmax(largest, std::fmax(std::fabs((double) n.lo[k]), std::fabs((double) n.hi[k])));
+				}
+			} else {
+				for (size_t c = i + 1; c < i + n.skip && c < rest.size(); c += rest[c].skip ? rest[c].skip : 1)
+					for (unsigned k = 0; k < 3; ++k) {
+						n.lo[k] = std::fmin(n.lo[k], rest[c].lo[k]);
+						n.hi[k] = std::fmax(n.hi[k], rest[c].hi[k]);
+					}
+			}
+		}
+		const bool reorder = !debug_knob("OCRT_KEEP_CHILD_ORDER");  // (debug knob)
+		if (prunable && loose.empty()) {
+			by_camera = reorder ? nearest_children_first(rest, camera) : rest;
+		} else if (prunable) {
+			std::vector<NodeRec> own_tree = loose.size() == 1 ? loose : rebuild_walk_tree(loose);
+			if (rest.size() >= 3 && rest[0].skip == rest.size() && !own_tree.empty() &&
+			    (rest.size() + own_tree.size() + nodes.size() + 8) * sizeof(NodeRec) < (size_t) 1 << 32) {
+				if (reorder)
+					rest = nearest_children_first(rest, camera);
+				by_camera.clear();
+				by_camera.push_back(rest[0]);
+				by_camera[0].skip = (uint32_t) (rest.size() + own_tree.size());
+				for (unsigned k = 0; k < 3; ++k) {  // (the root holds the faces' own tree too)
+					by_camera[0].lo[k] = std::fmin(by_camera[0].lo[k], own_tree[0].lo[k]);
+					by_camera[0].hi[k] = std::fmax(by_camera[0].hi[k], own_tree[0].hi[k]);
+				}
+				by_camera.insert(by_camera.end(), own_tree.begin(), own_tree.end());
+				by_camera.insert(by_camera.end(), rest.begin() + 1, rest.end());
+				out.unpruned_bytes = (uint32_t) ((1 + own_tree.size()) * sizeof(NodeRec));
+			} else {
+				prunable = false;  // (nothing but such faces, or a tree this cannot be done to)
+			}
+		}
+		out.prune_margin = prunable && largest < 1e30 ? (float) (1e-5 * largest) + 1e-30f : std::numeric_limits<float>::infinity();
+		if (!prunable) {  // (nothing is pruned: the boxes as they were, every leaf where it was)
+			by_camera = debug_knob("OCRT_KEEP_CHILD_ORDER") ? nodes : nearest_children_first(nodes, camera);
+			out.unpruned_bytes = 0;
+		}
+	}
+	// (the primary rays' records: a node or two more or fewer than the others -- inner nodes go with the faces taken out of
+	// their tree, the faces' own tree brings some --, two END records, then the other copy)
+	const size_t records = by_camera.size() + 2;
+	out.primary_bytes = (uint32_t) (by_camera.size() * sizeof(NodeRec));
+	out.nodes.resize(with_ce ? records + nodes.size() + 2 : records);
 	auto padded = [&](const NodeRec &n, double origin[3]) {
 		NodeRec w = n;
 		for (unsigned k = 0; k < 3; ++k) {
@@ -375,17 +502,19 @@ WalkArray make_walk_array(const PackedScene &scene, float ao_max_distance) {
 	auto pad_slice = [&](size_t from, size_t to) {
 		for (size_t i = from; i < to; ++i) {
 			double origin[3];
-			out.nodes[i] = padded(by_camera[i], origin);
-			if (with_ce)
+			if (i < by_camera.size())
+				out.nodes[i] = padded(by_camera[i], origin);
+			if (with_ce && i < nodes.size())
 				out.nodes[records + i] = ce_record(padded(nodes[i], origin), origin);
 		}
 	};
 	{
-		const size_t slices = nodes.size() > 16384 ? 4 : 1, per = (nodes.size() + slices - 1) / slices;
+		const size_t longest = std::max(nodes.size(), by_camera.size());
+		const size_t slices = longest > 16384 ? 4 : 1, per = (longest + slices - 1) / slices;
 		std::vector<std::future<void>> running;
 		for (size_t k = 1; k < slices; ++k)
-			running.push_back(std::async(std::launch::async, pad_slice, k * per, std::min(nodes.size(), (k + 1) * per)));
-		pad_slice(0, std::min(nodes.size(), per));
+			running.push_back(std::async(std::launch::async, pad_slice, k * per, std::min(longest, (k + 1) * per)));
+		pad_slice(0, std::min(longest, per));
 		for (auto &r : running)
 			r.get();
 	}
@@ -398,8 +527,8 @@ WalkArray make_walk_array(const PackedScene &scene, float ao_max_distance) {
 	}
 	end.skip = 0;
 	end.leaf = WALK_END;
-	out.nodes[nodes.size()] = end;
-	out.nodes[nodes.size() + 1] = end;
+	out.nodes[by_camera.size()] = end;
+	out.nodes[by_camera.size() + 1] = end;
 	// The same records once more in CENTRE / HALF-EXTENT form, behind the END records, for the packets whose rays do not
 	// agree on the sign of their direction (kernels.hip, OCRT_TEST_CE_SCALED): with t_c = fma(c, inv, oi) the two planes
 	// of an axis are fma(-e, |inv|, t_c) and fma(e, |inv|, t_c) whatever the sign of inv -- nine fmas and no selects.
@@ -490,7 +619,10 @@ SceneFacts scene_facts(const PackedScene &scene, const WalkArray &walk) {
 	f.has_walk = !walk.nodes.empty();
 	f.origin_limit = walk.origin_limit;
 	f.ao_scale = walk.ao_scale;
-	f.prune_margin = scene.prune_margin;
+	f.prune_margin = walk.prune_margin;
+	f.unpruned_bytes = walk.unpruned_bytes;
+	f.primary_bytes = walk.primary_bytes;
+	f.ce_offset = walk.ce_offset;
 	return f;
 }
 
@@ -515,6 +647,9 @@ KernelParams make_kernel_params(const RayTracer &rt, uint32_t node_count, uint32
 	p.ao_divisor = p.ao_mode == AO_RANDOM ? ao_dirs - 1 : ao_dirs;
 	p.origin_limit = facts ? facts->origin_limit : 0.0f;
 	p.prune_margin = facts && !debug_knob("OCRT_NO_PRUNE") ? facts->prune_margin : __builtin_inff();  // (debug knob)
+	p.unpruned_bytes = facts ? facts->unpruned_bytes : 0u;
+	p.primary_walk_bytes = facts ? facts->primary_bytes : 0u;
+	p.walk_ce_bytes = facts ? facts->ce_offset : 0u;
 	// (the array's margins hold for the max_distance it was made for: the renderer re-makes it when that changes)
 	p.walk_scale = (facts && facts->ao_scale > 0.0f && facts->ao_scale == walk_scale_for(p.ao_max_distance) &&
 	                walk_scale_usable(facts->ao_scale, facts->origin_limit) &&

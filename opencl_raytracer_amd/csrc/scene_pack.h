@@ -2,6 +2,7 @@
 // records of device_types.h and derives the launch constants.  Host only.
 #pragma once
 #include <cstdint>
+#include <limits>
 #include <memory>
 #include <vector>
 
@@ -20,6 +21,9 @@ namespace ocrt {
 struct WalkArray {
 	std::vector<NodeRec> nodes;
 	float origin_limit = 0.0f;  // rays whose origin exceeds this magnitude on some axis take the exact form
+	float prune_margin = std::numeric_limits<float>::infinity();  // KernelParams::prune_margin (make_walk_array; +inf: the closest-hit walk must not prune)
+	uint32_t primary_bytes = 0;   // bytes of the plane-form records (the primary rays' tree; two END records follow, then the other copy at ce_offset)
+	uint32_t unpruned_bytes = 0;  // ... and the part at the head of the primary rays' records inside which no limit is lowered (the root and the faces without a bound)
 	float ao_scale = 0.0f;      // walk_scale_for(ao_max_distance) the margins were sized for (0: none)
 	uint32_t ce_offset = 0;     // byte offset of the same records in centre / half-extent form (0: none; ao_scale > 0 only)
 };
@@ -36,12 +40,6 @@ struct PackedScene {
 	bool nested = false;       // ... and every node's box contains its children's boxes (true for any tree built by
 	                           // uniting child boxes; arbitrary uploaded arrays need not be)
 	bool rebuilt = false;      // `nodes` is the rebuilt tree, not the uploaded one
-	// How far in front of its leaf box's near plane a hit of the reference's triangle test can lie (KernelParams::prune_margin):
-	// the test accepts s, t in [-1e-5, 1.00001], i.e. points up to ~1e-5 (|u| + |v|) outside the triangle -- and so outside the
-	// box around its vertices --, and the point, the box planes and the two distances compared carry the rounding of
-	// coordinates of the scene's magnitude.  4e-5 of the largest |u| + |v| plus 1e-5 of the largest coordinate; +inf where
-	// that is not finite (then nothing is ever pruned).
-	float prune_margin = 0.0f;
 	// Optional: the walk array made ahead of the upload (prepare_walk_array) for this AO_MAX_DISTANCE -- CPU work that a
 	// caller can do before it has a device; DeviceRenderer::upload makes its own when this one is absent or was made for
 	// another distance.
@@ -98,7 +96,8 @@ struct SceneFacts {
 	bool regular = false, nested = false, binary_tree = false;  // PackedScene's flags
 	bool has_walk = false;                                       // the padded walk array exists
 	float origin_limit = 0.0f, ao_scale = 0.0f;                  // WalkArray's
-	float prune_margin = 0.0f;                                   // PackedScene's
+	float prune_margin = 0.0f;                                   // WalkArray's
+	uint32_t unpruned_bytes = 0, primary_bytes = 0, ce_offset = 0;
 };
 SceneFacts scene_facts(const PackedScene &scene, const WalkArray &walk);
 KernelParams make_kernel_params(const RayTracer &rt, uint32_t node_count, uint32_t tri_count, uint32_t ao_dirs,

@@ -76,6 +76,20 @@ def test_padded_walk_boxes_never_lose_a_pair_the_reference_accepts(rt, tmp_path)
     assert r.returncode == 0, "the unpadded self-check found no miss: the test has no teeth\n" + r.stdout[-500:]
 
 
+def test_closest_hit_pruning_rests_on_boxes_that_hold_every_accepted_hit(rt, tmp_path):
+    """tests/prune_check.cc: in the primary rays' copy of the walk records (children nearest to the camera first, leaf
+    boxes grown by the triangle test's slack and rounding) no hit the reference's test accepts lies in front of its
+    leaf's box -- rays from the reference's camera through the bunny's vertices, shaken into the slack zone --; both
+    copies hold the same leaves; faces no box can promise anything about (needles, the HARDER interior stand-in's slivers) lie
+    at the head of that copy, where the walk lowers no limit."""
+    exe = tmp_path / "prune_check"
+    lib_dir = os.path.join(ROOT, "opencl_raytracer_amd", "lib")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-I", os.path.join(ROOT, "opencl_raytracer_amd", "csrc"), "-o", str(exe),
+                    os.path.join(ROOT, "tests", "prune_check.cc"), "-L" + lib_dir, "-locrt_hip", "-Wl,-rpath," + lib_dir], check=True)
+    r = subprocess.run([str(exe), os.path.join(ROOT, "meshes", "bunny.off"), os.path.join(ROOT, "meshes", "interior_hard.off")], capture_output=True, text=True)
+    assert r.returncode == 0 and "prune_check: ok" in r.stdout and r.stdout.count(" 0 violations") == 2, r.stdout[-2000:]
+
+
 def test_packed_triangles_carry_the_reciprocal_of_d(rt, tmp_path):
     """tests/tri_inverse_check.cc: TriRec::inv_d is RN(1 / D) where the short form of the any-hit triangle test may use
     it and a NaN elsewhere (zero-area, huge, tiny triangles), through pack_scene; tri_inverse_d's boundaries."""
