@@ -398,10 +398,17 @@ WalkArray make_walk_array(const PackedScene &scene, float ao_max_distance) {
 			const double grow = (2e-5 + 4.0 * eta) * (lu + lv) + 32.0 * std::ldexp(1.0, -24) * (coordinate + lu + lv + 2.0);
 			return grow < 1e30 ? grow : std::numeric_limits<double>::infinity();
 		};
+		// (once per triangle)
+		std::vector<float> growth(scene.tris.size());
+		for (size_t t = 0; t < scene.tris.size(); ++t) {
+			const double g = growth_of((uint32_t) t);
+			growth[t] = g < 1e30 ? std::nextafterf((float) g, std::numeric_limits<float>::infinity()) : std::numeric_limits<float>::infinity();
+		}
+		const auto grown_by = [&](uint32_t leaf) { return leaf < growth.size() ? (double) growth[leaf] : std::numeric_limits<double>::infinity(); };
 		// the leaves without a bound: out of the tree (inner nodes left with one child go too), into a tree of their own
 		std::vector<NodeRec> loose;
 		for (const NodeRec &n : nodes)
-			if (n.skip == 1 && !(growth_of(n.leaf) < 1e30))
+			if (n.skip == 1 && !(grown_by(n.leaf) < 1e30))
 				loose.push_back(n);
 		std::vector<NodeRec> rest;  // the tree of the others
 		if (loose.empty()) {
@@ -412,7 +419,7 @@ WalkArray make_walk_array(const PackedScene &scene, float ao_max_distance) {
 			std::vector<char> keep(total, 0);
 			for (size_t i = total; i-- > 0;) {
 				if (nodes[i].skip == 1) {
-					keep[i] = growth_of(nodes[i].leaf) < 1e30;
+					keep[i] = grown_by(nodes[i].leaf) < 1e30;
 					size[i] = keep[i] ? 1u : 0u;
 					continue;
 				}
@@ -436,7 +443,7 @@ WalkArray make_walk_array(const PackedScene &scene, float ao_max_distance) {
 		for (size_t i = rest.size(); i-- > 0;) {
 			NodeRec &n = rest[i];
 			if (n.skip == 1) {
-				const double grow = growth_of(n.leaf);
+				const double grow = grown_by(n.leaf);
 				if (!(grow < 1e30)) {
 					prunable = false;
 					break;
