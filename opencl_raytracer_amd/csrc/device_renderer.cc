@@ -213,7 +213,7 @@ size_t DeviceRenderer::upload(const PackedScene &scene) {
 	useDevice();
 	synchronize();
 	freeScene();
-	std::shared_ptr<const DeviceScene> made = DeviceScene::create(device, scene, opts);
+	std::shared_ptr<const DeviceScene> made = DeviceScene::create(device, scene, opts, expected_frames >= FRAMES_WORTH_INTERVALS);
 	const size_t scene_bytes = made->bytes();
 	return scene_bytes + adopt(std::move(made));
 }

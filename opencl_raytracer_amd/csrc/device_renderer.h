@@ -39,7 +39,8 @@ class DeviceScene {
 		// Blocking upload; `options`: the direction table (AO samples, angles, method) and the any-hit rays' reach
 		// (AO_MAX_DISTANCE, which sizes the walk array's margins) are baked in -- servesOptions() says whether another
 		// renderer's options agree.
-		static std::shared_ptr<const DeviceScene> create(int device, const PackedScene &scene, const RayTracer::Options &options);
+		// (`for_a_stream`: make_walk_array's -- what only pays over many frames of the scene)
+		static std::shared_ptr<const DeviceScene> create(int device, const PackedScene &scene, const RayTracer::Options &options, bool for_a_stream = true);
 		// A scene's arrays live in ONE device allocation.  A front end that knows the size of what is coming before it has
 		// the arrays (the triangle count of a mesh file's header) can have that allocation made ahead of time -- on the
 		// thread that brings the device up -- and create() takes it over if it is large enough (else it is dropped).

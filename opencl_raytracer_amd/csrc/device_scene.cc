@@ -16,7 +16,7 @@ int reserved_device = -1;
 size_t round_up(size_t bytes) { return (bytes + 255) & ~(size_t) 255; }
 }  // namespace
 
-std::shared_ptr<const DeviceScene> DeviceScene::create(int device, const PackedScene &scene, const RayTracer::Options &opts) {
+std::shared_ptr<const DeviceScene> DeviceScene::create(int device, const PackedScene &scene, const RayTracer::Options &opts, bool for_a_stream) {
 	UploadClock clock;
 	OCRT_HIP(hipSetDevice(device));
 	std::shared_ptr<DeviceScene> out(new DeviceScene());
@@ -41,8 +41,10 @@ std::shared_ptr<const DeviceScene> DeviceScene::create(int device, const PackedS
 		}
 	}
 	out->walk_distance = out->ao_on ? kernel_float(opts.aoMaxDistance) : 0.0f;
-	const std::shared_ptr<const WalkArray> made = (scene.walk && scene.walk_max_distance == out->walk_distance)
-	                                                  ? scene.walk : std::make_shared<const WalkArray>(make_walk_array(scene, out->walk_distance));
+	// (a prepared array is taken if it was made for this distance and for at least as much as is wanted now)
+	const std::shared_ptr<const WalkArray> made = (scene.walk && scene.walk_max_distance == out->walk_distance && (scene.walk_for_a_stream || !for_a_stream))
+	                                                  ? scene.walk
+	                                                  : std::make_shared<const WalkArray>(make_walk_array(scene, out->walk_distance, for_a_stream));
 	const WalkArray &walk = *made;
 	clock.mark("direction table + walk array (made here unless prepared)");
 	out->scene_facts_ = scene_facts(scene, walk);

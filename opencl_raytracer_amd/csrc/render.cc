@@ -378,7 +378,9 @@ int main(int argc, const char **argv) {
 		mesh.faces.clear();
 		bvh.triangles.clear();
 		packed = ocrt::pack_scene(sorted_faces, bvh.nodes, bvh.aabbs, mesh.vertices, mesh.vnormals);
-		ocrt::prepare_walk_array(packed, options.enableAO && options.aoNumSamples > 0 ? ocrt::kernel_float(options.aoMaxDistance) : 0.0f);
+		// (one frame, the reference's use: nothing that only pays over a stream of frames -- scene_pack.h, make_walk_array)
+		ocrt::prepare_walk_array(packed, options.enableAO && options.aoNumSamples > 0 ? ocrt::kernel_float(options.aoMaxDistance) : 0.0f,
+		                         options.frames >= 16);
 	} catch (const std::exception &e) {
 		if (warm_up.joinable())
 			warm_up.join();

@@ -316,7 +316,7 @@ static NodeRec ce_record(const NodeRec &padded, const double origin_bound[3]) {
 	return r;
 }
 
-WalkArray make_walk_array(const PackedScene &scene, float ao_max_distance) {
+WalkArray make_walk_array(const PackedScene &scene, float ao_max_distance, bool for_a_stream) {
 	WalkArray out;
 	const std::vector<NodeRec> &nodes = scene.nodes;
 	if (!(scene.regular && scene.nested) || nodes.empty())
@@ -369,9 +369,12 @@ WalkArray make_walk_array(const PackedScene &scene, float ao_max_distance) {
 	//     a small tree of their own (their own boxes), which becomes the FIRST child of the root: the walk meets them before
 	//     anything else, and while it is in there (`unpruned_bytes`) no lane's limit is lowered -- they are tested as the
 	//     reference tests them.  (Both interior stand-ins have a few dozen such faces among 75 000.)
-	bool prunable = true;
+	bool prunable = for_a_stream;
 	out.unpruned_bytes = 0;
-	{
+	if (!prunable) {
+		by_camera = nodes;  // (a one-shot host: nothing re-ordered, nothing grown, nothing pruned)
+		out.prune_margin = std::numeric_limits<float>::infinity();
+	} else {
 		const auto never_accepted = [&](const TriRec &t) {
 			return std::sqrt((double) t.n[0] * t.n[0] + (double) t.n[1] * t.n[1] + (double) t.n[2] * t.n[2]) < 9.9e-7;
 		};
@@ -555,9 +558,10 @@ WalkArray make_walk_array(const PackedScene &scene, float ao_max_distance) {
 	return out;
 }
 
-void prepare_walk_array(PackedScene &scene, float ao_max_distance) {
-	scene.walk = std::make_shared<const WalkArray>(make_walk_array(scene, ao_max_distance));
+void prepare_walk_array(PackedScene &scene, float ao_max_distance, bool for_a_stream) {
+	scene.walk = std::make_shared<const WalkArray>(make_walk_array(scene, ao_max_distance, for_a_stream));
 	scene.walk_max_distance = ao_max_distance;
+	scene.walk_for_a_stream = for_a_stream;
 }
 
 float kernel_float(float v) {
