@@ -147,8 +147,9 @@ uint32_t rt_local_to_global_row(const rt_host *h, uint32_t local_row);
 
 /* New: announce how many frames of the uploaded scene this host is going to render (default 1 -- the reference's use:
  * one frame per process, src/render.cc:86-111).  From 16 frames on an upload also prepares the walk intervals of the
- * tiles' any-hit packets (~0.5 ms once, 3 ... 16 % per frame after); before or after rt_upload.  Results never depend on
- * it.  A frame ring announces a stream by itself. */
+ * tiles' any-hit packets (~0.5 ms once, 3 ... 16 % per frame after) and the re-ordered, grown copy of the walk records that
+ * lets the primary rays' closest-hit walk prune (2-3 ms of CPU once; announce BEFORE rt_upload for that one); before or
+ * after rt_upload.  Results never depend on it.  A frame ring announces a stream by itself. */
 int rt_expect_frames(rt_host *h, uint64_t frames);
 
 /* Ray counts of the last frame, and the HIP-event time of its ray-casting passes on the launch stream in ms (the region
