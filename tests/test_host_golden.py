@@ -86,7 +86,8 @@ def test_closest_hit_pruning_rests_on_boxes_that_hold_every_accepted_hit(rt, tmp
     lib_dir = os.path.join(ROOT, "opencl_raytracer_amd", "lib")
     subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-I", os.path.join(ROOT, "opencl_raytracer_amd", "csrc"), "-o", str(exe),
                     os.path.join(ROOT, "tests", "prune_check.cc"), "-L" + lib_dir, "-locrt_hip", "-Wl,-rpath," + lib_dir], check=True)
-    r = subprocess.run([str(exe), os.path.join(ROOT, "meshes", "bunny.off"), os.path.join(ROOT, "meshes", "interior_hard.off")], capture_output=True, text=True)
+    from tools.meshes import bunny_path, interior_hard_path  # (decompressed / generated on first use)
+    r = subprocess.run([str(exe), bunny_path(), interior_hard_path()], capture_output=True, text=True)
     assert r.returncode == 0 and "prune_check: ok" in r.stdout and r.stdout.count(" 0 violations") == 2, r.stdout[-2000:]
 
 
